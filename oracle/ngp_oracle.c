@@ -1,0 +1,805 @@
+/*
+ * ngp_oracle.c -- CPU oracle for the NextGP.jl marker-effect Gibbs hot path.
+ *
+ * TEST INFRASTRUCTURE, NOT PRODUCT.  Only tests/, __graft_entry__.smoke() and
+ * bench.py's cpu_baseline leg may load this file's shared object.  The product
+ * (nextgp.jl_amd/csrc -> libnextgp_hip.so) never links, loads or calls it.
+ *
+ * PARITY UNPINNED: the reference ships no tests, golden vectors or fixtures
+ * for this path (/root/reference/test/runtests.jl:1-7 is an empty testset) and
+ * no Julia toolchain exists in the build container, so the reference itself
+ * cannot be executed.  This oracle is a plain-C restatement of the reference
+ * algorithm, pinned only by closed-form / statistical checks (tests/) and by
+ * its own committed golden vectors (tests/golden/).
+ *
+ * Third-party arithmetic the reference delegates to packages that are absent
+ * from /root/reference (Distributions.jl compat 0.25.58, Julia stdlib Random,
+ * OpenBLAS level-1; Project.toml:7-36) is replaced by an explicit, portable
+ * specification (docs in DESIGN.md "RNG and draw spec"):
+ *   - xoshiro256++ streams keyed by (seed, chain, iteration, kind, index)
+ *   - Normal: inverse CDF, Wichura AS241 PPND16
+ *   - Gamma/Chi-square/Beta: Marsaglia-Tsang (2000) on the same stream
+ *   - log: a fixed sequence of IEEE-754 double operations (det_log) so that
+ *     CPU and GPU produce identical bits.
+ *
+ * Two orderings of the same Markov chain are provided:
+ *   order 0  "reference order": per SNP add-back / dot / draw / subtract with
+ *            a second transposed copy of the panel, exactly the memory and
+ *            arithmetic pattern of
+ *              src/samplers.jl:23-106   (iteration driver)
+ *              src/functions.jl:39-53   (intercept, sampleX!)
+ *              src/functions.jl:118-137 (sampleBayesPR!, Symbol method)
+ *              src/functions.jl:157-195 (sampleBayesB!)
+ *              src/functions.jl:493-495, 509-511, 523-525, 531-533 (draws)
+ *              src/mme.jl:57,87-94,294-361,443-444,493-516 (set-up)
+ *            This is the spec oracle and the CPU timing baseline.
+ *   order 1  "blocked order": the 64-SNP block recursion with Gram
+ *            corrections and the exact reduction trees the HIP kernels use
+ *            (DESIGN.md "Blocked sweep arithmetic"), for bit-parity tests.
+ *
+ * Build: see oracle/Makefile (gcc -O3 -mavx2 -mfma -ffp-contract=off).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+#define ORA_OK 0
+#define ORA_ERR (-1)
+
+#define KIND_VARE_CHI2 1
+#define KIND_FIXED_NORMAL 2
+#define KIND_BETA_NORMAL 3
+#define KIND_REGION_CHI2 4
+#define KIND_B_UNIFORM 5
+#define KIND_B_LOCUS_CHI2 6
+#define KIND_PI_BETA 7
+
+#define METHOD_PR 0
+#define METHOD_B 1
+
+#define BLK 64
+#define SEG 256
+#define GRP 32
+
+/* ------------------------------------------------------------------ */
+/* RNG: xoshiro256++ keyed streams                                      */
+/* ------------------------------------------------------------------ */
+#define GOLD 0x9E3779B97F4A7C15ULL
+
+static inline uint64_t mix64(uint64_t z) {
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ULL;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBULL;
+    return z ^ (z >> 31);
+}
+
+typedef struct { uint64_t s[4]; } rng_t;
+
+static inline uint64_t rotl64(uint64_t x, int k) { return (x << k) | (x >> (64 - k)); }
+
+static inline uint64_t rng_next(rng_t *r) {
+    uint64_t *s = r->s;
+    uint64_t res = rotl64(s[0] + s[3], 23) + s[0];
+    uint64_t t = s[1] << 17;
+    s[2] ^= s[0]; s[3] ^= s[1]; s[1] ^= s[2]; s[0] ^= s[3];
+    s[2] ^= t; s[3] = rotl64(s[3], 45);
+    return res;
+}
+
+static inline uint64_t absorb(uint64_t h, uint64_t v) { return mix64(h ^ mix64(v + GOLD)); }
+
+static void rng_seed(rng_t *r, uint64_t seed, uint64_t chain, uint64_t iter, uint64_t kind, uint64_t index) {
+    uint64_t h = mix64(seed + GOLD);
+    h = absorb(h, chain);
+    h = absorb(h, iter);
+    h = absorb(h, kind);
+    h = absorb(h, index);
+    for (int i = 0; i < 4; i++) r->s[i] = mix64(h + (uint64_t)(i + 1) * GOLD);
+}
+
+/* uniform on the open interval (0,1): (k + 0.5) * 2^-52, k = top 52 bits */
+static inline double rng_uniform(rng_t *r) {
+    uint64_t k = rng_next(r) >> 12;
+    return ((double)k + 0.5) * 2.220446049250313080847263336181640625e-16;
+}
+
+/* ------------------------------------------------------------------ */
+/* det_log: fixed IEEE sequence (argument reduction + degree-14 series) */
+/* classic algorithm: x = 2^k (1+f), s = f/(2+f), log(1+f) = f - s(f-R) */
+/* ------------------------------------------------------------------ */
+static inline double det_log(double x) {
+    const double ln2_hi = 6.93147180369123816490e-01, ln2_lo = 1.90821492927058770002e-10;
+    const double Lg1 = 6.666666666666735130e-01, Lg2 = 3.999999999940941908e-01,
+                 Lg3 = 2.857142874366239149e-01, Lg4 = 2.222219843214978396e-01,
+                 Lg5 = 1.818357216161805012e-01, Lg6 = 1.531383769920937332e-01,
+                 Lg7 = 1.479819860511658591e-01;
+    uint64_t bits; memcpy(&bits, &x, 8);
+    if (x <= 0.0) return (x == 0.0) ? -INFINITY : NAN;
+    if ((bits >> 52) == 0x7FF) return x; /* inf / nan */
+    int k = 0;
+    if ((bits >> 52) == 0) { x *= 18014398509481984.0; memcpy(&bits, &x, 8); k = -54; } /* subnormal */
+    uint32_t hx = (uint32_t)(bits >> 32);
+    k += (int)(hx >> 20) - 1023;
+    hx &= 0x000fffffu;
+    uint32_t i = (hx + 0x95f64u) & 0x100000u;
+    uint64_t nb = ((uint64_t)(hx | (i ^ 0x3ff00000u)) << 32) | (bits & 0xffffffffULL);
+    k += (int)(i >> 20);
+    double xn; memcpy(&xn, &nb, 8);
+    double f = xn - 1.0;
+    double s = f / (2.0 + f);
+    double dk = (double)k;
+    double z = s * s;
+    double w = z * z;
+    double t1 = w * (Lg2 + w * (Lg4 + w * Lg6));
+    double t2 = z * (Lg1 + w * (Lg3 + w * (Lg5 + w * Lg7)));
+    double R = t2 + t1;
+    double hfsq = 0.5 * f * f;
+    return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+/* ------------------------------------------------------------------ */
+/* Normal quantile, Wichura (1988) AS241 PPND16                         */
+/* ------------------------------------------------------------------ */
+static inline double ppnd16(double p) {
+    double q = p - 0.5, r, val;
+    if (fabs(q) <= 0.425) {
+        r = 0.180625 - q * q;
+        double num = (((((((2.5090809287301226727e3 * r + 3.3430575583588128105e4) * r + 6.7265770927008700853e4) * r
+                          + 4.5921953931549871457e4) * r + 1.3731693765509461125e4) * r + 1.9715909503065514427e3) * r
+                       + 1.3314166789178437745e2) * r + 3.3871328727963666080e0);
+        double den = (((((((5.2264952788528545610e3 * r + 2.8729085735721942674e4) * r + 3.9307895800092710610e4) * r
+                          + 2.1213794301586595867e4) * r + 5.3941960214247511077e3) * r + 6.8718700749205790830e2) * r
+                       + 4.2313330701600911252e1) * r + 1.0);
+        return q * num / den;
+    }
+    r = (q < 0.0) ? p : 1.0 - p;
+    r = sqrt(-det_log(r));
+    if (r <= 5.0) {
+        r = r - 1.6;
+        double num = (((((((7.74545014278341407640e-4 * r + 2.27238449892691845833e-2) * r + 2.41780725177450611770e-1) * r
+                          + 1.27045825245236838258e0) * r + 3.64784832476320460504e0) * r + 5.76949722146069140550e0) * r
+                       + 4.63033784615654529590e0) * r + 1.42343711074968357734e0);
+        double den = (((((((1.05075007164441684324e-9 * r + 5.47593808499534494600e-4) * r + 1.51986665636164571966e-2) * r
+                          + 1.48103976427480074590e-1) * r + 6.89767334985100004550e-1) * r + 1.67638483018380384940e0) * r
+                       + 2.05319162663775882187e0) * r + 1.0);
+        val = num / den;
+    } else {
+        r = r - 5.0;
+        double num = (((((((2.01033439929228813265e-7 * r + 2.71155556874348757815e-5) * r + 1.24266094738807843860e-3) * r
+                          + 2.65321895265761230930e-2) * r + 2.96560571828504891230e-1) * r + 1.78482653991729133580e0) * r
+                       + 5.46378491116411436990e0) * r + 6.65790464350110377720e0);
+        double den = (((((((2.04426310338993978564e-15 * r + 1.42151175831644588870e-7) * r + 1.84631831751005468180e-5) * r
+                          + 7.86869131145613259100e-4) * r + 1.48753612908506148525e-2) * r + 1.36929880922735805310e-1) * r
+                       + 5.99832206555887937690e-1) * r + 1.0);
+        val = num / den;
+    }
+    return (q < 0.0) ? -val : val;
+}
+
+static inline double rng_normal(rng_t *r) { return ppnd16(rng_uniform(r)); }
+
+/* Marsaglia & Tsang (2000), shape a >= 1, scale 1; no squeeze step */
+static double rng_gamma(rng_t *r, double a) {
+    double d = a - 1.0 / 3.0;
+    double c = 1.0 / sqrt(9.0 * d);
+    for (;;) {
+        double x, v;
+        do { x = rng_normal(r); v = 1.0 + c * x; } while (v <= 0.0);
+        v = v * v * v;
+        double u = rng_uniform(r);
+        double x2 = x * x;
+        double lv = det_log(v);
+        double t = 1.0 - v;
+        t = t + lv;
+        t = d * t;
+        double h = 0.5 * x2;
+        double rhs = h + t;
+        if (det_log(u) < rhs) return d * v;
+    }
+}
+static inline double rng_chisq(rng_t *r, double nu) { return 2.0 * rng_gamma(r, 0.5 * nu); }
+static inline double rng_beta(rng_t *r, double a, double b) {
+    double ga = rng_gamma(r, a);
+    double gb = rng_gamma(r, b);
+    return ga / (ga + gb);
+}
+
+/* exported scalar probes so tests can pin the draw layer */
+double ora_det_log(double x) { return det_log(x); }
+double ora_ppnd16(double p) { return ppnd16(p); }
+void ora_draws(uint64_t seed, uint64_t chain, uint64_t iter, uint64_t kind, uint64_t index, int what, double p1, double p2,
+               int64_t n, double *out) {
+    /* what: 0 uniform, 1 normal, 2 chisq(p1), 3 beta(p1,p2), 4 gamma(p1); n successive draws of ONE stream */
+    rng_t r; rng_seed(&r, seed, chain, iter, kind, index);
+    for (int64_t i = 0; i < n; i++) {
+        switch (what) {
+            case 0: out[i] = rng_uniform(&r); break;
+            case 1: out[i] = rng_normal(&r); break;
+            case 2: out[i] = rng_chisq(&r, p1); break;
+            case 3: out[i] = rng_beta(&r, p1, p2); break;
+            default: out[i] = rng_gamma(&r, p1); break;
+        }
+    }
+}
+/* first draw of n different streams index0..index0+n-1 (how the sampler uses them) */
+void ora_draws_indexed(uint64_t seed, uint64_t chain, uint64_t iter, uint64_t kind, uint64_t index0, int what, double p1,
+                       double p2, int64_t n, double *out) {
+    for (int64_t i = 0; i < n; i++) ora_draws(seed, chain, iter, kind, index0 + (uint64_t)i, what, p1, p2, 1, out + i);
+}
+
+/* ------------------------------------------------------------------ */
+/* Synthetic panel: g_ij ~ Binomial(2,p_j),      */
+/* p_j ~ U(maf_lo, maf_hi), counter-based so CPU and GPU agree bitwise.  */
+/* ------------------------------------------------------------------ */
+static inline double panel_pj(uint64_t pseed, int64_t j, double lo, double hi) {
+    uint64_t h = mix64(mix64(pseed ^ 0xA5A5A5A55A5A5A5AULL) + (uint64_t)j * GOLD);
+    double u = ((double)(h >> 12) + 0.5) * 2.220446049250313080847263336181640625e-16;
+    return lo + (hi - lo) * u;
+}
+static inline int panel_gij(uint64_t pseed, int64_t i, int64_t j, uint32_t thr) {
+    uint64_t h = mix64(mix64(pseed + (uint64_t)j * 0xD1342543DE82EF95ULL) ^ ((uint64_t)i * GOLD + 0x632BE59BD9B4E019ULL));
+    return (int)((uint32_t)h < thr) + (int)((uint32_t)(h >> 32) < thr);
+}
+/* column-major N x P, centred fp32; optionally returns raw genotype sums per column */
+void ora_generate_panel(int64_t N, int64_t P, double maf_lo, double maf_hi, uint64_t pseed, float *X, double *col_mean) {
+    for (int64_t j = 0; j < P; j++) {
+        double pj = panel_pj(pseed, j, maf_lo, maf_hi);
+        uint32_t thr = (uint32_t)(pj * 4294967296.0);
+        float *col = X + j * N;
+        int64_t sum = 0;
+        for (int64_t i = 0; i < N; i++) { int g = panel_gij(pseed, i, j, thr); col[i] = (float)g; sum += g; }
+        double mu = (double)sum / (double)N;
+        for (int64_t i = 0; i < N; i++) col[i] = (float)((double)col[i] - mu);
+        if (col_mean) col_mean[j] = mu;
+    }
+}
+
+/* ------------------------------------------------------------------ */
+/* handle                                                               */
+/* ------------------------------------------------------------------ */
+typedef struct {
+    int64_t col0, ncol;
+    int method;
+    double df, scale;
+    int64_t nreg;
+    int64_t *reg_start, *reg_stop; /* 0-based [start,stop) relative to the set */
+    int64_t vb_off;                /* offset into varBeta[] */
+    double piHat[2], logPi[2];
+    int estPi;
+    double sum_pi[2];
+} oset_t;
+
+typedef struct {
+    int order; /* 0 reference, 1 blocked */
+    uint64_t seed; uint64_t chain;
+    int64_t N, P;
+    /* reference order storage (fp64 data + second transposed copy, mme.jl:308) */
+    double *data, *Mp;
+    /* blocked order storage */
+    int64_t R, S, NBLK, Ppad; /* rows per shard, shards, blocks */
+    float *tiles;             /* [s][t][j][i] */
+    double *gram;             /* [t][64][64] */
+    double *mpm;              /* Ppad (reference order: P) */
+    double *lhs0, *rhs0;      /* Ppad */
+    /* model */
+    int nsets; oset_t sets[16];
+    int64_t nvb; double *varBeta; double *sum_varBeta;
+    double e_df, e_scale;
+    int intercept;
+    /* state */
+    double *y;     /* N */
+    double *ycorr; /* N (blocked: S*R padded) */
+    double b;
+    double *beta;  /* Ppad */
+    int64_t *delta;
+    double varE;
+    int64_t iter;
+    /* schedule + posterior sums */
+    int64_t chainLength, burnIn, thin;
+    int64_t nKept;
+    double *sum_beta, *sum_beta2, *sum_delta;
+    double sum_varE, sum_b;
+    /* traces of the last ora_run */
+    int64_t ntrace; double *tr_varE, *tr_b;
+    /* scratch for blocked */
+    double *c, *w, *q, *T, *chi;
+    char err[256];
+} ora_t;
+
+int ora_create(int order, uint64_t seed, uint32_t chain, ora_t **out) {
+    ora_t *h = (ora_t *)calloc(1, sizeof(ora_t));
+    if (!h) return ORA_ERR;
+    h->order = order; h->seed = seed; h->chain = chain;
+    h->e_df = 4.0; h->e_scale = 0.0005; h->intercept = 1;
+    h->chainLength = 0; h->burnIn = 0; h->thin = 1;
+    *out = h; return ORA_OK;
+}
+static void free_sets(ora_t *h) {
+    for (int s = 0; s < h->nsets; s++) { free(h->sets[s].reg_start); free(h->sets[s].reg_stop); }
+}
+void ora_destroy(ora_t *h) {
+    if (!h) return;
+    free(h->data); free(h->Mp); free(h->tiles); free(h->gram); free(h->mpm); free(h->lhs0); free(h->rhs0);
+    free_sets(h); free(h->varBeta); free(h->sum_varBeta); free(h->y); free(h->ycorr); free(h->beta); free(h->delta);
+    free(h->sum_beta); free(h->sum_beta2); free(h->sum_delta); free(h->tr_varE); free(h->tr_b);
+    free(h->c); free(h->w); free(h->q); free(h->T); free(h->chi);
+    free(h);
+}
+const char *ora_last_error(ora_t *h) { return h->err; }
+
+/* hierarchical sequential sum of n shard partials in groups of GRP */
+static double group_sum(const double *p, int64_t n, int64_t stride) {
+    double tot = 0.0;
+    for (int64_t g = 0; g * GRP < n; g++) {
+        int64_t s0 = g * GRP, s1 = s0 + GRP < n ? s0 + GRP : n;
+        double gs = p[s0 * stride];
+        for (int64_t s = s0 + 1; s < s1; s++) gs = gs + p[s * stride];
+        tot = (g == 0) ? gs : tot + gs;
+    }
+    return tot;
+}
+
+/* the panel as the product stores it: fp32, column-major N x P, already centred.
+   For order 1 the caller states the device layout (rows per shard R, shards S). */
+int ora_set_panel_f32(ora_t *h, const float *X, int64_t N, int64_t P, int64_t R, int64_t S) {
+    h->N = N; h->P = P;
+    if (h->order == 0) {
+        h->data = (double *)malloc(sizeof(double) * N * P);
+        h->Mp = (double *)malloc(sizeof(double) * N * P);
+        h->mpm = (double *)calloc(P, sizeof(double));
+        if (!h->data || !h->Mp || !h->mpm) { snprintf(h->err, 256, "out of memory"); return ORA_ERR; }
+        for (int64_t j = 0; j < P; j++) {
+            const float *c = X + j * N; double *d = h->data + j * N, *m = h->Mp + j * N;
+            double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            int64_t i = 0;
+            for (; i + 8 <= N; i += 8)
+                for (int l = 0; l < 8; l++) { double v = (double)c[i + l]; d[i + l] = v; m[i + l] = v; acc[l] = __builtin_fma(v, v, acc[l]); }
+            double tail = 0;
+            for (; i < N; i++) { double v = (double)c[i]; d[i] = v; m[i] = v; tail = __builtin_fma(v, v, tail); }
+            h->mpm[j] = ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7])) + tail; /* mme.jl:305-307 */
+        }
+        h->Ppad = P;
+    } else {
+        if (R % 4 || R * S < N || R <= 0) { snprintf(h->err, 256, "bad layout R=%lld S=%lld", (long long)R, (long long)S); return ORA_ERR; }
+        h->R = R; h->S = S; h->NBLK = (P + BLK - 1) / BLK; h->Ppad = h->NBLK * BLK;
+        size_t tile = (size_t)R * BLK;
+        h->tiles = (float *)calloc((size_t)S * h->NBLK * tile, sizeof(float));
+        h->gram = (double *)calloc((size_t)h->NBLK * BLK * BLK, sizeof(double));
+        h->mpm = (double *)calloc(h->Ppad, sizeof(double));
+        if (!h->tiles || !h->gram || !h->mpm) { snprintf(h->err, 256, "out of memory"); return ORA_ERR; }
+        for (int64_t j = 0; j < P; j++) {
+            int64_t t = j / BLK, jj = j % BLK;
+            for (int64_t i = 0; i < N; i++) {
+                int64_t s = i / R, ii = i % R;
+                h->tiles[((size_t)s * h->NBLK + t) * tile + jj * R + ii] = X[j * N + i];
+            }
+        }
+        /* Gram blocks: shard partial = sequential fma over the shard's rows, then group sums */
+        double *part = (double *)malloc(sizeof(double) * S);
+        for (int64_t t = 0; t < h->NBLK; t++)
+            for (int k = 0; k < BLK; k++)
+                for (int j = 0; j <= k; j++) {
+                    for (int64_t s = 0; s < S; s++) {
+                        const float *tl = h->tiles + ((size_t)s * h->NBLK + t) * tile;
+                        double acc = 0.0;
+                        for (int64_t i = 0; i < R; i++) acc = __builtin_fma((double)tl[k * R + i], (double)tl[j * R + i], acc);
+                        part[s] = acc;
+                    }
+                    double g = group_sum(part, S, 1);
+                    h->gram[((size_t)t * BLK + k) * BLK + j] = g;
+                    h->gram[((size_t)t * BLK + j) * BLK + k] = g;
+                }
+        free(part);
+        for (int64_t k = 0; k < h->Ppad; k++) h->mpm[k] = h->gram[((size_t)(k / BLK) * BLK + k % BLK) * BLK + k % BLK];
+    }
+    h->lhs0 = (double *)calloc(h->Ppad, sizeof(double));
+    h->rhs0 = (double *)calloc(h->Ppad, sizeof(double));
+    h->beta = (double *)calloc(h->Ppad, sizeof(double));               /* mme.jl:443 */
+    h->delta = (int64_t *)malloc(sizeof(int64_t) * h->Ppad);          /* mme.jl:444 */
+    for (int64_t k = 0; k < h->Ppad; k++) h->delta[k] = 1;
+    h->sum_beta = (double *)calloc(h->Ppad, sizeof(double));
+    h->sum_beta2 = (double *)calloc(h->Ppad, sizeof(double));
+    h->sum_delta = (double *)calloc(h->Ppad, sizeof(double));
+    h->c = (double *)calloc(h->Ppad, sizeof(double)); h->w = (double *)calloc(h->Ppad, sizeof(double));
+    h->q = (double *)calloc(h->Ppad, sizeof(double)); h->T = (double *)calloc(h->Ppad, sizeof(double));
+    h->chi = (double *)calloc(h->Ppad, sizeof(double));
+    return ORA_OK;
+}
+
+/* marker set = consecutive column range with its prior (mme.jl:324-361, 493-516).
+   regions: 0-based [start,stop) relative to the set.  varBeta0: nreg initial values. */
+int ora_add_marker_set(ora_t *h, int64_t col0, int64_t ncol, int method, double df, double scale, const int64_t *reg_start,
+                       const int64_t *reg_stop, int64_t nreg, const double *varBeta0, double pi0, int estPi,
+                       const double *lhs0, const double *rhs0, int *set_id) {
+    if (h->nsets >= 16) { snprintf(h->err, 256, "too many sets"); return ORA_ERR; }
+    if (col0 < 0 || col0 + ncol > h->P) { snprintf(h->err, 256, "set outside panel"); return ORA_ERR; }
+    oset_t *s = &h->sets[h->nsets];
+    memset(s, 0, sizeof(*s));
+    s->col0 = col0; s->ncol = ncol; s->method = method; s->df = df; s->scale = scale; s->nreg = nreg; s->estPi = estPi;
+    s->reg_start = (int64_t *)malloc(sizeof(int64_t) * nreg); s->reg_stop = (int64_t *)malloc(sizeof(int64_t) * nreg);
+    memcpy(s->reg_start, reg_start, sizeof(int64_t) * nreg); memcpy(s->reg_stop, reg_stop, sizeof(int64_t) * nreg);
+    s->vb_off = h->nvb;
+    h->varBeta = (double *)realloc(h->varBeta, sizeof(double) * (h->nvb + nreg));
+    h->sum_varBeta = (double *)realloc(h->sum_varBeta, sizeof(double) * (h->nvb + nreg));
+    for (int64_t r = 0; r < nreg; r++) { h->varBeta[h->nvb + r] = varBeta0[r]; h->sum_varBeta[h->nvb + r] = 0.0; }
+    h->nvb += nreg;
+    s->piHat[0] = 1.0 - pi0; s->piHat[1] = pi0; /* mme.jl:351,360 */
+    if (h->order == 0) { s->logPi[0] = log(1.0 - pi0); s->logPi[1] = log(pi0); }
+    else { s->logPi[0] = det_log(1.0 - pi0); s->logPi[1] = det_log(pi0); }
+    for (int64_t k = 0; k < ncol; k++) {
+        h->lhs0[col0 + k] = lhs0 ? lhs0[k] : 0.0; /* mme.jl:314-322 */
+        h->rhs0[col0 + k] = rhs0 ? rhs0[k] : 0.0;
+    }
+    if (set_id) *set_id = h->nsets;
+    h->nsets++;
+    return ORA_OK;
+}
+
+int ora_set_y(ora_t *h, const double *y, int64_t N) {
+    if (N != h->N) { snprintf(h->err, 256, "y length mismatch"); return ORA_ERR; }
+    int64_t L = (h->order == 0) ? N : h->R * h->S;
+    free(h->y); free(h->ycorr);
+    h->y = (double *)malloc(sizeof(double) * N);
+    h->ycorr = (double *)calloc(L, sizeof(double));
+    memcpy(h->y, y, sizeof(double) * N);
+    memcpy(h->ycorr, y, sizeof(double) * N); /* mme.jl:57 */
+    h->b = 0.0; h->iter = 0;
+    return ORA_OK;
+}
+int ora_set_residual_prior(ora_t *h, double df, double scale) { h->e_df = df; h->e_scale = scale; return ORA_OK; }
+int ora_set_intercept(ora_t *h, int on) { h->intercept = on; return ORA_OK; }
+int ora_set_schedule(ora_t *h, int64_t chainLength, int64_t burnIn, int64_t thin) {
+    h->chainLength = chainLength; h->burnIn = burnIn; h->thin = thin < 1 ? 1 : thin; return ORA_OK;
+}
+
+/* samplers.jl:26  these2Keep = (burnIn+thin):thin:chainLength */
+static int is_kept(const ora_t *h, int64_t iter) {
+    if (iter < h->burnIn + h->thin || iter > h->chainLength) return 0;
+    return ((iter - h->burnIn) % h->thin) == 0;
+}
+
+static void accumulate(ora_t *h) {
+    for (int64_t k = 0; k < h->P; k++) {
+        double b = h->beta[k];
+        h->sum_beta[k] += b; h->sum_beta2[k] += b * b; h->sum_delta[k] += (double)h->delta[k];
+    }
+    for (int64_t r = 0; r < h->nvb; r++) h->sum_varBeta[r] += h->varBeta[r];
+    for (int s = 0; s < h->nsets; s++) { h->sets[s].sum_pi[0] += h->sets[s].piHat[0]; h->sets[s].sum_pi[1] += h->sets[s].piHat[1]; }
+    h->sum_varE += h->varE; h->sum_b += h->b; h->nKept++;
+}
+
+/* ------------------------------------------------------------------ */
+/* order 0: reference order                                             */
+/* ------------------------------------------------------------------ */
+static inline double dot8(const double *a, const double *b, int64_t n) {
+    double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int64_t i = 0;
+    for (; i + 8 <= n; i += 8)
+        for (int l = 0; l < 8; l++) acc[l] = __builtin_fma(a[i + l], b[i + l], acc[l]);
+    double tail = 0;
+    for (; i < n; i++) tail = __builtin_fma(a[i], b[i], tail);
+    return ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7])) + tail;
+}
+static inline void axpy(double a, const double *x, double *y, int64_t n) {
+    for (int64_t i = 0; i < n; i++) y[i] = __builtin_fma(a, x[i], y[i]);
+}
+
+static void iter_ref(ora_t *h) {
+    const int64_t N = h->N;
+    const int64_t it = h->iter + 1;
+    rng_t r;
+    /* samplers.jl:32-35 -> functions.jl:523-525 */
+    rng_seed(&r, h->seed, h->chain, it, KIND_VARE_CHI2, 0);
+    double varE = (h->e_df * h->e_scale + dot8(h->ycorr, h->ycorr, N)) / rng_chisq(&r, h->e_df + (double)N);
+    h->varE = varE;
+    double iVarE = 1.0 / varE;
+    /* samplers.jl:39-41 -> functions.jl:41-47 (single column of ones) */
+    if (h->intercept) {
+        double s = 0.0;
+        for (int64_t i = 0; i < N; i++) { h->ycorr[i] += h->b; }
+        double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0}; int64_t i = 0;
+        for (; i + 8 <= N; i += 8) for (int l = 0; l < 8; l++) acc[l] += h->ycorr[i + l];
+        for (; i < N; i++) s += h->ycorr[i];
+        s += ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7]));
+        double rhs = s * iVarE + 0.0;
+        double lhs = (double)N * iVarE + 0.0;
+        double mean = rhs / lhs;
+        rng_seed(&r, h->seed, h->chain, it, KIND_FIXED_NORMAL, 0);
+        h->b = mean + sqrt(1.0 / lhs) * rng_normal(&r);
+        for (int64_t k = 0; k < N; k++) h->ycorr[k] -= h->b;
+    }
+    /* samplers.jl:50-53 */
+    for (int si = 0; si < h->nsets; si++) {
+        oset_t *S = &h->sets[si];
+        double *vb = h->varBeta + S->vb_off;
+        if (S->method == METHOD_PR) {
+            /* functions.jl:118-137 */
+            for (int64_t rg = 0; rg < S->nreg; rg++) {
+                double iVarBeta = 1.0 / vb[rg];
+                double ssq = 0.0;
+                for (int64_t l = S->reg_start[rg]; l < S->reg_stop[rg]; l++) {
+                    int64_t j = S->col0 + l;
+                    const double *col = h->data + j * N, *mp = h->Mp + j * N;
+                    axpy(h->beta[j], col, h->ycorr, N);                                   /* :128 */
+                    double rhs = dot8(mp, h->ycorr, N) * iVarE + h->rhs0[j];              /* :129 */
+                    double lhs = h->mpm[j] * iVarE + h->lhs0[j] + iVarBeta;               /* :130 */
+                    double mean = rhs / lhs;                                              /* :131 */
+                    rng_seed(&r, h->seed, h->chain, it, KIND_BETA_NORMAL, ((uint64_t)si << 40) | (uint64_t)l);
+                    h->beta[j] = mean + sqrt(1.0 / lhs) * rng_normal(&r);                 /* :132, :493-495 */
+                    axpy(-1.0 * h->beta[j], col, h->ycorr, N);                            /* :133 */
+                    ssq = __builtin_fma(h->beta[j], h->beta[j], ssq);
+                }
+                rng_seed(&r, h->seed, h->chain, it, KIND_REGION_CHI2, ((uint64_t)si << 40) | (uint64_t)rg);
+                double n_r = (double)(S->reg_stop[rg] - S->reg_start[rg]);
+                vb[rg] = (S->scale * S->df + ssq) / rng_chisq(&r, S->df + n_r);         /* :135, :509-511 */
+            }
+        } else {
+            /* functions.jl:157-195; one region per locus (mme.jl:356-358) */
+            int64_t nLoci = 0;
+            for (int64_t l = 0; l < S->ncol; l++) {
+                int64_t j = S->col0 + l;
+                const double *col = h->data + j * N, *mp = h->Mp + j * N;
+                double iVarBeta = 1.0 / vb[l];                                            /* :165 */
+                axpy(h->beta[j], col, h->ycorr, N);                                       /* :167 */
+                double rrr = dot8(col, h->ycorr, N);                                      /* :168 */
+                double v0 = h->mpm[j] * varE;                                             /* :169 */
+                double v1 = (h->mpm[j] * h->mpm[j]) * vb[l] + v0;                         /* :170 */
+                double logDelta0 = -0.5 * (log(v0) + (rrr * rrr) / v0) + S->logPi[0];    /* :171 */
+                double logDelta1 = -0.5 * (log(v1) + (rrr * rrr) / v1) + S->logPi[1];    /* :172 */
+                double probDelta1 = 1.0 / (1.0 + exp(logDelta0 - logDelta1));            /* :173 */
+                rng_seed(&r, h->seed, h->chain, it, KIND_B_UNIFORM, ((uint64_t)si << 40) | (uint64_t)l);
+                double u = rng_uniform(&r);
+                if (u < probDelta1) {                                                     /* :174 */
+                    h->delta[j] = 1; nLoci++;
+                    double rhs = dot8(mp, h->ycorr, N) * iVarE + h->rhs0[j];              /* :177 */
+                    double lhs = h->mpm[j] * iVarE + h->lhs0[j] + iVarBeta;               /* :178 */
+                    double mean = rhs / lhs;
+                    rng_seed(&r, h->seed, h->chain, it, KIND_BETA_NORMAL, ((uint64_t)si << 40) | (uint64_t)l);
+                    h->beta[j] = mean + sqrt(1.0 / lhs) * rng_normal(&r);                 /* :180 */
+                    axpy(-1.0 * h->beta[j], col, h->ycorr, N);                            /* :181 */
+                    rng_seed(&r, h->seed, h->chain, it, KIND_B_LOCUS_CHI2, ((uint64_t)si << 40) | (uint64_t)l);
+                    vb[l] = (S->scale * S->df + h->beta[j] * h->beta[j]) / rng_chisq(&r, S->df + 1.0); /* :182 */
+                } else {
+                    h->beta[j] = 0.0; h->delta[j] = 0; vb[l] = 0.0;                       /* :184-186 */
+                }
+            }
+            if (S->estPi) {                                                               /* :190-194, :531-533 */
+                rng_seed(&r, h->seed, h->chain, it, KIND_PI_BETA, (uint64_t)si);
+                double piIn = rng_beta(&r, (double)nLoci + 1.0, (double)(S->ncol - nLoci) + 1.0);
+                S->piHat[0] = 1.0 - piIn; S->piHat[1] = piIn;
+                S->logPi[0] = log(1.0 - piIn); S->logPi[1] = log(piIn);
+            }
+        }
+    }
+    h->iter = it;
+}
+
+/* ------------------------------------------------------------------ */
+/* order 1: blocked order (mirrors the HIP kernels operation by op)     */
+/* ------------------------------------------------------------------ */
+static double wave_butterfly(double *v) { /* 64 lanes, xor 32..1 */
+    double t[64];
+    for (int off = 32; off >= 1; off >>= 1) {
+        for (int l = 0; l < 64; l++) t[l] = v[l] + v[l ^ off];
+        memcpy(v, t, sizeof(t));
+    }
+    return v[0];
+}
+
+static void iter_blocked(ora_t *h) {
+    const int64_t N = h->N, R = h->R, S = h->S, L = R * S, NBLK = h->NBLK;
+    const int64_t it = h->iter + 1;
+    rng_t r;
+    /* ---- iter_head: 1024-thread strided reduce, wave butterflies, 16 wave sums */
+    double wyy[16], wsy[16];
+    for (int wv = 0; wv < 16; wv++) {
+        double lyy[64], lsy[64];
+        for (int l = 0; l < 64; l++) {
+            double ayy = 0.0, asy = 0.0;
+            for (int64_t i = wv * 64 + l; i < L; i += 1024) { double v = h->ycorr[i]; ayy = __builtin_fma(v, v, ayy); asy = asy + v; }
+            lyy[l] = ayy; lsy[l] = asy;
+        }
+        wyy[wv] = wave_butterfly(lyy); wsy[wv] = wave_butterfly(lsy);
+    }
+    double yy = wyy[0], sy = wsy[0];
+    for (int wv = 1; wv < 16; wv++) { yy = yy + wyy[wv]; sy = sy + wsy[wv]; }
+    rng_seed(&r, h->seed, h->chain, it, KIND_VARE_CHI2, 0);
+    double chi = rng_chisq(&r, h->e_df + (double)N);
+    double t = h->e_df * h->e_scale; t = t + yy;
+    double varE = t / chi;
+    double iVarE = 1.0 / varE;
+    h->varE = varE;
+    if (h->intercept) {
+        double Nd = (double)N;
+        double tb = Nd * h->b; double sb = sy + tb;
+        double rhs = sb * iVarE; double lhs = Nd * iVarE;
+        double mean = rhs / lhs; double sd = sqrt(1.0 / lhs);
+        rng_seed(&r, h->seed, h->chain, it, KIND_FIXED_NORMAL, 0);
+        double z = rng_normal(&r);
+        double tz = sd * z; double bn = mean + tz;
+        double db = bn - h->b;
+        h->b = bn;
+        for (int64_t i = 0; i < N; i++) h->ycorr[i] = h->ycorr[i] - db;
+    }
+    /* ---- set_prep: per-locus coefficients */
+    for (int64_t k = 0; k < h->Ppad; k++) { h->c[k] = 0.0; h->w[k] = 0.0; h->q[k] = 0.0; h->T[k] = 1.0; h->chi[k] = 1.0; }
+    for (int si = 0; si < h->nsets; si++) {
+        oset_t *Sx = &h->sets[si];
+        double *vb = h->varBeta + Sx->vb_off;
+        for (int64_t rg = 0; rg < Sx->nreg; rg++)
+            for (int64_t l = Sx->reg_start[rg]; l < Sx->reg_stop[rg]; l++) {
+                int64_t k = Sx->col0 + l;
+                double vbk = (Sx->method == METHOD_B) ? vb[l] : vb[rg];
+                double mpm = h->mpm[k];
+                double t1 = mpm * iVarE; double t2 = t1 + h->lhs0[k];
+                double ivb = 1.0 / vbk; double lhs = t2 + ivb;
+                double ilhs = 1.0 / lhs;
+                double c = iVarE * ilhs; double s = sqrt(ilhs);
+                rng_seed(&r, h->seed, h->chain, it, KIND_BETA_NORMAL, ((uint64_t)si << 40) | (uint64_t)l);
+                double z = rng_normal(&r);
+                double sz = s * z;
+                double tw = h->rhs0[k] * ilhs; tw = tw + sz;
+                h->c[k] = c; h->w[k] = tw - h->beta[k];
+                if (Sx->method == METHOD_B) {
+                    double v0 = mpm * varE;
+                    double m2 = mpm * mpm; m2 = m2 * vbk; double v1 = m2 + v0;
+                    double i1 = 1.0 / v1, i0 = 1.0 / v0; double dq = i1 - i0;
+                    h->q[k] = 0.5 * dq;
+                    rng_seed(&r, h->seed, h->chain, it, KIND_B_UNIFORM, ((uint64_t)si << 40) | (uint64_t)l);
+                    double u = rng_uniform(&r);
+                    double om = 1.0 - u;
+                    double Lu = det_log(om) - det_log(u);
+                    double dl = det_log(v1) - det_log(v0); dl = 0.5 * dl;
+                    double T = Lu - dl; double lp = Sx->logPi[0] - Sx->logPi[1];
+                    h->T[k] = T - lp;
+                    rng_seed(&r, h->seed, h->chain, it, KIND_B_LOCUS_CHI2, ((uint64_t)si << 40) | (uint64_t)l);
+                    h->chi[k] = rng_chisq(&r, Sx->df + 1.0);
+                }
+            }
+    }
+    /* ---- block sweep */
+    const size_t tile = (size_t)R * BLK;
+    double *part = (double *)malloc(sizeof(double) * S * BLK);
+    for (int64_t tb = 0; tb < NBLK; tb++) {
+        const int64_t k0 = tb * BLK;
+        /* GEMV partials: 4 waves over strided quads, lane = column */
+        for (int64_t s = 0; s < S; s++) {
+            const float *tl = h->tiles + ((size_t)s * NBLK + tb) * tile;
+            const double *ys = h->ycorr + s * R;
+            for (int j = 0; j < BLK; j++) {
+                double a[4];
+                for (int wv = 0; wv < 4; wv++) {
+                    double acc = 0.0;
+                    for (int64_t qd = wv; qd < R / 4; qd += 4)
+                        for (int e = 0; e < 4; e++) { int64_t i = 4 * qd + e; acc = __builtin_fma((double)tl[j * R + i], ys[i], acc); }
+                    a[wv] = acc;
+                }
+                part[s * BLK + j] = ((a[0] + a[1]) + a[2]) + a[3];
+            }
+        }
+        double rr[BLK], dlt[BLK]; int inc[BLK];
+        const double *G = h->gram + (size_t)tb * BLK * BLK;
+        for (int j = 0; j < BLK; j++) {
+            double tot = group_sum(part + j, S, BLK);
+            rr[j] = __builtin_fma(G[j * BLK + j], h->beta[k0 + j], tot);
+        }
+        for (int k = 0; k < BLK; k++) {
+            double rk = rr[k];
+            double r2 = rk * rk;
+            double lhsq = r2 * h->q[k0 + k];
+            int in = lhsq < h->T[k0 + k];
+            double d = __builtin_fma(rk, h->c[k0 + k], h->w[k0 + k]);
+            double dk = in ? d : -h->beta[k0 + k];
+            dlt[k] = dk; inc[k] = in;
+            for (int j = k + 1; j < BLK; j++) rr[j] = __builtin_fma(-G[j * BLK + k], dk, rr[j]);
+        }
+        /* y update: per row, columns ascending */
+        for (int64_t s = 0; s < S; s++) {
+            const float *tl = h->tiles + ((size_t)s * NBLK + tb) * tile;
+            double *ys = h->ycorr + s * R;
+            for (int64_t i = 0; i < R; i++) {
+                double yv = ys[i];
+                for (int j = 0; j < BLK; j++) yv = __builtin_fma(-(double)tl[j * R + i], dlt[j], yv);
+                ys[i] = yv;
+            }
+        }
+        for (int k = 0; k < BLK; k++) {
+            h->beta[k0 + k] = h->beta[k0 + k] + dlt[k];
+            h->delta[k0 + k] = inc[k];
+        }
+    }
+    free(part);
+    /* ---- variance components / pi */
+    for (int si = 0; si < h->nsets; si++) {
+        oset_t *Sx = &h->sets[si];
+        double *vb = h->varBeta + Sx->vb_off;
+        if (Sx->method == METHOD_PR) {
+            for (int64_t rg = 0; rg < Sx->nreg; rg++) {
+                double tot = 0.0; int first = 1;
+                for (int64_t l0 = Sx->reg_start[rg]; l0 < Sx->reg_stop[rg]; l0 += SEG) {
+                    int64_t l1 = l0 + SEG < Sx->reg_stop[rg] ? l0 + SEG : Sx->reg_stop[rg];
+                    double p = 0.0;
+                    for (int64_t l = l0; l < l1; l++) { double bv = h->beta[Sx->col0 + l]; p = __builtin_fma(bv, bv, p); }
+                    tot = first ? p : tot + p; first = 0;
+                }
+                rng_seed(&r, h->seed, h->chain, it, KIND_REGION_CHI2, ((uint64_t)si << 40) | (uint64_t)rg);
+                double n_r = (double)(Sx->reg_stop[rg] - Sx->reg_start[rg]);
+                double ch = rng_chisq(&r, Sx->df + n_r);
+                double tt = Sx->scale * Sx->df; tt = tt + tot;
+                vb[rg] = tt / ch;
+            }
+        } else {
+            int64_t nLoci = 0;
+            for (int64_t l = 0; l < Sx->ncol; l++) {
+                int64_t k = Sx->col0 + l;
+                if (h->delta[k]) {
+                    nLoci++;
+                    double bv = h->beta[k];
+                    double tt = Sx->scale * Sx->df; double b2 = bv * bv; tt = tt + b2;
+                    vb[l] = tt / h->chi[k];
+                } else vb[l] = 0.0;
+            }
+            if (Sx->estPi) {
+                rng_seed(&r, h->seed, h->chain, it, KIND_PI_BETA, (uint64_t)si);
+                double piIn = rng_beta(&r, (double)nLoci + 1.0, (double)(Sx->ncol - nLoci) + 1.0);
+                Sx->piHat[0] = 1.0 - piIn; Sx->piHat[1] = piIn;
+                Sx->logPi[0] = det_log(Sx->piHat[0]); Sx->logPi[1] = det_log(piIn);
+            }
+        }
+    }
+    h->iter = it;
+}
+
+/* advance the chain by niter iterations (samplers.jl:29-105) */
+int ora_run(ora_t *h, int64_t niter) {
+    if (!h->ycorr || !h->beta) { snprintf(h->err, 256, "panel / y not set"); return ORA_ERR; }
+    free(h->tr_varE); free(h->tr_b);
+    h->tr_varE = (double *)malloc(sizeof(double) * (niter > 0 ? niter : 1));
+    h->tr_b = (double *)malloc(sizeof(double) * (niter > 0 ? niter : 1));
+    h->ntrace = niter;
+    for (int64_t n = 0; n < niter; n++) {
+        if (h->order == 0) iter_ref(h); else iter_blocked(h);
+        h->tr_varE[n] = h->varE; h->tr_b[n] = h->b;
+        if (is_kept(h, h->iter)) accumulate(h);
+    }
+    return ORA_OK;
+}
+
+int ora_get_state(ora_t *h, double *ycorr, double *beta, int64_t *delta, double *varBeta, double *piHat, double *varE, double *b,
+                  int64_t *iter) {
+    if (ycorr) memcpy(ycorr, h->ycorr, sizeof(double) * h->N);
+    if (beta) memcpy(beta, h->beta, sizeof(double) * h->P);
+    if (delta) memcpy(delta, h->delta, sizeof(int64_t) * h->P);
+    if (varBeta) memcpy(varBeta, h->varBeta, sizeof(double) * h->nvb);
+    if (piHat) for (int s = 0; s < h->nsets; s++) { piHat[2 * s] = h->sets[s].piHat[0]; piHat[2 * s + 1] = h->sets[s].piHat[1]; }
+    if (varE) *varE = h->varE;
+    if (b) *b = h->b;
+    if (iter) *iter = h->iter;
+    return ORA_OK;
+}
+int ora_get_trace(ora_t *h, double *varE, double *b, int64_t n) {
+    if (n > h->ntrace) n = h->ntrace;
+    if (varE) memcpy(varE, h->tr_varE, sizeof(double) * n);
+    if (b) memcpy(b, h->tr_b, sizeof(double) * n);
+    return ORA_OK;
+}
+int ora_get_posterior_sums(ora_t *h, double *sum_beta, double *sum_beta2, double *sum_delta, double *sum_varBeta, double *sum_pi,
+                           double *sum_varE, double *sum_b, int64_t *nKept) {
+    if (sum_beta) memcpy(sum_beta, h->sum_beta, sizeof(double) * h->P);
+    if (sum_beta2) memcpy(sum_beta2, h->sum_beta2, sizeof(double) * h->P);
+    if (sum_delta) memcpy(sum_delta, h->sum_delta, sizeof(double) * h->P);
+    if (sum_varBeta) memcpy(sum_varBeta, h->sum_varBeta, sizeof(double) * h->nvb);
+    if (sum_pi) for (int s = 0; s < h->nsets; s++) { sum_pi[2 * s] = h->sets[s].sum_pi[0]; sum_pi[2 * s + 1] = h->sets[s].sum_pi[1]; }
+    if (sum_varE) *sum_varE = h->sum_varE;
+    if (sum_b) *sum_b = h->sum_b;
+    if (nKept) *nKept = h->nKept;
+    return ORA_OK;
+}
+int64_t ora_nvb(ora_t *h) { return h->nvb; }
+/* Gram block access for parity tests of the device Gram kernel (order 1 only) */
+int ora_get_gram(ora_t *h, int64_t t, double *out) {
+    if (h->order != 1 || t < 0 || t >= h->NBLK) return ORA_ERR;
+    memcpy(out, h->gram + (size_t)t * BLK * BLK, sizeof(double) * BLK * BLK);
+    return ORA_OK;
+}

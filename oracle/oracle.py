@@ -1,0 +1,165 @@
+"""ctypes wrapper for the CPU oracle (oracle/ngp_oracle.c).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and
+bench.py's cpu_baseline leg.  The product package never imports this module.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "libngp_oracle.so")
+
+PR, B = 0, 1
+KIND = dict(VARE_CHI2=1, FIXED_NORMAL=2, BETA_NORMAL=3, REGION_CHI2=4, B_UNIFORM=5, B_LOCUS_CHI2=6, PI_BETA=7)
+
+
+def build(force=False):
+    src = os.path.join(_HERE, "ngp_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "-B" if force else "-s"])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = C.CDLL(_SO)
+        L.ora_det_log.restype = C.c_double
+        L.ora_det_log.argtypes = [C.c_double]
+        L.ora_ppnd16.restype = C.c_double
+        L.ora_ppnd16.argtypes = [C.c_double]
+        L.ora_last_error.restype = C.c_char_p
+        L.ora_nvb.restype = C.c_int64
+        _lib = L
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def det_log(x):
+    return lib().ora_det_log(float(x))
+
+
+def ppnd16(p):
+    return lib().ora_ppnd16(float(p))
+
+
+def draws(seed, chain, it, kind, index, what, n, p1=0.0, p2=0.0, indexed=False):
+    """what: 0 uniform, 1 normal, 2 chisq(p1), 3 beta(p1,p2), 4 gamma(p1)."""
+    out = np.empty(n, dtype=np.float64)
+    f = lib().ora_draws_indexed if indexed else lib().ora_draws
+    f(C.c_uint64(seed), C.c_uint64(chain), C.c_uint64(it), C.c_uint64(kind), C.c_uint64(index), C.c_int(what),
+      C.c_double(p1), C.c_double(p2), C.c_int64(n), _p(out, C.c_double))
+    return out
+
+
+def generate_panel(N, P, maf_lo=0.05, maf_hi=0.5, seed=20250509):
+    """Synthetic centred fp32 panel, column-major (returned as an (N,P) Fortran-ordered array)."""
+    X = np.empty((N, P), dtype=np.float32, order="F")
+    mu = np.empty(P, dtype=np.float64)
+    lib().ora_generate_panel(C.c_int64(N), C.c_int64(P), C.c_double(maf_lo), C.c_double(maf_hi), C.c_uint64(seed),
+                             _p(X, C.c_float), _p(mu, C.c_double))
+    return X, mu
+
+
+class Oracle:
+    """Handle-style driver with the same call sequence as the product's C ABI."""
+
+    def __init__(self, order=0, seed=1, chain=0):
+        self.L = lib()
+        self.h = C.c_void_p()
+        self._chk(self.L.ora_create(C.c_int(order), C.c_uint64(seed), C.c_uint32(chain), C.byref(self.h)))
+        self.order = order
+        self.nsets = 0
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise RuntimeError("oracle: " + (self.L.ora_last_error(self.h) or b"?").decode())
+
+    def close(self):
+        if self.h:
+            self.L.ora_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def set_panel_f32(self, X, R=0, S=0):
+        X = np.asfortranarray(X, dtype=np.float32)
+        self.N, self.P = X.shape
+        self._chk(self.L.ora_set_panel_f32(self.h, _p(X, C.c_float), C.c_int64(self.N), C.c_int64(self.P), C.c_int64(R),
+                                           C.c_int64(S)))
+
+    def add_marker_set(self, col0, ncol, method, df, scale, regions, varBeta0, pi0=0.0, estPi=False, lhs0=None, rhs0=None):
+        rs = np.ascontiguousarray([r[0] for r in regions], dtype=np.int64)
+        re = np.ascontiguousarray([r[1] for r in regions], dtype=np.int64)
+        vb = np.ascontiguousarray(varBeta0, dtype=np.float64)
+        assert len(vb) == len(rs)
+        l0 = None if lhs0 is None else np.ascontiguousarray(lhs0, dtype=np.float64)
+        r0 = None if rhs0 is None else np.ascontiguousarray(rhs0, dtype=np.float64)
+        sid = C.c_int()
+        self._chk(self.L.ora_add_marker_set(self.h, C.c_int64(col0), C.c_int64(ncol), C.c_int(method), C.c_double(df),
+                                            C.c_double(scale), _p(rs, C.c_int64), _p(re, C.c_int64), C.c_int64(len(rs)),
+                                            _p(vb, C.c_double), C.c_double(pi0), C.c_int(int(estPi)), _p(l0, C.c_double),
+                                            _p(r0, C.c_double), C.byref(sid)))
+        self.nsets += 1
+        return sid.value
+
+    def set_y(self, y):
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        self._chk(self.L.ora_set_y(self.h, _p(y, C.c_double), C.c_int64(len(y))))
+
+    def set_residual_prior(self, df, scale):
+        self._chk(self.L.ora_set_residual_prior(self.h, C.c_double(df), C.c_double(scale)))
+
+    def set_intercept(self, on):
+        self._chk(self.L.ora_set_intercept(self.h, C.c_int(int(on))))
+
+    def set_schedule(self, chainLength, burnIn, thin):
+        self._chk(self.L.ora_set_schedule(self.h, C.c_int64(chainLength), C.c_int64(burnIn), C.c_int64(thin)))
+
+    def run(self, niter):
+        self._chk(self.L.ora_run(self.h, C.c_int64(niter)))
+
+    def get_state(self):
+        nvb = self.L.ora_nvb(self.h)
+        yc = np.empty(self.N); beta = np.empty(self.P); delta = np.empty(self.P, dtype=np.int64)
+        vb = np.empty(nvb); pi = np.empty(2 * max(self.nsets, 1))
+        varE = C.c_double(); b = C.c_double(); it = C.c_int64()
+        self._chk(self.L.ora_get_state(self.h, _p(yc, C.c_double), _p(beta, C.c_double), _p(delta, C.c_int64),
+                                       _p(vb, C.c_double), _p(pi, C.c_double), C.byref(varE), C.byref(b), C.byref(it)))
+        return dict(ycorr=yc, beta=beta, delta=delta, varBeta=vb, piHat=pi[:2 * self.nsets], varE=varE.value, b=b.value,
+                    iter=it.value)
+
+    def get_trace(self, n):
+        v = np.empty(n); b = np.empty(n)
+        self._chk(self.L.ora_get_trace(self.h, _p(v, C.c_double), _p(b, C.c_double), C.c_int64(n)))
+        return dict(varE=v, b=b)
+
+    def get_posterior_sums(self):
+        nvb = self.L.ora_nvb(self.h)
+        sb = np.empty(self.P); sb2 = np.empty(self.P); sd = np.empty(self.P); sv = np.empty(nvb)
+        sp = np.empty(2 * max(self.nsets, 1)); se = C.c_double(); sbb = C.c_double(); nk = C.c_int64()
+        self._chk(self.L.ora_get_posterior_sums(self.h, _p(sb, C.c_double), _p(sb2, C.c_double), _p(sd, C.c_double),
+                                                _p(sv, C.c_double), _p(sp, C.c_double), C.byref(se), C.byref(sbb),
+                                                C.byref(nk)))
+        return dict(sum_beta=sb, sum_beta2=sb2, sum_delta=sd, sum_varBeta=sv, sum_pi=sp[:2 * self.nsets], sum_varE=se.value,
+                    sum_b=sbb.value, nKept=nk.value)
+
+    def get_gram(self, t):
+        out = np.empty((64, 64))
+        self._chk(self.L.ora_get_gram(self.h, C.c_int64(t), _p(out, C.c_double)))
+        return out
