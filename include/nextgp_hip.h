@@ -1,0 +1,132 @@
+/*
+ * nextgp_hip.h -- C ABI of libnextgp_hip.so, the MI355X (gfx950) replacement for the
+ * marker-effect Gibbs hot path of NextGP.jl.
+ *
+ * Every entry point is what a Julia `ccall((:sym, "libnextgp_hip"), Cint, (...), ...)` binds;
+ * INTEGRATION.md shows the reference-side shim.  All functions return 0 on success and a
+ * negative code on failure; the message is retrievable with ngp_last_error().  No C++
+ * exception, signal handler or exit() crosses this boundary.  Arrays are Julia-native:
+ * column-major, contiguous, Float64 / Int64.  The library never retains a caller pointer
+ * beyond the call; anything it keeps (panel, y, priors) is copied to device memory.
+ *
+ * Reference interfaces replaced (file:line under /root/reference):
+ *   - coarse seam: samplers.runSampler!            src/samplers.jl:23-106 (called at src/MCMC.jl:39)
+ *   - fine seam:   M[set].funct callback           src/samplers.jl:52, stored at src/mme.jl:326,333,355
+ *                  = sampleBayesPR!/sampleBayesB!  src/functions.jl:118-137, 157-195
+ *   - marker-matrix builders                       src/prepMatVec.jl:113-134, src/mme.jl:282-347,443-446,492-520
+ */
+#ifndef NEXTGP_HIP_H
+#define NEXTGP_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define NGP_ABI_VERSION 1
+
+#define NGP_OK 0
+#define NGP_ERR_ARG (-1)     /* bad argument (null, size mismatch, non-finite value) */
+#define NGP_ERR_STATE (-2)   /* call sequence error (panel / y / sets missing) */
+#define NGP_ERR_HIP (-3)     /* HIP runtime error (message carries hipGetErrorString) */
+#define NGP_ERR_NOMEM (-4)
+#define NGP_ERR_NODEVICE (-5) /* no usable gfx950 device: the library has NO CPU fallback */
+
+#define NGP_METHOD_BAYESPR 0 /* src/runTime.jl:30-45 */
+#define NGP_METHOD_BAYESB 1  /* src/runTime.jl:48-61 */
+
+typedef struct ngp_handle ngp_handle;
+
+int32_t ngp_abi_version(void);
+
+/* One handle = one chain on one device (reference: one Julia task, src/samplers.jl:23).
+ * seed/chain_id key every random stream (the reference never seeds its RNG). */
+int32_t ngp_create(int32_t device, uint64_t seed, uint32_t chain_id, ngp_handle **out);
+int32_t ngp_destroy(ngp_handle *h);
+/* Message of the last failing call on h (h == NULL: last failing ngp_create). Valid until the next call. */
+const char *ngp_last_error(ngp_handle *h);
+
+/* Marker panel, N individuals x P SNPs, column-major with leading dimension ld >= N
+ * (replaces M[set][:data] + the M[set][:Mp] copy, src/prepMatVec.jl:116-131, src/mme.jl:305-311).
+ * centre != 0: subtract the column mean first (src/prepMatVec.jl:129).  Stored as fp32, re-tiled. */
+int32_t ngp_set_panel_f64(ngp_handle *h, const double *M, int64_t N, int64_t P, int64_t ld, int32_t centre);
+int32_t ngp_set_panel_f32(ngp_handle *h, const float *M, int64_t N, int64_t P, int64_t ld, int32_t centre);
+/* Synthetic panel generated on the device: g_ij ~ Binomial(2,p_j), p_j ~ U(maf_lo,maf_hi). */
+int32_t ngp_generate_panel(ngp_handle *h, int64_t N, int64_t P, double maf_lo, double maf_hi, uint64_t panel_seed);
+/* Device tiling chosen for the panel: rows per shard R, shards S, 64-SNP blocks NBLK (the blocked
+ * oracle needs R and S to reproduce the reduction tree). */
+int32_t ngp_get_layout(ngp_handle *h, int64_t *R, int64_t *S, int64_t *nblk);
+/* x'x per SNP (M[set][:mpm], src/mme.jl:305-307); out has P entries. */
+int32_t ngp_get_mpm(ngp_handle *h, double *out, int64_t P);
+/* One 64x64 Gram block X_t'X_t (row-major); parity probe. */
+int32_t ngp_get_gram(ngp_handle *h, int64_t t, double *out);
+/* out = X * beta (N entries), X the stored fp32 panel: used to simulate phenotypes and to check
+ * the invariant ycorr = y - 1b - X beta. */
+int32_t ngp_xbeta(ngp_handle *h, const double *beta, int64_t P, double *out, int64_t N);
+
+/* A marker set = columns [col0, col0+ncol) with its prior (src/mme.jl:324-361, 492-520).
+ * method NGP_METHOD_*; df, scale as computed at src/mme.jl:493,501; regions are 0-based
+ * [reg_start[r], reg_stop[r]) relative to the set (M[set][:regionArray], src/mme.jl:335-358);
+ * varBeta0 holds nreg initial variances (src/mme.jl:516); BayesB needs nreg == ncol (one region
+ * per locus, src/mme.jl:356), pi0 = prior inclusion probability, estPi (src/mme.jl:359);
+ * lhs0/rhs0 (ncol each or NULL) are the summary-statistics terms (src/mme.jl:314-322). */
+int32_t ngp_add_marker_set(ngp_handle *h, int64_t col0, int64_t ncol, int32_t method, double df, double scale,
+                           const int64_t *reg_start, const int64_t *reg_stop, int64_t nreg, const double *varBeta0,
+                           double pi0, int32_t estPi, const double *lhs0, const double *rhs0, int32_t *set_id);
+
+/* Phenotypes; resets the chain state: ycorr = y (src/mme.jl:57), b = 0, beta = 0, delta = 1, iter = 0. */
+int32_t ngp_set_y(ngp_handle *h, const double *y, int64_t N);
+/* E.df, E.scale (src/mme.jl:87-94). */
+int32_t ngp_set_residual_prior(ngp_handle *h, double df, double scale);
+/* Whether the model has the intercept column (src/functions.jl:41-47); default on. */
+int32_t ngp_set_intercept(ngp_handle *h, int32_t on);
+/* chainLength, burnIn, outputFreq of runSampler! (src/samplers.jl:23-26): iterations
+ * burnIn+thin : thin : chainLength are accumulated into the posterior sums. */
+int32_t ngp_set_schedule(ngp_handle *h, int64_t chainLength, int64_t burnIn, int64_t thin);
+
+/* Coarse seam: advance the chain by niter full iterations on the device
+ * (varE -> intercept -> every marker set -> variance / pi draws; src/samplers.jl:29-55). */
+int32_t ngp_run(ngp_handle *h, int64_t niter);
+
+/* Chain state after the last iteration.  Any pointer may be NULL.  ycorr: N; beta, delta: P;
+ * varBeta: sum of nreg over sets; piHat: 2 per set ([1-pi, pi], src/mme.jl:360). */
+int32_t ngp_get_state(ngp_handle *h, double *ycorr, double *beta, int64_t *delta, double *varBeta, double *piHat, double *varE,
+                      double *b, int64_t *iter);
+/* Resume support: overwrite the chain state (same shapes as ngp_get_state). */
+int32_t ngp_set_state(ngp_handle *h, const double *ycorr, const double *beta, const int64_t *delta, const double *varBeta,
+                      const double *piHat, double varE, double b, int64_t iter);
+/* varE and intercept of each iteration of the last ngp_run (n <= niter entries). */
+int32_t ngp_get_trace(ngp_handle *h, double *varE, double *b, int64_t n);
+/* Sums over kept iterations (posterior mean = sum / nKept; replaces summaryMCMC, src/misc.jl:241-244). */
+int32_t ngp_get_posterior_sums(ngp_handle *h, double *sum_beta, double *sum_beta2, double *sum_delta, double *sum_varBeta,
+                               double *sum_pi, double *sum_varE, double *sum_b, int64_t *nKept);
+/* Same sums packed into a DEVICE buffer [sum_beta P | sum_beta2 P | sum_delta P | sum_varBeta nvb |
+ * sum_pi 2*nsets | sum_varE | sum_b | nKept] so the host can all-reduce them over RCCL without a
+ * PCIe round trip.  len = 3P + nvb + 2 nsets + 3 doubles. */
+int32_t ngp_posterior_len(ngp_handle *h, int64_t *len);
+int32_t ngp_export_posterior_device(ngp_handle *h, void *device_ptr, int64_t len);
+
+/* Fine seam: one call of M[set].funct(mSet, M, beta, delta, ycorr, varE, varBeta) (src/samplers.jl:52).
+ * In/out arrays are the caller's: ycorr N, beta ncol, delta ncol (out), varBeta nreg, piHat 2 (BayesB). */
+int32_t ngp_sweep_set(ngp_handle *h, int32_t set_id, double varE, double *ycorr, double *beta, int64_t *delta, double *varBeta,
+                      double *piHat);
+
+/* Device time of the sweep kernels accumulated since the last call (HIP events on the handle's stream). */
+int32_t ngp_get_timing(ngp_handle *h, double *sweep_ms, int64_t *sweep_launches, double *iter_ms, int64_t *iters);
+/* Runs ONE extra iteration with a HIP event pair around every sweep-kernel launch and returns the
+ * average launch duration of the dominant (panel-streaming) kernel, its launch count and the
+ * algorithmic bytes one launch streams (bench.py roofline). */
+int32_t ngp_profile_iteration(ngp_handle *h, double *avg_ms, int64_t *launches, double *bytes_per_launch);
+
+/* Test probe of the device draw layer: n first draws of streams (seed,chain,iter,kind,index0+i);
+ * what: 0 uniform, 1 normal, 2 chisq(p1), 3 beta(p1,p2), 4 gamma(p1). */
+int32_t ngp_draws_indexed(ngp_handle *h, uint64_t iter, uint64_t kind, uint64_t index0, int32_t what, double p1, double p2,
+                          int64_t n, double *out);
+/* det_log / ppnd16 evaluated on the device (bit-parity probe), n inputs -> n outputs. */
+int32_t ngp_eval_math(ngp_handle *h, int32_t which, const double *in, int64_t n, double *out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,6 @@
+"""nextgp.jl_amd -- MI355X-native marker-effect Gibbs sampler behind NextGP.jl's runLMEM interface.
+
+The directory name contains a dot, so it is loaded by path (see `ngp_pkg.py` at the repo root):
+    from ngp_pkg import load_pkg; ngp = load_pkg()
+"""
+from ._lib import LIB_PATH, METHOD_BAYESB, METHOD_BAYESPR, SYMBOLS, NextGPHipError, Sampler, load  # noqa: F401

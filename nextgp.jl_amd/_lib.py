@@ -1,0 +1,224 @@
+"""ctypes binding of libnextgp_hip.so (include/nextgp_hip.h).
+
+This is the stand-in for the Julia `ccall` shim (julia/NextGPHIP.jl): one thin method per C entry
+point, no arithmetic on the Python side.  There is no CPU fallback: if the shared library is
+missing, or no gfx950 device is usable, construction raises.
+"""
+import ctypes as C
+import os
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libnextgp_hip.so")
+
+METHOD_BAYESPR, METHOD_BAYESB = 0, 1
+
+# every symbol include/nextgp_hip.h declares
+SYMBOLS = [
+    "ngp_abi_version", "ngp_create", "ngp_destroy", "ngp_last_error", "ngp_set_panel_f64", "ngp_set_panel_f32",
+    "ngp_generate_panel", "ngp_get_layout", "ngp_get_mpm", "ngp_get_gram", "ngp_xbeta", "ngp_add_marker_set", "ngp_set_y",
+    "ngp_set_residual_prior", "ngp_set_intercept", "ngp_set_schedule", "ngp_run", "ngp_get_state", "ngp_set_state",
+    "ngp_get_trace", "ngp_get_posterior_sums", "ngp_posterior_len", "ngp_export_posterior_device", "ngp_sweep_set",
+    "ngp_get_timing", "ngp_profile_iteration", "ngp_draws_indexed", "ngp_eval_math",
+]
+
+_lib = None
+
+
+class NextGPHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the HIP library; raises if it has not been built (see __graft_entry__.build)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise NextGPHipError(
+                f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                "(hipcc --offload-arch=gfx950). There is no CPU fallback.")
+        L = C.CDLL(LIB_PATH)
+        L.ngp_last_error.restype = C.c_char_p
+        L.ngp_last_error.argtypes = [C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+class Sampler:
+    """One chain on one device == one `ngp_handle` (reference: one Julia task running runSampler!)."""
+
+    def __init__(self, device=0, seed=1, chain=0):
+        self.L = load()
+        self.h = C.c_void_p()
+        rc = self.L.ngp_create(C.c_int32(device), C.c_uint64(seed), C.c_uint32(chain), C.byref(self.h))
+        if rc != 0:
+            raise NextGPHipError(f"ngp_create failed ({rc}): " + (self.L.ngp_last_error(None) or b"").decode())
+        self.nsets = 0
+        self.set_shapes = []  # (ncol, nreg) per set
+
+    def _chk(self, rc):
+        if rc != 0:
+            raise NextGPHipError(f"libnextgp_hip error {rc}: " + (self.L.ngp_last_error(self.h) or b"").decode())
+
+    def close(self):
+        if getattr(self, "h", None):
+            self.L.ngp_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    # ---- panel -------------------------------------------------------------------------
+    def set_panel(self, M, centre=False):
+        M = np.asarray(M)
+        if M.dtype == np.float32:
+            M = np.asfortranarray(M)
+            f, t = self.L.ngp_set_panel_f32, C.c_float
+        else:
+            M = np.asfortranarray(M, dtype=np.float64)
+            f, t = self.L.ngp_set_panel_f64, C.c_double
+        self.N, self.P = M.shape
+        self._chk(f(self.h, _p(M, t), C.c_int64(self.N), C.c_int64(self.P), C.c_int64(self.N), C.c_int32(int(centre))))
+
+    def generate_panel(self, N, P, maf_lo=0.05, maf_hi=0.5, seed=20250509):
+        self._chk(self.L.ngp_generate_panel(self.h, C.c_int64(N), C.c_int64(P), C.c_double(maf_lo), C.c_double(maf_hi),
+                                            C.c_uint64(seed)))
+        self.N, self.P = N, P
+
+    def layout(self):
+        R, S, nb = C.c_int64(), C.c_int64(), C.c_int64()
+        self._chk(self.L.ngp_get_layout(self.h, C.byref(R), C.byref(S), C.byref(nb)))
+        return R.value, S.value, nb.value
+
+    def mpm(self):
+        out = np.empty(self.P)
+        self._chk(self.L.ngp_get_mpm(self.h, _p(out, C.c_double), C.c_int64(self.P)))
+        return out
+
+    def gram(self, t):
+        out = np.empty((64, 64))
+        self._chk(self.L.ngp_get_gram(self.h, C.c_int64(t), _p(out, C.c_double)))
+        return out
+
+    def xbeta(self, beta):
+        beta = np.ascontiguousarray(beta, dtype=np.float64)
+        out = np.empty(self.N)
+        self._chk(self.L.ngp_xbeta(self.h, _p(beta, C.c_double), C.c_int64(len(beta)), _p(out, C.c_double), C.c_int64(self.N)))
+        return out
+
+    # ---- model -------------------------------------------------------------------------
+    def add_marker_set(self, col0, ncol, method, df, scale, regions, varBeta0, pi0=0.0, estPi=False, lhs0=None, rhs0=None):
+        rs = np.ascontiguousarray([r[0] for r in regions], dtype=np.int64)
+        re = np.ascontiguousarray([r[1] for r in regions], dtype=np.int64)
+        vb = np.ascontiguousarray(varBeta0, dtype=np.float64)
+        if len(vb) != len(rs):
+            raise ValueError("varBeta0 needs one entry per region")
+        l0 = None if lhs0 is None else np.ascontiguousarray(lhs0, dtype=np.float64)
+        r0 = None if rhs0 is None else np.ascontiguousarray(rhs0, dtype=np.float64)
+        sid = C.c_int32()
+        self._chk(self.L.ngp_add_marker_set(self.h, C.c_int64(col0), C.c_int64(ncol), C.c_int32(method), C.c_double(df),
+                                            C.c_double(scale), _p(rs, C.c_int64), _p(re, C.c_int64), C.c_int64(len(rs)),
+                                            _p(vb, C.c_double), C.c_double(pi0), C.c_int32(int(estPi)), _p(l0, C.c_double),
+                                            _p(r0, C.c_double), C.byref(sid)))
+        self.nsets += 1
+        self.set_shapes.append((ncol, len(rs)))
+        return sid.value
+
+    def set_y(self, y):
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        self._chk(self.L.ngp_set_y(self.h, _p(y, C.c_double), C.c_int64(len(y))))
+
+    def set_residual_prior(self, df, scale):
+        self._chk(self.L.ngp_set_residual_prior(self.h, C.c_double(df), C.c_double(scale)))
+
+    def set_intercept(self, on):
+        self._chk(self.L.ngp_set_intercept(self.h, C.c_int32(int(on))))
+
+    def set_schedule(self, chainLength, burnIn, thin):
+        self._chk(self.L.ngp_set_schedule(self.h, C.c_int64(chainLength), C.c_int64(burnIn), C.c_int64(thin)))
+
+    # ---- run / read back ---------------------------------------------------------------
+    def run(self, niter):
+        self._chk(self.L.ngp_run(self.h, C.c_int64(niter)))
+
+    @property
+    def nvb(self):
+        return sum(s[1] for s in self.set_shapes)
+
+    def get_state(self):
+        yc = np.empty(self.N); beta = np.empty(self.P); delta = np.empty(self.P, dtype=np.int64)
+        vb = np.empty(max(self.nvb, 1)); pi = np.empty(2 * max(self.nsets, 1))
+        varE, b, it = C.c_double(), C.c_double(), C.c_int64()
+        self._chk(self.L.ngp_get_state(self.h, _p(yc, C.c_double), _p(beta, C.c_double), _p(delta, C.c_int64), _p(vb, C.c_double),
+                                       _p(pi, C.c_double), C.byref(varE), C.byref(b), C.byref(it)))
+        return dict(ycorr=yc, beta=beta, delta=delta, varBeta=vb[:self.nvb], piHat=pi[:2 * self.nsets], varE=varE.value,
+                    b=b.value, iter=it.value)
+
+    def set_state(self, st):
+        yc = np.ascontiguousarray(st["ycorr"], dtype=np.float64); beta = np.ascontiguousarray(st["beta"], dtype=np.float64)
+        delta = np.ascontiguousarray(st["delta"], dtype=np.int64); vb = np.ascontiguousarray(st["varBeta"], dtype=np.float64)
+        pi = np.ascontiguousarray(st["piHat"], dtype=np.float64)
+        self._chk(self.L.ngp_set_state(self.h, _p(yc, C.c_double), _p(beta, C.c_double), _p(delta, C.c_int64), _p(vb, C.c_double),
+                                       _p(pi, C.c_double), C.c_double(st["varE"]), C.c_double(st["b"]), C.c_int64(st["iter"])))
+
+    def get_trace(self, n):
+        v = np.empty(n); b = np.empty(n)
+        self._chk(self.L.ngp_get_trace(self.h, _p(v, C.c_double), _p(b, C.c_double), C.c_int64(n)))
+        return dict(varE=v, b=b)
+
+    def get_posterior_sums(self):
+        sb = np.empty(self.P); sb2 = np.empty(self.P); sd = np.empty(self.P); sv = np.empty(max(self.nvb, 1))
+        sp = np.empty(2 * max(self.nsets, 1)); se, sbb, nk = C.c_double(), C.c_double(), C.c_int64()
+        self._chk(self.L.ngp_get_posterior_sums(self.h, _p(sb, C.c_double), _p(sb2, C.c_double), _p(sd, C.c_double),
+                                                _p(sv, C.c_double), _p(sp, C.c_double), C.byref(se), C.byref(sbb), C.byref(nk)))
+        return dict(sum_beta=sb, sum_beta2=sb2, sum_delta=sd, sum_varBeta=sv[:self.nvb], sum_pi=sp[:2 * self.nsets],
+                    sum_varE=se.value, sum_b=sbb.value, nKept=nk.value)
+
+    def posterior_len(self):
+        n = C.c_int64()
+        self._chk(self.L.ngp_posterior_len(self.h, C.byref(n)))
+        return n.value
+
+    def export_posterior_device(self, device_ptr, length):
+        self._chk(self.L.ngp_export_posterior_device(self.h, C.c_void_p(device_ptr), C.c_int64(length)))
+
+    def sweep_set(self, set_id, varE, ycorr, beta, varBeta, piHat=None):
+        """Fine seam (M[set].funct): arrays are updated in place; returns delta."""
+        assert ycorr.dtype == np.float64 and beta.dtype == np.float64 and varBeta.dtype == np.float64
+        delta = np.empty(len(beta), dtype=np.int64)
+        self._chk(self.L.ngp_sweep_set(self.h, C.c_int32(set_id), C.c_double(varE), _p(ycorr, C.c_double), _p(beta, C.c_double),
+                                       _p(delta, C.c_int64), _p(varBeta, C.c_double), _p(piHat, C.c_double)))
+        return delta
+
+    def get_timing(self):
+        sm, it = C.c_double(), C.c_double()
+        sl, ni = C.c_int64(), C.c_int64()
+        self._chk(self.L.ngp_get_timing(self.h, C.byref(sm), C.byref(sl), C.byref(it), C.byref(ni)))
+        return dict(sweep_ms=sm.value, sweep_launches=sl.value, iter_ms=it.value, iters=ni.value)
+
+    def profile_iteration(self):
+        ms, by = C.c_double(), C.c_double()
+        n = C.c_int64()
+        self._chk(self.L.ngp_profile_iteration(self.h, C.byref(ms), C.byref(n), C.byref(by)))
+        return dict(avg_ms=ms.value, launches=n.value, bytes_per_launch=by.value)
+
+    # ---- probes ------------------------------------------------------------------------
+    def draws_indexed(self, it, kind, index0, what, n, p1=0.0, p2=0.0):
+        out = np.empty(n)
+        self._chk(self.L.ngp_draws_indexed(self.h, C.c_uint64(it), C.c_uint64(kind), C.c_uint64(index0), C.c_int32(what),
+                                           C.c_double(p1), C.c_double(p2), C.c_int64(n), _p(out, C.c_double)))
+        return out
+
+    def eval_math(self, which, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        out = np.empty(len(x))
+        self._chk(self.L.ngp_eval_math(self.h, C.c_int32(which), _p(x, C.c_double), C.c_int64(len(x)), _p(out, C.c_double)))
+        return out

@@ -1,0 +1,830 @@
+// ngp_api.hip -- C ABI of libnextgp_hip.so (include/nextgp_hip.h): handle lifecycle, panel
+// upload / generation with re-tiling, model set-up, the per-iteration launch sequence of the
+// blocked Gibbs sweep, state and posterior read-back.  gfx950 only; there is NO CPU fallback:
+// without a usable device every entry point fails with NGP_ERR_NODEVICE / NGP_ERR_HIP.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/nextgp_hip.h"
+#include "ngp_kernels.h"
+
+using namespace ngp;
+
+namespace {
+
+struct HSet {
+    int64_t col0, ncol;
+    int method;
+    double df, scale;
+    int64_t nreg;
+    int64_t vb_off;
+    int estPi;
+    uint64_t fine_calls;
+};
+
+std::string g_create_err;
+
+}  // namespace
+
+struct ngp_handle {
+    int device = 0;
+    uint64_t seed = 0;
+    uint32_t chain = 0;
+    hipStream_t stream = nullptr;
+    int64_t N = 0, P = 0, R = 0, S = 0, NBLK = 0, Ppad = 0, L = 0;
+    size_t lds_step = 0;
+    float *d_tiles = nullptr;
+    double *d_gram = nullptr, *d_mpm = nullptr, *d_lhs0 = nullptr, *d_rhs0 = nullptr, *d_beta = nullptr;
+    double *d_c = nullptr, *d_w = nullptr, *d_q = nullptr, *d_T = nullptr, *d_chi = nullptr;
+    int8_t *d_setof = nullptr;
+    int32_t *d_loc = nullptr, *d_vbidx = nullptr;
+    uint8_t *d_delta = nullptr;
+    double *d_sum_beta = nullptr, *d_sum_beta2 = nullptr, *d_sum_delta = nullptr;
+    double *d_ycorr = nullptr, *d_part = nullptr, *d_dlt = nullptr;
+    DSet *d_sets = nullptr;
+    DScal *d_scal = nullptr;
+    double *d_varBeta = nullptr, *d_sum_varBeta = nullptr;
+    int64_t vb_cap = 0;
+    // PR region tables
+    DReg *d_regs = nullptr;
+    long long *d_seg_k0 = nullptr;
+    int32_t *d_seg_len = nullptr;
+    double *d_segpart = nullptr;
+    std::vector<DReg> h_regs;
+    std::vector<long long> h_seg_k0;
+    std::vector<int32_t> h_seg_len;
+    bool tables_dirty = false;
+    // model (host mirror)
+    std::vector<HSet> sets;
+    std::vector<int8_t> h_setof;
+    std::vector<int32_t> h_loc, h_vbidx;
+    int64_t nvb = 0;
+    double e_df = 4.0, e_scale = 0.0005;
+    int intercept = 1;
+    int64_t chainLength = 0, burnIn = 0, thin = 1;
+    int64_t iter = 0;
+    bool have_y = false;
+    // traces
+    double *d_tr_varE = nullptr, *d_tr_b = nullptr;
+    int64_t ntrace = 0, trace_cap = 0;
+    // timing
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    double iter_ms = 0.0;
+    int64_t iters_timed = 0;
+    double sweep_ms = 0.0;
+    int64_t sweep_launches = 0;
+    std::string err;
+};
+
+namespace {
+
+int fail(ngp_handle *h, int code, const std::string &msg) {
+    if (h) h->err = msg; else g_create_err = msg;
+    return code;
+}
+
+#define HCHK(call)                                                                                          \
+    do {                                                                                                    \
+        hipError_t e_ = (call);                                                                             \
+        if (e_ != hipSuccess)                                                                               \
+            return fail(h, NGP_ERR_HIP, std::string(#call) + ": " + hipGetErrorString(e_));                 \
+    } while (0)
+
+#define REQUIRE(cond, code, msg)                \
+    do {                                        \
+        if (!(cond)) return fail(h, code, msg); \
+    } while (0)
+
+int enter(ngp_handle *h) {
+    if (!h) return fail(nullptr, NGP_ERR_ARG, "null handle");
+    hipError_t e = hipSetDevice(h->device);
+    if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("hipSetDevice: ") + hipGetErrorString(e));
+    return NGP_OK;
+}
+
+template <typename T>
+int dalloc(ngp_handle *h, T **p, size_t n) {
+    if (*p) { (void)hipFree(*p); *p = nullptr; }
+    hipError_t e = hipMalloc((void **)p, std::max<size_t>(n, 1) * sizeof(T));
+    if (e != hipSuccess) return fail(h, NGP_ERR_NOMEM, std::string("hipMalloc: ") + hipGetErrorString(e));
+    e = hipMemsetAsync(*p, 0, std::max<size_t>(n, 1) * sizeof(T), h->stream);
+    if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("hipMemset: ") + hipGetErrorString(e));
+    return NGP_OK;
+}
+template <typename T>
+void dfree(T *&p) {
+    if (p) { (void)hipFree(p); p = nullptr; }
+}
+
+// rows per shard R = 4*odd (conflict-free ds_read_b128 in both read patterns), S = ceil(N/R)
+void choose_layout(int64_t N, int64_t *R, int64_t *S) {
+    int64_t r0 = (N + 255) / 256;
+    int64_t m = (r0 + 3) / 4;
+    if (m < 1) m = 1;
+    if ((m & 1) == 0) m += 1;
+    int64_t r = 4 * m;
+    if (r > 508) r = 508;  // LDS bound of the streaming kernel: R*264 + 2048 <= 160 KiB
+    *R = r;
+    *S = (N + r - 1) / r;
+}
+
+int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
+    REQUIRE(N > 0 && P > 0, NGP_ERR_ARG, "panel dimensions must be positive");
+    REQUIRE(N <= (int64_t)508 * 1024, NGP_ERR_ARG, "N too large for this build (max 520192)");
+    h->N = N; h->P = P;
+    choose_layout(N, &h->R, &h->S);
+    h->NBLK = (P + NGP_BLK - 1) / NGP_BLK;
+    h->Ppad = h->NBLK * NGP_BLK;
+    h->L = h->R * h->S;
+    h->lds_step = (size_t)h->R * 264 + 2048;
+    int rc;
+    size_t tile_elems = (size_t)h->R * NGP_BLK;
+    if ((rc = dalloc(h, &h->d_tiles, (size_t)h->NBLK * h->S * tile_elems))) return rc;
+    if ((rc = dalloc(h, &h->d_gram, (size_t)h->NBLK * NGP_BLK * NGP_BLK))) return rc;
+    const size_t pp = (size_t)h->Ppad;
+    if ((rc = dalloc(h, &h->d_mpm, pp))) return rc;
+    if ((rc = dalloc(h, &h->d_lhs0, pp))) return rc;
+    if ((rc = dalloc(h, &h->d_rhs0, pp))) return rc;
+    if ((rc = dalloc(h, &h->d_beta, pp))) return rc;
+    if ((rc = dalloc(h, &h->d_c, pp))) return rc;
+    if ((rc = dalloc(h, &h->d_w, pp))) return rc;
+    if ((rc = dalloc(h, &h->d_q, pp))) return rc;
+    if ((rc = dalloc(h, &h->d_T, pp))) return rc;
+    if ((rc = dalloc(h, &h->d_chi, pp))) return rc;
+    if ((rc = dalloc(h, &h->d_setof, pp))) return rc;
+    if ((rc = dalloc(h, &h->d_loc, pp))) return rc;
+    if ((rc = dalloc(h, &h->d_vbidx, pp))) return rc;
+    if ((rc = dalloc(h, &h->d_delta, pp))) return rc;
+    if ((rc = dalloc(h, &h->d_sum_beta, pp))) return rc;
+    if ((rc = dalloc(h, &h->d_sum_beta2, pp))) return rc;
+    if ((rc = dalloc(h, &h->d_sum_delta, pp))) return rc;
+    if ((rc = dalloc(h, &h->d_ycorr, (size_t)h->L))) return rc;
+    if ((rc = dalloc(h, &h->d_part, (size_t)h->S * NGP_BLK))) return rc;
+    if ((rc = dalloc(h, &h->d_dlt, NGP_BLK))) return rc;
+    if ((rc = dalloc(h, &h->d_sets, 16))) return rc;
+    if ((rc = dalloc(h, &h->d_scal, 1))) return rc;
+    HCHK(hipMemsetAsync(h->d_setof, 0xFF, pp, h->stream));
+    HCHK(hipMemsetAsync(h->d_delta, 1, pp, h->stream));
+    h->h_setof.assign(pp, -1);
+    h->h_loc.assign(pp, 0);
+    h->h_vbidx.assign(pp, 0);
+    h->sets.clear(); h->nvb = 0; h->h_regs.clear(); h->h_seg_k0.clear(); h->h_seg_len.clear();
+    dfree(h->d_varBeta); dfree(h->d_sum_varBeta); h->vb_cap = 0;
+    h->have_y = false; h->iter = 0;
+    HCHK(hipFuncSetAttribute((const void *)k_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_step));
+    HCHK(hipFuncSetAttribute((const void *)k_gram_part, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)h->R * 256)));
+    HCHK(hipStreamSynchronize(h->stream));
+    return NGP_OK;
+}
+
+int build_gram(ngp_handle *h) {
+    // batches of blocks so the shard-partial scratch stays <= ~1 GiB
+    const size_t per_block = (size_t)h->S * NGP_BLK * NGP_BLK * sizeof(double);
+    int nb_max = (int)std::max<size_t>(1, std::min<size_t>((size_t)h->NBLK, ((size_t)1 << 30) / per_block));
+    nb_max = std::min(nb_max, 32768);
+    double *d_gpart = nullptr;
+    int rc;
+    if ((rc = dalloc(h, &d_gpart, (size_t)nb_max * h->S * NGP_BLK * NGP_BLK))) return rc;
+    for (int64_t t0 = 0; t0 < h->NBLK; t0 += nb_max) {
+        int nb = (int)std::min<int64_t>(nb_max, h->NBLK - t0);
+        hipLaunchKernelGGL(k_gram_part, dim3((unsigned)h->S, (unsigned)nb), dim3(256), (size_t)h->R * 256, h->stream, h->d_tiles,
+                           d_gpart, (int)h->R, (int)h->S, (int)t0);
+        long long ne = (long long)nb * NGP_BLK * NGP_BLK;
+        hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, h->stream, d_gpart, h->d_gram, h->d_mpm,
+                           (int)h->S, (int)t0, nb);
+    }
+    hipError_t e = hipStreamSynchronize(h->stream);
+    dfree(d_gpart);
+    if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("gram: ") + hipGetErrorString(e));
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("gram launch: ") + hipGetErrorString(e));
+    return NGP_OK;
+}
+
+template <typename TIn>
+int set_panel_host(ngp_handle *h, const TIn *M, int64_t N, int64_t P, int64_t ld, int centre) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(M != nullptr, NGP_ERR_ARG, "null panel pointer");
+    REQUIRE(ld >= N, NGP_ERR_ARG, "leading dimension smaller than N");
+    if ((rc = alloc_panel(h, N, P))) return rc;
+    const int64_t R = h->R, S = h->S;
+    const size_t blk_elems = (size_t)S * R * NGP_BLK;
+    std::vector<float> buf(blk_elems);
+    for (int64_t t = 0; t < h->NBLK; t++) {
+        std::fill(buf.begin(), buf.end(), 0.0f);
+        for (int jj = 0; jj < NGP_BLK; jj++) {
+            int64_t j = t * NGP_BLK + jj;
+            if (j >= P) break;
+            const TIn *col = M + (size_t)j * ld;
+            double mu = 0.0;
+            if (centre) {  // src/prepMatVec.jl:129
+                double sum = 0.0;
+                for (int64_t i = 0; i < N; i++) sum += (double)col[i];
+                mu = sum / (double)N;
+            }
+            for (int64_t i = 0; i < N; i++) {
+                double v = (double)col[i];
+                if (!std::isfinite(v)) return fail(h, NGP_ERR_ARG, "non-finite genotype value in panel");
+                int64_t s = i / R, ii = i - s * R;
+                buf[((size_t)s * NGP_BLK + jj) * R + ii] = (float)(v - mu);
+            }
+        }
+        HCHK(hipMemcpy(h->d_tiles + (size_t)t * blk_elems, buf.data(), blk_elems * sizeof(float), hipMemcpyHostToDevice));
+    }
+    return build_gram(h);
+}
+
+int sync_tables(ngp_handle *h) {
+    if (!h->tables_dirty) return NGP_OK;
+    int rc;
+    const size_t pp = (size_t)h->Ppad;
+    HCHK(hipMemcpy(h->d_setof, h->h_setof.data(), pp, hipMemcpyHostToDevice));
+    HCHK(hipMemcpy(h->d_loc, h->h_loc.data(), pp * sizeof(int32_t), hipMemcpyHostToDevice));
+    HCHK(hipMemcpy(h->d_vbidx, h->h_vbidx.data(), pp * sizeof(int32_t), hipMemcpyHostToDevice));
+    if ((rc = dalloc(h, &h->d_regs, h->h_regs.size()))) return rc;
+    if ((rc = dalloc(h, &h->d_seg_k0, h->h_seg_k0.size()))) return rc;
+    if ((rc = dalloc(h, &h->d_seg_len, h->h_seg_len.size()))) return rc;
+    if ((rc = dalloc(h, &h->d_segpart, h->h_seg_k0.size()))) return rc;
+    if (!h->h_regs.empty()) {
+        HCHK(hipMemcpy(h->d_regs, h->h_regs.data(), h->h_regs.size() * sizeof(DReg), hipMemcpyHostToDevice));
+        HCHK(hipMemcpy(h->d_seg_k0, h->h_seg_k0.data(), h->h_seg_k0.size() * sizeof(long long), hipMemcpyHostToDevice));
+        HCHK(hipMemcpy(h->d_seg_len, h->h_seg_len.data(), h->h_seg_len.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    h->tables_dirty = false;
+    return NGP_OK;
+}
+
+bool is_kept(const ngp_handle *h, int64_t it) {  // src/samplers.jl:26
+    if (it < h->burnIn + h->thin || it > h->chainLength) return false;
+    return ((it - h->burnIn) % h->thin) == 0;
+}
+
+// the block loop of one sweep over blocks [tb0, tb1)
+void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
+    const int R = (int)h->R, S = (int)h->S;
+    int e = 0;
+    for (int64_t t = tb0; t <= tb1; t++) {
+        const int do_upd = t > tb0, do_gemv = t < tb1;
+        if (evs && do_gemv) (void)hipEventRecord(evs[e++], h->stream);
+        hipLaunchKernelGGL(k_step, dim3((unsigned)S), dim3(256), h->lds_step, h->stream, h->d_tiles, h->d_ycorr, h->d_dlt, h->d_part, R,
+                           S, (int)t, do_upd, do_gemv);
+        if (evs && do_gemv) (void)hipEventRecord(evs[e++], h->stream);
+        if (do_gemv)
+            hipLaunchKernelGGL(k_recur, dim3(1), dim3(256), 0, h->stream, h->d_part, h->d_gram, S, (int)t, h->d_beta, h->d_delta, h->d_c,
+                               h->d_w, h->d_q, h->d_T, h->d_chi, h->d_setof, h->d_vbidx, h->d_sets, h->d_varBeta, h->d_dlt);
+    }
+    h->sweep_launches += 2 * (tb1 - tb0) + 1;
+}
+
+void launch_variance(ngp_handle *h, int active_set, uint64_t it) {
+    const long long nseg = (long long)h->h_seg_k0.size(), nreg = (long long)h->h_regs.size();
+    if (nseg > 0) {
+        hipLaunchKernelGGL(k_regssq, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, h->stream, nseg, h->d_seg_k0, h->d_seg_len,
+                           h->d_beta, h->d_segpart);
+        hipLaunchKernelGGL(k_regdraw, dim3((unsigned)((nreg + 63) / 64)), dim3(64), 0, h->stream, nreg, h->d_regs, h->d_segpart,
+                           h->d_sets, h->d_varBeta, active_set, h->seed, (uint64_t)h->chain, it);
+    }
+    hipLaunchKernelGGL(k_pidraw, dim3(1), dim3(64), 0, h->stream, (int)h->sets.size(), h->d_sets, active_set, h->seed,
+                       (uint64_t)h->chain, it);
+}
+
+int one_iteration(ngp_handle *h, int64_t trace_idx, hipEvent_t *evs) {
+    const uint64_t it = (uint64_t)(h->iter + 1);
+    hipLaunchKernelGGL(k_head, dim3(1), dim3(1024), 0, h->stream, h->d_ycorr, (long long)h->L, (long long)h->N, h->d_scal, h->e_df,
+                       h->e_scale, h->intercept, 1, h->seed, (uint64_t)h->chain, it, h->d_tr_varE, h->d_tr_b, (long long)trace_idx);
+    hipLaunchKernelGGL(k_prep, dim3((unsigned)(h->Ppad / 256 + 1)), dim3(256), 0, h->stream, (long long)h->Ppad, h->d_setof, h->d_loc,
+                       h->d_vbidx, h->d_sets, h->d_scal, h->d_varBeta, h->d_mpm, h->d_lhs0, h->d_rhs0, h->d_beta, h->d_c, h->d_w,
+                       h->d_q, h->d_T, h->d_chi, -1, h->seed, (uint64_t)h->chain, it);
+    launch_sweep(h, 0, h->NBLK, evs);
+    launch_variance(h, -1, it);
+    h->iter += 1;
+    if (is_kept(h, h->iter)) {
+        long long n = std::max<long long>(std::max<long long>(h->P, h->nvb), 16);
+        hipLaunchKernelGGL(k_accum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (long long)h->P, (long long)h->nvb,
+                           (int)h->sets.size(), h->d_beta, h->d_delta, h->d_varBeta, h->d_sum_beta, h->d_sum_beta2, h->d_sum_delta,
+                           h->d_sum_varBeta, h->d_sets, h->d_scal);
+    }
+    return NGP_OK;
+}
+
+int ready(ngp_handle *h) {
+    REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
+    REQUIRE(h->have_y, NGP_ERR_STATE, "y not set");
+    REQUIRE(!h->sets.empty(), NGP_ERR_STATE, "no marker set added");
+    return sync_tables(h);
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t ngp_abi_version(void) { return NGP_ABI_VERSION; }
+
+int32_t ngp_create(int32_t device, uint64_t seed, uint32_t chain_id, ngp_handle **out) {
+    if (!out) return fail(nullptr, NGP_ERR_ARG, "null out pointer");
+    *out = nullptr;
+    int ndev = 0;
+    hipError_t e = hipGetDeviceCount(&ndev);
+    if (e != hipSuccess || ndev <= 0)
+        return fail(nullptr, NGP_ERR_NODEVICE, std::string("no HIP device available (") + hipGetErrorString(e) +
+                                                   "); libnextgp_hip has no CPU fallback");
+    if (device < 0 || device >= ndev) return fail(nullptr, NGP_ERR_ARG, "device index out of range");
+    hipDeviceProp_t prop;
+    e = hipGetDeviceProperties(&prop, device);
+    if (e != hipSuccess) return fail(nullptr, NGP_ERR_HIP, std::string("hipGetDeviceProperties: ") + hipGetErrorString(e));
+    if (std::string(prop.gcnArchName).rfind("gfx950", 0) != 0)
+        return fail(nullptr, NGP_ERR_NODEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
+    ngp_handle *h = new (std::nothrow) ngp_handle();
+    if (!h) return fail(nullptr, NGP_ERR_NOMEM, "out of host memory");
+    h->device = device; h->seed = seed; h->chain = chain_id;
+    if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&h->stream)) != hipSuccess ||
+        (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess) {
+        std::string m = std::string("ngp_create: ") + hipGetErrorString(e);
+        delete h;
+        return fail(nullptr, NGP_ERR_HIP, m);
+    }
+    *out = h;
+    return NGP_OK;
+}
+
+int32_t ngp_destroy(ngp_handle *h) {
+    if (!h) return NGP_OK;
+    (void)hipSetDevice(h->device);
+    if (h->stream) (void)hipStreamSynchronize(h->stream);
+    dfree(h->d_tiles); dfree(h->d_gram); dfree(h->d_mpm); dfree(h->d_lhs0); dfree(h->d_rhs0); dfree(h->d_beta);
+    dfree(h->d_c); dfree(h->d_w); dfree(h->d_q); dfree(h->d_T); dfree(h->d_chi); dfree(h->d_setof); dfree(h->d_loc);
+    dfree(h->d_vbidx); dfree(h->d_delta); dfree(h->d_sum_beta); dfree(h->d_sum_beta2); dfree(h->d_sum_delta);
+    dfree(h->d_ycorr); dfree(h->d_part); dfree(h->d_dlt); dfree(h->d_sets); dfree(h->d_scal); dfree(h->d_varBeta);
+    dfree(h->d_sum_varBeta); dfree(h->d_regs); dfree(h->d_seg_k0); dfree(h->d_seg_len); dfree(h->d_segpart);
+    dfree(h->d_tr_varE); dfree(h->d_tr_b);
+    if (h->ev0) (void)hipEventDestroy(h->ev0);
+    if (h->ev1) (void)hipEventDestroy(h->ev1);
+    if (h->stream) (void)hipStreamDestroy(h->stream);
+    delete h;
+    return NGP_OK;
+}
+
+const char *ngp_last_error(ngp_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
+
+int32_t ngp_set_panel_f64(ngp_handle *h, const double *M, int64_t N, int64_t P, int64_t ld, int32_t centre) {
+    return set_panel_host<double>(h, M, N, P, ld, centre);
+}
+int32_t ngp_set_panel_f32(ngp_handle *h, const float *M, int64_t N, int64_t P, int64_t ld, int32_t centre) {
+    return set_panel_host<float>(h, M, N, P, ld, centre);
+}
+
+int32_t ngp_generate_panel(ngp_handle *h, int64_t N, int64_t P, double maf_lo, double maf_hi, uint64_t panel_seed) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(maf_lo > 0.0 && maf_hi < 1.0 && maf_lo <= maf_hi, NGP_ERR_ARG, "maf range must satisfy 0 < lo <= hi < 1");
+    if ((rc = alloc_panel(h, N, P))) return rc;
+    double *d_mu = nullptr;
+    uint32_t *d_thr = nullptr;
+    if ((rc = dalloc(h, &d_mu, (size_t)P))) return rc;
+    if ((rc = dalloc(h, &d_thr, (size_t)P))) { dfree(d_mu); return rc; }
+    hipLaunchKernelGGL(k_gen_colmean, dim3((unsigned)P), dim3(256), 0, h->stream, (long long)N, (long long)P, maf_lo, maf_hi, panel_seed,
+                       d_mu, d_thr);
+    hipLaunchKernelGGL(k_gen_fill, dim3((unsigned)h->S, (unsigned)h->NBLK), dim3(256), 0, h->stream, h->d_tiles, (long long)N,
+                       (long long)P, (int)h->R, (int)h->S, panel_seed, d_mu, d_thr);
+    hipError_t e = hipStreamSynchronize(h->stream);
+    dfree(d_mu); dfree(d_thr);
+    if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("generate_panel: ") + hipGetErrorString(e));
+    return build_gram(h);
+}
+
+int32_t ngp_get_layout(ngp_handle *h, int64_t *R, int64_t *S, int64_t *nblk) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
+    if (R) *R = h->R;
+    if (S) *S = h->S;
+    if (nblk) *nblk = h->NBLK;
+    return NGP_OK;
+}
+
+int32_t ngp_get_mpm(ngp_handle *h, double *out, int64_t P) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
+    REQUIRE(out && P == h->P, NGP_ERR_ARG, "mpm buffer must hold P entries");
+    HCHK(hipMemcpy(out, h->d_mpm, (size_t)P * sizeof(double), hipMemcpyDeviceToHost));
+    return NGP_OK;
+}
+
+int32_t ngp_get_gram(ngp_handle *h, int64_t t, double *out) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
+    REQUIRE(out && t >= 0 && t < h->NBLK, NGP_ERR_ARG, "block index out of range");
+    HCHK(hipMemcpy(out, h->d_gram + (size_t)t * NGP_BLK * NGP_BLK, NGP_BLK * NGP_BLK * sizeof(double), hipMemcpyDeviceToHost));
+    return NGP_OK;
+}
+
+int32_t ngp_xbeta(ngp_handle *h, const double *beta, int64_t P, double *out, int64_t N) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
+    REQUIRE(beta && out && P == h->P && N == h->N, NGP_ERR_ARG, "xbeta: size mismatch");
+    double *d_b = nullptr, *d_o = nullptr;
+    if ((rc = dalloc(h, &d_b, (size_t)h->Ppad))) return rc;
+    if ((rc = dalloc(h, &d_o, (size_t)h->L))) { dfree(d_b); return rc; }
+    hipError_t e = hipMemcpyAsync(d_b, beta, (size_t)P * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    hipLaunchKernelGGL(k_xbeta, dim3((unsigned)h->S), dim3(256), 0, h->stream, h->d_tiles, d_b, d_o, (int)h->R, (int)h->S,
+                       (long long)h->NBLK);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_o, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    dfree(d_b); dfree(d_o);
+    if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("xbeta: ") + hipGetErrorString(e));
+    return NGP_OK;
+}
+
+int32_t ngp_add_marker_set(ngp_handle *h, int64_t col0, int64_t ncol, int32_t method, double df, double scale,
+                           const int64_t *reg_start, const int64_t *reg_stop, int64_t nreg, const double *varBeta0, double pi0,
+                           int32_t estPi, const double *lhs0, const double *rhs0, int32_t *set_id) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
+    REQUIRE(h->sets.size() < 16, NGP_ERR_ARG, "at most 16 marker sets");
+    REQUIRE(col0 >= 0 && ncol > 0 && col0 + ncol <= h->P, NGP_ERR_ARG, "marker set outside the panel");
+    REQUIRE(method == NGP_METHOD_BAYESPR || method == NGP_METHOD_BAYESB, NGP_ERR_ARG, "unknown method");
+    REQUIRE(reg_start && reg_stop && varBeta0 && nreg > 0, NGP_ERR_ARG, "regions / varBeta0 missing");
+    REQUIRE(std::isfinite(df) && std::isfinite(scale) && df > 0, NGP_ERR_ARG, "df/scale must be finite, df > 0");
+    for (int64_t k = col0; k < col0 + ncol; k++) REQUIRE(h->h_setof[k] < 0, NGP_ERR_ARG, "marker sets overlap");
+    if (method == NGP_METHOD_BAYESB) {
+        REQUIRE(nreg == ncol, NGP_ERR_ARG, "BayesB needs one region per locus (src/mme.jl:356)");
+        REQUIRE(pi0 > 0.0 && pi0 < 1.0, NGP_ERR_ARG, "BayesB pi must be in (0,1)");
+    }
+    // regions must tile [0,ncol) in order (regionArray of UnitRanges, src/mme.jl:335-347)
+    int64_t expect = 0;
+    for (int64_t r = 0; r < nreg; r++) {
+        REQUIRE(reg_start[r] == expect && reg_stop[r] > reg_start[r], NGP_ERR_ARG, "regions must be consecutive and non-empty");
+        REQUIRE(std::isfinite(varBeta0[r]) && varBeta0[r] >= 0.0, NGP_ERR_ARG, "varBeta0 must be finite and >= 0");
+        expect = reg_stop[r];
+    }
+    REQUIRE(expect == ncol, NGP_ERR_ARG, "regions must cover the whole set");
+    const int si = (int)h->sets.size();
+    HSet hs{col0, ncol, method, df, scale, nreg, h->nvb, estPi, 0};
+    // grow varBeta storage
+    const int64_t new_nvb = h->nvb + nreg;
+    if (new_nvb > h->vb_cap) {
+        int64_t cap = std::max<int64_t>(new_nvb, 2 * h->vb_cap);
+        double *nv = nullptr, *ns = nullptr;
+        if ((rc = dalloc(h, &nv, (size_t)cap))) return rc;
+        if ((rc = dalloc(h, &ns, (size_t)cap))) return rc;
+        if (h->nvb > 0) {
+            HCHK(hipMemcpyAsync(nv, h->d_varBeta, (size_t)h->nvb * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            HCHK(hipMemcpyAsync(ns, h->d_sum_varBeta, (size_t)h->nvb * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        }
+        HCHK(hipStreamSynchronize(h->stream));
+        dfree(h->d_varBeta); dfree(h->d_sum_varBeta);
+        h->d_varBeta = nv; h->d_sum_varBeta = ns; h->vb_cap = cap;
+    }
+    HCHK(hipMemcpy(h->d_varBeta + h->nvb, varBeta0, (size_t)nreg * sizeof(double), hipMemcpyHostToDevice));
+    for (int64_t r = 0; r < nreg; r++)
+        for (int64_t l = reg_start[r]; l < reg_stop[r]; l++) {
+            int64_t k = col0 + l;
+            h->h_setof[k] = (int8_t)si;
+            h->h_loc[k] = (int32_t)l;
+            h->h_vbidx[k] = (int32_t)(h->nvb + (method == NGP_METHOD_BAYESB ? l : r));
+        }
+    if (method == NGP_METHOD_BAYESPR) {
+        for (int64_t r = 0; r < nreg; r++) {
+            DReg dr;
+            dr.seg0 = (long long)h->h_seg_k0.size();
+            dr.set = si; dr.rg = (int)r; dr.vb = (int)(h->nvb + r); dr.n = reg_stop[r] - reg_start[r];
+            int ns = 0;
+            for (int64_t l0 = reg_start[r]; l0 < reg_stop[r]; l0 += NGP_SEG) {
+                h->h_seg_k0.push_back(col0 + l0);
+                h->h_seg_len.push_back((int32_t)std::min<int64_t>(NGP_SEG, reg_stop[r] - l0));
+                ns++;
+            }
+            dr.nseg = ns;
+            h->h_regs.push_back(dr);
+        }
+    }
+    std::vector<double> z((size_t)ncol, 0.0);
+    HCHK(hipMemcpy(h->d_lhs0 + col0, lhs0 ? lhs0 : z.data(), (size_t)ncol * sizeof(double), hipMemcpyHostToDevice));
+    HCHK(hipMemcpy(h->d_rhs0 + col0, rhs0 ? rhs0 : z.data(), (size_t)ncol * sizeof(double), hipMemcpyHostToDevice));
+    DSet ds;
+    memset(&ds, 0, sizeof(ds));
+    ds.method = method; ds.estPi = estPi; ds.df = df; ds.scale = scale; ds.sdf = scale * df; ds.col0 = col0; ds.ncol = ncol;
+    HCHK(hipMemcpy(h->d_sets + si, &ds, sizeof(DSet), hipMemcpyHostToDevice));
+    const double p1 = pi0, p0 = 1.0 - pi0;
+    hipLaunchKernelGGL(k_set_pi, dim3(1), dim3(1), 0, h->stream, h->d_sets, si, p0, p1);  // src/mme.jl:351,360
+    HCHK(hipStreamSynchronize(h->stream));
+    h->nvb = new_nvb;
+    h->sets.push_back(hs);
+    h->tables_dirty = true;
+    if (set_id) *set_id = si;
+    return NGP_OK;
+}
+
+int32_t ngp_set_y(ngp_handle *h, const double *y, int64_t N) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
+    REQUIRE(y && N == h->N, NGP_ERR_ARG, "y must have N entries");
+    for (int64_t i = 0; i < N; i++) REQUIRE(std::isfinite(y[i]), NGP_ERR_ARG, "non-finite phenotype");
+    HCHK(hipMemsetAsync(h->d_ycorr, 0, (size_t)h->L * sizeof(double), h->stream));
+    HCHK(hipMemcpyAsync(h->d_ycorr, y, (size_t)N * sizeof(double), hipMemcpyHostToDevice, h->stream));  // src/mme.jl:57
+    HCHK(hipMemsetAsync(h->d_beta, 0, (size_t)h->Ppad * sizeof(double), h->stream));                  // src/mme.jl:443
+    HCHK(hipMemsetAsync(h->d_delta, 1, (size_t)h->Ppad, h->stream));                                  // src/mme.jl:444
+    HCHK(hipMemsetAsync(h->d_scal, 0, sizeof(DScal), h->stream));
+    HCHK(hipMemsetAsync(h->d_sum_beta, 0, (size_t)h->Ppad * sizeof(double), h->stream));
+    HCHK(hipMemsetAsync(h->d_sum_beta2, 0, (size_t)h->Ppad * sizeof(double), h->stream));
+    HCHK(hipMemsetAsync(h->d_sum_delta, 0, (size_t)h->Ppad * sizeof(double), h->stream));
+    HCHK(hipStreamSynchronize(h->stream));
+    h->iter = 0; h->have_y = true;
+    return NGP_OK;
+}
+
+int32_t ngp_set_residual_prior(ngp_handle *h, double df, double scale) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(std::isfinite(df) && std::isfinite(scale) && df > 0 && scale >= 0, NGP_ERR_ARG, "bad residual prior");
+    h->e_df = df; h->e_scale = scale;
+    return NGP_OK;
+}
+int32_t ngp_set_intercept(ngp_handle *h, int32_t on) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    h->intercept = on ? 1 : 0;
+    return NGP_OK;
+}
+int32_t ngp_set_schedule(ngp_handle *h, int64_t chainLength, int64_t burnIn, int64_t thin) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(chainLength >= 0 && burnIn >= 0 && thin >= 1, NGP_ERR_ARG, "bad schedule");
+    h->chainLength = chainLength; h->burnIn = burnIn; h->thin = thin;
+    return NGP_OK;
+}
+
+int32_t ngp_run(ngp_handle *h, int64_t niter) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    if ((rc = ready(h))) return rc;
+    REQUIRE(niter >= 0, NGP_ERR_ARG, "niter must be >= 0");
+    if (niter > h->trace_cap) {
+        if ((rc = dalloc(h, &h->d_tr_varE, (size_t)niter))) return rc;
+        if ((rc = dalloc(h, &h->d_tr_b, (size_t)niter))) return rc;
+        h->trace_cap = niter;
+    }
+    h->ntrace = niter;
+    HCHK(hipEventRecord(h->ev0, h->stream));
+    for (int64_t n = 0; n < niter; n++) {
+        if ((rc = one_iteration(h, n, nullptr))) return rc;
+        if ((n & 15) == 15) HCHK(hipStreamSynchronize(h->stream));  // bound the launch queue
+    }
+    HCHK(hipEventRecord(h->ev1, h->stream));
+    HCHK(hipStreamSynchronize(h->stream));
+    HCHK(hipGetLastError());
+    float ms = 0.f;
+    HCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    h->iter_ms += ms; h->iters_timed += niter;
+    return NGP_OK;
+}
+
+int32_t ngp_get_state(ngp_handle *h, double *ycorr, double *beta, int64_t *delta, double *varBeta, double *piHat, double *varE,
+                      double *b, int64_t *iter) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(h->d_tiles != nullptr && h->have_y, NGP_ERR_STATE, "panel / y not set");
+    HCHK(hipStreamSynchronize(h->stream));
+    if (ycorr) HCHK(hipMemcpy(ycorr, h->d_ycorr, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost));
+    if (beta) HCHK(hipMemcpy(beta, h->d_beta, (size_t)h->P * sizeof(double), hipMemcpyDeviceToHost));
+    if (delta) {
+        std::vector<uint8_t> d((size_t)h->P);
+        HCHK(hipMemcpy(d.data(), h->d_delta, (size_t)h->P, hipMemcpyDeviceToHost));
+        for (int64_t k = 0; k < h->P; k++) delta[k] = d[k];
+    }
+    if (varBeta && h->nvb) HCHK(hipMemcpy(varBeta, h->d_varBeta, (size_t)h->nvb * sizeof(double), hipMemcpyDeviceToHost));
+    if (piHat && !h->sets.empty()) {
+        std::vector<DSet> ds(h->sets.size());
+        HCHK(hipMemcpy(ds.data(), h->d_sets, ds.size() * sizeof(DSet), hipMemcpyDeviceToHost));
+        for (size_t s = 0; s < ds.size(); s++) { piHat[2 * s] = ds[s].piHat0; piHat[2 * s + 1] = ds[s].piHat1; }
+    }
+    DScal sc;
+    HCHK(hipMemcpy(&sc, h->d_scal, sizeof(DScal), hipMemcpyDeviceToHost));
+    if (varE) *varE = sc.varE;
+    if (b) *b = sc.b;
+    if (iter) *iter = h->iter;
+    return NGP_OK;
+}
+
+int32_t ngp_set_state(ngp_handle *h, const double *ycorr, const double *beta, const int64_t *delta, const double *varBeta,
+                      const double *piHat, double varE, double b, int64_t iter) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(h->d_tiles != nullptr && h->have_y, NGP_ERR_STATE, "panel / y not set");
+    REQUIRE(std::isfinite(varE) && std::isfinite(b) && iter >= 0, NGP_ERR_ARG, "bad scalar state");
+    if (ycorr) HCHK(hipMemcpy(h->d_ycorr, ycorr, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice));
+    if (beta) HCHK(hipMemcpy(h->d_beta, beta, (size_t)h->P * sizeof(double), hipMemcpyHostToDevice));
+    if (delta) {
+        std::vector<uint8_t> d((size_t)h->P);
+        for (int64_t k = 0; k < h->P; k++) d[k] = (uint8_t)(delta[k] != 0);
+        HCHK(hipMemcpy(h->d_delta, d.data(), (size_t)h->P, hipMemcpyHostToDevice));
+    }
+    if (varBeta && h->nvb) HCHK(hipMemcpy(h->d_varBeta, varBeta, (size_t)h->nvb * sizeof(double), hipMemcpyHostToDevice));
+    if (piHat)
+        for (size_t s = 0; s < h->sets.size(); s++)
+            hipLaunchKernelGGL(k_set_pi, dim3(1), dim3(1), 0, h->stream, h->d_sets, (int)s, piHat[2 * s], piHat[2 * s + 1]);
+    DScal sc;
+    HCHK(hipMemcpy(&sc, h->d_scal, sizeof(DScal), hipMemcpyDeviceToHost));
+    sc.varE = varE; sc.iVarE = 1.0 / varE; sc.b = b;
+    HCHK(hipMemcpy(h->d_scal, &sc, sizeof(DScal), hipMemcpyHostToDevice));
+    HCHK(hipStreamSynchronize(h->stream));
+    h->iter = iter;
+    return NGP_OK;
+}
+
+int32_t ngp_get_trace(ngp_handle *h, double *varE, double *b, int64_t n) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    n = std::min(n, h->ntrace);
+    if (n <= 0) return NGP_OK;
+    if (varE) HCHK(hipMemcpy(varE, h->d_tr_varE, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    if (b) HCHK(hipMemcpy(b, h->d_tr_b, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
+    return NGP_OK;
+}
+
+int32_t ngp_get_posterior_sums(ngp_handle *h, double *sum_beta, double *sum_beta2, double *sum_delta, double *sum_varBeta,
+                               double *sum_pi, double *sum_varE, double *sum_b, int64_t *nKept) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
+    HCHK(hipStreamSynchronize(h->stream));
+    const size_t pb = (size_t)h->P * sizeof(double);
+    if (sum_beta) HCHK(hipMemcpy(sum_beta, h->d_sum_beta, pb, hipMemcpyDeviceToHost));
+    if (sum_beta2) HCHK(hipMemcpy(sum_beta2, h->d_sum_beta2, pb, hipMemcpyDeviceToHost));
+    if (sum_delta) HCHK(hipMemcpy(sum_delta, h->d_sum_delta, pb, hipMemcpyDeviceToHost));
+    if (sum_varBeta && h->nvb) HCHK(hipMemcpy(sum_varBeta, h->d_sum_varBeta, (size_t)h->nvb * sizeof(double), hipMemcpyDeviceToHost));
+    if (sum_pi && !h->sets.empty()) {
+        std::vector<DSet> ds(h->sets.size());
+        HCHK(hipMemcpy(ds.data(), h->d_sets, ds.size() * sizeof(DSet), hipMemcpyDeviceToHost));
+        for (size_t s = 0; s < ds.size(); s++) { sum_pi[2 * s] = ds[s].sum_pi0; sum_pi[2 * s + 1] = ds[s].sum_pi1; }
+    }
+    DScal sc;
+    HCHK(hipMemcpy(&sc, h->d_scal, sizeof(DScal), hipMemcpyDeviceToHost));
+    if (sum_varE) *sum_varE = sc.sum_varE;
+    if (sum_b) *sum_b = sc.sum_b;
+    if (nKept) *nKept = sc.nKept;
+    return NGP_OK;
+}
+
+int32_t ngp_posterior_len(ngp_handle *h, int64_t *len) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(len != nullptr, NGP_ERR_ARG, "null len");
+    *len = 3 * h->P + h->nvb + 2 * (int64_t)h->sets.size() + 3;
+    return NGP_OK;
+}
+
+int32_t ngp_export_posterior_device(ngp_handle *h, void *device_ptr, int64_t len) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
+    const int64_t need = 3 * h->P + h->nvb + 2 * (int64_t)h->sets.size() + 3;
+    REQUIRE(device_ptr && len == need, NGP_ERR_ARG, "export buffer length mismatch (see ngp_posterior_len)");
+    double *o = (double *)device_ptr;
+    const size_t pb = (size_t)h->P * sizeof(double);
+    HCHK(hipMemcpyAsync(o, h->d_sum_beta, pb, hipMemcpyDeviceToDevice, h->stream));
+    HCHK(hipMemcpyAsync(o + h->P, h->d_sum_beta2, pb, hipMemcpyDeviceToDevice, h->stream));
+    HCHK(hipMemcpyAsync(o + 2 * h->P, h->d_sum_delta, pb, hipMemcpyDeviceToDevice, h->stream));
+    if (h->nvb) HCHK(hipMemcpyAsync(o + 3 * h->P, h->d_sum_varBeta, (size_t)h->nvb * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    std::vector<DSet> ds(h->sets.size());
+    HCHK(hipStreamSynchronize(h->stream));
+    if (!ds.empty()) HCHK(hipMemcpy(ds.data(), h->d_sets, ds.size() * sizeof(DSet), hipMemcpyDeviceToHost));
+    DScal sc;
+    HCHK(hipMemcpy(&sc, h->d_scal, sizeof(DScal), hipMemcpyDeviceToHost));
+    std::vector<double> tail;
+    for (auto &s : ds) { tail.push_back(s.sum_pi0); tail.push_back(s.sum_pi1); }
+    tail.push_back(sc.sum_varE); tail.push_back(sc.sum_b); tail.push_back((double)sc.nKept);
+    HCHK(hipMemcpy(o + 3 * h->P + h->nvb, tail.data(), tail.size() * sizeof(double), hipMemcpyHostToDevice));
+    return NGP_OK;
+}
+
+int32_t ngp_sweep_set(ngp_handle *h, int32_t set_id, double varE, double *ycorr, double *beta, int64_t *delta, double *varBeta,
+                      double *piHat) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
+    REQUIRE(set_id >= 0 && set_id < (int)h->sets.size(), NGP_ERR_ARG, "unknown set id");
+    REQUIRE(ycorr && beta && varBeta, NGP_ERR_ARG, "null state pointer");
+    REQUIRE(std::isfinite(varE) && varE > 0.0, NGP_ERR_ARG, "varE must be finite and positive");
+    if ((rc = sync_tables(h))) return rc;
+    HSet &hs = h->sets[set_id];
+    for (int64_t r = 0; r < hs.nreg; r++) REQUIRE(std::isfinite(varBeta[r]) && varBeta[r] >= 0.0, NGP_ERR_ARG, "varBeta must be finite, >= 0");
+    if (hs.method == NGP_METHOD_BAYESB) REQUIRE(piHat != nullptr, NGP_ERR_ARG, "BayesB needs piHat");
+    const uint64_t it = ++hs.fine_calls;
+    HCHK(hipMemsetAsync(h->d_ycorr, 0, (size_t)h->L * sizeof(double), h->stream));
+    HCHK(hipMemcpyAsync(h->d_ycorr, ycorr, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HCHK(hipMemcpyAsync(h->d_beta + hs.col0, beta, (size_t)hs.ncol * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    HCHK(hipMemcpyAsync(h->d_varBeta + hs.vb_off, varBeta, (size_t)hs.nreg * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (hs.method == NGP_METHOD_BAYESB)
+        hipLaunchKernelGGL(k_set_pi, dim3(1), dim3(1), 0, h->stream, h->d_sets, (int)set_id, piHat[0], piHat[1]);
+    hipLaunchKernelGGL(k_set_varE, dim3(1), dim3(1), 0, h->stream, h->d_scal, varE);
+    hipLaunchKernelGGL(k_prep, dim3((unsigned)(h->Ppad / 256 + 1)), dim3(256), 0, h->stream, (long long)h->Ppad, h->d_setof, h->d_loc,
+                       h->d_vbidx, h->d_sets, h->d_scal, h->d_varBeta, h->d_mpm, h->d_lhs0, h->d_rhs0, h->d_beta, h->d_c, h->d_w,
+                       h->d_q, h->d_T, h->d_chi, (int)set_id, h->seed, (uint64_t)h->chain, it);
+    const int64_t tb0 = hs.col0 / NGP_BLK, tb1 = (hs.col0 + hs.ncol - 1) / NGP_BLK + 1;
+    launch_sweep(h, tb0, tb1, nullptr);
+    launch_variance(h, (int)set_id, it);
+    HCHK(hipMemcpyAsync(ycorr, h->d_ycorr, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HCHK(hipMemcpyAsync(beta, h->d_beta + hs.col0, (size_t)hs.ncol * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HCHK(hipMemcpyAsync(varBeta, h->d_varBeta + hs.vb_off, (size_t)hs.nreg * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HCHK(hipStreamSynchronize(h->stream));
+    HCHK(hipGetLastError());
+    if (delta) {
+        std::vector<uint8_t> d((size_t)hs.ncol);
+        HCHK(hipMemcpy(d.data(), h->d_delta + hs.col0, (size_t)hs.ncol, hipMemcpyDeviceToHost));
+        for (int64_t k = 0; k < hs.ncol; k++) delta[k] = d[k];
+    }
+    if (piHat) {
+        DSet ds;
+        HCHK(hipMemcpy(&ds, h->d_sets + set_id, sizeof(DSet), hipMemcpyDeviceToHost));
+        piHat[0] = ds.piHat0; piHat[1] = ds.piHat1;
+    }
+    return NGP_OK;
+}
+
+int32_t ngp_get_timing(ngp_handle *h, double *sweep_ms, int64_t *sweep_launches, double *iter_ms, int64_t *iters) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    if (sweep_ms) *sweep_ms = h->sweep_ms;
+    if (sweep_launches) *sweep_launches = h->sweep_launches;
+    if (iter_ms) *iter_ms = h->iter_ms;
+    if (iters) *iters = h->iters_timed;
+    h->sweep_ms = 0; h->sweep_launches = 0; h->iter_ms = 0; h->iters_timed = 0;
+    return NGP_OK;
+}
+
+int32_t ngp_profile_iteration(ngp_handle *h, double *avg_ms, int64_t *launches, double *bytes_per_launch) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    if ((rc = ready(h))) return rc;
+    const int64_t n = h->NBLK;
+    std::vector<hipEvent_t> evs((size_t)(2 * n));
+    for (auto &e : evs) HCHK(hipEventCreate(&e));
+    if (h->trace_cap < 1) {
+        if ((rc = dalloc(h, &h->d_tr_varE, 1))) return rc;
+        if ((rc = dalloc(h, &h->d_tr_b, 1))) return rc;
+        h->trace_cap = 1;
+    }
+    h->ntrace = 1;
+    rc = one_iteration(h, 0, evs.data());
+    hipError_t e = hipStreamSynchronize(h->stream);
+    double tot = 0.0;
+    if (rc == NGP_OK && e == hipSuccess)
+        for (int64_t i = 0; i < n; i++) {
+            float ms = 0.f;
+            (void)hipEventElapsedTime(&ms, evs[2 * i], evs[2 * i + 1]);
+            tot += ms;
+        }
+    for (auto &ev : evs) (void)hipEventDestroy(ev);
+    if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("profile_iteration: ") + hipGetErrorString(e));
+    if (avg_ms) *avg_ms = tot / (double)n;
+    if (launches) *launches = n;
+    if (bytes_per_launch) *bytes_per_launch = (double)h->N * NGP_BLK * 4.0;
+    return rc;
+}
+
+int32_t ngp_draws_indexed(ngp_handle *h, uint64_t iter, uint64_t kind, uint64_t index0, int32_t what, double p1, double p2, int64_t n,
+                          double *out) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(out && n > 0, NGP_ERR_ARG, "bad output buffer");
+    double *d = nullptr;
+    if ((rc = dalloc(h, &d, (size_t)n))) return rc;
+    hipLaunchKernelGGL(k_draws_indexed, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, h->seed, (uint64_t)h->chain, iter, kind,
+                       index0, what, p1, p2, (long long)n, d);
+    hipError_t e = hipMemcpyAsync(out, d, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    dfree(d);
+    if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("draws: ") + hipGetErrorString(e));
+    return NGP_OK;
+}
+
+int32_t ngp_eval_math(ngp_handle *h, int32_t which, const double *in, int64_t n, double *out) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(in && out && n > 0, NGP_ERR_ARG, "bad buffers");
+    double *di = nullptr, *dout = nullptr;
+    if ((rc = dalloc(h, &di, (size_t)n))) return rc;
+    if ((rc = dalloc(h, &dout, (size_t)n))) { dfree(di); return rc; }
+    hipError_t e = hipMemcpyAsync(di, in, (size_t)n * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    hipLaunchKernelGGL(k_eval_math, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, which, di, (long long)n, dout);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, dout, (size_t)n * sizeof(double), hipMemcpyDeviceToHost, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    dfree(di); dfree(dout);
+    if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("eval_math: ") + hipGetErrorString(e));
+    return NGP_OK;
+}
+
+}  // extern "C"

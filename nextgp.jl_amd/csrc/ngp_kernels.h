@@ -1,0 +1,552 @@
+// ngp_kernels.h -- gfx950 kernels of the blocked marker-effect Gibbs sweep ("stage A": one
+// streaming kernel + one recursion kernel per 64-SNP block).  DESIGN.md "Blocked sweep
+// arithmetic" is the normative description of every summation order used here; the CPU
+// oracle's order-1 path reproduces it operation by operation.
+//
+// Reference arithmetic being replaced (under /root/reference):
+//   src/functions.jl:118-137  sampleBayesPR!   (add-back daxpy, ddot, draw, update daxpy per SNP)
+//   src/functions.jl:157-195  sampleBayesB!
+//   src/functions.jl:41-47    intercept        src/functions.jl:523-525 sampleVarE
+//   src/functions.jl:509-511  sampleVarBetaPR  src/functions.jl:531-533 samplePi
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "ngp_rng.h"
+
+#pragma clang fp contract(off)
+
+#define NGP_BLK 64
+#define NGP_SEG 256
+#define NGP_GRP 32
+
+namespace ngp {
+
+struct DSet {  // one marker set (src/mme.jl:324-361, 492-520)
+    int method, estPi;
+    double df, scale, sdf;  // sdf = scale*df
+    long long col0, ncol;
+    double piHat0, piHat1, logPi0, logPi1;
+    int nloci;  // included loci of the running BayesB sweep
+    int pad_;
+    double sum_pi0, sum_pi1;
+};
+
+struct DScal {  // chain scalars
+    double varE, iVarE, b, db;
+    double sum_varE, sum_b;
+    long long nKept;
+};
+
+__device__ inline double readlane_d(double v, int lane) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_readlane(lo, lane);
+    hi = __builtin_amdgcn_readlane(hi, lane);
+    return __hiloint2double(hi, lo);
+}
+
+// ------------------------------------------------------------------------------------------
+// iteration head: varE draw from ycorr'ycorr (functions.jl:523-525), intercept draw and
+// ycorr -= db (functions.jl:41-47).  ONE workgroup of 1024 threads.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_head(double *__restrict__ ycorr, long long L, long long N, DScal *__restrict__ sc,
+                                               double e_df, double e_scale, int intercept, int draw_varE, uint64_t seed,
+                                               uint64_t chain, uint64_t it, double *__restrict__ tr_varE,
+                                               double *__restrict__ tr_b, long long trace_idx) {
+    __shared__ double wyy[16], wsy[16];
+    __shared__ double s_db;
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    double ayy = 0.0, asy = 0.0;
+    for (long long i = tid; i < L; i += 1024) {
+        double v = ycorr[i];
+        ayy = __builtin_fma(v, v, ayy);
+        asy = asy + v;
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+        ayy = ayy + __shfl_xor(ayy, off);
+        asy = asy + __shfl_xor(asy, off);
+    }
+    if (lane == 0) {
+        wyy[wv] = ayy;
+        wsy[wv] = asy;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        double yy = wyy[0], sy = wsy[0];
+        for (int k = 1; k < 16; k++) {
+            yy = yy + wyy[k];
+            sy = sy + wsy[k];
+        }
+        double varE = sc->varE, iVarE = sc->iVarE;
+        if (draw_varE) {
+            Rng r = rng_seed(seed, chain, it, NGP_KIND_VARE_CHI2, 0);
+            double chi = rng_chisq(r, e_df + (double)N);
+            double t = e_df * e_scale;
+            t = t + yy;
+            varE = t / chi;
+            iVarE = 1.0 / varE;
+            sc->varE = varE;
+            sc->iVarE = iVarE;
+        }
+        double db = 0.0;
+        if (intercept) {
+            double Nd = (double)N;
+            double bo = sc->b;
+            double tb = Nd * bo;
+            double sb = sy + tb;
+            double rhs = sb * iVarE;
+            double lhs = Nd * iVarE;
+            double mean = rhs / lhs;
+            double sd = det_sqrt(1.0 / lhs);
+            Rng r = rng_seed(seed, chain, it, NGP_KIND_FIXED_NORMAL, 0);
+            double z = rng_normal(r);
+            double tz = sd * z;
+            double bn = mean + tz;
+            db = bn - bo;
+            sc->b = bn;
+        }
+        sc->db = db;
+        s_db = db;
+        if (tr_varE) {
+            tr_varE[trace_idx] = varE;
+            tr_b[trace_idx] = sc->b;
+        }
+    }
+    __syncthreads();
+    if (intercept) {
+        double db = s_db;
+        for (long long i = tid; i < N; i += 1024) ycorr[i] = ycorr[i] - db;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// per-locus coefficients of the block recursion (everything the serial chain does NOT need to
+// compute): c, w, q, T and the pre-drawn chi-square of BayesB.  active_set < 0: all sets.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_prep(long long Ppad, const int8_t *__restrict__ setof, const int32_t *__restrict__ loc,
+                                              const int32_t *__restrict__ vbidx, const DSet *__restrict__ sets,
+                                              const DScal *__restrict__ sc, const double *__restrict__ varBeta,
+                                              const double *__restrict__ mpm, const double *__restrict__ lhs0,
+                                              const double *__restrict__ rhs0, const double *__restrict__ beta,
+                                              double *__restrict__ c, double *__restrict__ w, double *__restrict__ q,
+                                              double *__restrict__ T, double *__restrict__ chi, int active_set, uint64_t seed,
+                                              uint64_t chain, uint64_t it) {
+    long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k >= Ppad) return;
+    int si = setof[k];
+    if (si < 0 || (active_set >= 0 && si != active_set)) {
+        c[k] = 0.0;
+        w[k] = 0.0;
+        q[k] = 0.0;
+        T[k] = 1.0;
+        chi[k] = 1.0;
+        return;
+    }
+    const DSet S = sets[si];
+    const double varE = sc->varE, iVarE = sc->iVarE;
+    const uint64_t l = (uint64_t)loc[k];
+    const uint64_t key = ((uint64_t)si << 40) | l;
+    double vbk = varBeta[vbidx[k]];
+    double m = mpm[k];
+    double t1 = m * iVarE;
+    double t2 = t1 + lhs0[k];
+    double ivb = 1.0 / vbk;
+    double lhs = t2 + ivb;
+    double ilhs = 1.0 / lhs;
+    double cc = iVarE * ilhs;
+    double s = det_sqrt(ilhs);
+    Rng r = rng_seed(seed, chain, it, NGP_KIND_BETA_NORMAL, key);
+    double z = rng_normal(r);
+    double sz = s * z;
+    double tw = rhs0[k] * ilhs;
+    tw = tw + sz;
+    c[k] = cc;
+    w[k] = tw - beta[k];
+    if (S.method == 1) {
+        double v0 = m * varE;
+        double m2 = m * m;
+        m2 = m2 * vbk;
+        double v1 = m2 + v0;
+        double i1 = 1.0 / v1, i0 = 1.0 / v0;
+        double dq = i1 - i0;
+        q[k] = 0.5 * dq;
+        Rng ru = rng_seed(seed, chain, it, NGP_KIND_B_UNIFORM, key);
+        double u = rng_uniform(ru);
+        double om = 1.0 - u;
+        double Lu = det_log(om) - det_log(u);
+        double dl = det_log(v1) - det_log(v0);
+        dl = 0.5 * dl;
+        double TT = Lu - dl;
+        double lp = S.logPi0 - S.logPi1;
+        T[k] = TT - lp;
+        Rng rc = rng_seed(seed, chain, it, NGP_KIND_B_LOCUS_CHI2, key);
+        chi[k] = rng_chisq(rc, S.df + 1.0);
+    } else {
+        q[k] = 0.0;
+        T[k] = 1.0;
+        chi[k] = 1.0;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// streaming step of block t: (U) ycorr -= X_{t-1} dlt_{t-1}  then  (G) partial r = X_t' ycorr.
+// grid = S shards, 256 threads; tile (t,s) = [64 columns][R rows] fp32, contiguous.
+// dynamic LDS: R*256 (tile) + R*8 (ycorr shard) + 2048 (wave partials)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_step(const float *__restrict__ tiles, double *__restrict__ ycorr,
+                                              const double *__restrict__ dlt, double *__restrict__ part, int R, int S, int t,
+                                              int do_upd, int do_gemv) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *tl = (float *)smem;
+    double *ys = (double *)(smem + (size_t)R * 256);
+    double *red = ys + R;
+    const int s = blockIdx.x, tid = threadIdx.x;
+    const size_t tile_elems = (size_t)R * NGP_BLK;
+    double *yg = ycorr + (size_t)s * R;
+    if (do_upd) {
+        const float *tp = tiles + ((size_t)(t - 1) * S + s) * tile_elems;
+        for (int i = tid; i < R; i += 256) {
+            double yv = yg[i];
+#pragma unroll 16
+            for (int j = 0; j < NGP_BLK; j++) yv = __builtin_fma(-(double)tp[(size_t)j * R + i], dlt[j], yv);
+            yg[i] = yv;
+            ys[i] = yv;
+        }
+    } else {
+        for (int i = tid; i < R; i += 256) ys[i] = yg[i];
+    }
+    if (!do_gemv) return;
+    const float4 *src = (const float4 *)(tiles + ((size_t)t * S + s) * tile_elems);
+    float4 *dst = (float4 *)tl;
+    for (int idx = tid; idx < R * 16; idx += 256) dst[idx] = src[idx];
+    __syncthreads();
+    const int wv = tid >> 6, j = tid & 63;
+    const float *col = tl + (size_t)j * R;
+    double acc = 0.0;
+    for (int qd = wv; qd < (R >> 2); qd += 4) {
+        float4 x = *(const float4 *)(col + 4 * qd);
+        const double *yq = ys + 4 * qd;
+        acc = __builtin_fma((double)x.x, yq[0], acc);
+        acc = __builtin_fma((double)x.y, yq[1], acc);
+        acc = __builtin_fma((double)x.z, yq[2], acc);
+        acc = __builtin_fma((double)x.w, yq[3], acc);
+    }
+    red[wv * 64 + j] = acc;
+    __syncthreads();
+    if (wv == 0) {
+        double p = ((red[j] + red[64 + j]) + red[128 + j]) + red[192 + j];
+        part[(size_t)s * NGP_BLK + j] = p;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// block recursion of block t: reduce the S shard partials (groups of 32, sequential), then
+// the 64-step serial chain on wave 0 with the Gram block in registers.  ONE workgroup.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_recur(const double *__restrict__ part, const double *__restrict__ gram, int S, int t,
+                                               double *__restrict__ beta, uint8_t *__restrict__ delta,
+                                               const double *__restrict__ c, const double *__restrict__ w,
+                                               const double *__restrict__ q, const double *__restrict__ T,
+                                               const double *__restrict__ chi, const int8_t *__restrict__ setof,
+                                               const int32_t *__restrict__ vbidx, DSet *__restrict__ sets,
+                                               double *__restrict__ varBeta, double *__restrict__ dlt) {
+    __shared__ double gs[32 * NGP_BLK];
+    const int tid = threadIdx.x, j = tid & 63, g4 = tid >> 6;
+    const int ngroups = (S + NGP_GRP - 1) / NGP_GRP;
+    for (int g = g4; g < ngroups; g += 4) {
+        int s0 = g * NGP_GRP, s1 = min(s0 + NGP_GRP, S);
+        double v = part[(size_t)s0 * NGP_BLK + j];
+        for (int s = s0 + 1; s < s1; s++) v = v + part[(size_t)s * NGP_BLK + j];
+        gs[g * NGP_BLK + j] = v;
+    }
+    __syncthreads();
+    if (g4 != 0) return;
+    double tot = gs[j];
+    for (int g = 1; g < ngroups; g++) tot = tot + gs[g * NGP_BLK + j];
+    const long long k = (long long)t * NGP_BLK + j;
+    const double *G = gram + (size_t)t * NGP_BLK * NGP_BLK;
+    double Gr[NGP_BLK];
+#pragma unroll
+    for (int kk = 0; kk < NGP_BLK; kk++) Gr[kk] = G[kk * NGP_BLK + j];
+    const double gd = G[j * NGP_BLK + j];
+    const double bo = beta[k], cc = c[k], ww = w[k], qq = q[k], TT = T[k];
+    double r = __builtin_fma(gd, bo, tot);
+    double dsave = 0.0;
+    int isave = 1;
+#pragma unroll
+    for (int kk = 0; kk < NGP_BLK; kk++) {
+        double r2 = r * r;
+        double lq = r2 * qq;
+        int in = lq < TT;
+        double d = __builtin_fma(r, cc, ww);
+        double dl = in ? d : -bo;
+        if (j == kk) {
+            dsave = dl;
+            isave = in;
+        }
+        double dk = readlane_d(dl, kk);
+        r = __builtin_fma(-Gr[kk], dk, r);
+    }
+    const double bn = bo + dsave;
+    beta[k] = bn;
+    delta[k] = (uint8_t)isave;
+    dlt[j] = dsave;
+    const int si = setof[k];
+    if (si >= 0 && sets[si].method == 1) {
+        double vb = 0.0;
+        if (isave) {
+            double tt = sets[si].sdf;
+            double b2 = bn * bn;
+            tt = tt + b2;
+            vb = tt / chi[k];
+            atomicAdd(&sets[si].nloci, 1);
+        }
+        varBeta[vbidx[k]] = vb;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// region variances of BayesPR sets (functions.jl:135, :509-511): 256-locus segment partials,
+// then one thread per region.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_regssq(long long nseg, const long long *__restrict__ seg_k0,
+                                                const int32_t *__restrict__ seg_len, const double *__restrict__ beta,
+                                                double *__restrict__ segpart) {
+    long long sg = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (sg >= nseg) return;
+    const double *b = beta + seg_k0[sg];
+    int n = seg_len[sg];
+    double p = 0.0;
+    for (int i = 0; i < n; i++) {
+        double v = b[i];
+        p = __builtin_fma(v, v, p);
+    }
+    segpart[sg] = p;
+}
+
+struct DReg {
+    long long seg0;
+    int nseg, set, rg, vb;
+    long long n;
+};
+
+__global__ __launch_bounds__(64) void k_regdraw(long long nreg, const DReg *__restrict__ regs, const double *__restrict__ segpart,
+                                                const DSet *__restrict__ sets, double *__restrict__ varBeta, int active_set,
+                                                uint64_t seed, uint64_t chain, uint64_t it) {
+    long long rg = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (rg >= nreg) return;
+    const DReg R = regs[rg];
+    if (active_set >= 0 && R.set != active_set) return;
+    double tot = segpart[R.seg0];
+    for (int s = 1; s < R.nseg; s++) tot = tot + segpart[R.seg0 + s];
+    const DSet S = sets[R.set];
+    Rng r = rng_seed(seed, chain, it, NGP_KIND_REGION_CHI2, ((uint64_t)R.set << 40) | (uint64_t)R.rg);
+    double ch = rng_chisq(r, S.df + (double)R.n);
+    double tt = S.scale * S.df;
+    tt = tt + tot;
+    varBeta[R.vb] = tt / ch;
+}
+
+// pi draw of BayesB sets (functions.jl:190-194, :531-533); also clears the inclusion counters
+__global__ void k_pidraw(int nsets, DSet *__restrict__ sets, int active_set, uint64_t seed, uint64_t chain, uint64_t it) {
+    int si = threadIdx.x;
+    if (si >= nsets) return;
+    if (active_set >= 0 && si != active_set) return;
+    DSet *S = &sets[si];
+    if (S->method == 1 && S->estPi) {
+        int nLoci = S->nloci;
+        Rng r = rng_seed(seed, chain, it, NGP_KIND_PI_BETA, (uint64_t)si);
+        double piIn = rng_beta(r, (double)nLoci + 1.0, (double)(S->ncol - nLoci) + 1.0);
+        S->piHat0 = 1.0 - piIn;
+        S->piHat1 = piIn;
+        S->logPi0 = det_log(S->piHat0);
+        S->logPi1 = det_log(piIn);
+    }
+    S->nloci = 0;
+}
+
+__global__ void k_set_pi(DSet *__restrict__ sets, int si, double p0, double p1) {
+    sets[si].piHat0 = p0;
+    sets[si].piHat1 = p1;
+    sets[si].logPi0 = det_log(p0);
+    sets[si].logPi1 = det_log(p1);
+    sets[si].nloci = 0;
+}
+__global__ void k_set_varE(DScal *__restrict__ sc, double varE) {
+    sc->varE = varE;
+    sc->iVarE = 1.0 / varE;
+}
+
+// posterior sums of a kept iteration (samplers.jl:56-103 writes rows; misc.jl:241-244 averages)
+__global__ __launch_bounds__(256) void k_accum(long long P, long long nvb, int nsets, const double *__restrict__ beta,
+                                               const uint8_t *__restrict__ delta, const double *__restrict__ varBeta,
+                                               double *__restrict__ sum_beta, double *__restrict__ sum_beta2,
+                                               double *__restrict__ sum_delta, double *__restrict__ sum_varBeta,
+                                               DSet *__restrict__ sets, DScal *__restrict__ sc) {
+    long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k < P) {
+        double b = beta[k];
+        sum_beta[k] += b;
+        sum_beta2[k] += b * b;
+        sum_delta[k] += (double)delta[k];
+    }
+    if (k < nvb) sum_varBeta[k] += varBeta[k];
+    if (k < nsets) {
+        sets[k].sum_pi0 += sets[k].piHat0;
+        sets[k].sum_pi1 += sets[k].piHat1;
+    }
+    if (k == 0) {
+        sc->sum_varE += sc->varE;
+        sc->sum_b += sc->b;
+        sc->nKept += 1;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// set-up kernels: Gram blocks, synthetic panel, X*beta
+// ------------------------------------------------------------------------------------------
+// shard partial of X_t'X_t: 256 threads, thread (tk,tj) owns the 4x4 sub-block; rows ascending
+__global__ __launch_bounds__(256) void k_gram_part(const float *__restrict__ tiles, double *__restrict__ gpart, int R, int S, int t0) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    float *tl = (float *)smem;
+    const int s = blockIdx.x, tb = blockIdx.y, tid = threadIdx.x;
+    const size_t tile_elems = (size_t)R * NGP_BLK;
+    const float4 *src = (const float4 *)(tiles + ((size_t)(t0 + tb) * S + s) * tile_elems);
+    float4 *dst = (float4 *)tl;
+    for (int idx = tid; idx < R * 16; idx += 256) dst[idx] = src[idx];
+    __syncthreads();
+    const int tk = tid >> 4, tj = tid & 15;
+    double acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = 0.0;
+    for (int i = 0; i < R; i += 4) {
+        float4 xk[4], xj[4];
+#pragma unroll
+        for (int a = 0; a < 4; a++) {
+            xk[a] = *(const float4 *)(tl + (size_t)(4 * tk + a) * R + i);
+            xj[a] = *(const float4 *)(tl + (size_t)(4 * tj + a) * R + i);
+        }
+#pragma unroll
+        for (int a = 0; a < 4; a++)
+#pragma unroll
+            for (int b = 0; b < 4; b++) {
+                acc[a][b] = __builtin_fma((double)xk[a].x, (double)xj[b].x, acc[a][b]);
+                acc[a][b] = __builtin_fma((double)xk[a].y, (double)xj[b].y, acc[a][b]);
+                acc[a][b] = __builtin_fma((double)xk[a].z, (double)xj[b].z, acc[a][b]);
+                acc[a][b] = __builtin_fma((double)xk[a].w, (double)xj[b].w, acc[a][b]);
+            }
+    }
+    double *out = gpart + ((size_t)tb * S + s) * (NGP_BLK * NGP_BLK);
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) out[(4 * tk + a) * NGP_BLK + 4 * tj + b] = acc[a][b];
+}
+
+__global__ __launch_bounds__(256) void k_gram_reduce(const double *__restrict__ gpart, double *__restrict__ gram,
+                                                     double *__restrict__ mpm, int S, int t0, int nb) {
+    long long e = (long long)blockIdx.x * 256 + threadIdx.x;  // (tb, k, j)
+    if (e >= (long long)nb * NGP_BLK * NGP_BLK) return;
+    int tb = (int)(e / (NGP_BLK * NGP_BLK)), kj = (int)(e % (NGP_BLK * NGP_BLK));
+    const double *p = gpart + (size_t)tb * S * (NGP_BLK * NGP_BLK) + kj;
+    const int ngroups = (S + NGP_GRP - 1) / NGP_GRP;
+    double tot = 0.0;
+    for (int g = 0; g < ngroups; g++) {
+        int s0 = g * NGP_GRP, s1 = min(s0 + NGP_GRP, S);
+        double v = p[(size_t)s0 * (NGP_BLK * NGP_BLK)];
+        for (int s = s0 + 1; s < s1; s++) v = v + p[(size_t)s * (NGP_BLK * NGP_BLK)];
+        tot = (g == 0) ? v : tot + v;
+    }
+    gram[(size_t)(t0 + tb) * (NGP_BLK * NGP_BLK) + kj] = tot;
+    int k = kj / NGP_BLK, j = kj % NGP_BLK;
+    if (k == j) mpm[(size_t)(t0 + tb) * NGP_BLK + k] = tot;
+}
+
+// synthetic genotypes: per-column mean of g_ij (integer sum), then centred fp32 tiles
+__global__ __launch_bounds__(256) void k_gen_colmean(long long N, long long P, double lo, double hi, uint64_t pseed,
+                                                     double *__restrict__ mu, uint32_t *__restrict__ thr) {
+    __shared__ int wsum[4];
+    const long long j = blockIdx.x;
+    const int tid = threadIdx.x;
+    double pj = panel_pj(pseed, j, lo, hi);
+    uint32_t th = (uint32_t)(pj * 4294967296.0);
+    uint64_t ck = panel_colkey(pseed, j);
+    int sum = 0;
+    for (long long i = tid; i < N; i += 256) sum += panel_gij(ck, i, th);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    if ((tid & 63) == 0) wsum[tid >> 6] = sum;
+    __syncthreads();
+    if (tid == 0) {
+        long long tot = (long long)wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        mu[j] = (double)tot / (double)N;
+        thr[j] = th;
+    }
+}
+__global__ __launch_bounds__(256) void k_gen_fill(float *__restrict__ tiles, long long N, long long P, int R, int S, uint64_t pseed,
+                                                  const double *__restrict__ mu, const uint32_t *__restrict__ thr) {
+    const int s = blockIdx.x;
+    const long long t = blockIdx.y;
+    float *tp = tiles + ((size_t)t * S + s) * ((size_t)R * NGP_BLK);
+    for (int idx = threadIdx.x; idx < R * NGP_BLK; idx += 256) {
+        int jj = idx / R, ii = idx - jj * R;
+        long long i = (long long)s * R + ii, j = t * NGP_BLK + jj;
+        float v = 0.0f;
+        if (i < N && j < P) {
+            int g = panel_gij(panel_colkey(pseed, j), i, thr[j]);
+            v = (float)((double)g - mu[j]);
+        }
+        tp[idx] = v;
+    }
+}
+
+// out_i = sum_k x_ik beta_k, k ascending (utility, not on the hot path)
+__global__ __launch_bounds__(256) void k_xbeta(const float *__restrict__ tiles, const double *__restrict__ beta,
+                                               double *__restrict__ out, int R, int S, long long NBLK) {
+    const int s = blockIdx.x;
+    for (int i = threadIdx.x; i < R; i += 256) {
+        double acc = 0.0;
+        for (long long t = 0; t < NBLK; t++) {
+            const float *tp = tiles + ((size_t)t * S + s) * ((size_t)R * NGP_BLK);
+            for (int j = 0; j < NGP_BLK; j++) acc = __builtin_fma((double)tp[(size_t)j * R + i], beta[t * NGP_BLK + j], acc);
+        }
+        out[(size_t)s * R + i] = acc;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// probes
+// ------------------------------------------------------------------------------------------
+__global__ void k_draws_indexed(uint64_t seed, uint64_t chain, uint64_t it, uint64_t kind, uint64_t index0, int what, double p1,
+                                double p2, long long n, double *__restrict__ out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Rng r = rng_seed(seed, chain, it, kind, index0 + (uint64_t)i);
+    double v;
+    switch (what) {
+        case 0: v = rng_uniform(r); break;
+        case 1: v = rng_normal(r); break;
+        case 2: v = rng_chisq(r, p1); break;
+        case 3: v = rng_beta(r, p1, p2); break;
+        default: v = rng_gamma(r, p1); break;
+    }
+    out[i] = v;
+}
+__global__ void k_eval_math(int which, const double *__restrict__ in, long long n, double *__restrict__ out) {
+    long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    double x = in[i];
+    double v;
+    switch (which) {
+        case 0: v = det_log(x); break;
+        case 1: v = ppnd16(x); break;
+        case 2: v = det_sqrt(x); break;
+        default: v = 1.0 / x; break;
+    }
+    out[i] = v;
+}
+
+}  // namespace ngp

@@ -1,0 +1,64 @@
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+@pytest.fixture(scope="session")
+def O():
+    from oracle import oracle
+    oracle.build()
+    return oracle
+
+
+@pytest.fixture(scope="session")
+def ngp():
+    from ngp_pkg import load_pkg
+    return load_pkg()
+
+
+def make_problem(O, N, P, seed=1, ncausal=10, h2=0.5, panel_seed=20250509):
+    """Synthetic panel + phenotype as BASELINE.md section 4 describes (small sizes)."""
+    X, mu = O.generate_panel(N, P, seed=panel_seed)
+    rng = np.random.default_rng(seed)
+    bt = np.zeros(P)
+    idx = rng.choice(P, min(ncausal, P), replace=False)
+    bt[idx] = rng.normal(size=len(idx))
+    g = X.astype(np.float64) @ bt
+    vg = g.var() if g.var() > 0 else 1.0
+    e = rng.normal(size=N) * np.sqrt(vg * (1 - h2) / h2)
+    y = 10.0 + g + e
+    twopq = float((2 * mu / 2 * (1 - mu / 2)).sum())
+    v = 0.5 * y.var() / max(twopq, 1e-9)
+    return X, y, bt, v
+
+
+def add_sets(m, spec, v):
+    """spec: list of (col0, ncol, 'PR'|'B'|'PR1'|('PRw', width)); same calls on oracle and product."""
+    df = 4.0
+    for col0, ncol, kind in spec:
+        if kind == "PR":
+            m.add_marker_set(col0, ncol, 0, df, v * (df - 2) / df, [(0, ncol)], [v])
+        elif kind == "PR1":
+            m.add_marker_set(col0, ncol, 0, df, v * (df - 2) / df, [(j, j + 1) for j in range(ncol)], [v] * ncol)
+        elif isinstance(kind, tuple) and kind[0] == "PRw":
+            w = kind[1]
+            regs = [(a, min(a + w, ncol)) for a in range(0, ncol, w)]
+            m.add_marker_set(col0, ncol, 0, df, v * (df - 2) / df, regs, [v] * len(regs))
+        elif kind == "B":
+            m.add_marker_set(col0, ncol, 1, df, v * (df - 2) / df, [(j, j + 1) for j in range(ncol)], [v] * ncol, pi0=0.05,
+                             estPi=True)
+        elif kind == "Bfix":
+            m.add_marker_set(col0, ncol, 1, df, v * (df - 2) / df, [(j, j + 1) for j in range(ncol)], [v] * ncol, pi0=0.2,
+                             estPi=False)
+        else:
+            raise ValueError(kind)

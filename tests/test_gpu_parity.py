@@ -1,0 +1,186 @@
+"""GPU parity tests proper: the HIP path, called through the C ABI, against the CPU oracle.
+
+Bar (north_star): bit-exact for indices / indicators; floating point: bit-exact against the
+blocked-order oracle (same summation trees), and |diff| <= 1e-9 * scale against the
+reference-order oracle (different summation order of the same chain)."""
+import numpy as np
+import pytest
+
+from conftest import add_sets, make_problem
+
+pytestmark = pytest.mark.gpu
+
+KINDS = dict(VARE_CHI2=1, FIXED_NORMAL=2, BETA_NORMAL=3, REGION_CHI2=4, B_UNIFORM=5, B_LOCUS_CHI2=6, PI_BETA=7)
+
+
+@pytest.fixture(scope="module")
+def dev(ngp):
+    return ngp.Sampler(device=0, seed=1234, chain=3)
+
+
+def test_math_bit_exact(dev, O):
+    rng = np.random.default_rng(0)
+    x = np.concatenate([10.0 ** rng.uniform(-300, 300, 20000), rng.uniform(0.5, 2.0, 20000), [1.0, 2.0, 0.5, 1e-310]])
+    got = dev.eval_math(0, x)
+    exp = np.array([O.det_log(v) for v in x])
+    assert np.array_equal(got, exp)
+    p = np.concatenate([rng.uniform(0, 1, 40000), [1e-300, 1e-20, 0.075, 0.925, 0.5, 1 - 2.0 ** -53]])
+    assert np.array_equal(dev.eval_math(1, p), np.array([O.ppnd16(v) for v in p]))
+    assert np.array_equal(dev.eval_math(2, x), np.sqrt(x))        # IEEE sqrt
+    assert np.array_equal(dev.eval_math(3, x), 1.0 / x)           # IEEE divide
+
+
+@pytest.mark.parametrize("what,p1,p2", [(0, 0, 0), (1, 0, 0), (2, 5.0, 0), (2, 10004.0, 0), (3, 3.0, 98.0), (4, 1.0, 0)])
+def test_draws_bit_exact(dev, O, what, p1, p2):
+    n = 5000
+    got = dev.draws_indexed(17, KINDS["BETA_NORMAL"], (2 << 40) | 5, what, n, p1, p2)
+    exp = O.draws(1234, 3, 17, KINDS["BETA_NORMAL"], (2 << 40) | 5, what, n, p1, p2, indexed=True)
+    assert np.array_equal(got, exp)
+
+
+def _pair(ngp, O, X, seed=1001, chain=0):
+    s = ngp.Sampler(device=0, seed=seed, chain=chain)
+    s.set_panel(X)
+    R, S, nblk = s.layout()
+    o = O.Oracle(order=1, seed=seed, chain=chain)
+    o.set_panel_f32(X, R=R, S=S)
+    return s, o
+
+
+def test_gram_and_mpm(ngp, O):
+    X, y, bt, v = make_problem(O, 333, 150)
+    s, o = _pair(ngp, O, X)
+    for t in range(3):
+        assert np.array_equal(s.gram(t), o.get_gram(t))
+    G = X.astype(np.float64).T @ X.astype(np.float64)
+    assert np.allclose(s.mpm(), np.diag(G), rtol=1e-12)
+    b = np.random.default_rng(1).normal(size=150)
+    assert np.allclose(s.xbeta(b), X.astype(np.float64) @ b, rtol=1e-11, atol=1e-11)
+
+
+def test_generated_panel_matches_oracle(ngp, O):
+    N, P = 517, 130
+    X, mu = O.generate_panel(N, P, seed=99)
+    s = ngp.Sampler(device=0, seed=1, chain=0)
+    s.generate_panel(N, P, seed=99)
+    # X*e_j recovers column j exactly (single non-zero term)
+    for j in (0, 63, 64, 129):
+        e = np.zeros(P); e[j] = 1.0
+        assert np.array_equal(s.xbeta(e), X[:, j].astype(np.float64))
+
+
+CASES = [
+    ("pr_single", 500, 1000, [(0, 1000, "PR")]),
+    ("pr_ragged", 257, 130, [(0, 130, "PR")]),                 # P not a multiple of 64, N not of R
+    ("pr_regions", 300, 200, [(0, 200, ("PRw", 37))]),
+    ("pr_r1", 200, 100, [(0, 100, "PR1")]),                    # BayesA-like, one region per SNP
+    ("b_single", 500, 600, [(0, 600, "B")]),
+    ("b_fixpi", 300, 128, [(0, 128, "Bfix")]),
+    ("multi", 400, 450, [(0, 150, "PR"), (150, 170, "B"), (320, 130, "PR")]),   # sets straddle 64-blocks
+    ("tiny", 7, 3, [(0, 3, "PR")]),
+]
+
+
+@pytest.mark.parametrize("name,N,P,spec", CASES, ids=[c[0] for c in CASES])
+def test_chain_bit_exact_vs_blocked_oracle(ngp, O, name, N, P, spec):
+    X, y, bt, v = make_problem(O, N, P, seed=5)
+    s, o = _pair(ngp, O, X)
+    niter = 12
+    for m in (s, o):
+        add_sets(m, spec, v)
+        m.set_y(y)
+        m.set_residual_prior(4.0, 0.5 * y.var() * 0.5)
+        m.set_schedule(niter, 4, 2)
+        m.run(niter)
+    a, b = s.get_state(), o.get_state()
+    assert np.array_equal(a["delta"], b["delta"])
+    for k in ("ycorr", "beta", "varBeta", "piHat"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["varE"] == b["varE"] and a["b"] == b["b"] and a["iter"] == b["iter"] == niter
+    ta, tb = s.get_trace(niter), o.get_trace(niter)
+    assert np.array_equal(ta["varE"], tb["varE"]) and np.array_equal(ta["b"], tb["b"])
+    pa, pb = s.get_posterior_sums(), o.get_posterior_sums()
+    assert pa["nKept"] == pb["nKept"] == 4
+    for k in ("sum_beta", "sum_beta2", "sum_delta", "sum_varBeta", "sum_pi"):
+        assert np.array_equal(pa[k], pb[k]), k
+    assert pa["sum_varE"] == pb["sum_varE"] and pa["sum_b"] == pb["sum_b"]
+    # self-consistency: ycorr == y - 1 b - X beta recomputed from scratch
+    resid = y - a["b"] - s.xbeta(a["beta"])
+    assert np.abs(a["ycorr"] - resid).max() <= 1e-10 * max(1.0, np.abs(y).max())
+
+
+@pytest.mark.parametrize("kind", ["PR", "B"])
+def test_chain_vs_reference_order_oracle(ngp, O, kind):
+    """Same Markov chain, reference summation order: indicators identical, floats within 1e-9 relative."""
+    N, P = 500, 1000
+    X, y, bt, v = make_problem(O, N, P, seed=9)
+    s = ngp.Sampler(device=0, seed=77, chain=1)
+    s.set_panel(X)
+    o = O.Oracle(order=0, seed=77, chain=1)
+    o.set_panel_f32(X)
+    for m in (s, o):
+        add_sets(m, [(0, P, kind)], v)
+        m.set_y(y); m.set_residual_prior(4.0, 0.25 * y.var()); m.set_schedule(30, 10, 5); m.run(30)
+    a, b = s.get_state(), o.get_state()
+    assert np.array_equal(a["delta"], b["delta"])
+    tol = 1e-9
+    assert np.abs(a["beta"] - b["beta"]).max() <= tol * max(1e-3, np.abs(b["beta"]).max())
+    assert np.abs(a["ycorr"] - b["ycorr"]).max() <= tol * np.abs(b["ycorr"]).max()
+    assert abs(a["varE"] - b["varE"]) <= tol * b["varE"]
+    assert np.abs(a["varBeta"] - b["varBeta"]).max() <= tol * max(1e-12, np.abs(b["varBeta"]).max())
+    pa, pb = s.get_posterior_sums(), o.get_posterior_sums()
+    assert pa["nKept"] == pb["nKept"]
+    assert np.abs(pa["sum_beta"] - pb["sum_beta"]).max() <= tol * max(1e-3, np.abs(pb["sum_beta"]).max())
+
+
+def test_fine_seam_matches_coarse(ngp, O):
+    """ngp_sweep_set driven by host-side varE/intercept == the blocked oracle's set sweep on the same state."""
+    N, P = 300, 192
+    X, y, bt, v = make_problem(O, N, P, seed=2)
+    s = ngp.Sampler(device=0, seed=5, chain=0)
+    s.set_panel(X)
+    add_sets(s, [(0, P, "PR")], v)
+    ycorr = y - y.mean()
+    beta = np.zeros(P); vb = np.array([v])
+    for it in range(3):
+        d = s.sweep_set(0, 1.3, ycorr, beta, vb)
+        assert d.min() == 1 and np.isfinite(beta).all() and vb[0] > 0
+        resid = (y - y.mean()) - s.xbeta(beta)
+        assert np.abs(ycorr - resid).max() < 1e-10
+
+
+def test_resume_state_roundtrip(ngp, O):
+    N, P = 200, 128
+    X, y, bt, v = make_problem(O, N, P, seed=4)
+    runs = []
+    for split in (None, 5):
+        s = ngp.Sampler(device=0, seed=3, chain=0)
+        s.set_panel(X); add_sets(s, [(0, P, "B")], v); s.set_y(y); s.set_residual_prior(4.0, 1.0); s.set_schedule(0, 0, 1)
+        if split is None:
+            s.run(10)
+        else:
+            s.run(split)
+            st = s.get_state()
+            s2 = ngp.Sampler(device=0, seed=3, chain=0)
+            s2.set_panel(X); add_sets(s2, [(0, P, "B")], v); s2.set_y(y); s2.set_residual_prior(4.0, 1.0)
+            s2.set_state(st)
+            s2.run(10 - split)
+            s = s2
+        runs.append(s.get_state())
+    for k in ("ycorr", "beta", "delta", "varBeta", "piHat"):
+        assert np.array_equal(runs[0][k], runs[1][k]), k
+
+
+def test_errors_are_reported_not_thrown(ngp):
+    s = ngp.Sampler(device=0, seed=1, chain=0)
+    with pytest.raises(ngp.NextGPHipError, match="panel not set"):
+        s.set_y(np.zeros(3))
+    s.set_panel(np.zeros((4, 2), dtype=np.float32))
+    with pytest.raises(ngp.NextGPHipError, match="N entries"):
+        s.set_y(np.zeros(3))
+    with pytest.raises(ngp.NextGPHipError, match="non-finite"):
+        s.set_y(np.array([0.0, np.nan, 0.0, 0.0]))
+    with pytest.raises(ngp.NextGPHipError, match="outside the panel"):
+        s.add_marker_set(0, 5, 0, 4.0, 0.1, [(0, 5)], [0.1])
+    with pytest.raises(ngp.NextGPHipError, match="no marker set"):
+        s.set_y(np.zeros(4)); s.run(1)
