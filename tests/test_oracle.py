@@ -1,0 +1,177 @@
+"""CPU tests of the oracle itself (no GPU): draw layer against scipy, closed forms, the two
+orderings of the chain against each other, committed golden vectors."""
+import math
+import os
+
+import numpy as np
+import pytest
+from scipy import stats
+
+from conftest import add_sets, make_problem
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def test_det_log_within_one_ulp(O):
+    rng = np.random.default_rng(0)
+    xs = np.concatenate([10.0 ** rng.uniform(-300, 300, 5000), rng.uniform(0.5, 2.0, 5000), [1.0, 2.0, 4.9e-324, 1e-310]])
+    for x in xs:
+        ref = math.log(x)
+        assert abs(O.det_log(x) - ref) <= 1.01 * np.spacing(abs(ref)) + 1e-323
+    assert O.det_log(1.0) == 0.0 and O.det_log(0.0) == -math.inf and math.isnan(O.det_log(-1.0))
+
+
+def test_ppnd16_matches_scipy(O):
+    ps = np.concatenate([np.random.default_rng(1).uniform(0, 1, 5000), [1e-300, 1e-20, 0.075, 0.0749, 0.925, 0.5, 1 - 1e-16]])
+    for p in ps:
+        ref = stats.norm.ppf(p)
+        assert abs(O.ppnd16(p) - ref) <= 2e-15 * max(1.0, abs(ref))
+    assert O.ppnd16(0.5) == 0.0
+
+
+def test_streams_are_keyed_and_reproducible(O):
+    a = O.draws(5, 1, 9, 3, 77, 1, 100)
+    assert np.array_equal(a, O.draws(5, 1, 9, 3, 77, 1, 100))
+    for other in [(6, 1, 9, 3, 77), (5, 2, 9, 3, 77), (5, 1, 10, 3, 77), (5, 1, 9, 4, 77), (5, 1, 9, 3, 78)]:
+        assert not np.array_equal(a, O.draws(*other, 1, 100))
+    # first draw of consecutive indices: no serial correlation
+    z = O.draws(5, 1, 9, 3, 0, 1, 50000, indexed=True)
+    assert abs(np.corrcoef(z[:-1], z[1:])[0, 1]) < 0.02 and abs(z.mean()) < 0.02 and abs(z.var() - 1) < 0.03
+    u = O.draws(5, 1, 9, 5, 0, 0, 50000, indexed=True)
+    assert 0.0 < u.min() and u.max() < 1.0
+
+
+@pytest.mark.parametrize("what,p1,p2,dist,args", [
+    (0, 0, 0, "uniform", ()), (1, 0, 0, "norm", ()), (2, 5.0, 0, "chi2", (5.0,)), (2, 10004.0, 0, "chi2", (10004.0,)),
+    (3, 3.0, 98.0, "beta", (3.0, 98.0)), (4, 1.0, 0, "gamma", (1.0,)), (4, 2.5, 0, "gamma", (2.5,))])
+def test_draw_distributions(O, what, p1, p2, dist, args):
+    x = O.draws(11, 0, 1, 1, 0, what, 40000, p1, p2)
+    assert stats.kstest(x, dist, args=args).pvalue > 1e-3
+
+
+def test_panel_generator(O):
+    X, mu = O.generate_panel(400, 50, seed=3)
+    assert X.dtype == np.float32 and X.shape == (400, 50)
+    raw = X.astype(np.float64) + mu
+    assert np.abs(raw - np.rint(raw)).max() < 1e-6 and set(np.unique(np.rint(raw))) <= {0.0, 1.0, 2.0}
+    assert np.abs(X.astype(np.float64).sum(axis=0)).max() < 1e-3      # centred
+    assert 0.02 <= mu.min() and mu.max() <= 1.15                      # sample mean of 2p, p in [0.05, 0.5]
+    X2, _ = O.generate_panel(400, 50, seed=3)
+    assert np.array_equal(X, X2)
+
+
+def test_single_snp_conjugate_posterior(O):
+    """One SNP, variances effectively fixed: beta | rest ~ N(x'y/(x'x+varE/varB), varE/(x'x+varE/varB))."""
+    N = 50
+    rng = np.random.default_rng(0)
+    x = rng.normal(size=(N, 1)).astype(np.float32)
+    x -= x.mean()
+    y = 0.7 * x[:, 0].astype(np.float64) + rng.normal(size=N)
+    big = 1e12  # huge prior df pins varE and varBeta at their scales
+    varE, varB = 1.3, 0.4
+    means = []
+    for chain in range(400):
+        o = O.Oracle(0, seed=2, chain=chain)
+        o.set_panel_f32(x)
+        o.add_marker_set(0, 1, 0, big, varB, [(0, 1)], [varB])
+        o.set_y(y); o.set_intercept(False); o.set_residual_prior(big, varE); o.run(1)
+        means.append(o.get_state()["beta"][0])
+    xx = float((x.astype(np.float64) ** 2).sum()); xy = float(x[:, 0].astype(np.float64) @ y)
+    lhs = xx + varE / varB
+    m, sd = xy / lhs, math.sqrt(varE / lhs)
+    assert abs(np.mean(means) - m) < 4 * sd / math.sqrt(400)
+    assert abs(np.std(means) - sd) < 0.15 * sd
+
+
+def test_ridge_limit(O):
+    """Variances pinned: the long-run mean of beta is the ridge / BLUP solution (X'X + lambda I)^-1 X'y."""
+    N, P = 120, 30
+    X, y, bt, v = make_problem(O, N, P, seed=3)
+    big, varE, varB = 1e12, 1.0, 0.05
+    o = O.Oracle(0, seed=8, chain=0)
+    o.set_panel_f32(X)
+    o.add_marker_set(0, P, 0, big, varB, [(0, P)], [varB])
+    o.set_y(y); o.set_residual_prior(big, varE); o.set_schedule(4000, 500, 1); o.run(4000)
+    ps = o.get_posterior_sums()
+    Xd = X.astype(np.float64)
+    yc = y - y.mean()
+    ridge = np.linalg.solve(Xd.T @ Xd + (varE / varB) * np.eye(P), Xd.T @ yc)
+    mean = ps["sum_beta"] / ps["nKept"]
+    sd = np.sqrt(np.maximum(ps["sum_beta2"] / ps["nKept"] - mean ** 2, 1e-12))
+    assert ps["nKept"] == 3500
+    assert np.abs(mean - ridge).max() < 6 * sd.max() / math.sqrt(3500 / 10)   # autocorrelation allowance
+    assert abs(ps["sum_b"] / ps["nKept"] - y.mean()) < 0.05
+
+
+@pytest.mark.parametrize("spec", [[(0, 300, "PR")], [(0, 300, "B")], [(0, 100, "PR"), (100, 120, "B"), (220, 80, ("PRw", 17))]],
+                         ids=["PR", "B", "multi"])
+def test_blocked_order_equals_reference_order(O, spec):
+    N, P = 257, 300
+    X, y, bt, v = make_problem(O, N, P, seed=6)
+    a = O.Oracle(0, seed=42, chain=1); a.set_panel_f32(X)
+    b = O.Oracle(1, seed=42, chain=1); b.set_panel_f32(X, R=12, S=22)
+    for m in (a, b):
+        add_sets(m, spec, v); m.set_y(y); m.set_residual_prior(4.0, 0.25 * y.var()); m.set_schedule(40, 10, 3); m.run(40)
+    sa, sb = a.get_state(), b.get_state()
+    assert np.array_equal(sa["delta"], sb["delta"])                      # bit-exact indicators
+    for k in ("beta", "ycorr", "varBeta", "piHat"):
+        assert np.abs(sa[k] - sb[k]).max() <= 1e-10 * max(1e-3, np.abs(sa[k]).max()), k
+    assert abs(sa["varE"] - sb["varE"]) <= 1e-10 * sa["varE"]
+    # residual invariant of both
+    for s in (sa, sb):
+        assert np.abs(s["ycorr"] - (y - s["b"] - X.astype(np.float64) @ s["beta"])).max() < 1e-10
+    assert a.get_posterior_sums()["nKept"] == b.get_posterior_sums()["nKept"] == 10
+
+
+def test_layout_independence_of_blocked_order(O):
+    """Different shard layouts change only the summation tree: results agree to rounding, indicators exactly."""
+    N, P = 200, 128
+    X, y, bt, v = make_problem(O, N, P, seed=7)
+    out = []
+    for R, S in ((4, 50), (20, 10), (200, 1)):
+        o = O.Oracle(1, seed=3, chain=0); o.set_panel_f32(X, R=R, S=S)
+        add_sets(o, [(0, P, "B")], v); o.set_y(y); o.set_residual_prior(4.0, 1.0); o.run(15)
+        out.append(o.get_state())
+    for s in out[1:]:
+        assert np.array_equal(s["delta"], out[0]["delta"])
+        assert np.abs(s["beta"] - out[0]["beta"]).max() < 1e-11
+
+
+def test_bayesb_quirk_excluded_locus_has_zero_variance(O):
+    """functions.jl:184-186: an excluded locus gets beta = 0, delta = 0, varBeta = 0."""
+    N, P = 150, 64
+    X, y, bt, v = make_problem(O, N, P, seed=8)
+    for order, kw in ((0, {}), (1, dict(R=4, S=38))):
+        o = O.Oracle(order, seed=5, chain=0); o.set_panel_f32(X, **kw)
+        add_sets(o, [(0, P, "Bfix")], v); o.set_y(y); o.set_residual_prior(4.0, 1.0); o.run(8)
+        s = o.get_state()
+        out = s["delta"] == 0
+        assert out.any() and (~out).any()
+        assert np.all(s["beta"][out] == 0.0) and np.all(s["varBeta"][out] == 0.0) and np.all(s["varBeta"][~out] > 0.0)
+
+
+def test_schedule_keeps_reference_iterations(O):
+    """samplers.jl:26: kept = (burnIn+thin):thin:chainLength."""
+    X, y, bt, v = make_problem(O, 40, 8, seed=1)
+    o = O.Oracle(0, seed=1, chain=0); o.set_panel_f32(X); add_sets(o, [(0, 8, "PR")], v); o.set_y(y)
+    o.set_schedule(23, 5, 4); o.run(30)
+    assert o.get_posterior_sums()["nKept"] == len(range(5 + 4, 23 + 1, 4))
+
+
+@pytest.mark.parametrize("name", ["pr_50x200", "b_50x200"])
+def test_golden_vectors(O, name):
+    """Committed fixtures generated by tests/golden/make_golden.py from the reference-order oracle."""
+    g = np.load(os.path.join(GOLD, name + ".npz"))
+    X = np.asfortranarray(g["X"])
+    for order, kw, tol in ((0, {}, 0.0), (1, dict(R=4, S=13), 1e-11)):
+        o = O.Oracle(order, seed=int(g["seed"]), chain=int(g["chain"])); o.set_panel_f32(X, **kw)
+        kind = "PR" if name.startswith("pr") else "B"
+        add_sets(o, [(0, X.shape[1], kind)], float(g["v"])); o.set_y(g["y"]); o.set_residual_prior(4.0, float(g["e_scale"]))
+        done = 0
+        for it in (1, 2, 10):
+            o.run(it - done); done = it
+            s = o.get_state()
+            assert np.array_equal(s["delta"], g[f"delta_{it}"])
+            assert np.abs(s["beta"] - g[f"beta_{it}"]).max() <= tol * max(1.0, np.abs(g[f"beta_{it}"]).max())
+            assert abs(s["varE"] - float(g[f"varE_{it}"])) <= tol * float(g[f"varE_{it}"])
+            assert np.abs(s["varBeta"] - g[f"varBeta_{it}"]).max() <= tol * max(1e-9, np.abs(g[f"varBeta_{it}"]).max())
