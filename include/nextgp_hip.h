@@ -47,6 +47,13 @@ int32_t ngp_destroy(ngp_handle *h);
 /* Message of the last failing call on h (h == NULL: last failing ngp_create). Valid until the next call. */
 const char *ngp_last_error(ngp_handle *h);
 
+/* Sweep engine, to be chosen BEFORE the panel is set (it fixes the tiling and the Gram window):
+ * mode 1 (default) = one persistent kernel per iteration with look-ahead `lag` (1..8 blocks of 64 SNPs),
+ * mode 0 = one streaming + one recursion launch per 64-SNP block (lag 1).  Both replace the same
+ * reference loop (src/functions.jl:124-136) and draw the same chain; only summation order differs. */
+int32_t ngp_configure(ngp_handle *h, int32_t mode, int32_t lag);
+int32_t ngp_get_config(ngp_handle *h, int32_t *mode, int32_t *lag);
+
 /* Marker panel, N individuals x P SNPs, column-major with leading dimension ld >= N
  * (replaces M[set][:data] + the M[set][:Mp] copy, src/prepMatVec.jl:116-131, src/mme.jl:305-311).
  * centre != 0: subtract the column mean first (src/prepMatVec.jl:129).  Stored as fp32, re-tiled. */

@@ -20,7 +20,7 @@ SYMBOLS = [
     "ngp_generate_panel", "ngp_get_layout", "ngp_get_mpm", "ngp_get_gram", "ngp_xbeta", "ngp_add_marker_set", "ngp_set_y",
     "ngp_set_residual_prior", "ngp_set_intercept", "ngp_set_schedule", "ngp_run", "ngp_get_state", "ngp_set_state",
     "ngp_get_trace", "ngp_get_posterior_sums", "ngp_posterior_len", "ngp_export_posterior_device", "ngp_sweep_set",
-    "ngp_get_timing", "ngp_profile_iteration", "ngp_draws_indexed", "ngp_eval_math",
+    "ngp_get_timing", "ngp_profile_iteration", "ngp_draws_indexed", "ngp_eval_math", "ngp_configure", "ngp_get_config",
 ]
 
 _lib = None
@@ -52,7 +52,7 @@ def _p(a, t):
 class Sampler:
     """One chain on one device == one `ngp_handle` (reference: one Julia task running runSampler!)."""
 
-    def __init__(self, device=0, seed=1, chain=0):
+    def __init__(self, device=0, seed=1, chain=0, mode=None, lag=None):
         self.L = load()
         self.h = C.c_void_p()
         rc = self.L.ngp_create(C.c_int32(device), C.c_uint64(seed), C.c_uint32(chain), C.byref(self.h))
@@ -60,6 +60,16 @@ class Sampler:
             raise NextGPHipError(f"ngp_create failed ({rc}): " + (self.L.ngp_last_error(None) or b"").decode())
         self.nsets = 0
         self.set_shapes = []  # (ncol, nreg) per set
+        if mode is not None or lag is not None:
+            self.configure(1 if mode is None else mode, 6 if lag is None else lag)
+
+    def configure(self, mode, lag):
+        self._chk(self.L.ngp_configure(self.h, C.c_int32(mode), C.c_int32(lag)))
+
+    def config(self):
+        m, l = C.c_int32(), C.c_int32()
+        self._chk(self.L.ngp_get_config(self.h, C.byref(m), C.byref(l)))
+        return m.value, l.value
 
     def _chk(self, rc):
         if rc != 0:

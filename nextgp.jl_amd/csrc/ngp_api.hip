@@ -13,6 +13,7 @@
 
 #include "../../include/nextgp_hip.h"
 #include "ngp_kernels.h"
+#include "ngp_sweep.h"
 
 using namespace ngp;
 
@@ -38,9 +39,17 @@ struct ngp_handle {
     uint32_t chain = 0;
     hipStream_t stream = nullptr;
     int64_t N = 0, P = 0, R = 0, S = 0, NBLK = 0, Ppad = 0, L = 0;
-    size_t lds_step = 0;
+    size_t lds_step = 0, lds_sweep = 0;
+    int mode = 1;      // 1: persistent sweep kernel, 0: one streaming + one recursion launch per block
+    int lag = 6;       // look-ahead D of the persistent sweep (blocks)
+    int D = 1;         // Gram planes stored per block (= lag in mode 1, 1 in mode 0)
+    int NG = 1;        // reducer groups = ceil(S/32)
+    int cu_count = 256;
+    double *d_cpart = nullptr, *d_cgsum = nullptr, *d_cdlt = nullptr;
+    unsigned *d_ccnt = nullptr, *d_abort = nullptr;
+    size_t ccnt_words = 0;
     float *d_tiles = nullptr;
-    double *d_gram = nullptr, *d_mpm = nullptr, *d_lhs0 = nullptr, *d_rhs0 = nullptr, *d_beta = nullptr;
+    double *d_gramx = nullptr, *d_mpm = nullptr, *d_lhs0 = nullptr, *d_rhs0 = nullptr, *d_beta = nullptr;
     double *d_c = nullptr, *d_w = nullptr, *d_q = nullptr, *d_T = nullptr, *d_chi = nullptr;
     int8_t *d_setof = nullptr;
     int32_t *d_loc = nullptr, *d_vbidx = nullptr;
@@ -123,8 +132,8 @@ void dfree(T *&p) {
 }
 
 // rows per shard R = 4*odd (conflict-free ds_read_b128 in both read patterns), S = ceil(N/R)
-void choose_layout(int64_t N, int64_t *R, int64_t *S) {
-    int64_t r0 = (N + 255) / 256;
+void choose_layout(int64_t N, int64_t max_shards, int64_t *R, int64_t *S) {
+    int64_t r0 = (N + max_shards - 1) / max_shards;
     int64_t m = (r0 + 3) / 4;
     if (m < 1) m = 1;
     if ((m & 1) == 0) m += 1;
@@ -138,7 +147,16 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
     REQUIRE(N > 0 && P > 0, NGP_ERR_ARG, "panel dimensions must be positive");
     REQUIRE(N <= (int64_t)508 * 1024, NGP_ERR_ARG, "N too large for this build (max 520192)");
     h->N = N; h->P = P;
-    choose_layout(N, &h->R, &h->S);
+    // persistent mode: sampler + reducers + S streamers must all be resident, one workgroup per CU
+    int64_t max_shards = 256;
+    if (h->mode == 1) {
+        max_shards = h->cu_count - 1 - (h->cu_count + NGP_GRP - 1) / NGP_GRP;
+        if (N > max_shards * 508) h->mode = 0;  // too many rows for one resident wave of streamers
+        else choose_layout(N, max_shards, &h->R, &h->S);
+    }
+    if (h->mode == 0) choose_layout(N, 256, &h->R, &h->S);
+    h->NG = (int)((h->S + NGP_GRP - 1) / NGP_GRP);
+    h->D = (h->mode == 1) ? h->lag : 1;
     h->NBLK = (P + NGP_BLK - 1) / NGP_BLK;
     h->Ppad = h->NBLK * NGP_BLK;
     h->L = h->R * h->S;
@@ -146,7 +164,7 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
     int rc;
     size_t tile_elems = (size_t)h->R * NGP_BLK;
     if ((rc = dalloc(h, &h->d_tiles, (size_t)h->NBLK * h->S * tile_elems))) return rc;
-    if ((rc = dalloc(h, &h->d_gram, (size_t)h->NBLK * NGP_BLK * NGP_BLK))) return rc;
+    if ((rc = dalloc(h, &h->d_gramx, (size_t)h->NBLK * h->D * NGP_BLK * NGP_BLK))) return rc;
     const size_t pp = (size_t)h->Ppad;
     if ((rc = dalloc(h, &h->d_mpm, pp))) return rc;
     if ((rc = dalloc(h, &h->d_lhs0, pp))) return rc;
@@ -178,7 +196,18 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
     dfree(h->d_varBeta); dfree(h->d_sum_varBeta); h->vb_cap = 0;
     h->have_y = false; h->iter = 0;
     HCHK(hipFuncSetAttribute((const void *)k_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_step));
-    HCHK(hipFuncSetAttribute((const void *)k_gram_part, hipFuncAttributeMaxDynamicSharedMemorySize, (int)((size_t)h->R * 256)));
+    if (h->mode == 1) {
+        const size_t lds_streamer = (size_t)h->R * 264 + 2048 + 512 + 64;
+        const size_t lds_sampler = (size_t)(4 * 4096 + 2 * NGP_RING * NGP_BLK) * sizeof(double) + 64;
+        h->lds_sweep = std::max(lds_streamer, lds_sampler);
+        HCHK(hipFuncSetAttribute((const void *)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_sweep));
+        if ((rc = dalloc(h, &h->d_cpart, (size_t)NGP_RING * h->S * NGP_BLK))) return rc;
+        if ((rc = dalloc(h, &h->d_cgsum, (size_t)NGP_RING * h->NG * NGP_BLK))) return rc;
+        if ((rc = dalloc(h, &h->d_cdlt, (size_t)NGP_RING * NGP_BLK))) return rc;
+        h->ccnt_words = (size_t)NGP_RING * h->NG * 32 + (size_t)NGP_RING * 32 + 32;
+        if ((rc = dalloc(h, &h->d_ccnt, h->ccnt_words))) return rc;
+        if ((rc = dalloc(h, &h->d_abort, 32))) return rc;
+    }
     HCHK(hipStreamSynchronize(h->stream));
     return NGP_OK;
 }
@@ -191,14 +220,15 @@ int build_gram(ngp_handle *h) {
     double *d_gpart = nullptr;
     int rc;
     if ((rc = dalloc(h, &d_gpart, (size_t)nb_max * h->S * NGP_BLK * NGP_BLK))) return rc;
-    for (int64_t t0 = 0; t0 < h->NBLK; t0 += nb_max) {
-        int nb = (int)std::min<int64_t>(nb_max, h->NBLK - t0);
-        hipLaunchKernelGGL(k_gram_part, dim3((unsigned)h->S, (unsigned)nb), dim3(256), (size_t)h->R * 256, h->stream, h->d_tiles,
-                           d_gpart, (int)h->R, (int)h->S, (int)t0);
-        long long ne = (long long)nb * NGP_BLK * NGP_BLK;
-        hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, h->stream, d_gpart, h->d_gram, h->d_mpm,
-                           (int)h->S, (int)t0, nb);
-    }
+    for (int d = 0; d < h->D; d++)
+        for (int64_t t0 = 0; t0 < h->NBLK; t0 += nb_max) {
+            int nb = (int)std::min<int64_t>(nb_max, h->NBLK - t0);
+            hipLaunchKernelGGL(k_gram_part, dim3((unsigned)h->S, (unsigned)nb), dim3(256), 0, h->stream, h->d_tiles, d_gpart, (int)h->R,
+                               (int)h->S, (int)t0, d);
+            long long ne = (long long)nb * NGP_BLK * NGP_BLK;
+            hipLaunchKernelGGL(k_gram_reduce, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, h->stream, d_gpart, h->d_gramx, h->d_mpm,
+                               (int)h->S, (int)t0, nb, d, h->D);
+        }
     hipError_t e = hipStreamSynchronize(h->stream);
     dfree(d_gpart);
     if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("gram: ") + hipGetErrorString(e));
@@ -266,9 +296,25 @@ bool is_kept(const ngp_handle *h, int64_t it) {  // src/samplers.jl:26
     return ((it - h->burnIn) % h->thin) == 0;
 }
 
-// the block loop of one sweep over blocks [tb0, tb1)
+// one sweep over blocks [tb0, tb1): persistent kernel (mode 1) or two launches per block (mode 0)
 void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
     const int R = (int)h->R, S = (int)h->S;
+    if (h->mode == 1) {
+        (void)hipMemsetAsync(h->d_ccnt, 0, h->ccnt_words * sizeof(unsigned), h->stream);
+        SweepArgs A;
+        A.tiles = h->d_tiles; A.ycorr = h->d_ycorr; A.gramx = h->d_gramx;
+        A.D = h->D; A.R = R; A.S = S; A.NG = h->NG; A.t0 = (int)tb0; A.t1 = (int)tb1;
+        A.beta = h->d_beta; A.delta = h->d_delta; A.c = h->d_c; A.w = h->d_w; A.q = h->d_q; A.T = h->d_T; A.chi = h->d_chi;
+        A.setof = h->d_setof; A.vbidx = h->d_vbidx; A.sets = h->d_sets; A.varBeta = h->d_varBeta;
+        A.part = h->d_cpart; A.gsum = h->d_cgsum; A.dlt = h->d_cdlt;
+        A.cnt_part = h->d_ccnt; A.cnt_gs = h->d_ccnt + (size_t)NGP_RING * h->NG * 32;
+        A.flag_dlt = A.cnt_gs + (size_t)NGP_RING * 32; A.abort_w = h->d_abort;
+        if (evs) (void)hipEventRecord(evs[0], h->stream);
+        hipLaunchKernelGGL(k_sweep, dim3((unsigned)(1 + h->NG + S)), dim3(256), h->lds_sweep, h->stream, A);
+        if (evs) (void)hipEventRecord(evs[1], h->stream);
+        h->sweep_launches += 1;
+        return;
+    }
     int e = 0;
     for (int64_t t = tb0; t <= tb1; t++) {
         const int do_upd = t > tb0, do_gemv = t < tb1;
@@ -277,10 +323,22 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
                            S, (int)t, do_upd, do_gemv);
         if (evs && do_gemv) (void)hipEventRecord(evs[e++], h->stream);
         if (do_gemv)
-            hipLaunchKernelGGL(k_recur, dim3(1), dim3(256), 0, h->stream, h->d_part, h->d_gram, S, (int)t, h->d_beta, h->d_delta, h->d_c,
-                               h->d_w, h->d_q, h->d_T, h->d_chi, h->d_setof, h->d_vbidx, h->d_sets, h->d_varBeta, h->d_dlt);
+            hipLaunchKernelGGL(k_recur, dim3(1), dim3(256), 0, h->stream, h->d_part, h->d_gramx, h->D, S, (int)t, h->d_beta, h->d_delta,
+                               h->d_c, h->d_w, h->d_q, h->d_T, h->d_chi, h->d_setof, h->d_vbidx, h->d_sets, h->d_varBeta, h->d_dlt);
     }
     h->sweep_launches += 2 * (tb1 - tb0) + 1;
+}
+
+int check_abort(ngp_handle *h) {
+    if (h->mode != 1) return NGP_OK;
+    unsigned code = 0;
+    HCHK(hipMemcpy(&code, h->d_abort, sizeof(unsigned), hipMemcpyDeviceToHost));
+    if (code != 0) {
+        (void)hipMemset(h->d_abort, 0, sizeof(unsigned));
+        return fail(h, NGP_ERR_HIP, "persistent sweep kernel gave up waiting (role code " + std::to_string(code) +
+                                        "): workgroups not co-resident or a hand-off was lost");
+    }
+    return NGP_OK;
 }
 
 void launch_variance(ngp_handle *h, int active_set, uint64_t it) {
@@ -343,7 +401,7 @@ int32_t ngp_create(int32_t device, uint64_t seed, uint32_t chain_id, ngp_handle 
         return fail(nullptr, NGP_ERR_NODEVICE, std::string("device is ") + prop.gcnArchName + ", this library is built for gfx950 only");
     ngp_handle *h = new (std::nothrow) ngp_handle();
     if (!h) return fail(nullptr, NGP_ERR_NOMEM, "out of host memory");
-    h->device = device; h->seed = seed; h->chain = chain_id;
+    h->device = device; h->seed = seed; h->chain = chain_id; h->cu_count = prop.multiProcessorCount;
     if ((e = hipSetDevice(device)) != hipSuccess || (e = hipStreamCreate(&h->stream)) != hipSuccess ||
         (e = hipEventCreate(&h->ev0)) != hipSuccess || (e = hipEventCreate(&h->ev1)) != hipSuccess) {
         std::string m = std::string("ngp_create: ") + hipGetErrorString(e);
@@ -358,7 +416,7 @@ int32_t ngp_destroy(ngp_handle *h) {
     if (!h) return NGP_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    dfree(h->d_tiles); dfree(h->d_gram); dfree(h->d_mpm); dfree(h->d_lhs0); dfree(h->d_rhs0); dfree(h->d_beta);
+    dfree(h->d_tiles); dfree(h->d_gramx); dfree(h->d_cpart); dfree(h->d_cgsum); dfree(h->d_cdlt); dfree(h->d_ccnt); dfree(h->d_abort); dfree(h->d_mpm); dfree(h->d_lhs0); dfree(h->d_rhs0); dfree(h->d_beta);
     dfree(h->d_c); dfree(h->d_w); dfree(h->d_q); dfree(h->d_T); dfree(h->d_chi); dfree(h->d_setof); dfree(h->d_loc);
     dfree(h->d_vbidx); dfree(h->d_delta); dfree(h->d_sum_beta); dfree(h->d_sum_beta2); dfree(h->d_sum_delta);
     dfree(h->d_ycorr); dfree(h->d_part); dfree(h->d_dlt); dfree(h->d_sets); dfree(h->d_scal); dfree(h->d_varBeta);
@@ -423,7 +481,7 @@ int32_t ngp_get_gram(ngp_handle *h, int64_t t, double *out) {
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
     REQUIRE(out && t >= 0 && t < h->NBLK, NGP_ERR_ARG, "block index out of range");
-    HCHK(hipMemcpy(out, h->d_gram + (size_t)t * NGP_BLK * NGP_BLK, NGP_BLK * NGP_BLK * sizeof(double), hipMemcpyDeviceToHost));
+    HCHK(hipMemcpy(out, h->d_gramx + (size_t)t * h->D * NGP_BLK * NGP_BLK, NGP_BLK * NGP_BLK * sizeof(double), hipMemcpyDeviceToHost));
     return NGP_OK;
 }
 
@@ -580,11 +638,15 @@ int32_t ngp_run(ngp_handle *h, int64_t niter) {
     HCHK(hipEventRecord(h->ev0, h->stream));
     for (int64_t n = 0; n < niter; n++) {
         if ((rc = one_iteration(h, n, nullptr))) return rc;
-        if ((n & 15) == 15) HCHK(hipStreamSynchronize(h->stream));  // bound the launch queue
+        if ((n & 15) == 15) {  // bound the launch queue
+            HCHK(hipStreamSynchronize(h->stream));
+            if ((rc = check_abort(h))) return rc;
+        }
     }
     HCHK(hipEventRecord(h->ev1, h->stream));
     HCHK(hipStreamSynchronize(h->stream));
     HCHK(hipGetLastError());
+    if ((rc = check_abort(h))) return rc;
     float ms = 0.f;
     HCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->iter_ms += ms; h->iters_timed += niter;
@@ -741,6 +803,7 @@ int32_t ngp_sweep_set(ngp_handle *h, int32_t set_id, double varE, double *ycorr,
     HCHK(hipMemcpyAsync(varBeta, h->d_varBeta + hs.vb_off, (size_t)hs.nreg * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HCHK(hipStreamSynchronize(h->stream));
     HCHK(hipGetLastError());
+    if ((rc = check_abort(h))) return rc;
     if (delta) {
         std::vector<uint8_t> d((size_t)hs.ncol);
         HCHK(hipMemcpy(d.data(), h->d_delta + hs.col0, (size_t)hs.ncol, hipMemcpyDeviceToHost));
@@ -769,7 +832,7 @@ int32_t ngp_profile_iteration(ngp_handle *h, double *avg_ms, int64_t *launches, 
     int rc;
     if ((rc = enter(h))) return rc;
     if ((rc = ready(h))) return rc;
-    const int64_t n = h->NBLK;
+    const int64_t n = (h->mode == 1) ? 1 : h->NBLK;
     std::vector<hipEvent_t> evs((size_t)(2 * n));
     for (auto &e : evs) HCHK(hipEventCreate(&e));
     if (h->trace_cap < 1) {
@@ -789,10 +852,29 @@ int32_t ngp_profile_iteration(ngp_handle *h, double *avg_ms, int64_t *launches, 
         }
     for (auto &ev : evs) (void)hipEventDestroy(ev);
     if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("profile_iteration: ") + hipGetErrorString(e));
+    if (rc == NGP_OK) rc = check_abort(h);
     if (avg_ms) *avg_ms = tot / (double)n;
     if (launches) *launches = n;
-    if (bytes_per_launch) *bytes_per_launch = (double)h->N * NGP_BLK * 4.0;
+    if (bytes_per_launch) *bytes_per_launch = (h->mode == 1) ? (double)h->N * (double)h->P * 4.0 : (double)h->N * NGP_BLK * 4.0;
     return rc;
+}
+
+int32_t ngp_configure(ngp_handle *h, int32_t mode, int32_t lag) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(h->d_tiles == nullptr, NGP_ERR_STATE, "ngp_configure must precede the panel upload");
+    REQUIRE(mode == 0 || mode == 1, NGP_ERR_ARG, "mode must be 0 (per-block launches) or 1 (persistent sweep)");
+    REQUIRE(lag >= 1 && lag <= NGP_MAX_LAG, NGP_ERR_ARG, "lag must be in 1..8");
+    h->mode = mode; h->lag = lag;
+    return NGP_OK;
+}
+
+int32_t ngp_get_config(ngp_handle *h, int32_t *mode, int32_t *lag) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    if (mode) *mode = h->mode;
+    if (lag) *lag = h->D;
+    return NGP_OK;
 }
 
 int32_t ngp_draws_indexed(ngp_handle *h, uint64_t iter, uint64_t kind, uint64_t index0, int32_t what, double p1, double p2, int64_t n,

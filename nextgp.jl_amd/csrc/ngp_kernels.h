@@ -244,7 +244,7 @@ __global__ __launch_bounds__(256) void k_step(const float *__restrict__ tiles, d
 // block recursion of block t: reduce the S shard partials (groups of 32, sequential), then
 // the 64-step serial chain on wave 0 with the Gram block in registers.  ONE workgroup.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_recur(const double *__restrict__ part, const double *__restrict__ gram, int S, int t,
+__global__ __launch_bounds__(256) void k_recur(const double *__restrict__ part, const double *__restrict__ gramx, int D, int S, int t,
                                                double *__restrict__ beta, uint8_t *__restrict__ delta,
                                                const double *__restrict__ c, const double *__restrict__ w,
                                                const double *__restrict__ q, const double *__restrict__ T,
@@ -265,7 +265,7 @@ __global__ __launch_bounds__(256) void k_recur(const double *__restrict__ part, 
     double tot = gs[j];
     for (int g = 1; g < ngroups; g++) tot = tot + gs[g * NGP_BLK + j];
     const long long k = (long long)t * NGP_BLK + j;
-    const double *G = gram + (size_t)t * NGP_BLK * NGP_BLK;
+    const double *G = gramx + (size_t)t * D * NGP_BLK * NGP_BLK;
     double Gr[NGP_BLK];
 #pragma unroll
     for (int kk = 0; kk < NGP_BLK; kk++) Gr[kk] = G[kk * NGP_BLK + j];
@@ -406,38 +406,51 @@ __global__ __launch_bounds__(256) void k_accum(long long P, long long nvb, int n
 // ------------------------------------------------------------------------------------------
 // set-up kernels: Gram blocks, synthetic panel, X*beta
 // ------------------------------------------------------------------------------------------
-// shard partial of X_t'X_t: 256 threads, thread (tk,tj) owns the 4x4 sub-block; rows ascending
-__global__ __launch_bounds__(256) void k_gram_part(const float *__restrict__ tiles, double *__restrict__ gpart, int R, int S, int t0) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    float *tl = (float *)smem;
+// shard partial of Gx[t][d][k][j] = x_{t-d,k}' x_{t,j} (d = 0: the symmetric diagonal block): 256 threads,
+// thread (tk,tj) owns a 4x4 sub-block; rows ascending; both tiles staged through LDS in chunks of RC rows
+#define NGP_GRAM_RC 128
+__global__ __launch_bounds__(256) void k_gram_part(const float *__restrict__ tiles, double *__restrict__ gpart, int R, int S, int t0,
+                                                   int d) {
+    __shared__ __attribute__((aligned(16))) float ta[NGP_BLK * NGP_GRAM_RC];
+    __shared__ __attribute__((aligned(16))) float tt[NGP_BLK * NGP_GRAM_RC];
     const int s = blockIdx.x, tb = blockIdx.y, tid = threadIdx.x;
+    const int t = t0 + tb;
     const size_t tile_elems = (size_t)R * NGP_BLK;
-    const float4 *src = (const float4 *)(tiles + ((size_t)(t0 + tb) * S + s) * tile_elems);
-    float4 *dst = (float4 *)tl;
-    for (int idx = tid; idx < R * 16; idx += 256) dst[idx] = src[idx];
-    __syncthreads();
+    const float *src_t = tiles + ((size_t)t * S + s) * tile_elems;
+    const float *src_a = tiles + ((size_t)(t - d) * S + s) * tile_elems;
     const int tk = tid >> 4, tj = tid & 15;
     double acc[4][4];
 #pragma unroll
     for (int a = 0; a < 4; a++)
 #pragma unroll
         for (int b = 0; b < 4; b++) acc[a][b] = 0.0;
-    for (int i = 0; i < R; i += 4) {
-        float4 xk[4], xj[4];
-#pragma unroll
-        for (int a = 0; a < 4; a++) {
-            xk[a] = *(const float4 *)(tl + (size_t)(4 * tk + a) * R + i);
-            xj[a] = *(const float4 *)(tl + (size_t)(4 * tj + a) * R + i);
+    if (t - d < 0) return;  // block-uniform
+    for (int i0 = 0; i0 < R; i0 += NGP_GRAM_RC) {
+        const int rc = min(NGP_GRAM_RC, R - i0);  // multiple of 4
+        __syncthreads();
+        for (int idx = tid; idx < NGP_BLK * (rc >> 2); idx += 256) {
+            int j = idx / (rc >> 2), q4 = idx - j * (rc >> 2);
+            *(float4 *)(tt + j * NGP_GRAM_RC + 4 * q4) = *(const float4 *)(src_t + (size_t)j * R + i0 + 4 * q4);
+            *(float4 *)(ta + j * NGP_GRAM_RC + 4 * q4) = *(const float4 *)(src_a + (size_t)j * R + i0 + 4 * q4);
         }
+        __syncthreads();
+        for (int i = 0; i < rc; i += 4) {
+            float4 xk[4], xj[4];
 #pragma unroll
-        for (int a = 0; a < 4; a++)
-#pragma unroll
-            for (int b = 0; b < 4; b++) {
-                acc[a][b] = __builtin_fma((double)xk[a].x, (double)xj[b].x, acc[a][b]);
-                acc[a][b] = __builtin_fma((double)xk[a].y, (double)xj[b].y, acc[a][b]);
-                acc[a][b] = __builtin_fma((double)xk[a].z, (double)xj[b].z, acc[a][b]);
-                acc[a][b] = __builtin_fma((double)xk[a].w, (double)xj[b].w, acc[a][b]);
+            for (int a = 0; a < 4; a++) {
+                xk[a] = *(const float4 *)(ta + (4 * tk + a) * NGP_GRAM_RC + i);
+                xj[a] = *(const float4 *)(tt + (4 * tj + a) * NGP_GRAM_RC + i);
             }
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) {
+                    acc[a][b] = __builtin_fma((double)xk[a].x, (double)xj[b].x, acc[a][b]);
+                    acc[a][b] = __builtin_fma((double)xk[a].y, (double)xj[b].y, acc[a][b]);
+                    acc[a][b] = __builtin_fma((double)xk[a].z, (double)xj[b].z, acc[a][b]);
+                    acc[a][b] = __builtin_fma((double)xk[a].w, (double)xj[b].w, acc[a][b]);
+                }
+        }
     }
     double *out = gpart + ((size_t)tb * S + s) * (NGP_BLK * NGP_BLK);
 #pragma unroll
@@ -446,11 +459,13 @@ __global__ __launch_bounds__(256) void k_gram_part(const float *__restrict__ til
         for (int b = 0; b < 4; b++) out[(4 * tk + a) * NGP_BLK + 4 * tj + b] = acc[a][b];
 }
 
-__global__ __launch_bounds__(256) void k_gram_reduce(const double *__restrict__ gpart, double *__restrict__ gram,
-                                                     double *__restrict__ mpm, int S, int t0, int nb) {
+// group sums over shards -> gramx[t][d][k][j]; d == 0 also fills mpm
+__global__ __launch_bounds__(256) void k_gram_reduce(const double *__restrict__ gpart, double *__restrict__ gramx,
+                                                     double *__restrict__ mpm, int S, int t0, int nb, int d, int D) {
     long long e = (long long)blockIdx.x * 256 + threadIdx.x;  // (tb, k, j)
     if (e >= (long long)nb * NGP_BLK * NGP_BLK) return;
     int tb = (int)(e / (NGP_BLK * NGP_BLK)), kj = (int)(e % (NGP_BLK * NGP_BLK));
+    if (t0 + tb - d < 0) return;
     const double *p = gpart + (size_t)tb * S * (NGP_BLK * NGP_BLK) + kj;
     const int ngroups = (S + NGP_GRP - 1) / NGP_GRP;
     double tot = 0.0;
@@ -460,9 +475,9 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const double *__restrict__ 
         for (int s = s0 + 1; s < s1; s++) v = v + p[(size_t)s * (NGP_BLK * NGP_BLK)];
         tot = (g == 0) ? v : tot + v;
     }
-    gram[(size_t)(t0 + tb) * (NGP_BLK * NGP_BLK) + kj] = tot;
+    gramx[((size_t)(t0 + tb) * D + d) * (NGP_BLK * NGP_BLK) + kj] = tot;
     int k = kj / NGP_BLK, j = kj % NGP_BLK;
-    if (k == j) mpm[(size_t)(t0 + tb) * NGP_BLK + k] = tot;
+    if (d == 0 && k == j) mpm[(size_t)(t0 + tb) * NGP_BLK + k] = tot;
 }
 
 // synthetic genotypes: per-column mean of g_ij (integer sum), then centred fp32 tiles

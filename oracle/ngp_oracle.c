@@ -278,6 +278,8 @@ typedef struct {
     double *data, *Mp;
     /* blocked order storage */
     int64_t R, S, NBLK, Ppad; /* rows per shard, shards, blocks */
+    int64_t D;                /* lag of the pipelined sweep (1 = no look-ahead) */
+    double *gramx;            /* [t][d][k][j], d = 1..D-1: x_{t-d,k}' x_{t,j} */
     float *tiles;             /* [s][t][j][i] */
     double *gram;             /* [t][64][64] */
     double *mpm;              /* Ppad (reference order: P) */
@@ -320,7 +322,7 @@ static void free_sets(ora_t *h) {
 }
 void ora_destroy(ora_t *h) {
     if (!h) return;
-    free(h->data); free(h->Mp); free(h->tiles); free(h->gram); free(h->mpm); free(h->lhs0); free(h->rhs0);
+    free(h->data); free(h->Mp); free(h->tiles); free(h->gram); free(h->gramx); free(h->mpm); free(h->lhs0); free(h->rhs0);
     free_sets(h); free(h->varBeta); free(h->sum_varBeta); free(h->y); free(h->ycorr); free(h->beta); free(h->delta);
     free(h->sum_beta); free(h->sum_beta2); free(h->sum_delta); free(h->tr_varE); free(h->tr_b);
     free(h->c); free(h->w); free(h->q); free(h->T); free(h->chi);
@@ -342,7 +344,7 @@ static double group_sum(const double *p, int64_t n, int64_t stride) {
 
 /* the panel as the product stores it: fp32, column-major N x P, already centred.
    For order 1 the caller states the device layout (rows per shard R, shards S). */
-int ora_set_panel_f32(ora_t *h, const float *X, int64_t N, int64_t P, int64_t R, int64_t S) {
+int ora_set_panel_f32(ora_t *h, const float *X, int64_t N, int64_t P, int64_t R, int64_t S, int64_t D) {
     h->N = N; h->P = P;
     if (h->order == 0) {
         h->data = (double *)malloc(sizeof(double) * N * P);
@@ -362,7 +364,8 @@ int ora_set_panel_f32(ora_t *h, const float *X, int64_t N, int64_t P, int64_t R,
         h->Ppad = P;
     } else {
         if (R % 4 || R * S < N || R <= 0) { snprintf(h->err, 256, "bad layout R=%lld S=%lld", (long long)R, (long long)S); return ORA_ERR; }
-        h->R = R; h->S = S; h->NBLK = (P + BLK - 1) / BLK; h->Ppad = h->NBLK * BLK;
+        if (D < 1 || D > 16) { snprintf(h->err, 256, "bad lag D=%lld", (long long)D); return ORA_ERR; }
+        h->R = R; h->S = S; h->D = D; h->NBLK = (P + BLK - 1) / BLK; h->Ppad = h->NBLK * BLK;
         size_t tile = (size_t)R * BLK;
         h->tiles = (float *)calloc((size_t)S * h->NBLK * tile, sizeof(float));
         h->gram = (double *)calloc((size_t)h->NBLK * BLK * BLK, sizeof(double));
@@ -390,6 +393,24 @@ int ora_set_panel_f32(ora_t *h, const float *X, int64_t N, int64_t P, int64_t R,
                     h->gram[((size_t)t * BLK + k) * BLK + j] = g;
                     h->gram[((size_t)t * BLK + j) * BLK + k] = g;
                 }
+        /* cross blocks of the look-ahead window: Gx[t][d][k][j] = x_{t-d,k}' x_{t,j} */
+        if (D > 1) {
+            h->gramx = (double *)calloc((size_t)h->NBLK * D * BLK * BLK, sizeof(double));
+            if (!h->gramx) { snprintf(h->err, 256, "out of memory"); return ORA_ERR; }
+            for (int64_t t = 0; t < h->NBLK; t++)
+                for (int64_t d = 1; d < D && d <= t; d++)
+                    for (int k = 0; k < BLK; k++)
+                        for (int j = 0; j < BLK; j++) {
+                            for (int64_t s = 0; s < S; s++) {
+                                const float *ta = h->tiles + ((size_t)s * h->NBLK + (t - d)) * tile;
+                                const float *tt = h->tiles + ((size_t)s * h->NBLK + t) * tile;
+                                double acc = 0.0;
+                                for (int64_t i = 0; i < R; i++) acc = __builtin_fma((double)ta[k * R + i], (double)tt[j * R + i], acc);
+                                part[s] = acc;
+                            }
+                            h->gramx[(((size_t)t * D + d) * BLK + k) * BLK + j] = group_sum(part, S, 1);
+                        }
+        }
         free(part);
         for (int64_t k = 0; k < h->Ppad; k++) h->mpm[k] = h->gram[((size_t)(k / BLK) * BLK + k % BLK) * BLK + k % BLK];
     }
@@ -658,30 +679,56 @@ static void iter_blocked(ora_t *h) {
                 }
             }
     }
-    /* ---- block sweep */
+    /* ---- block sweep with lag D: the GEMV of block t sees ycorr with the updates of blocks <= t-D;
+       the missing updates enter through the cross Gram blocks (DESIGN.md "Blocked sweep arithmetic") */
     const size_t tile = (size_t)R * BLK;
+    const int64_t D = h->D;
     double *part = (double *)malloc(sizeof(double) * S * BLK);
-    for (int64_t tb = 0; tb < NBLK; tb++) {
+    double *hist = (double *)calloc((size_t)NBLK * BLK, sizeof(double)); /* dlt of every block */
+    for (int64_t tb = 0; tb < NBLK + D; tb++) {
+        if (tb >= D) { /* y update with block a = tb - D: per row, columns ascending */
+            const int64_t a = tb - D;
+            for (int64_t s = 0; s < S; s++) {
+                const float *tl = h->tiles + ((size_t)s * NBLK + a) * tile;
+                double *ys = h->ycorr + s * R;
+                for (int64_t i = 0; i < R; i++) {
+                    double yv = ys[i];
+                    for (int j = 0; j < BLK; j++) yv = __builtin_fma(-(double)tl[j * R + i], hist[a * BLK + j], yv);
+                    ys[i] = yv;
+                }
+            }
+        }
+        if (tb >= NBLK) continue;
         const int64_t k0 = tb * BLK;
         /* GEMV partials: 4 waves over strided quads, lane = column */
         for (int64_t s = 0; s < S; s++) {
             const float *tl = h->tiles + ((size_t)s * NBLK + tb) * tile;
             const double *ys = h->ycorr + s * R;
             for (int j = 0; j < BLK; j++) {
-                double a[4];
+                double a4[4];
                 for (int wv = 0; wv < 4; wv++) {
                     double acc = 0.0;
                     for (int64_t qd = wv; qd < R / 4; qd += 4)
                         for (int e = 0; e < 4; e++) { int64_t i = 4 * qd + e; acc = __builtin_fma((double)tl[j * R + i], ys[i], acc); }
-                    a[wv] = acc;
+                    a4[wv] = acc;
                 }
-                part[s * BLK + j] = ((a[0] + a[1]) + a[2]) + a[3];
+                part[s * BLK + j] = ((a4[0] + a4[1]) + a4[2]) + a4[3];
             }
         }
         double rr[BLK], dlt[BLK]; int inc[BLK];
         const double *G = h->gram + (size_t)tb * BLK * BLK;
         for (int j = 0; j < BLK; j++) {
             double tot = group_sum(part + j, S, BLK);
+            /* cross corrections of the not yet applied blocks a = tb-D+1 .. tb-1, ascending */
+            double c = 0.0; int have = 0;
+            for (int64_t a = (tb - D + 1 > 0 ? tb - D + 1 : 0); a < tb; a++) {
+                const double *Gx = h->gramx + (((size_t)tb * D + (tb - a)) * BLK) * BLK;
+                double s4[4] = {0, 0, 0, 0};
+                for (int k = 0; k < BLK; k++) s4[k & 3] = __builtin_fma(Gx[k * BLK + j], hist[a * BLK + k], s4[k & 3]);
+                double v = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+                c = have ? c + v : v; have = 1;
+            }
+            if (have) tot = tot - c;
             rr[j] = __builtin_fma(G[j * BLK + j], h->beta[k0 + j], tot);
         }
         for (int k = 0; k < BLK; k++) {
@@ -694,22 +741,13 @@ static void iter_blocked(ora_t *h) {
             dlt[k] = dk; inc[k] = in;
             for (int j = k + 1; j < BLK; j++) rr[j] = __builtin_fma(-G[j * BLK + k], dk, rr[j]);
         }
-        /* y update: per row, columns ascending */
-        for (int64_t s = 0; s < S; s++) {
-            const float *tl = h->tiles + ((size_t)s * NBLK + tb) * tile;
-            double *ys = h->ycorr + s * R;
-            for (int64_t i = 0; i < R; i++) {
-                double yv = ys[i];
-                for (int j = 0; j < BLK; j++) yv = __builtin_fma(-(double)tl[j * R + i], dlt[j], yv);
-                ys[i] = yv;
-            }
-        }
         for (int k = 0; k < BLK; k++) {
+            hist[tb * BLK + k] = dlt[k];
             h->beta[k0 + k] = h->beta[k0 + k] + dlt[k];
             h->delta[k0 + k] = inc[k];
         }
     }
-    free(part);
+    free(part); free(hist);
     /* ---- variance components / pi */
     for (int si = 0; si < h->nsets; si++) {
         oset_t *Sx = &h->sets[si];

@@ -97,11 +97,11 @@ class Oracle:
         except Exception:
             pass
 
-    def set_panel_f32(self, X, R=0, S=0):
+    def set_panel_f32(self, X, R=0, S=0, D=1):
         X = np.asfortranarray(X, dtype=np.float32)
         self.N, self.P = X.shape
         self._chk(self.L.ora_set_panel_f32(self.h, _p(X, C.c_float), C.c_int64(self.N), C.c_int64(self.P), C.c_int64(R),
-                                           C.c_int64(S)))
+                                           C.c_int64(S), C.c_int64(D)))
 
     def add_marker_set(self, col0, ncol, method, df, scale, regions, varBeta0, pi0=0.0, estPi=False, lhs0=None, rhs0=None):
         rs = np.ascontiguousarray([r[0] for r in regions], dtype=np.int64)

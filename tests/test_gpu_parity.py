@@ -38,12 +38,18 @@ def test_draws_bit_exact(dev, O, what, p1, p2):
     assert np.array_equal(got, exp)
 
 
-def _pair(ngp, O, X, seed=1001, chain=0):
-    s = ngp.Sampler(device=0, seed=seed, chain=chain)
+ENGINES = [(0, 1), (1, 1), (1, 2), (1, 3), (1, 6), (1, 8)]   # (mode, lag): per-block launches / persistent sweep
+ENGINE_IDS = ["blocklaunch", "persist_lag1", "persist_lag2", "persist_lag3", "persist_lag6", "persist_lag8"]
+
+
+def _pair(ngp, O, X, seed=1001, chain=0, engine=(1, 6)):
+    s = ngp.Sampler(device=0, seed=seed, chain=chain, mode=engine[0], lag=engine[1])
     s.set_panel(X)
     R, S, nblk = s.layout()
+    mode, D = s.config()
+    assert mode == engine[0] and D == (engine[1] if mode == 1 else 1)
     o = O.Oracle(order=1, seed=seed, chain=chain)
-    o.set_panel_f32(X, R=R, S=S)
+    o.set_panel_f32(X, R=R, S=S, D=D)
     return s, o
 
 
@@ -81,10 +87,11 @@ CASES = [
 ]
 
 
+@pytest.mark.parametrize("engine", ENGINES, ids=ENGINE_IDS)
 @pytest.mark.parametrize("name,N,P,spec", CASES, ids=[c[0] for c in CASES])
-def test_chain_bit_exact_vs_blocked_oracle(ngp, O, name, N, P, spec):
+def test_chain_bit_exact_vs_blocked_oracle(ngp, O, name, N, P, spec, engine):
     X, y, bt, v = make_problem(O, N, P, seed=5)
-    s, o = _pair(ngp, O, X)
+    s, o = _pair(ngp, O, X, engine=engine)
     niter = 12
     for m in (s, o):
         add_sets(m, spec, v)
@@ -109,12 +116,13 @@ def test_chain_bit_exact_vs_blocked_oracle(ngp, O, name, N, P, spec):
     assert np.abs(a["ycorr"] - resid).max() <= 1e-10 * max(1.0, np.abs(y).max())
 
 
+@pytest.mark.parametrize("engine", [(0, 1), (1, 6)], ids=["blocklaunch", "persist_lag6"])
 @pytest.mark.parametrize("kind", ["PR", "B"])
-def test_chain_vs_reference_order_oracle(ngp, O, kind):
+def test_chain_vs_reference_order_oracle(ngp, O, kind, engine):
     """Same Markov chain, reference summation order: indicators identical, floats within 1e-9 relative."""
     N, P = 500, 1000
     X, y, bt, v = make_problem(O, N, P, seed=9)
-    s = ngp.Sampler(device=0, seed=77, chain=1)
+    s = ngp.Sampler(device=0, seed=77, chain=1, mode=engine[0], lag=engine[1])
     s.set_panel(X)
     o = O.Oracle(order=0, seed=77, chain=1)
     o.set_panel_f32(X)
@@ -133,11 +141,12 @@ def test_chain_vs_reference_order_oracle(ngp, O, kind):
     assert np.abs(pa["sum_beta"] - pb["sum_beta"]).max() <= tol * max(1e-3, np.abs(pb["sum_beta"]).max())
 
 
-def test_fine_seam_matches_coarse(ngp, O):
+@pytest.mark.parametrize("engine", [(0, 1), (1, 4)], ids=["blocklaunch", "persist_lag4"])
+def test_fine_seam_matches_coarse(ngp, O, engine):
     """ngp_sweep_set driven by host-side varE/intercept == the blocked oracle's set sweep on the same state."""
     N, P = 300, 192
     X, y, bt, v = make_problem(O, N, P, seed=2)
-    s = ngp.Sampler(device=0, seed=5, chain=0)
+    s = ngp.Sampler(device=0, seed=5, chain=0, mode=engine[0], lag=engine[1])
     s.set_panel(X)
     add_sets(s, [(0, P, "PR")], v)
     ycorr = y - y.mean()
