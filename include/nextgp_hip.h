@@ -53,6 +53,9 @@ const char *ngp_last_error(ngp_handle *h);
  * reference loop (src/functions.jl:124-136) and draw the same chain; only summation order differs. */
 int32_t ngp_configure(ngp_handle *h, int32_t mode, int32_t lag);
 int32_t ngp_get_config(ngp_handle *h, int32_t *mode, int32_t *lag);
+/* Diagnostic only: enable != 0 makes the persistent kernel write 100 MHz time stamps (sampler: 4 words per
+ * block at [4u..4u+3]; streamer 0: 2 words per block from word 2^20); out/n copies the first n words back. */
+int32_t ngp_debug_stamps(ngp_handle *h, int32_t enable, uint64_t *out, int64_t n);
 
 /* Marker panel, N individuals x P SNPs, column-major with leading dimension ld >= N
  * (replaces M[set][:data] + the M[set][:Mp] copy, src/prepMatVec.jl:116-131, src/mme.jl:305-311).

@@ -20,7 +20,7 @@ SYMBOLS = [
     "ngp_generate_panel", "ngp_get_layout", "ngp_get_mpm", "ngp_get_gram", "ngp_xbeta", "ngp_add_marker_set", "ngp_set_y",
     "ngp_set_residual_prior", "ngp_set_intercept", "ngp_set_schedule", "ngp_run", "ngp_get_state", "ngp_set_state",
     "ngp_get_trace", "ngp_get_posterior_sums", "ngp_posterior_len", "ngp_export_posterior_device", "ngp_sweep_set",
-    "ngp_get_timing", "ngp_profile_iteration", "ngp_draws_indexed", "ngp_eval_math", "ngp_configure", "ngp_get_config",
+    "ngp_get_timing", "ngp_profile_iteration", "ngp_draws_indexed", "ngp_eval_math", "ngp_configure", "ngp_get_config", "ngp_debug_stamps",
 ]
 
 _lib = None
@@ -70,6 +70,11 @@ class Sampler:
         m, l = C.c_int32(), C.c_int32()
         self._chk(self.L.ngp_get_config(self.h, C.byref(m), C.byref(l)))
         return m.value, l.value
+
+    def debug_stamps(self, enable=True, n=0):
+        out = np.zeros(max(n, 1), dtype=np.uint64)
+        self._chk(self.L.ngp_debug_stamps(self.h, C.c_int32(int(enable)), _p(out, C.c_uint64) if n else None, C.c_int64(n)))
+        return out
 
     def _chk(self, rc):
         if rc != 0:

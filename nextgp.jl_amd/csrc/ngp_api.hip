@@ -47,6 +47,7 @@ struct ngp_handle {
     int cu_count = 256;
     double *d_cpart = nullptr, *d_cgsum = nullptr, *d_cdlt = nullptr;
     unsigned *d_ccnt = nullptr, *d_abort = nullptr;
+    unsigned long long *d_dbg = nullptr;
     size_t ccnt_words = 0;
     float *d_tiles = nullptr;
     double *d_gramx = nullptr, *d_mpm = nullptr, *d_lhs0 = nullptr, *d_rhs0 = nullptr, *d_beta = nullptr;
@@ -198,7 +199,7 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
     HCHK(hipFuncSetAttribute((const void *)k_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_step));
     if (h->mode == 1) {
         const size_t lds_streamer = (size_t)h->R * 264 + 2048 + 512 + 64;
-        const size_t lds_sampler = (size_t)(4 * 4096 + 2 * NGP_RING * NGP_BLK) * sizeof(double) + 64;
+        const size_t lds_sampler = (size_t)(4 * 4096 + 2 * NGP_RING * NGP_BLK + 4 * NGP_BLK) * sizeof(double) + 2 * NGP_BLK * sizeof(int) + 64;
         h->lds_sweep = std::max(lds_streamer, lds_sampler);
         HCHK(hipFuncSetAttribute((const void *)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_sweep));
         if ((rc = dalloc(h, &h->d_cpart, (size_t)NGP_RING * h->S * NGP_BLK))) return rc;
@@ -310,7 +311,8 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
         A.cnt_part = h->d_ccnt; A.cnt_gs = h->d_ccnt + (size_t)NGP_RING * h->NG * 32;
         A.flag_dlt = A.cnt_gs + (size_t)NGP_RING * 32; A.abort_w = h->d_abort;
         if (evs) (void)hipEventRecord(evs[0], h->stream);
-        hipLaunchKernelGGL(k_sweep, dim3((unsigned)(1 + h->NG + S)), dim3(256), h->lds_sweep, h->stream, A);
+        A.dbg = h->d_dbg;
+        hipLaunchKernelGGL(k_sweep, dim3((unsigned)(1 + h->NG + S)), dim3(NGP_WG), h->lds_sweep, h->stream, A);
         if (evs) (void)hipEventRecord(evs[1], h->stream);
         h->sweep_launches += 1;
         return;
@@ -416,7 +418,7 @@ int32_t ngp_destroy(ngp_handle *h) {
     if (!h) return NGP_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    dfree(h->d_tiles); dfree(h->d_gramx); dfree(h->d_cpart); dfree(h->d_cgsum); dfree(h->d_cdlt); dfree(h->d_ccnt); dfree(h->d_abort); dfree(h->d_mpm); dfree(h->d_lhs0); dfree(h->d_rhs0); dfree(h->d_beta);
+    dfree(h->d_tiles); dfree(h->d_gramx); dfree(h->d_cpart); dfree(h->d_cgsum); dfree(h->d_cdlt); dfree(h->d_ccnt); dfree(h->d_abort); dfree(h->d_dbg); dfree(h->d_mpm); dfree(h->d_lhs0); dfree(h->d_rhs0); dfree(h->d_beta);
     dfree(h->d_c); dfree(h->d_w); dfree(h->d_q); dfree(h->d_T); dfree(h->d_chi); dfree(h->d_setof); dfree(h->d_loc);
     dfree(h->d_vbidx); dfree(h->d_delta); dfree(h->d_sum_beta); dfree(h->d_sum_beta2); dfree(h->d_sum_delta);
     dfree(h->d_ycorr); dfree(h->d_part); dfree(h->d_dlt); dfree(h->d_sets); dfree(h->d_scal); dfree(h->d_varBeta);
@@ -857,6 +859,16 @@ int32_t ngp_profile_iteration(ngp_handle *h, double *avg_ms, int64_t *launches, 
     if (launches) *launches = n;
     if (bytes_per_launch) *bytes_per_launch = (h->mode == 1) ? (double)h->N * (double)h->P * 4.0 : (double)h->N * NGP_BLK * 4.0;
     return rc;
+}
+
+int32_t ngp_debug_stamps(ngp_handle *h, int32_t enable, uint64_t *out, int64_t n) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    const size_t words = (size_t)2 << 20;
+    if (enable && !h->d_dbg) { if ((rc = dalloc(h, &h->d_dbg, words))) return rc; HCHK(hipStreamSynchronize(h->stream)); }
+    if (out && h->d_dbg) HCHK(hipMemcpy(out, h->d_dbg, std::min<size_t>((size_t)n, words) * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    if (!enable && h->d_dbg) { HCHK(hipStreamSynchronize(h->stream)); dfree(h->d_dbg); }
+    return NGP_OK;
 }
 
 int32_t ngp_configure(ngp_handle *h, int32_t mode, int32_t lag) {

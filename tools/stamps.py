@@ -1,0 +1,30 @@
+import sys, numpy as np, time
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from ngp_pkg import load_pkg
+ngp = load_pkg()
+lag = int(sys.argv[1]) if len(sys.argv)>1 else 6
+N,P = 10000, 100000
+s = ngp.Sampler(device=0, seed=1001, chain=0, mode=1, lag=lag)
+s.generate_panel(N,P)
+rng=np.random.default_rng(1); bt=np.zeros(P); idx=rng.choice(P,1000,replace=False); bt[idx]=rng.normal(size=1000)
+g=s.xbeta(bt); y=10+g+np.random.default_rng(2).normal(size=N)*np.sqrt(g.var())
+v=0.5*y.var()/(s.mpm().sum()/N)
+s.add_marker_set(0,P,0,4.0,v*0.5,[(0,P)],[v]); s.set_y(y); s.set_residual_prior(4.0,0.25*y.var())
+s.run(3)
+t=time.perf_counter(); s.run(10); dt=(time.perf_counter()-t)/10
+print(f"lag {lag}: {dt*1e3:.2f} ms/iter  layout {s.layout()}")
+s.debug_stamps(True); s.run(1)
+d = s.debug_stamps(True, n=(1<<20)+2*1600).astype(np.int64)
+nb = 1563
+S = d[:4*nb].reshape(nb,4)
+T = d[(1<<20):(1<<20)+2*(nb+lag)].reshape(nb+lag,2)
+u = np.arange(200,1400)
+start, chain_end, pub = S[u,0], S[u,1], S[u,2]
+print("per-block period (start[u+1]-start[u]) us:", np.median(np.diff(S[200:1400,0]))/100.0)
+print("chain time us:", np.median(chain_end-start)/100.0)
+print("publish after chain end us:", np.median(pub-chain_end)/100.0)
+# streamer 0: time partial(u) published vs sampler block start
+print("streamer0 partial(u) published before sampler start(u) by us:", np.median(S[u,0]-T[u,0])/100.0)
+print("streamer0 got dlt(u-D) after publish(u-D) us:", np.median(T[u+lag,1]-S[u,2])/100.0)
+print("streamer0 loop period us:", np.median(np.diff(T[200:1400,0]))/100.0)
