@@ -44,6 +44,7 @@ struct ngp_handle {
     int lag = 6;       // look-ahead D of the persistent sweep (blocks)
     int D = 1;         // Gram planes stored per block (= lag in mode 1, 1 in mode 0)
     int NG = 1;        // reducer groups = ceil(S/32)
+    int NS = 1;        // LDS tile slots of a streamer workgroup
     int cu_count = 256;
     double *d_cpart = nullptr, *d_cgsum = nullptr, *d_cdlt = nullptr;
     unsigned *d_ccnt = nullptr, *d_abort = nullptr;
@@ -152,7 +153,7 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
     int64_t max_shards = 256;
     if (h->mode == 1) {
         max_shards = h->cu_count - 1 - (h->cu_count + NGP_GRP - 1) / NGP_GRP;
-        if (N > max_shards * 508) h->mode = 0;  // too many rows for one resident wave of streamers
+        if (N > max_shards * 300) h->mode = 0;  // too many rows for one resident wave of streamers (LDS: tile + partials)
         else choose_layout(N, max_shards, &h->R, &h->S);
     }
     if (h->mode == 0) choose_layout(N, 256, &h->R, &h->S);
@@ -198,9 +199,12 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
     h->have_y = false; h->iter = 0;
     HCHK(hipFuncSetAttribute((const void *)k_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_step));
     if (h->mode == 1) {
-        const size_t lds_streamer = (size_t)h->R * 264 + 2048 + 512 + 64;
         const size_t lds_sampler = (size_t)(4 * 4096 + 2 * NGP_RING * NGP_BLK + 4 * NGP_BLK) * sizeof(double) + 2 * NGP_BLK * sizeof(int) + 64;
-        h->lds_sweep = std::max(lds_streamer, lds_sampler);
+        const size_t lds_max = 160 * 1024;
+        const size_t misc = (size_t)h->R * 8 + 2048 + 512 + 128 + 3072 + (size_t)h->R * 64;
+        const size_t TB = (size_t)h->R * 256;
+        h->NS = (int)std::min<size_t>((size_t)h->D + 2, (lds_max - misc) / TB);  // >= 1 because R <= 508
+        h->lds_sweep = std::max((size_t)h->NS * TB + misc, lds_sampler);
         HCHK(hipFuncSetAttribute((const void *)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_sweep));
         if ((rc = dalloc(h, &h->d_cpart, (size_t)NGP_RING * h->S * NGP_BLK))) return rc;
         if ((rc = dalloc(h, &h->d_cgsum, (size_t)NGP_RING * h->NG * NGP_BLK))) return rc;
@@ -304,12 +308,12 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
         (void)hipMemsetAsync(h->d_ccnt, 0, h->ccnt_words * sizeof(unsigned), h->stream);
         SweepArgs A;
         A.tiles = h->d_tiles; A.ycorr = h->d_ycorr; A.gramx = h->d_gramx;
-        A.D = h->D; A.R = R; A.S = S; A.NG = h->NG; A.t0 = (int)tb0; A.t1 = (int)tb1;
+        A.D = h->D; A.R = R; A.S = S; A.NG = h->NG; A.NS = h->NS; A.t0 = (int)tb0; A.t1 = (int)tb1;
         A.beta = h->d_beta; A.delta = h->d_delta; A.c = h->d_c; A.w = h->d_w; A.q = h->d_q; A.T = h->d_T; A.chi = h->d_chi;
         A.setof = h->d_setof; A.vbidx = h->d_vbidx; A.sets = h->d_sets; A.varBeta = h->d_varBeta;
         A.part = h->d_cpart; A.gsum = h->d_cgsum; A.dlt = h->d_cdlt;
         A.cnt_part = h->d_ccnt; A.cnt_gs = h->d_ccnt + (size_t)NGP_RING * h->NG * 32;
-        A.flag_dlt = A.cnt_gs + (size_t)NGP_RING * 32; A.abort_w = h->d_abort;
+        A.flag_dlt = A.cnt_gs + (size_t)NGP_RING * 32; A.abort_w = h->d_abort; A.xcc_w = h->d_abort + 16;
         if (evs) (void)hipEventRecord(evs[0], h->stream);
         A.dbg = h->d_dbg;
         hipLaunchKernelGGL(k_sweep, dim3((unsigned)(1 + h->NG + S)), dim3(NGP_WG), h->lds_sweep, h->stream, A);
@@ -876,7 +880,7 @@ int32_t ngp_configure(ngp_handle *h, int32_t mode, int32_t lag) {
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles == nullptr, NGP_ERR_STATE, "ngp_configure must precede the panel upload");
     REQUIRE(mode == 0 || mode == 1, NGP_ERR_ARG, "mode must be 0 (per-block launches) or 1 (persistent sweep)");
-    REQUIRE(lag >= 1 && lag <= NGP_MAX_LAG, NGP_ERR_ARG, "lag must be in 1..8");
+    REQUIRE(lag >= 1 && lag <= NGP_MAX_LAG, NGP_ERR_ARG, "lag must be in 1..6");
     h->mode = mode; h->lag = lag;
     return NGP_OK;
 }

@@ -138,7 +138,7 @@ __global__ __launch_bounds__(256) void k_prep(long long Ppad, const int8_t *__re
     if (si < 0 || (active_set >= 0 && si != active_set)) {
         c[k] = 0.0;
         w[k] = 0.0;
-        q[k] = 0.0;
+        q[k] = -1.0;
         T[k] = 1.0;
         chi[k] = 1.0;
         return;
@@ -170,7 +170,7 @@ __global__ __launch_bounds__(256) void k_prep(long long Ppad, const int8_t *__re
         double v1 = m2 + v0;
         double i1 = 1.0 / v1, i0 = 1.0 / v0;
         double dq = i1 - i0;
-        q[k] = 0.5 * dq;
+        double qq = 0.5 * dq;
         Rng ru = rng_seed(seed, chain, it, NGP_KIND_B_UNIFORM, key);
         double u = rng_uniform(ru);
         double om = 1.0 - u;
@@ -179,11 +179,21 @@ __global__ __launch_bounds__(256) void k_prep(long long Ppad, const int8_t *__re
         dl = 0.5 * dl;
         double TT = Lu - dl;
         double lp = S.logPi0 - S.logPi1;
-        T[k] = TT - lp;
+        TT = TT - lp;
+        // inclusion test r^2*q < T rearranged so that the serial chain only compares |r| with a threshold
+        double st;
+        if (qq < 0.0) {
+            double thr2 = TT / qq;
+            st = (thr2 < 0.0) ? -1.0 : det_sqrt(thr2);
+        } else {
+            st = (0.0 < TT) ? -1.0 : __builtin_huge_val();
+        }
+        q[k] = st;
+        T[k] = TT;
         Rng rc = rng_seed(seed, chain, it, NGP_KIND_B_LOCUS_CHI2, key);
         chi[k] = rng_chisq(rc, S.df + 1.0);
     } else {
-        q[k] = 0.0;
+        q[k] = -1.0;  // BayesPR: always included
         T[k] = 1.0;
         chi[k] = 1.0;
     }
@@ -207,9 +217,17 @@ __global__ __launch_bounds__(256) void k_step(const float *__restrict__ tiles, d
     if (do_upd) {
         const float *tp = tiles + ((size_t)(t - 1) * S + s) * tile_elems;
         for (int i = tid; i < R; i += 256) {
-            double yv = yg[i];
-#pragma unroll 16
-            for (int j = 0; j < NGP_BLK; j++) yv = __builtin_fma(-(double)tp[(size_t)j * R + i], dlt[j], yv);
+            // y_i -= sum_j x_ij dlt_j: eight chains of eight columns, then a fixed pairwise tree
+            double p8[8];
+#pragma unroll
+            for (int c = 0; c < 8; c++) {
+                double p = 0.0;
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++) p = __builtin_fma((double)tp[(size_t)(8 * c + jj) * R + i], dlt[8 * c + jj], p);
+                p8[c] = p;
+            }
+            double T = ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
+            double yv = yg[i] - T;
             yg[i] = yv;
             ys[i] = yv;
         }
@@ -270,15 +288,13 @@ __global__ __launch_bounds__(256) void k_recur(const double *__restrict__ part, 
 #pragma unroll
     for (int kk = 0; kk < NGP_BLK; kk++) Gr[kk] = G[kk * NGP_BLK + j];
     const double gd = G[j * NGP_BLK + j];
-    const double bo = beta[k], cc = c[k], ww = w[k], qq = q[k], TT = T[k];
+    const double bo = beta[k], cc = c[k], ww = w[k], st = q[k];
     double r = __builtin_fma(gd, bo, tot);
     double dsave = 0.0;
     int isave = 1;
 #pragma unroll
     for (int kk = 0; kk < NGP_BLK; kk++) {
-        double r2 = r * r;
-        double lq = r2 * qq;
-        int in = lq < TT;
+        int in = __builtin_fabs(r) > st;
         double d = __builtin_fma(r, cc, ww);
         double dl = in ? d : -bo;
         if (j == kk) {

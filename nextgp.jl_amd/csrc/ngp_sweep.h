@@ -27,9 +27,12 @@
 #pragma clang fp contract(off)
 
 #define NGP_RING 16        // slots of every communication ring (>= lag D)
-#define NGP_MAX_LAG 8
+#define NGP_MAX_LAG 6
 #define NGP_SPIN_LIMIT (1u << 21)
 #define NGP_WG 512          // threads per workgroup of the persistent kernel
+#define NGP_DBG_WAVES (1u << 19)   // sampler: 8 words per block, end-of-work stamp of every wave
+#define NGP_DBG_RED (3u << 18)     // reducer 0: 2 words per block (counter complete, group sum published)
+#define NGP_DBG_ALL (7u << 17)     // every streamer: publish time of local block 800 and its XCC id
 #define NGP_DBG_STREAM (1u << 20)  // offset of streamer 0's stamps in the debug buffer
 
 namespace ngp {
@@ -38,7 +41,7 @@ struct SweepArgs {
     const float *tiles;
     double *ycorr;
     const double *gramx;
-    int D, R, S, NG, t0, t1;
+    int D, R, S, NG, NS, t0, t1;  // NS: LDS tile slots of a streamer
     double *beta;
     uint8_t *delta;
     const double *c, *w, *q, *T, *chi;
@@ -54,6 +57,7 @@ struct SweepArgs {
     unsigned *cnt_gs;    // [RING] counters, one 128-B line each
     unsigned *flag_dlt;  // number of blocks the sampler has finished
     unsigned *abort_w;   // != 0: a spin timed out (code = role)
+    unsigned *xcc_w;     // sampler's XCC id + 1 (speed only: same-XCD streamers warm the L2 with Gram blocks)
     unsigned long long *dbg;  // optional time stamps (diagnostic runs only), else nullptr
 };
 
@@ -66,6 +70,8 @@ __device__ inline double ld_f64(const double *p) {
 __device__ inline void st_f64(double *p, double v) {
     __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// XCC (XCD) id of the executing wave: HW_REG_XCC_ID (id 20), bits 3:0
+__device__ inline unsigned xcc_id() { return (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xFu; }
 __device__ inline void drain_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // ONE lane polls ONE word; bounded; false = give up (abort word set by us or by somebody else)
@@ -96,48 +102,121 @@ __device__ inline double gemv4(GLoad G, const double *d) {
 }
 
 // ------------------------------------------------------------------------------------------
-// 512-thread workgroups (8 waves).  Streamer: all waves load / update, waves 0-3 do the GEMV.
+// 512-thread workgroups (8 waves).  Streamer s keeps its ycorr shard in LDS for the whole sweep and
+// walks the blocks through a ring of NS LDS tile slots filled by LDS-DMA (global_load_lds_dwordx4,
+// tiles are contiguous in HBM) one block ahead.  With NS >= D+2 a tile stays in LDS from its GEMV
+// until its update D blocks later (ONE HBM read per tile, no re-read); otherwise the update
+// re-reads the tile from global memory (L2 / Infinity Cache).
+//   waves 4-6  LDS-DMA of the next tile        wave 7  waits for dlt of block u-D and stages it in LDS
+//   waves 0-3  GEMV (lane = column, strided row quads); wave 0 publishes the 64 partial sums
 __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem) {
-    const int R = A.R, S = A.S, D = A.D, tid = threadIdx.x;
-    float *tl = (float *)smem;
-    double *ys = (double *)(smem + (size_t)R * 256);
+    const int R = A.R, S = A.S, D = A.D, NS = A.NS, tid = threadIdx.x;
+    const int wv = tid >> 6, j = tid & 63;
+    const size_t TB = (size_t)R * 256;  // tile bytes
+    char *ring = smem;                  // NS slots of TB bytes (TB is a multiple of 1 KiB)
+    double *ys = (double *)(smem + (size_t)NS * TB);
     double *red = ys + R;
     double *dl = red + 256;
     int *sflag = (int *)(dl + 64);
+    char *scratch = (char *)(dl + 64) + 64;  // 3 KiB sink of the L2-warming DMA
+    double *pp = (double *)(scratch + 3072);  // 8 x R partial sums of the update
     const size_t tile_elems = (size_t)R * NGP_BLK;
+    const bool resident = NS >= D + 2;  // tiles live in LDS until their update
+    const int pd = NS >= 2 ? 1 : 0;     // DMA prefetch distance in blocks
+    const int nchunk = R >> 2;          // 1 KiB pieces per tile
     double *yg = A.ycorr + (size_t)s * R;
-    for (int i = tid; i < R; i += NGP_WG) ys[i] = yg[i];
-    __syncthreads();
     const int g = s / NGP_GRP;
-    const int wv = tid >> 6, j = tid & 63;
     const int nb = A.t1 - A.t0;
+    auto dma_tile = [&](int ub) {  // waves 4..6 copy tile ub into its ring slot, 1 KiB per wave-instruction
+        const char *src = (const char *)(A.tiles + ((size_t)(A.t0 + ub) * S + s) * tile_elems);
+        char *dst = ring + (size_t)(ub % NS) * TB;
+        for (int c = wv - 4; c < nchunk; c += 3)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)c * 1024 + (size_t)j * 16),
+                                             (__attribute__((address_space(3))) void *)(dst + (size_t)c * 1024), 16, 0, 0);
+    };
+    for (int i = tid; i < R; i += NGP_WG) ys[i] = yg[i];
+    if (tid == 0) *sflag = 1;
+    if (wv >= 4 && wv <= 6 && pd == 1 && nb > 0) dma_tile(0);
+    // speed only: streamers that share the sampler's XCD pull the Gram blocks of the block after their own
+    // into that XCD's L2, so the sampler CU (one CU, latency-bound on HBM) finds them there
+    const unsigned my_xcc = xcc_id() + 1u;
+    const int nslice = max(1, S / 8);
+    const int slice = (s / 8) % nslice;
+    const size_t gram_bytes = (size_t)D * NGP_BLK * NGP_BLK * sizeof(double);
+    const size_t slice_bytes = ((gram_bytes / nslice + 1023) / 1024) * 1024;
+    bool same_xcd = false;
+    unsigned long long accA = 0, accB = 0, accC = 0, accP = 0, tt0 = 0;
+    __syncthreads();
     for (int u = 0; u < nb + D; ++u) {
-        if (u >= D) {  // update with local block a = u - D
-            const int a = u - D;
-            if (tid == 0) {
-                *sflag = wait_ge(A.flag_dlt, (unsigned)(a + 1), A.abort_w, 1u) ? 1 : 0;
-                if (A.dbg && s == 0) A.dbg[NGP_DBG_STREAM + 2 * (size_t)u + 1] = wall_clock64();
+        const int a = u - D;  // block whose update is applied in this iteration (if >= 0)
+        if (A.dbg) tt0 = wall_clock64();
+        // ---------------- phase A: everything that waits on memory ----------------
+        if (wv >= 4 && wv <= 6) {
+            drain_vm();  // tile u (issued one iteration ago) has landed
+            if (u + pd < nb) dma_tile(u + pd);
+            if ((u & 7) == 0 && !same_xcd) same_xcd = (ld_u32(A.xcc_w) == my_xcc);
+            if (same_xcd && u + 1 < nb) {  // fire-and-forget: the lines only have to reach this XCD's L2
+                const char *gb = (const char *)(A.gramx + (size_t)(A.t0 + u + 1) * D * NGP_BLK * NGP_BLK);
+                const size_t lo = (size_t)slice * slice_bytes, hi = min((size_t)(slice + 1) * slice_bytes, gram_bytes);
+                for (size_t off = lo + (size_t)(wv - 4) * 1024; off + 1024 <= hi; off += 3 * 1024)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gb + off + (size_t)j * 16),
+                                                     (__attribute__((address_space(3))) void *)(scratch + (wv - 4) * 1024), 16, 0, 0);
             }
-            __syncthreads();
-            if (!*sflag) return;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            if (tid < 64) dl[tid] = ld_f64(&A.dlt[(size_t)(a % NGP_RING) * NGP_BLK + tid]);
-            __syncthreads();
-            const float *tp = A.tiles + ((size_t)(A.t0 + a) * S + s) * tile_elems;
-            for (int i = tid; i < R; i += NGP_WG) {
-                double yv = ys[i];
-#pragma unroll 16
-                for (int jj = 0; jj < NGP_BLK; jj++) yv = __builtin_fma(-(double)tp[(size_t)jj * R + i], dl[jj], yv);
-                ys[i] = yv;
+            if (pd == 0) drain_vm();
+        } else if (wv == 7) {
+            if (a >= 0) {
+                int ok = 1;
+                if (j == 0) {
+                    ok = wait_ge(A.flag_dlt, (unsigned)(a + 1), A.abort_w, 1u) ? 1 : 0;
+                    if (A.dbg && s == 0) A.dbg[NGP_DBG_STREAM + 2 * (size_t)u + 1] = wall_clock64();
+                    *sflag = ok;
+                }
+                ok = __shfl(ok, 0);
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (ok) dl[j] = ld_f64(&A.dlt[(size_t)(a % NGP_RING) * NGP_BLK + j]);
             }
         }
-        if (u < nb) {
-            const float4 *src = (const float4 *)(A.tiles + ((size_t)(A.t0 + u) * S + s) * tile_elems);
-            float4 *dst = (float4 *)tl;
-            for (int idx = tid; idx < R * 16; idx += NGP_WG) dst[idx] = src[idx];
+        if (A.dbg && (tid == 448 || tid == 256)) accP += wall_clock64() - tt0;  // wave 7 poll / wave 4 DMA drain
+        __syncthreads();
+        if (!*sflag) return;
+        if (A.dbg && tid == 0) { unsigned long long n = wall_clock64(); accA += n - tt0; tt0 = n; }
+        // ---------------- phase B: ycorr -= X_a dlt_a for the own rows ----------------
+        if (a >= 0) {
+            // y_i -= sum_j x_ij dlt_j with 8 R tasks (c, i): task = 8-column chain c of row i -> pp[c][i]; then row i adds
+            // the eight partial sums in a fixed pairwise tree.  Consecutive lanes = consecutive rows: conflict-free.
+            for (int q0 = 0; q0 < 8 * R; q0 += NGP_WG) {
+                const int q = min(q0 + tid, 8 * R - 1);  // clamp instead of predicating loads (idle lanes redo the last task)
+                const int c = q / R, i = q - c * R;
+                double p = 0.0;
+                if (resident) {
+                    const float *tp = (const float *)(ring + (size_t)(a % NS) * TB) + (size_t)(8 * c) * R + i;
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) p = __builtin_fma((double)tp[jj * R], dl[8 * c + jj], p);
+                } else {
+                    const float *tp = A.tiles + ((size_t)(A.t0 + a) * S + s) * tile_elems + (size_t)(8 * c) * R + i;
+                    float xv[8];
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) xv[jj] = tp[(size_t)jj * R];
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) p = __builtin_fma((double)xv[jj], dl[8 * c + jj], p);
+                }
+                pp[(size_t)c * R + i] = p;
+            }
             __syncthreads();
+            for (int i = tid; i < R; i += NGP_WG) {
+                const double T = ((pp[i] + pp[R + i]) + (pp[2 * R + i] + pp[3 * R + i])) +
+                                 ((pp[4 * R + i] + pp[5 * R + i]) + (pp[6 * R + i] + pp[7 * R + i]));
+                ys[i] = ys[i] - T;
+            }
+        } else {
+            __syncthreads();
+        }
+        __syncthreads();
+        if (A.dbg && tid == 0) { unsigned long long n = wall_clock64(); accB += n - tt0; tt0 = n; }
+        // ---------------- phase C: partial X_u' ycorr ----------------
+        if (u < nb) {
             if (wv < 4) {
-                const float *col = tl + (size_t)j * R;
+                const float *col = (const float *)(ring + (size_t)(u % NS) * TB) + (size_t)j * R;
                 double acc = 0.0;
                 for (int qd = wv; qd < (R >> 2); qd += 4) {
                     float4 x = *(const float4 *)(col + 4 * qd);
@@ -158,10 +237,19 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
                 if (j == 0) {
                     atomicAdd(&A.cnt_part[((size_t)slot * A.NG + g) * 32], 1u);
                     if (A.dbg && s == 0) A.dbg[NGP_DBG_STREAM + 2 * (size_t)u] = wall_clock64();
+                    if (A.dbg && (u == 800 || u == 1200)) {
+                        A.dbg[NGP_DBG_ALL + 4 * (size_t)s + (u == 800 ? 0 : 2)] = wall_clock64();
+                        A.dbg[NGP_DBG_ALL + 4 * (size_t)s + 1] = my_xcc;
+                        A.dbg[NGP_DBG_ALL + 4 * (size_t)s + 3] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+                    }
                 }
             }
         }
+        if (A.dbg && tid == 0) accC += wall_clock64() - tt0;
     }
+    if (A.dbg && tid == 0) { A.dbg[NGP_DBG_ALL + 4096 + 8 * (size_t)s] = accA; A.dbg[NGP_DBG_ALL + 4096 + 8 * (size_t)s + 1] = accB; A.dbg[NGP_DBG_ALL + 4096 + 8 * (size_t)s + 2] = accC; }
+    if (A.dbg && tid == 448) A.dbg[NGP_DBG_ALL + 4096 + 8 * (size_t)s + 3] = accP;
+    if (A.dbg && tid == 256) A.dbg[NGP_DBG_ALL + 4096 + 8 * (size_t)s + 4] = accP;
     __syncthreads();
     for (int i = tid; i < R; i += NGP_WG) yg[i] = ys[i];
 }
@@ -178,6 +266,7 @@ __device__ inline void role_reducer(const SweepArgs &A, const int g) {
         if (lane == 0) ok = wait_ge(&A.cnt_part[((size_t)slot * A.NG + g) * 32], (unsigned)((round + 1) * gsize), A.abort_w, 2u) ? 1 : 0;
         ok = __shfl(ok, 0);
         if (!ok) return;
+        if (A.dbg && g == 0 && lane == 0) A.dbg[NGP_DBG_RED + 2 * (size_t)u] = wall_clock64();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const double *p = A.part + ((size_t)slot * S + s0) * NGP_BLK + lane;
         double vals[NGP_GRP];
@@ -189,27 +278,28 @@ __device__ inline void role_reducer(const SweepArgs &A, const int g) {
             if (s < gsize) v = v + vals[s];
         st_f64(&A.gsum[((size_t)slot * A.NG + g) * NGP_BLK + lane], v);
         drain_vm();
-        if (lane == 0) atomicAdd(&A.cnt_gs[(size_t)slot * 32], 1u);
+        if (lane == 0) {
+            atomicAdd(&A.cnt_gs[(size_t)slot * 32], 1u);
+            if (A.dbg && g == 0) A.dbg[NGP_DBG_RED + 2 * (size_t)u + 1] = wall_clock64();
+        }
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// sampler (8 waves): wave 0 = serial chain (LDS + ALU only), wave 1 = publisher of the finished
-// block, waves 2-7 = Gram traffic (LDS prefetch of the next diagonal / lag-1 blocks, far
-// corrections straight from global memory); wave 2 also fetches the next block's group sums.
-// LDS: Gd[2][4096] | Gx[2][4096] | hist[RING][64] | vacc[RING][64] | r0[2][64] | outb[2][64] | outi[2][64] | flags
 struct CoefRegs {
-    double bo, cc, ww, qq, TT;
+    double bo, cc, ww, st;
 };
 __device__ inline CoefRegs load_coef(const SweepArgs &A, long long k) {
     CoefRegs c;
     c.bo = A.beta[k];
     c.cc = A.c[k];
     c.ww = A.w[k];
-    c.qq = A.q[k];
-    c.TT = A.T[k];
+    c.st = A.q[k];  // inclusion threshold: included iff |r| > st (st < 0: always)
     return c;
 }
+
+// workgroup barrier that drains LDS traffic only: global loads issued before it stay in flight
+__device__ inline void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // group sums of local block u -> per-lane total (lane 0 polls, whole wave loads); false on abort
 __device__ inline bool fetch_group_sums(const SweepArgs &A, int u, int j, double *tot_out) {
@@ -231,8 +321,43 @@ __device__ inline bool fetch_group_sums(const SweepArgs &A, int u, int j, double
     return true;
 }
 
+// results of a finished block: dlt first (sc1 + drain + flag: the streamers are waiting), then beta / delta / varBeta
+__device__ inline void publish_block(const SweepArgs &A, int up, int j, const double *hist, const double *outb, const int *outi) {
+    const int pslot = up % NGP_RING, pbuf = up & 1;
+    const long long k = (long long)(A.t0 + up) * NGP_BLK + j;
+    st_f64(&A.dlt[(size_t)pslot * NGP_BLK + j], hist[pslot * NGP_BLK + j]);
+    drain_vm();
+    if (j == 0) {
+        st_u32(A.flag_dlt, (unsigned)(up + 1));
+        if (A.dbg) A.dbg[4 * (size_t)up + 2] = wall_clock64();
+    }
+    const double bn = outb[pbuf * NGP_BLK + j];
+    const int isave = outi[pbuf * NGP_BLK + j];
+    A.beta[k] = bn;
+    A.delta[k] = (uint8_t)isave;
+    const int si = A.setof[k];
+    if (si >= 0 && A.sets[si].method == 1) {
+        double vb = 0.0;
+        if (isave) {
+            double tt = A.sets[si].sdf;
+            double b2 = bn * bn;
+            tt = tt + b2;
+            vb = tt / A.chi[k];
+            atomicAdd(&A.sets[si].nloci, 1);
+        }
+        A.varBeta[A.vbidx[k]] = vb;
+    }
+}
+
+// sampler (8 waves), one raw barrier per block:
+//   wave 0   serial chain of block u (LDS + ALU only; coefficients prefetched one block ahead)
+//   wave 1   publishes block u-1 (dlt -> streamers, beta/delta/varBeta)
+//   wave 2   fetches the group sums of block u+1 into LDS
+//   wave 3   LDS-DMA of the diagonal and lag-1 Gram blocks of block u+1
+//   wave 4-7 far corrections G[t',a] dlt_a, lag x = 2..5, Gram rows loaded one block ahead into registers
+// LDS: Gd[2][4096] | Gx[2][4096] | hist[RING][64] | vacc[RING][64] | r0[2][64] | outb[2][64] | outi[2][64] | flags
 __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
-    const int D = A.D, NG = A.NG, tid = threadIdx.x, wv = tid >> 6, j = tid & 63;
+    const int D = A.D, tid = threadIdx.x, wv = tid >> 6, j = tid & 63;
     double *Gd = (double *)smem;                // 2 x 4096
     double *Gx = Gd + 2 * 4096;                 // 2 x 4096 (lag-1 cross block, [k][j])
     double *hist = Gx + 2 * 4096;               // RING x 64
@@ -243,7 +368,11 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
     int *sabort = outi + 2 * NGP_BLK;
     const int nb = A.t1 - A.t0;
     const size_t bsz = NGP_BLK * NGP_BLK;
-    if (tid == 0) *sabort = 0;
+    if (tid == 0) {
+        *sabort = 0;
+        st_u32(A.xcc_w, xcc_id() + 1u);
+        if (A.dbg) { A.dbg[NGP_DBG_ALL - 2] = xcc_id(); A.dbg[NGP_DBG_ALL - 1] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4); }
+    }
     // prologue: diagonal Gram block of local block 0 (all waves) and its group sums (wave 2)
     {
         const double *gd = A.gramx + ((size_t)A.t0 * D + 0) * bsz;
@@ -255,14 +384,20 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
         if (fetch_group_sums(A, 0, j, &tot)) r0[j] = tot;
         else if (j == 0) *sabort = 1;
     }
-    CoefRegs cur = {0, 0, 0, 0, 1}, nxt = {0, 0, 0, 0, 1};
-    if (wv == 0) cur = load_coef(A, (long long)A.t0 * NGP_BLK + j);
     __syncthreads();
     if (*sabort) return;
-    for (int u = 0; u < nb; ++u) {
-        const int t = A.t0 + u, buf = u & 1, slot = u % NGP_RING;
-        if (wv == 0) {
-            // ---------------- critical wave: LDS + ALU only ----------------
+#define NGP_END_OF_BLOCK()                                                                       \
+    do {                                                                                         \
+        if (A.dbg && j == 0) A.dbg[NGP_DBG_WAVES + 8 * (size_t)u + wv] = wall_clock64();           \
+        wg_barrier();                                                                            \
+        if (*sabort) return;                                                                     \
+    } while (0)
+    // every role runs its own block loop (own register budget); all meet at ONE raw barrier per block
+    if (wv == 0) {
+        // ---------------- critical wave: LDS + ALU only ----------------
+        CoefRegs cur = load_coef(A, (long long)A.t0 * NGP_BLK + j), nxt = cur;
+        for (int u = 0; u < nb; ++u) {
+            const int t = A.t0 + u, buf = u & 1, slot = u % NGP_RING;
             if (u + 1 < nb) nxt = load_coef(A, (long long)(t + 1) * NGP_BLK + j);
             if (A.dbg && j == 0) A.dbg[4 * (size_t)u] = wall_clock64();
             double tot = r0[buf * NGP_BLK + j];
@@ -280,128 +415,133 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
             }
             if (have_far || have_one) tot = tot - cor;
             const double *gdb = Gd + buf * 4096;
-            const double bo = cur.bo, cc = cur.cc, ww = cur.ww, qq = cur.qq, TT = cur.TT;
+            const double bo = cur.bo, cc = cur.cc, ww = cur.ww, st = cur.st;
             double r = __builtin_fma(gdb[j * NGP_BLK + j], bo, tot);
             double Gr[NGP_BLK];
 #pragma unroll
             for (int kk = 0; kk < NGP_BLK; kk++) Gr[kk] = gdb[kk * NGP_BLK + j];
             double dsave = 0.0;
             int isave = 1;
+            if (__ballot(st >= 0.0) == 0ull) {
+                // every locus of the block is always included (BayesPR): fma -> broadcast -> fma per step
 #pragma unroll
-            for (int kk = 0; kk < NGP_BLK; kk++) {
-                double r2 = r * r;
-                double lq = r2 * qq;
-                int in = lq < TT;
-                double d = __builtin_fma(r, cc, ww);
-                double dlv = in ? d : -bo;
-                if (j == kk) {
-                    dsave = dlv;
-                    isave = in;
+                for (int kk = 0; kk < NGP_BLK; kk++) {
+                    double d = __builtin_fma(r, cc, ww);
+                    if (j == kk) dsave = d;
+                    double dk = readlane_d(d, kk);
+                    r = __builtin_fma(-Gr[kk], dk, r);
                 }
-                double dk = readlane_d(dlv, kk);
-                r = __builtin_fma(-Gr[kk], dk, r);
+            } else {
+#pragma unroll
+                for (int kk = 0; kk < NGP_BLK; kk++) {
+                    int in = __builtin_fabs(r) > st;
+                    double d = __builtin_fma(r, cc, ww);
+                    double dlv = in ? d : -bo;
+                    if (j == kk) {
+                        dsave = dlv;
+                        isave = in;
+                    }
+                    double dk = readlane_d(dlv, kk);
+                    r = __builtin_fma(-Gr[kk], dk, r);
+                }
             }
             hist[slot * NGP_BLK + j] = dsave;
             outb[buf * NGP_BLK + j] = bo + dsave;
             outi[buf * NGP_BLK + j] = isave;
             if (A.dbg && j == 0) A.dbg[4 * (size_t)u + 1] = wall_clock64();
             cur = nxt;
-        } else if (wv == 1) {
-            // ---------------- publisher: results of local block u-1 ----------------
-            if (u >= 1) {
-                const int up = u - 1, pslot = up % NGP_RING, pbuf = up & 1;
-                const long long k = (long long)(A.t0 + up) * NGP_BLK + j;
-                const double dv = hist[pslot * NGP_BLK + j];
-                st_f64(&A.dlt[(size_t)pslot * NGP_BLK + j], dv);
+            NGP_END_OF_BLOCK();
+        }
+    } else if (wv == 1) {
+        for (int u = 0; u < nb; ++u) {
+            if (u >= 1) publish_block(A, u - 1, j, hist, outb, outi);
+            NGP_END_OF_BLOCK();
+        }
+        if (nb >= 1) publish_block(A, nb - 1, j, hist, outb, outi);
+    } else if (wv == 2) {
+        // group sums of block u+1 -> r0[next].  The counter of block u+2 is probed (one relaxed load, no spin)
+        // while the loads of block u+1 are in flight, so in steady state each block costs ONE memory round trip.
+        bool ready_next = false;  // counter of local block u+1 already seen complete
+        for (int u = 0; u < nb; ++u) {
+            if (u + 1 < nb && D >= 2) {
+                const int un = u + 1, nslot = un % NGP_RING;
+                const int NG = A.NG;
+                unsigned probe = 0;
+                const bool can_probe = (u + 2 < nb) && (D >= 3);
+                const unsigned *pc = &A.cnt_gs[(size_t)((u + 2) % NGP_RING) * 32];
+                int ok = 1;
+                if (!ready_next) {
+                    if (j == 0) ok = wait_ge(&A.cnt_gs[(size_t)nslot * 32], (unsigned)((un / NGP_RING + 1) * NG), A.abort_w, 3u) ? 1 : 0;
+                    ok = __shfl(ok, 0);
+                }
+                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                if (A.dbg && j == 0) A.dbg[4 * (size_t)un + 3] = wall_clock64();
+                if (ok) {
+                    const double *gp = A.gsum + (size_t)nslot * NG * NGP_BLK + j;
+                    double gv[8];
+#pragma unroll
+                    for (int g = 0; g < 8; g++) gv[g] = ld_f64(gp + (size_t)min(g, NG - 1) * NGP_BLK);
+                    if (can_probe) probe = ld_u32(pc);
+                    double tot = gv[0];
+#pragma unroll
+                    for (int g = 1; g < 8; g++)
+                        if (g < NG) tot = tot + gv[g];
+                    r0[((u & 1) ^ 1) * NGP_BLK + j] = tot;
+                    ready_next = can_probe && (__shfl((int)probe, 0) >= (int)(((u + 2) / NGP_RING + 1) * NG));
+                } else if (j == 0) {
+                    *sabort = 1;
+                }
+            }
+            NGP_END_OF_BLOCK();
+        }
+    } else if (wv == 3) {
+        // LDS-DMA (global_load_lds_dwordx4): 2 x 32 KiB in flight, no VGPR staging; drained before the barrier
+        for (int u = 0; u < nb; ++u) {
+            if (u + 1 < nb) {
+                for (int x = 0; x < 2 && x < D; x++) {
+                    const char *gsrc = (const char *)(A.gramx + ((size_t)(A.t0 + u + 1) * D + x) * bsz) + (size_t)j * 16;
+                    char *gdst = (char *)((x == 0 ? Gd : Gx) + ((u & 1) ^ 1) * 4096);
+#pragma unroll
+                    for (int i = 0; i < 32; i++)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + (size_t)i * 1024),
+                                                         (__attribute__((address_space(3))) void *)(gdst + i * 1024), 16, 0, 0);
+                }
                 drain_vm();
-                if (j == 0) {
-                    st_u32(A.flag_dlt, (unsigned)(up + 1));
-                    if (A.dbg) A.dbg[4 * (size_t)up + 2] = wall_clock64();
-                }
-                const double bn = outb[pbuf * NGP_BLK + j];
-                const int isave = outi[pbuf * NGP_BLK + j];
-                A.beta[k] = bn;
-                A.delta[k] = (uint8_t)isave;
-                const int si = A.setof[k];
-                if (si >= 0 && A.sets[si].method == 1) {
-                    double vb = 0.0;
-                    if (isave) {
-                        double tt = A.sets[si].sdf;
-                        double b2 = bn * bn;
-                        tt = tt + b2;
-                        vb = tt / A.chi[k];
-                        atomicAdd(&A.sets[si].nloci, 1);
-                    }
-                    A.varBeta[A.vbidx[k]] = vb;
-                }
             }
-        } else {
-            // ---------------- Gram waves 2..7: units x = 0..D-1, wave gw takes x = gw, gw+6 ----------------
-            const int gw = wv - 2;
-            double *r0n = r0 + (buf ^ 1) * NGP_BLK;
-            for (int x = gw; x < D; x += 6) {
-                if (x <= 1) {  // LDS prefetch of the next block's diagonal (x=0) / lag-1 (x=1) Gram block
-                    if (u + 1 < nb) {
-                        const double2 *gsrc = (const double2 *)(A.gramx + ((size_t)(t + 1) * D + x) * bsz);
-                        double2 *gdst = (double2 *)((x == 0 ? Gd : Gx) + (buf ^ 1) * 4096);
-                        double2 tmp[32];
-#pragma unroll
-                        for (int i = 0; i < 32; i++) tmp[i] = gsrc[i * 64 + j];
-#pragma unroll
-                        for (int i = 0; i < 32; i++) gdst[i * 64 + j] = tmp[i];
-                    }
-                } else if (u >= 1) {  // far correction with dlt of local block a = u-1 for target a + x
-                    const int a = u - 1, upb = a + x;
-                    if (upb < nb) {
-                        const double *gx = A.gramx + ((size_t)(A.t0 + upb) * D + x) * bsz;
-                        const double *dp = hist + (a % NGP_RING) * NGP_BLK;
-                        double gr[NGP_BLK];
-#pragma unroll
-                        for (int kk = 0; kk < NGP_BLK; kk++) gr[kk] = gx[kk * NGP_BLK + j];
-                        double v = gemv4([&](int kk) { return gr[kk]; }, dp);
-                        double *va = vacc + (upb % NGP_RING) * NGP_BLK + j;
-                        const bool first = (x == D - 1) || (a == 0);
-                        *va = first ? v : *va + v;
-                    }
-                }
-            }
-            if (gw == 0 && u + 1 < nb && D >= 2) {  // group sums of the next block -> r0[next]
-                double tot;
-                if (fetch_group_sums(A, u + 1, j, &tot)) r0n[j] = tot;
-                else if (j == 0) *sabort = 1;
-            }
+            NGP_END_OF_BLOCK();
         }
-        __syncthreads();
-        if (*sabort) return;
-    }
-    // publish the last block
-    if (wv == 1 && nb >= 1) {
-        const int up = nb - 1, pslot = up % NGP_RING, pbuf = up & 1;
-        const long long k = (long long)(A.t0 + up) * NGP_BLK + j;
-        st_f64(&A.dlt[(size_t)pslot * NGP_BLK + j], hist[pslot * NGP_BLK + j]);
-        drain_vm();
-        if (j == 0) st_u32(A.flag_dlt, (unsigned)(up + 1));
-        const double bn = outb[pbuf * NGP_BLK + j];
-        const int isave = outi[pbuf * NGP_BLK + j];
-        A.beta[k] = bn;
-        A.delta[k] = (uint8_t)isave;
-        const int si = A.setof[k];
-        if (si >= 0 && A.sets[si].method == 1) {
-            double vb = 0.0;
-            if (isave) {
-                double tt = A.sets[si].sdf;
-                double b2 = bn * bn;
-                tt = tt + b2;
-                vb = tt / A.chi[k];
-                atomicAdd(&A.sets[si].nloci, 1);
+    } else {
+        // far correction waves: lag fx = 2..5; Gram rows of the pair handled in the NEXT block are loaded one block ahead
+        const int fx = wv - 2;
+        double gr[NGP_BLK];
+#pragma unroll
+        for (int kk = 0; kk < NGP_BLK; kk++) gr[kk] = 0.0;
+        bool have = false;
+        for (int u = 0; u < nb; ++u) {
+            if (fx < D) {
+                if (u >= 1 && have) {  // dlt of local block a = u-1, target a + fx
+                    const int a = u - 1, upb = a + fx;
+                    const double *dp = hist + (a % NGP_RING) * NGP_BLK;
+                    double v = gemv4([&](int kk) { return gr[kk]; }, dp);
+                    double *va = vacc + (upb % NGP_RING) * NGP_BLK + j;
+                    const bool first = (fx == D - 1) || (a == 0);
+                    *va = first ? v : *va + v;
+                }
+                have = (u + fx < nb) && (u + 1 < nb);  // rows for the next block: a' = u, target u + fx
+                if (have) {
+                    const double *gx = A.gramx + ((size_t)(A.t0 + u + fx) * D + fx) * bsz;
+#pragma unroll
+                    for (int kk = 0; kk < NGP_BLK; kk++) gr[kk] = gx[kk * NGP_BLK + j];
+                }
             }
-            A.varBeta[A.vbidx[k]] = vb;
+            NGP_END_OF_BLOCK();
         }
     }
+#undef NGP_END_OF_BLOCK
 }
 
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(NGP_WG) void k_sweep(SweepArgs A) {
+__global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sweep(SweepArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x;
     if (b == 0)

@@ -644,7 +644,7 @@ static void iter_blocked(ora_t *h) {
         for (int64_t i = 0; i < N; i++) h->ycorr[i] = h->ycorr[i] - db;
     }
     /* ---- set_prep: per-locus coefficients */
-    for (int64_t k = 0; k < h->Ppad; k++) { h->c[k] = 0.0; h->w[k] = 0.0; h->q[k] = 0.0; h->T[k] = 1.0; h->chi[k] = 1.0; }
+    for (int64_t k = 0; k < h->Ppad; k++) { h->c[k] = 0.0; h->w[k] = 0.0; h->q[k] = -1.0; h->T[k] = 1.0; h->chi[k] = 1.0; }
     for (int si = 0; si < h->nsets; si++) {
         oset_t *Sx = &h->sets[si];
         double *vb = h->varBeta + Sx->vb_off;
@@ -666,14 +666,20 @@ static void iter_blocked(ora_t *h) {
                     double v0 = mpm * varE;
                     double m2 = mpm * mpm; m2 = m2 * vbk; double v1 = m2 + v0;
                     double i1 = 1.0 / v1, i0 = 1.0 / v0; double dq = i1 - i0;
-                    h->q[k] = 0.5 * dq;
+                    double qq = 0.5 * dq;
                     rng_seed(&r, h->seed, h->chain, it, KIND_B_UNIFORM, ((uint64_t)si << 40) | (uint64_t)l);
                     double u = rng_uniform(&r);
                     double om = 1.0 - u;
                     double Lu = det_log(om) - det_log(u);
                     double dl = det_log(v1) - det_log(v0); dl = 0.5 * dl;
                     double T = Lu - dl; double lp = Sx->logPi[0] - Sx->logPi[1];
-                    h->T[k] = T - lp;
+                    double TT = T - lp;
+                    /* inclusion test rr*q < T rearranged so the serial chain only compares |r| with a threshold:
+                       q < 0: r^2 > T/q  <=>  |r| > sqrt(T/q) (always true when T/q < 0);  q == 0: 0 < T */
+                    double st;
+                    if (qq < 0.0) { double thr2 = TT / qq; st = (thr2 < 0.0) ? -1.0 : sqrt(thr2); }
+                    else st = (0.0 < TT) ? -1.0 : INFINITY;
+                    h->q[k] = st; h->T[k] = TT;
                     rng_seed(&r, h->seed, h->chain, it, KIND_B_LOCUS_CHI2, ((uint64_t)si << 40) | (uint64_t)l);
                     h->chi[k] = rng_chisq(&r, Sx->df + 1.0);
                 }
@@ -692,9 +698,15 @@ static void iter_blocked(ora_t *h) {
                 const float *tl = h->tiles + ((size_t)s * NBLK + a) * tile;
                 double *ys = h->ycorr + s * R;
                 for (int64_t i = 0; i < R; i++) {
-                    double yv = ys[i];
-                    for (int j = 0; j < BLK; j++) yv = __builtin_fma(-(double)tl[j * R + i], hist[a * BLK + j], yv);
-                    ys[i] = yv;
+                    /* y_i -= sum_j x_ij dlt_j: eight chains of eight columns, then a fixed pairwise tree */
+                    double p8[8];
+                    for (int c = 0; c < 8; c++) {
+                        double p = 0.0;
+                        for (int jj = 0; jj < 8; jj++) p = __builtin_fma((double)tl[(8 * c + jj) * R + i], hist[a * BLK + 8 * c + jj], p);
+                        p8[c] = p;
+                    }
+                    double T = ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
+                    ys[i] = ys[i] - T;
                 }
             }
         }
@@ -733,9 +745,7 @@ static void iter_blocked(ora_t *h) {
         }
         for (int k = 0; k < BLK; k++) {
             double rk = rr[k];
-            double r2 = rk * rk;
-            double lhsq = r2 * h->q[k0 + k];
-            int in = lhsq < h->T[k0 + k];
+            int in = fabs(rk) > h->q[k0 + k];
             double d = __builtin_fma(rk, h->c[k0 + k], h->w[k0 + k]);
             double dk = in ? d : -h->beta[k0 + k];
             dlt[k] = dk; inc[k] = in;

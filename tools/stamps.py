@@ -28,3 +28,30 @@ print("publish after chain end us:", np.median(pub-chain_end)/100.0)
 print("streamer0 partial(u) published before sampler start(u) by us:", np.median(S[u,0]-T[u,0])/100.0)
 print("streamer0 got dlt(u-D) after publish(u-D) us:", np.median(T[u+lag,1]-S[u,2])/100.0)
 print("streamer0 loop period us:", np.median(np.diff(T[200:1400,0]))/100.0)
+
+W = d[(1<<19):(1<<19)+8*nb].reshape(nb,8)
+for w in range(8):
+    print(f"wave {w} end-of-work after block start us:", np.median(W[u,w]-S[u,0])/100.0)
+
+Rd = d[(3<<18):(3<<18)+2*nb].reshape(nb,2)
+print("reducer0: counter complete for block u, relative to sampler start(u) us:", np.median(Rd[u,0]-S[u,0])/100.0)
+print("reducer0: publish latency (complete -> gsum published) us:", np.median(Rd[u,1]-Rd[u,0])/100.0)
+print("streamer0 publish(u) -> reducer0 complete(u) us:", np.median(Rd[u,0]-T[u,0])/100.0)
+print("wave2 poll success for block u relative to sampler start(u) us:", np.median(S[u,3]-S[u,0])/100.0)
+print("reducer0 published(u) -> wave2 poll success(u) us:", np.median(S[u,3]-Rd[u,1])/100.0)
+
+Sn = s.layout()[1]
+Aall = d[(7<<17):(7<<17)+4*Sn].reshape(Sn,4)
+print("sampler xcc", d[(7<<17)-2], "hwid", hex(int(d[(7<<17)-1])))
+for col,blk in ((0,800),(2,1200)):
+    rel = (Aall[:,col]-S[blk,0])/100.0
+    order = np.argsort(rel)[-4:]
+    print("block",blk,"publish rel sampler start: min %.1f med %.1f max %.1f" % (rel.min(), np.median(rel), rel.max()), "slowest:", [(int(i), round(float(rel[i]),1), int(Aall[i,1])-1, hex(int(Aall[i,3]))) for i in order])
+
+Acc = d[(7<<17)+4096:(7<<17)+4096+8*Sn].reshape(Sn,8)[:, :5].astype(np.float64)/100.0/(nb+lag)
+tot = Acc[:,0]+Acc[:,1]+Acc[:,2]
+print("per-block avg us  phaseA(wait) phaseB(update) phaseC(gemv+pub)  w7poll  w4dma :  median", np.round(np.median(Acc,axis=0),2))
+worst = np.argsort(Acc[:,3])[-3:]
+for i in worst: print("   streamer", int(i), "xcc", int(Aall[i,1])-1, np.round(Acc[i],2))
+best = np.argsort(Acc[:,3])[:2]
+for i in best: print("   streamer", int(i), "xcc", int(Aall[i,1])-1, np.round(Acc[i],2))
