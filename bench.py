@@ -173,7 +173,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "ngp::k_step (streams one 64-SNP column block: N*64*4 algorithmic bytes per launch)",
+                "kernel": "ngp::k_sweep (persistent sweep: one launch streams the whole N x P fp32 panel once)" if prof["launches"] == 1 else "ngp::k_step (one 64-SNP column block per launch)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -153,12 +153,13 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
     int64_t max_shards = 256;
     if (h->mode == 1) {
         max_shards = h->cu_count - 1 - (h->cu_count + NGP_GRP - 1) / NGP_GRP;
-        if (N > max_shards * 300) h->mode = 0;  // too many rows for one resident wave of streamers (LDS: tile + partials)
+        if (N > max_shards * 256) h->mode = 0;  // too many rows for one resident wave of streamers (2 LDS tile slots + partials)
         else choose_layout(N, max_shards, &h->R, &h->S);
     }
     if (h->mode == 0) choose_layout(N, 256, &h->R, &h->S);
     h->NG = (int)((h->S + NGP_GRP - 1) / NGP_GRP);
     h->D = (h->mode == 1) ? h->lag : 1;
+    if (h->mode == 1 && h->R > 128 && h->D > 4) h->D = 4;  // tall shards: the register delay line holds 4 tiles at most
     h->NBLK = (P + NGP_BLK - 1) / NGP_BLK;
     h->Ppad = h->NBLK * NGP_BLK;
     h->L = h->R * h->S;
@@ -203,8 +204,9 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
         const size_t lds_max = 160 * 1024;
         const size_t misc = (size_t)h->R * 8 + 2048 + 512 + 128 + 3072 + (size_t)h->R * 64;
         const size_t TB = (size_t)h->R * 256;
-        h->NS = (int)std::min<size_t>((size_t)h->D + 2, (lds_max - misc) / TB);  // >= 1 because R <= 508
-        h->lds_sweep = std::max((size_t)h->NS * TB + misc, lds_sampler);
+        h->NS = 2;
+        h->lds_sweep = std::max(2 * TB + misc, lds_sampler);
+        if (h->lds_sweep > lds_max) return fail(h, NGP_ERR_ARG, "panel too tall for the persistent sweep (LDS)");
         HCHK(hipFuncSetAttribute((const void *)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_sweep));
         if ((rc = dalloc(h, &h->d_cpart, (size_t)NGP_RING * h->S * NGP_BLK))) return rc;
         if ((rc = dalloc(h, &h->d_cgsum, (size_t)NGP_RING * h->NG * NGP_BLK))) return rc;

@@ -102,150 +102,171 @@ __device__ inline double gemv4(GLoad G, const double *d) {
 }
 
 // ------------------------------------------------------------------------------------------
-// 512-thread workgroups (8 waves).  Streamer s keeps its ycorr shard in LDS for the whole sweep and
-// walks the blocks through a ring of NS LDS tile slots filled by LDS-DMA (global_load_lds_dwordx4,
-// tiles are contiguous in HBM) one block ahead.  With NS >= D+2 a tile stays in LDS from its GEMV
-// until its update D blocks later (ONE HBM read per tile, no re-read); otherwise the update
-// re-reads the tile from global memory (L2 / Infinity Cache).
+// 512-thread workgroups (8 waves).  Streamer s keeps its ycorr shard in LDS for the whole sweep.
+// Every tile is read from HBM exactly ONCE: LDS-DMA (global_load_lds_dwordx4, tiles are contiguous)
+// brings tile u+1 into one of two LDS slots while tile u is used for the GEMV; in the same phase each
+// thread copies the elements of tile u that ITS update tasks will need into registers, where they
+// wait D blocks (a D-deep register delay line, statically indexed through the unrolled inner loop)
+// until dlt of block u arrives.  LDS is the staging / transposition buffer, registers are the delay.
 //   waves 4-6  LDS-DMA of the next tile        wave 7  waits for dlt of block u-D and stages it in LDS
 //   waves 0-3  GEMV (lane = column, strided row quads); wave 0 publishes the 64 partial sums
+//   all waves  update tasks (c, i): 8-column chain c of row i
+// TPT = update tasks per thread: 8*R <= TPT * NGP_WG (R <= 64 / 128 / 256 for TPT = 1 / 2 / 4)
+template <int DT, int NGP_TPT>
 __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem) {
-    const int R = A.R, S = A.S, D = A.D, NS = A.NS, tid = threadIdx.x;
+    const int R = A.R, S = A.S, tid = threadIdx.x;
     const int wv = tid >> 6, j = tid & 63;
-    const size_t TB = (size_t)R * 256;  // tile bytes
-    char *ring = smem;                  // NS slots of TB bytes (TB is a multiple of 1 KiB)
-    double *ys = (double *)(smem + (size_t)NS * TB);
+    const size_t TB = (size_t)R * 256;  // tile bytes (a multiple of 1 KiB)
+    char *ring = smem;                  // 2 slots of TB bytes
+    double *ys = (double *)(smem + 2 * TB);
     double *red = ys + R;
     double *dl = red + 256;
     int *sflag = (int *)(dl + 64);
-    char *scratch = (char *)(dl + 64) + 64;  // 3 KiB sink of the L2-warming DMA
+    char *scratch = (char *)(dl + 64) + 64;   // 3 KiB sink of the L2-warming DMA
     double *pp = (double *)(scratch + 3072);  // 8 x R partial sums of the update
     const size_t tile_elems = (size_t)R * NGP_BLK;
-    const bool resident = NS >= D + 2;  // tiles live in LDS until their update
-    const int pd = NS >= 2 ? 1 : 0;     // DMA prefetch distance in blocks
-    const int nchunk = R >> 2;          // 1 KiB pieces per tile
+    const int nchunk = R >> 2;  // 1 KiB pieces per tile
+    const int ntask = (8 * R + NGP_WG - 1) / NGP_WG;
     double *yg = A.ycorr + (size_t)s * R;
     const int g = s / NGP_GRP;
     const int nb = A.t1 - A.t0;
-    auto dma_tile = [&](int ub) {  // waves 4..6 copy tile ub into its ring slot, 1 KiB per wave-instruction
+    auto dma_tile = [&](int ub) {  // waves 4..6 copy tile ub into slot ub&1, 1 KiB per wave-instruction
         const char *src = (const char *)(A.tiles + ((size_t)(A.t0 + ub) * S + s) * tile_elems);
-        char *dst = ring + (size_t)(ub % NS) * TB;
+        char *dst = ring + (size_t)(ub & 1) * TB;
         for (int c = wv - 4; c < nchunk; c += 3)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)c * 1024 + (size_t)j * 16),
                                              (__attribute__((address_space(3))) void *)(dst + (size_t)c * 1024), 16, 0, 0);
     };
+    // the update tasks of this thread (fixed for the whole sweep): q -> (c, i); surplus lanes redo the last task
+    int tc[NGP_TPT], ti[NGP_TPT];
+#pragma unroll
+    for (int tp = 0; tp < NGP_TPT; tp++) {
+        const int q = min(tp * NGP_WG + tid, 8 * R - 1);
+        tc[tp] = q / R;
+        ti[tp] = q - tc[tp] * R;
+    }
+    float keep[DT][NGP_TPT][8];
+#pragma unroll
+    for (int d = 0; d < DT; d++)
+#pragma unroll
+        for (int tp = 0; tp < NGP_TPT; tp++)
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) keep[d][tp][jj] = 0.0f;
     for (int i = tid; i < R; i += NGP_WG) ys[i] = yg[i];
     if (tid == 0) *sflag = 1;
-    if (wv >= 4 && wv <= 6 && pd == 1 && nb > 0) dma_tile(0);
+    if (wv >= 4 && wv <= 6 && nb > 0) dma_tile(0);
     // speed only: streamers that share the sampler's XCD pull the Gram blocks of the block after their own
     // into that XCD's L2, so the sampler CU (one CU, latency-bound on HBM) finds them there
     const unsigned my_xcc = xcc_id() + 1u;
     const int nslice = max(1, S / 8);
     const int slice = (s / 8) % nslice;
-    const size_t gram_bytes = (size_t)D * NGP_BLK * NGP_BLK * sizeof(double);
+    const size_t gram_bytes = (size_t)DT * NGP_BLK * NGP_BLK * sizeof(double);
     const size_t slice_bytes = ((gram_bytes / nslice + 1023) / 1024) * 1024;
     bool same_xcd = false;
     unsigned long long accA = 0, accB = 0, accC = 0, accP = 0, tt0 = 0;
     __syncthreads();
-    for (int u = 0; u < nb + D; ++u) {
-        const int a = u - D;  // block whose update is applied in this iteration (if >= 0)
-        if (A.dbg) tt0 = wall_clock64();
-        // ---------------- phase A: everything that waits on memory ----------------
-        if (wv >= 4 && wv <= 6) {
-            drain_vm();  // tile u (issued one iteration ago) has landed
-            if (u + pd < nb) dma_tile(u + pd);
-            if ((u & 7) == 0 && !same_xcd) same_xcd = (ld_u32(A.xcc_w) == my_xcc);
-            if (same_xcd && u + 1 < nb) {  // fire-and-forget: the lines only have to reach this XCD's L2
-                const char *gb = (const char *)(A.gramx + (size_t)(A.t0 + u + 1) * D * NGP_BLK * NGP_BLK);
-                const size_t lo = (size_t)slice * slice_bytes, hi = min((size_t)(slice + 1) * slice_bytes, gram_bytes);
-                for (size_t off = lo + (size_t)(wv - 4) * 1024; off + 1024 <= hi; off += 3 * 1024)
-                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gb + off + (size_t)j * 16),
-                                                     (__attribute__((address_space(3))) void *)(scratch + (wv - 4) * 1024), 16, 0, 0);
+    for (int u0 = 0; u0 < nb + DT; u0 += DT) {
+#pragma unroll
+        for (int d = 0; d < DT; d++) {
+            const int u = u0 + d;
+            if (u >= nb + DT) break;
+            const int a = u - DT;  // block whose update is applied in this iteration (if >= 0); its tile sits in keep[d]
+            if (A.dbg) tt0 = wall_clock64();
+            // ---------------- phase A: everything that waits on memory ----------------
+            if (wv >= 4 && wv <= 6) {
+                drain_vm();  // tile u (issued one iteration ago) has landed
+                if (u + 1 < nb) dma_tile(u + 1);
+                if ((u & 7) == 0 && !same_xcd) same_xcd = (ld_u32(A.xcc_w) == my_xcc);
+                if (same_xcd && u + 1 < nb) {  // fire-and-forget: the lines only have to reach this XCD's L2
+                    const char *gb = (const char *)(A.gramx + (size_t)(A.t0 + u + 1) * DT * NGP_BLK * NGP_BLK);
+                    const size_t lo = (size_t)slice * slice_bytes, hi = min((size_t)(slice + 1) * slice_bytes, gram_bytes);
+                    for (size_t off = lo + (size_t)(wv - 4) * 1024; off + 1024 <= hi; off += 3 * 1024)
+                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gb + off + (size_t)j * 16),
+                                                         (__attribute__((address_space(3))) void *)(scratch + (wv - 4) * 1024), 16, 0, 0);
+                }
+            } else if (wv == 7) {
+                if (a >= 0) {
+                    int ok = 1;
+                    if (j == 0) {
+                        ok = wait_ge(A.flag_dlt, (unsigned)(a + 1), A.abort_w, 1u) ? 1 : 0;
+                        if (A.dbg && s == 0) A.dbg[NGP_DBG_STREAM + 2 * (size_t)u + 1] = wall_clock64();
+                        *sflag = ok;
+                    }
+                    ok = __shfl(ok, 0);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (ok) dl[j] = ld_f64(&A.dlt[(size_t)(a % NGP_RING) * NGP_BLK + j]);
+                }
             }
-            if (pd == 0) drain_vm();
-        } else if (wv == 7) {
+            if (A.dbg && (tid == 448 || tid == 256)) accP += wall_clock64() - tt0;  // wave 7 poll / wave 4 DMA drain
+            __syncthreads();
+            if (!*sflag) return;
+            if (A.dbg && tid == 0) { unsigned long long n = wall_clock64(); accA += n - tt0; tt0 = n; }
+            // ---------------- phase B: ycorr -= X_a dlt_a (tile a waits in keep[d]) ----------------
             if (a >= 0) {
-                int ok = 1;
-                if (j == 0) {
-                    ok = wait_ge(A.flag_dlt, (unsigned)(a + 1), A.abort_w, 1u) ? 1 : 0;
-                    if (A.dbg && s == 0) A.dbg[NGP_DBG_STREAM + 2 * (size_t)u + 1] = wall_clock64();
-                    *sflag = ok;
+#pragma unroll
+                for (int tp = 0; tp < NGP_TPT; tp++) {
+                    if (tp < ntask) {
+                        const double *dq = dl + 8 * tc[tp];
+                        double p = 0.0;
+#pragma unroll
+                        for (int jj = 0; jj < 8; jj++) p = __builtin_fma((double)keep[d][tp][jj], dq[jj], p);
+                        pp[(size_t)tc[tp] * R + ti[tp]] = p;
+                    }
                 }
-                ok = __shfl(ok, 0);
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (ok) dl[j] = ld_f64(&A.dlt[(size_t)(a % NGP_RING) * NGP_BLK + j]);
-            }
-        }
-        if (A.dbg && (tid == 448 || tid == 256)) accP += wall_clock64() - tt0;  // wave 7 poll / wave 4 DMA drain
-        __syncthreads();
-        if (!*sflag) return;
-        if (A.dbg && tid == 0) { unsigned long long n = wall_clock64(); accA += n - tt0; tt0 = n; }
-        // ---------------- phase B: ycorr -= X_a dlt_a for the own rows ----------------
-        if (a >= 0) {
-            // y_i -= sum_j x_ij dlt_j with 8 R tasks (c, i): task = 8-column chain c of row i -> pp[c][i]; then row i adds
-            // the eight partial sums in a fixed pairwise tree.  Consecutive lanes = consecutive rows: conflict-free.
-            for (int q0 = 0; q0 < 8 * R; q0 += NGP_WG) {
-                const int q = min(q0 + tid, 8 * R - 1);  // clamp instead of predicating loads (idle lanes redo the last task)
-                const int c = q / R, i = q - c * R;
-                double p = 0.0;
-                if (resident) {
-                    const float *tp = (const float *)(ring + (size_t)(a % NS) * TB) + (size_t)(8 * c) * R + i;
-#pragma unroll
-                    for (int jj = 0; jj < 8; jj++) p = __builtin_fma((double)tp[jj * R], dl[8 * c + jj], p);
-                } else {
-                    const float *tp = A.tiles + ((size_t)(A.t0 + a) * S + s) * tile_elems + (size_t)(8 * c) * R + i;
-                    float xv[8];
-#pragma unroll
-                    for (int jj = 0; jj < 8; jj++) xv[jj] = tp[(size_t)jj * R];
-#pragma unroll
-                    for (int jj = 0; jj < 8; jj++) p = __builtin_fma((double)xv[jj], dl[8 * c + jj], p);
+                __syncthreads();
+                for (int i = tid; i < R; i += NGP_WG) {
+                    const double T = ((pp[i] + pp[R + i]) + (pp[2 * R + i] + pp[3 * R + i])) +
+                                     ((pp[4 * R + i] + pp[5 * R + i]) + (pp[6 * R + i] + pp[7 * R + i]));
+                    ys[i] = ys[i] - T;
                 }
-                pp[(size_t)c * R + i] = p;
+            } else {
+                __syncthreads();
             }
             __syncthreads();
-            for (int i = tid; i < R; i += NGP_WG) {
-                const double T = ((pp[i] + pp[R + i]) + (pp[2 * R + i] + pp[3 * R + i])) +
-                                 ((pp[4 * R + i] + pp[5 * R + i]) + (pp[6 * R + i] + pp[7 * R + i]));
-                ys[i] = ys[i] - T;
-            }
-        } else {
-            __syncthreads();
-        }
-        __syncthreads();
-        if (A.dbg && tid == 0) { unsigned long long n = wall_clock64(); accB += n - tt0; tt0 = n; }
-        // ---------------- phase C: partial X_u' ycorr ----------------
-        if (u < nb) {
-            if (wv < 4) {
-                const float *col = (const float *)(ring + (size_t)(u % NS) * TB) + (size_t)j * R;
-                double acc = 0.0;
-                for (int qd = wv; qd < (R >> 2); qd += 4) {
-                    float4 x = *(const float4 *)(col + 4 * qd);
-                    const double *yq = ys + 4 * qd;
-                    acc = __builtin_fma((double)x.x, yq[0], acc);
-                    acc = __builtin_fma((double)x.y, yq[1], acc);
-                    acc = __builtin_fma((double)x.z, yq[2], acc);
-                    acc = __builtin_fma((double)x.w, yq[3], acc);
+            if (A.dbg && tid == 0) { unsigned long long n = wall_clock64(); accB += n - tt0; tt0 = n; }
+            // ---------------- phase C: partial X_u' ycorr, and tile u into the delay line ----------------
+            if (u < nb) {
+                const float *slotp = (const float *)(ring + (size_t)(u & 1) * TB);
+#pragma unroll
+                for (int tp = 0; tp < NGP_TPT; tp++) {
+                    if (tp < ntask) {
+                        const float *tq = slotp + (size_t)(8 * tc[tp]) * R + ti[tp];
+#pragma unroll
+                        for (int jj = 0; jj < 8; jj++) keep[d][tp][jj] = tq[jj * R];
+                    }
                 }
-                red[wv * 64 + j] = acc;
-            }
-            __syncthreads();
-            if (wv == 0) {
-                const int slot = u % NGP_RING;
-                double p = ((red[j] + red[64 + j]) + red[128 + j]) + red[192 + j];
-                st_f64(&A.part[((size_t)slot * S + s) * NGP_BLK + j], p);
-                drain_vm();
-                if (j == 0) {
-                    atomicAdd(&A.cnt_part[((size_t)slot * A.NG + g) * 32], 1u);
-                    if (A.dbg && s == 0) A.dbg[NGP_DBG_STREAM + 2 * (size_t)u] = wall_clock64();
-                    if (A.dbg && (u == 800 || u == 1200)) {
-                        A.dbg[NGP_DBG_ALL + 4 * (size_t)s + (u == 800 ? 0 : 2)] = wall_clock64();
-                        A.dbg[NGP_DBG_ALL + 4 * (size_t)s + 1] = my_xcc;
-                        A.dbg[NGP_DBG_ALL + 4 * (size_t)s + 3] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+                if (wv < 4) {
+                    const float *col = slotp + (size_t)j * R;
+                    double acc = 0.0;
+                    for (int qd = wv; qd < (R >> 2); qd += 4) {
+                        float4 x = *(const float4 *)(col + 4 * qd);
+                        const double *yq = ys + 4 * qd;
+                        acc = __builtin_fma((double)x.x, yq[0], acc);
+                        acc = __builtin_fma((double)x.y, yq[1], acc);
+                        acc = __builtin_fma((double)x.z, yq[2], acc);
+                        acc = __builtin_fma((double)x.w, yq[3], acc);
+                    }
+                    red[wv * 64 + j] = acc;
+                }
+                __syncthreads();
+                if (wv == 0) {
+                    const int slot = u % NGP_RING;
+                    double p = ((red[j] + red[64 + j]) + red[128 + j]) + red[192 + j];
+                    st_f64(&A.part[((size_t)slot * S + s) * NGP_BLK + j], p);
+                    drain_vm();
+                    if (j == 0) {
+                        atomicAdd(&A.cnt_part[((size_t)slot * A.NG + g) * 32], 1u);
+                        if (A.dbg && s == 0) A.dbg[NGP_DBG_STREAM + 2 * (size_t)u] = wall_clock64();
+                        if (A.dbg && (u == 800 || u == 1200)) {
+                            A.dbg[NGP_DBG_ALL + 4 * (size_t)s + (u == 800 ? 0 : 2)] = wall_clock64();
+                            A.dbg[NGP_DBG_ALL + 4 * (size_t)s + 1] = my_xcc;
+                            A.dbg[NGP_DBG_ALL + 4 * (size_t)s + 3] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+                        }
                     }
                 }
             }
+            if (A.dbg && tid == 0) accC += wall_clock64() - tt0;
         }
-        if (A.dbg && tid == 0) accC += wall_clock64() - tt0;
     }
     if (A.dbg && tid == 0) { A.dbg[NGP_DBG_ALL + 4096 + 8 * (size_t)s] = accA; A.dbg[NGP_DBG_ALL + 4096 + 8 * (size_t)s + 1] = accB; A.dbg[NGP_DBG_ALL + 4096 + 8 * (size_t)s + 2] = accC; }
     if (A.dbg && tid == 448) A.dbg[NGP_DBG_ALL + 4096 + 8 * (size_t)s + 3] = accP;
@@ -548,8 +569,33 @@ __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         role_sampler(A, smem);
     else if (b <= A.NG)
         role_reducer(A, b - 1);
-    else
-        role_streamer(A, b - 1 - A.NG, smem);
+    else {
+        const int s = b - 1 - A.NG;
+        const int tpt = (8 * A.R + NGP_WG - 1) / NGP_WG;  // 1..4
+#define NGP_DISPATCH_D(T)                                      \
+    switch (A.D) {                                             \
+        case 1: role_streamer<1, T>(A, s, smem); break;        \
+        case 2: role_streamer<2, T>(A, s, smem); break;        \
+        case 3: role_streamer<3, T>(A, s, smem); break;        \
+        default: role_streamer<4, T>(A, s, smem); break;       \
+    }
+        if (tpt <= 1) {
+            switch (A.D) {
+                case 5: role_streamer<5, 1>(A, s, smem); break;
+                case 6: role_streamer<6, 1>(A, s, smem); break;
+                default: NGP_DISPATCH_D(1)
+            }
+        } else if (tpt == 2) {
+            switch (A.D) {
+                case 5: role_streamer<5, 2>(A, s, smem); break;
+                case 6: role_streamer<6, 2>(A, s, smem); break;
+                default: NGP_DISPATCH_D(2)
+            }
+        } else {
+            NGP_DISPATCH_D(4)  // host clamps the lag to 4 for tall shards (register budget of the delay line)
+        }
+#undef NGP_DISPATCH_D
+    }
 }
 
 }  // namespace ngp
