@@ -163,7 +163,7 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
     h->NBLK = (P + NGP_BLK - 1) / NGP_BLK;
     h->Ppad = h->NBLK * NGP_BLK;
     h->L = h->R * h->S;
-    h->lds_step = (size_t)h->R * 264 + 2048;
+    h->lds_step = (size_t)h->R * 264 + 4096;
     int rc;
     size_t tile_elems = (size_t)h->R * NGP_BLK;
     if ((rc = dalloc(h, &h->d_tiles, (size_t)h->NBLK * h->S * tile_elems))) return rc;
@@ -202,7 +202,7 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
     if (h->mode == 1) {
         const size_t lds_sampler = (size_t)(4 * 4096 + 2 * NGP_RING * NGP_BLK + 4 * NGP_BLK) * sizeof(double) + 2 * NGP_BLK * sizeof(int) + 64;
         const size_t lds_max = 160 * 1024;
-        const size_t misc = (size_t)h->R * 8 + 2048 + 512 + 128 + 3072 + (size_t)h->R * 64;
+        const size_t misc = (size_t)h->R * 8 + 4096 + 2 * 512 + 128 + 3072 + (size_t)h->R * 64;
         const size_t TB = (size_t)h->R * 256;
         h->NS = 2;
         h->lds_sweep = std::max(2 * TB + misc, lds_sampler);

@@ -202,7 +202,7 @@ __global__ __launch_bounds__(256) void k_prep(long long Ppad, const int8_t *__re
 // ------------------------------------------------------------------------------------------
 // streaming step of block t: (U) ycorr -= X_{t-1} dlt_{t-1}  then  (G) partial r = X_t' ycorr.
 // grid = S shards, 256 threads; tile (t,s) = [64 columns][R rows] fp32, contiguous.
-// dynamic LDS: R*256 (tile) + R*8 (ycorr shard) + 2048 (wave partials)
+// dynamic LDS: R*256 (tile) + R*8 (ycorr shard) + 4096 (chain partials)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_step(const float *__restrict__ tiles, double *__restrict__ ycorr,
                                               const double *__restrict__ dlt, double *__restrict__ part, int R, int S, int t,
@@ -241,19 +241,23 @@ __global__ __launch_bounds__(256) void k_step(const float *__restrict__ tiles, d
     __syncthreads();
     const int wv = tid >> 6, j = tid & 63;
     const float *col = tl + (size_t)j * R;
-    double acc = 0.0;
-    for (int qd = wv; qd < (R >> 2); qd += 4) {
-        float4 x = *(const float4 *)(col + 4 * qd);
-        const double *yq = ys + 4 * qd;
-        acc = __builtin_fma((double)x.x, yq[0], acc);
-        acc = __builtin_fma((double)x.y, yq[1], acc);
-        acc = __builtin_fma((double)x.z, yq[2], acc);
-        acc = __builtin_fma((double)x.w, yq[3], acc);
+    // 8 chains over strided row quads (chain c: quads c, c+8, ...); this 4-wave kernel runs chains wv and wv+4
+#pragma unroll
+    for (int h = 0; h < 2; h++) {
+        double acc = 0.0;
+        for (int qd = wv + 4 * h; qd < (R >> 2); qd += 8) {
+            float4 x = *(const float4 *)(col + 4 * qd);
+            const double *yq = ys + 4 * qd;
+            acc = __builtin_fma((double)x.x, yq[0], acc);
+            acc = __builtin_fma((double)x.y, yq[1], acc);
+            acc = __builtin_fma((double)x.z, yq[2], acc);
+            acc = __builtin_fma((double)x.w, yq[3], acc);
+        }
+        red[(wv + 4 * h) * 64 + j] = acc;
     }
-    red[wv * 64 + j] = acc;
     __syncthreads();
     if (wv == 0) {
-        double p = ((red[j] + red[64 + j]) + red[128 + j]) + red[192 + j];
+        double p = ((red[j] + red[64 + j]) + (red[128 + j] + red[192 + j])) + ((red[256 + j] + red[320 + j]) + (red[384 + j] + red[448 + j]));
         part[(size_t)s * NGP_BLK + j] = p;
     }
 }

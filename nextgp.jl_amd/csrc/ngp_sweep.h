@@ -119,10 +119,10 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
     const size_t TB = (size_t)R * 256;  // tile bytes (a multiple of 1 KiB)
     char *ring = smem;                  // 2 slots of TB bytes
     double *ys = (double *)(smem + 2 * TB);
-    double *red = ys + R;
-    double *dl = red + 256;
-    int *sflag = (int *)(dl + 64);
-    char *scratch = (char *)(dl + 64) + 64;   // 3 KiB sink of the L2-warming DMA
+    double *red = ys + R;                     // 8 x 64 chain partials
+    double *dl = red + 512;                   // 2 x 64: dlt of the block being applied, double-buffered by iteration parity
+    int *sflag = (int *)(dl + 128);
+    char *scratch = (char *)(dl + 128) + 64;  // 3 KiB sink of the L2-warming DMA
     double *pp = (double *)(scratch + 3072);  // 8 x R partial sums of the update
     const size_t tile_elems = (size_t)R * NGP_BLK;
     const int nchunk = R >> 2;  // 1 KiB pieces per tile
@@ -136,6 +136,20 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
         for (int c = wv - 4; c < nchunk; c += 3)
             __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)c * 1024 + (size_t)j * 16),
                                              (__attribute__((address_space(3))) void *)(dst + (size_t)c * 1024), 16, 0, 0);
+    };
+    // wave 7: wait for dlt of local block (uu - DT) and stage it in dl[uu & 1]
+    auto poll_dlt = [&](int uu) {
+        const int aa = uu - DT;
+        if (aa < 0 || uu >= nb + DT) return;
+        int ok = 1;
+        if (j == 0) {
+            ok = wait_ge(A.flag_dlt, (unsigned)(aa + 1), A.abort_w, 1u) ? 1 : 0;
+            if (A.dbg && s == 0) A.dbg[NGP_DBG_STREAM + 2 * (size_t)uu + 1] = wall_clock64();
+            if (!ok) *sflag = 0;
+        }
+        ok = __shfl(ok, 0);
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (ok) dl[(uu & 1) * 64 + j] = ld_f64(&A.dlt[(size_t)(aa % NGP_RING) * NGP_BLK + j]);
     };
     // the update tasks of this thread (fixed for the whole sweep): q -> (c, i); surplus lanes redo the last task
     int tc[NGP_TPT], ti[NGP_TPT];
@@ -185,17 +199,8 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
                                                          (__attribute__((address_space(3))) void *)(scratch + (wv - 4) * 1024), 16, 0, 0);
                 }
             } else if (wv == 7) {
-                if (a >= 0) {
-                    int ok = 1;
-                    if (j == 0) {
-                        ok = wait_ge(A.flag_dlt, (unsigned)(a + 1), A.abort_w, 1u) ? 1 : 0;
-                        if (A.dbg && s == 0) A.dbg[NGP_DBG_STREAM + 2 * (size_t)u + 1] = wall_clock64();
-                        *sflag = ok;
-                    }
-                    ok = __shfl(ok, 0);
-                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                    if (ok) dl[j] = ld_f64(&A.dlt[(size_t)(a % NGP_RING) * NGP_BLK + j]);
-                }
+                if (DT <= 2 || u == 0) poll_dlt(u);  // lags 1-2 cannot poll ahead: the flag would (transitively, through the
+                                                     // sampler's own look-ahead fetch of the next group sums) need this block's partial
             }
             if (A.dbg && (tid == 448 || tid == 256)) accP += wall_clock64() - tt0;  // wave 7 poll / wave 4 DMA drain
             __syncthreads();
@@ -206,7 +211,7 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
 #pragma unroll
                 for (int tp = 0; tp < NGP_TPT; tp++) {
                     if (tp < ntask) {
-                        const double *dq = dl + 8 * tc[tp];
+                        const double *dq = dl + (u & 1) * 64 + 8 * tc[tp];
                         double p = 0.0;
 #pragma unroll
                         for (int jj = 0; jj < 8; jj++) p = __builtin_fma((double)keep[d][tp][jj], dq[jj], p);
@@ -235,10 +240,10 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
                         for (int jj = 0; jj < 8; jj++) keep[d][tp][jj] = tq[jj * R];
                     }
                 }
-                if (wv < 4) {
+                {   // chain wv: row quads wv, wv+8, ... (lane = column)
                     const float *col = slotp + (size_t)j * R;
                     double acc = 0.0;
-                    for (int qd = wv; qd < (R >> 2); qd += 4) {
+                    for (int qd = wv; qd < (R >> 2); qd += 8) {
                         float4 x = *(const float4 *)(col + 4 * qd);
                         const double *yq = ys + 4 * qd;
                         acc = __builtin_fma((double)x.x, yq[0], acc);
@@ -248,10 +253,11 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
                     }
                     red[wv * 64 + j] = acc;
                 }
+                if (wv == 7 && DT >= 3) poll_dlt(u + 1);  // next iteration's dlt: the round trips hide behind this phase
                 __syncthreads();
                 if (wv == 0) {
                     const int slot = u % NGP_RING;
-                    double p = ((red[j] + red[64 + j]) + red[128 + j]) + red[192 + j];
+                    double p = ((red[j] + red[64 + j]) + (red[128 + j] + red[192 + j])) + ((red[256 + j] + red[320 + j]) + (red[384 + j] + red[448 + j]));
                     st_f64(&A.part[((size_t)slot * S + s) * NGP_BLK + j], p);
                     drain_vm();
                     if (j == 0) {
@@ -265,6 +271,7 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
                     }
                 }
             }
+            else if (wv == 7 && DT >= 3) poll_dlt(u + 1);
             if (A.dbg && tid == 0) accC += wall_clock64() - tt0;
         }
     }

@@ -712,19 +712,19 @@ static void iter_blocked(ora_t *h) {
         }
         if (tb >= NBLK) continue;
         const int64_t k0 = tb * BLK;
-        /* GEMV partials: 4 waves over strided quads, lane = column */
+        /* GEMV partials: 8 chains over strided row quads, lane = column */
         for (int64_t s = 0; s < S; s++) {
             const float *tl = h->tiles + ((size_t)s * NBLK + tb) * tile;
             const double *ys = h->ycorr + s * R;
             for (int j = 0; j < BLK; j++) {
-                double a4[4];
-                for (int wv = 0; wv < 4; wv++) {
+                double a8[8];
+                for (int wv = 0; wv < 8; wv++) { /* chain wv: row quads wv, wv+8, ... */
                     double acc = 0.0;
-                    for (int64_t qd = wv; qd < R / 4; qd += 4)
+                    for (int64_t qd = wv; qd < R / 4; qd += 8)
                         for (int e = 0; e < 4; e++) { int64_t i = 4 * qd + e; acc = __builtin_fma((double)tl[j * R + i], ys[i], acc); }
-                    a4[wv] = acc;
+                    a8[wv] = acc;
                 }
-                part[s * BLK + j] = ((a4[0] + a4[1]) + a4[2]) + a4[3];
+                part[s * BLK + j] = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
             }
         }
         double rr[BLK], dlt[BLK]; int inc[BLK];

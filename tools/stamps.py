@@ -4,10 +4,11 @@ import bench
 from ngp_pkg import load_pkg
 ngp = load_pkg()
 lag = int(sys.argv[1]) if len(sys.argv)>1 else 6
-N,P = 10000, 100000
+N = int(sys.argv[2]) if len(sys.argv)>2 else 10000
+P = int(sys.argv[3]) if len(sys.argv)>3 else 100000
 s = ngp.Sampler(device=0, seed=1001, chain=0, mode=1, lag=lag)
 s.generate_panel(N,P)
-rng=np.random.default_rng(1); bt=np.zeros(P); idx=rng.choice(P,1000,replace=False); bt[idx]=rng.normal(size=1000)
+rng=np.random.default_rng(1); bt=np.zeros(P); idx=rng.choice(P,P//100,replace=False); bt[idx]=rng.normal(size=P//100)
 g=s.xbeta(bt); y=10+g+np.random.default_rng(2).normal(size=N)*np.sqrt(g.var())
 v=0.5*y.var()/(s.mpm().sum()/N)
 s.add_marker_set(0,P,0,4.0,v*0.5,[(0,P)],[v]); s.set_y(y); s.set_residual_prior(4.0,0.25*y.var())
@@ -15,19 +16,20 @@ s.run(3)
 t=time.perf_counter(); s.run(10); dt=(time.perf_counter()-t)/10
 print(f"lag {lag}: {dt*1e3:.2f} ms/iter  layout {s.layout()}")
 s.debug_stamps(True); s.run(1)
-d = s.debug_stamps(True, n=(1<<20)+2*1600).astype(np.int64)
-nb = 1563
+d = s.debug_stamps(True, n=(1<<20)+2*(s.layout()[2]+16)).astype(np.int64)
+nb = s.layout()[2]; lag = s.config()[1]
+u_lo, u_hi = nb//8, nb - nb//8
 S = d[:4*nb].reshape(nb,4)
 T = d[(1<<20):(1<<20)+2*(nb+lag)].reshape(nb+lag,2)
-u = np.arange(200,1400)
+u = np.arange(u_lo,u_hi)
 start, chain_end, pub = S[u,0], S[u,1], S[u,2]
-print("per-block period (start[u+1]-start[u]) us:", np.median(np.diff(S[200:1400,0]))/100.0)
+print("per-block period (start[u+1]-start[u]) us:", np.median(np.diff(S[u_lo:u_hi,0]))/100.0)
 print("chain time us:", np.median(chain_end-start)/100.0)
 print("publish after chain end us:", np.median(pub-chain_end)/100.0)
 # streamer 0: time partial(u) published vs sampler block start
 print("streamer0 partial(u) published before sampler start(u) by us:", np.median(S[u,0]-T[u,0])/100.0)
 print("streamer0 got dlt(u-D) after publish(u-D) us:", np.median(T[u+lag,1]-S[u,2])/100.0)
-print("streamer0 loop period us:", np.median(np.diff(T[200:1400,0]))/100.0)
+print("streamer0 loop period us:", np.median(np.diff(T[u_lo:u_hi,0]))/100.0)
 
 W = d[(1<<19):(1<<19)+8*nb].reshape(nb,8)
 for w in range(8):
@@ -43,7 +45,7 @@ print("reducer0 published(u) -> wave2 poll success(u) us:", np.median(S[u,3]-Rd[
 Sn = s.layout()[1]
 Aall = d[(7<<17):(7<<17)+4*Sn].reshape(Sn,4)
 print("sampler xcc", d[(7<<17)-2], "hwid", hex(int(d[(7<<17)-1])))
-for col,blk in ((0,800),(2,1200)):
+for col,blk in ((0,800),(2,1200)) if nb > 1300 else ():
     rel = (Aall[:,col]-S[blk,0])/100.0
     order = np.argsort(rel)[-4:]
     print("block",blk,"publish rel sampler start: min %.1f med %.1f max %.1f" % (rel.min(), np.median(rel), rel.max()), "slowest:", [(int(i), round(float(rel[i]),1), int(Aall[i,1])-1, hex(int(Aall[i,3]))) for i in order])
