@@ -134,6 +134,13 @@ def main():
     prof = s.profile_iteration()
     achieved = prof["bytes_per_launch"] / (prof["avg_ms"] * 1e-3) / 1e9
     bytes_iter = 4.0 * args.N * args.P
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the committed
+    # rocprofv3 summary of the same workload is quoted when the configuration matches (else null)
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "r01_pmc_k_sweep.json")
+    if os.path.exists(pmc) and (args.N, args.P, args.method) == (10000, 100000, "BayesPR") and prof["launches"] == 1:
+        pj = json.load(open(pmc))
+        traffic, traffic_src = pj["hbm_bytes_per_launch"], "profiles/r01_pmc_k_sweep.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
     # posterior means across chains: ONE all-reduce of the packed sums over RCCL / xGMI
     allreduce_ms = None
     n = s.posterior_len()
@@ -178,7 +185,8 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "launch_avg_ms": prof["avg_ms"],
                 "launches_per_iteration": prof["launches"],
                 "iteration_achieved": bytes_iter * (K / dt) / 1e9,

@@ -7,6 +7,7 @@
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -41,7 +42,7 @@ struct ngp_handle {
     int64_t N = 0, P = 0, R = 0, S = 0, NBLK = 0, Ppad = 0, L = 0;
     size_t lds_step = 0, lds_sweep = 0;
     int mode = 1;      // 1: persistent sweep kernel, 0: one streaming + one recursion launch per block
-    int lag = 6;       // look-ahead D of the persistent sweep (blocks)
+    int lag = 4;       // look-ahead D of the persistent sweep (blocks)
     int D = 1;         // Gram planes stored per block (= lag in mode 1, 1 in mode 0)
     int NG = 1;        // reducer groups = ceil(S/32)
     int NS = 1;        // LDS tile slots of a streamer workgroup
@@ -318,6 +319,7 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
         A.flag_dlt = A.cnt_gs + (size_t)NGP_RING * 32; A.abort_w = h->d_abort; A.xcc_w = h->d_abort + 16;
         if (evs) (void)hipEventRecord(evs[0], h->stream);
         A.dbg = h->d_dbg;
+        { const char *e = getenv("NGP_DEBUG_MODE"); A.dbg_mode = e ? atoi(e) : 0; }
         hipLaunchKernelGGL(k_sweep, dim3((unsigned)(1 + h->NG + S)), dim3(NGP_WG), h->lds_sweep, h->stream, A);
         if (evs) (void)hipEventRecord(evs[1], h->stream);
         h->sweep_launches += 1;

@@ -59,6 +59,7 @@ struct SweepArgs {
     unsigned *abort_w;   // != 0: a spin timed out (code = role)
     unsigned *xcc_w;     // sampler's XCC id + 1 (speed only: same-XCD streamers warm the L2 with Gram blocks)
     unsigned long long *dbg;  // optional time stamps (diagnostic runs only), else nullptr
+    int dbg_mode;             // diagnostic: 1 = streamers only move tiles (no hand-offs, results invalid)
 };
 
 __device__ inline unsigned ld_u32(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -198,7 +199,7 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
                         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gb + off + (size_t)j * 16),
                                                          (__attribute__((address_space(3))) void *)(scratch + (wv - 4) * 1024), 16, 0, 0);
                 }
-            } else if (wv == 7) {
+            } else if (wv == 7 && A.dbg_mode != 1) {
                 if (DT <= 2 || u == 0) poll_dlt(u);  // lags 1-2 cannot poll ahead: the flag would (transitively, through the
                                                      // sampler's own look-ahead fetch of the next group sums) need this block's partial
             }
@@ -207,7 +208,7 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
             if (!*sflag) return;
             if (A.dbg && tid == 0) { unsigned long long n = wall_clock64(); accA += n - tt0; tt0 = n; }
             // ---------------- phase B: ycorr -= X_a dlt_a (tile a waits in keep[d]) ----------------
-            if (a >= 0) {
+            if (a >= 0 && A.dbg_mode != 1) {
 #pragma unroll
                 for (int tp = 0; tp < NGP_TPT; tp++) {
                     if (tp < ntask) {
@@ -253,9 +254,9 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
                     }
                     red[wv * 64 + j] = acc;
                 }
-                if (wv == 7 && DT >= 3) poll_dlt(u + 1);  // next iteration's dlt: the round trips hide behind this phase
+                if (wv == 7 && DT >= 3 && A.dbg_mode != 1) poll_dlt(u + 1);  // next iteration's dlt: the round trips hide behind this phase
                 __syncthreads();
-                if (wv == 0) {
+                if (wv == 0 && A.dbg_mode != 1) {
                     const int slot = u % NGP_RING;
                     double p = ((red[j] + red[64 + j]) + (red[128 + j] + red[192 + j])) + ((red[256 + j] + red[320 + j]) + (red[384 + j] + red[448 + j]));
                     st_f64(&A.part[((size_t)slot * S + s) * NGP_BLK + j], p);
@@ -271,7 +272,7 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
                     }
                 }
             }
-            else if (wv == 7 && DT >= 3) poll_dlt(u + 1);
+            else if (wv == 7 && DT >= 3 && A.dbg_mode != 1) poll_dlt(u + 1);
             if (A.dbg && tid == 0) accC += wall_clock64() - tt0;
         }
     }
@@ -572,6 +573,7 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
 __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sweep(SweepArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x;
+    if (A.dbg_mode == 1 && b <= A.NG) return;
     if (b == 0)
         role_sampler(A, smem);
     else if (b <= A.NG)
