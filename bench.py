@@ -149,11 +149,11 @@ def main():
     if world > 1:
         torch.cuda.synchronize()
         ta = time.perf_counter()
-        dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+        ngp.multichain.allreduce_posterior(buf)
         torch.cuda.synchronize()
         allreduce_ms = (time.perf_counter() - ta) * 1e3
-    nkept = float(buf[-1].item())
-    post_mean_varE = float(buf[-3].item()) / max(nkept, 1.0)
+    pooled = ngp.multichain.unpack_means(buf.cpu().numpy(), args.P, s.nvb, s.nsets)
+    nkept, post_mean_varE = pooled["nKept"], pooled["varE"]
 
     out = None
     if rank == 0:
@@ -196,6 +196,7 @@ def main():
             "setup_s": setup_s,
             "allreduce_ms": allreduce_ms,
             "posterior_mean_varE": post_mean_varE,
+            "pooled_kept_samples": nkept,
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args.N, args.P, min(args.cpu_cols, args.P), args.cpu_iters)

@@ -1,0 +1,318 @@
+"""Host-side mirror of the NextGP.jl user interface for the accelerated path.
+
+Same names, argument meaning and output files as the reference, so a model script ports line by line:
+
+    reference (Julia)                                   this module (Python stand-in for the Julia shim)
+    ------------------------------------------------    ------------------------------------------------
+    runLMEM(f, data, nChain, nBurn, nThin; VCV, ...)    runLMEM(f, data, nChain, nBurn, nThin, VCV=..., ...)   src/MCMC.jl:31-41
+    BayesPR(r, v) / BayesB(pi, v; estimatePi)           BayesPR(r, v) / BayesB(pi, v, estimatePi=...)          src/runTime.jl:30-61
+    Random("I", v)          (residual prior, key :e)    Random("I", v)                (key "e")                 src/runTime.jl:135-146
+    SNP(M, "geno.txt"[, "map.txt"]) in the formula      the same text inside the formula string                src/runTime.jl:13-28
+    summaryMCMC("betaM"; outFolder)                     summaryMCMC("betaM", outFolder=...)                    src/misc.jl:241-244
+
+Only what the hot path needs is interpreted here: the response, the intercept `1` and `SNP(...)` terms.
+Fixed covariates, `PED(...)`, `(1|g)` terms, GBLUP priors, BayesC/R/RC/LV are outside the accelerated
+path and raise NotImplementedError naming the reference code that handles them.
+All arithmetic happens in libnextgp_hip.so; this file only parses, reshapes and writes files.
+"""
+import os
+import re
+from dataclasses import dataclass
+from typing import Optional
+
+import numpy as np
+
+from ._lib import METHOD_BAYESB, METHOD_BAYESPR, Sampler
+
+__all__ = ["BayesPR", "BayesB", "Random", "SNP", "runLMEM", "summaryMCMC", "read_genotypes", "prep2RegionData", "parse_formula"]
+
+
+# ----------------------------------------------------------------------------------------------
+# prior / term types (src/runTime.jl)
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class BayesPRType:  # src/runTime.jl:30-45
+    r: int
+    v: float
+    name: str = "BayesPR"
+
+
+@dataclass
+class BayesBType:  # src/runTime.jl:48-61
+    pi: float
+    v: float
+    name: str = "BayesB"
+    estimatePi: bool = False
+
+
+@dataclass
+class RandomEffectType:  # src/runTime.jl:135-146
+    str: object
+    v: float
+    type: int = 1
+
+
+@dataclass
+class GenomicTerm:  # src/runTime.jl:13-28
+    name: str
+    path: object
+    map: str = ""
+
+
+def BayesPR(r, v, name="BayesPR"):
+    return BayesPRType(int(r), float(v), name)
+
+
+def BayesB(pi, v, name="BayesB", estimatePi=False):
+    return BayesBType(float(pi), float(v), name, bool(estimatePi))
+
+
+def Random(str, v, type=1):
+    return RandomEffectType(str, float(v), type)
+
+
+def SNP(name, path, map=""):
+    return GenomicTerm(name, path, map)
+
+
+# ----------------------------------------------------------------------------------------------
+# formula (the subset of the StatsModels DSL the marker path uses, src/prepMatVec.jl:112-169)
+# ----------------------------------------------------------------------------------------------
+def parse_formula(formula):
+    """'y ~ 1 + SNP(M, "geno.txt", "map.txt")' -> (lhs, intercept, [GenomicTerm, ...])."""
+    if "~" not in formula:
+        raise ValueError("formula needs a '~'")
+    lhs, rhs = [t.strip() for t in formula.split("~", 1)]
+    terms, depth, cur = [], 0, ""
+    for ch in rhs:
+        if ch == "(":
+            depth += 1
+        elif ch == ")":
+            depth -= 1
+        if ch == "+" and depth == 0:
+            terms.append(cur.strip())
+            cur = ""
+        else:
+            cur += ch
+    if cur.strip():
+        terms.append(cur.strip())
+    intercept, snps = False, []
+    for t in terms:
+        if t == "1":
+            intercept = True
+        elif t == "0":
+            intercept = False
+        elif t.startswith("SNP(") and t.endswith(")"):
+            args = [a.strip() for a in re.split(r",(?=(?:[^\"]*\"[^\"]*\")*[^\"]*$)", t[4:-1])]
+            if len(args) < 2:
+                raise ValueError(f"SNP term needs a name and a path: {t}")
+            unq = [a.strip("\"'") for a in args]
+            snps.append(GenomicTerm(unq[0], unq[1], unq[2] if len(unq) > 2 else ""))
+        elif t.startswith("PED(") or "|" in t:
+            raise NotImplementedError(f"term '{t}': pedigree / (1|g) random effects stay on the reference's Julia path "
+                                      "(src/functions.jl:57-110, src/mme.jl:165-272); they are outside the accelerated sweep")
+        else:
+            raise NotImplementedError(f"term '{t}': fixed covariates other than the intercept stay on the reference's Julia path "
+                                      "(src/functions.jl:22-53); use the fine seam (ngp_sweep_set) to combine them with the GPU sweep")
+    return lhs, intercept, snps
+
+
+# ----------------------------------------------------------------------------------------------
+# marker-matrix builders (src/prepMatVec.jl:113-134, src/misc.jl:163-215)
+# ----------------------------------------------------------------------------------------------
+def read_genotypes(path):
+    """Space-delimited text, one row per individual, no header (prepMatVec.jl:116); columns holding a missing
+    value are dropped (prepMatVec.jl:118).  Returns a float64 (N, P) Fortran-ordered matrix, NOT centred."""
+    if isinstance(path, np.ndarray):
+        M = np.asarray(path, dtype=np.float64)
+    else:
+        M = np.genfromtxt(path, delimiter=" ", dtype=np.float64)
+        if M.ndim == 1:
+            M = M[:, None]
+    keep = ~np.isnan(M).any(axis=0)
+    return np.asfortranarray(M[:, keep])
+
+
+def prep2RegionData(outPutFolder, markerSet, mapFile, fixedRegSize):
+    """Region ranges from a map file with header snpID,snpOrder,chrID (src/misc.jl:163-215).
+    99 = one region per chromosome, 9999 = whole genome, anything else = windows of that many SNPs inside each
+    chromosome.  Writes groupInfo_<set>.txt like the reference and returns 0-based [start, stop) pairs."""
+    import csv
+    with open(mapFile, newline="") as f:
+        rows = list(csv.DictReader(f))
+    chrs = [r["chrID"] for r in rows]
+    groups, g = [], 0
+    if fixedRegSize == 9999:
+        groups = [1] * len(rows)
+    else:
+        order = []
+        for c in chrs:
+            if c not in order:
+                order.append(c)
+        gid = {}
+        for c in order:
+            idx = [i for i, x in enumerate(chrs) if x == c]
+            if fixedRegSize == 99:
+                g += 1
+                for i in idx:
+                    gid[i] = g
+            else:
+                for k, i in enumerate(idx):
+                    gid[i] = g + 1 + k // int(fixedRegSize)
+                g += (len(idx) + int(fixedRegSize) - 1) // int(fixedRegSize)
+        groups = [gid[i] for i in range(len(rows))]
+    if outPutFolder is not None:
+        with open(os.path.join(outPutFolder, f"groupInfo_{markerSet}.txt"), "w") as f:
+            f.write("snpID\tsnpOrder\tchrID\tgroupID\n")
+            for r, gg in zip(rows, groups):
+                f.write(f"{r['snpID']}\t{r['snpOrder']}\t{r['chrID']}\t{gg}\n")
+    regions, start = [], 0
+    for i in range(1, len(groups) + 1):
+        if i == len(groups) or groups[i] != groups[start]:
+            regions.append((start, i))
+            start = i
+    return regions
+
+
+def _regions_for(prior, P, map_path, out_folder, set_name):
+    """M[set][:regionArray] (src/mme.jl:324-358)."""
+    if isinstance(prior, BayesBType):
+        return [(j, j + 1) for j in range(P)]
+    if not map_path:
+        if prior.r == 1:
+            return [(j, j + 1) for j in range(P)]
+        if prior.r == 9999:
+            return [(0, P)]
+        raise ValueError("Please enter a valid region size (1 or 9999)")  # src/mme.jl:343
+    return prep2RegionData(out_folder, set_name, map_path, prior.r)
+
+
+# ----------------------------------------------------------------------------------------------
+# output files (src/outFiles.jl:17-21, headers src/mme.jl:545-595, rows src/samplers.jl:57-103)
+# ----------------------------------------------------------------------------------------------
+def _out(folder, name, row):
+    with open(os.path.join(folder, f"{name}Out"), "a") as f:
+        f.write("\t".join(row) + "\n")
+
+
+def _fmt(x):
+    return [repr(float(v)) for v in np.atleast_1d(x)]
+
+
+def summaryMCMC(param, outFolder=None):
+    """Posterior mean = column mean of <outFolder>/<param>Out, first row is the header (src/misc.jl:241-244)."""
+    outFolder = outFolder or os.path.join(os.getcwd(), "outMCMC")
+    return np.loadtxt(os.path.join(outFolder, f"{param}Out"), delimiter="\t", skiprows=1, ndmin=2).mean(axis=0, keepdims=True)
+
+
+# ----------------------------------------------------------------------------------------------
+# runLMEM (src/MCMC.jl:31-41)
+# ----------------------------------------------------------------------------------------------
+def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=None, outFolder="outMCMC", VCV=None, userPedData=None,
+            summaryStat=None, seed=1, chain=0, device=0, samples="text", overwrite=False, engine=None):
+    """Runs the chain on the GPU and writes the reference's *Out files.
+
+    Differences from the reference, all deliberate: (1) `seed`/`chain` key the random streams (the reference never
+    seeds); (2) an existing non-empty outFolder is refused unless overwrite=True (the reference deletes it,
+    src/misc.jl:221-227); (3) samples="none" skips the per-iteration text rows and only returns posterior means.
+    Returns a dict of posterior means taken from the on-device sums."""
+    if blockThese:
+        raise NotImplementedError("blockThese: blocked fixed effects stay on the Julia path (src/functions.jl:22-36)")
+    if userPedData is not None and len(userPedData):
+        raise NotImplementedError("userPedData: pedigree effects stay on the Julia path (src/mme.jl:26-46)")
+    VCV = dict(VCV or {})
+    summaryStat = dict(summaryStat or {})
+    lhs, intercept, snps = parse_formula(formula)
+    if not snps:
+        raise ValueError("the accelerated path needs at least one SNP(...) term")
+    y = np.asarray(userData[lhs], dtype=np.float64)
+    # folderHandler (src/misc.jl:221-232) -- without the silent rm -r
+    if os.path.isdir(outFolder) and os.listdir(outFolder):
+        if not overwrite:
+            raise FileExistsError(f"output folder {outFolder} exists and is not empty (pass overwrite=True to clear it)")
+        for fn in os.listdir(outFolder):
+            os.remove(os.path.join(outFolder, fn))
+    os.makedirs(outFolder, exist_ok=True)
+    # prep: SNP branch (src/prepMatVec.jl:113-134); marker sets become consecutive column ranges of ONE panel
+    mats = [read_genotypes(t.path) for t in snps]
+    for M in mats:
+        if M.shape[0] != len(y):
+            raise ValueError("genotype rows must match the phenotype records (marker files are ordered as the data, runTime.jl:23)")
+    panel = np.asfortranarray(np.concatenate(mats, axis=1))
+    smp = Sampler(device=device, seed=seed, chain=chain, **(dict(mode=engine[0], lag=engine[1]) if engine else {}))
+    smp.set_panel(panel, centre=True)  # centring: src/prepMatVec.jl:129
+    # residual prior (src/mme.jl:63-94)
+    e_prior = VCV.get("e", Random("I", 100.0))
+    if not (e_prior.str in ("I", "", None) or (isinstance(e_prior.str, (list, tuple)) and len(e_prior.str) == 0)):
+        raise NotImplementedError("weighted residuals (E.str == \"D\") stay on the Julia path (src/mme.jl:71-75)")
+    e_df = 4.0
+    e_scale = 0.0005 if e_prior.v == 0.0 else e_prior.v * (e_df - 2.0) / e_df
+    smp.set_residual_prior(e_df, e_scale)
+    smp.set_intercept(intercept)
+    # marker sets (src/mme.jl:287-347, 492-520)
+    sets, col0 = [], 0
+    for t, M in zip(snps, mats):
+        P = M.shape[1]
+        prior = VCV.get(t.name)
+        if prior is None:  # src/mme.jl:324-329, 504, 518
+            prior = BayesPR(9999, 0.05)
+        if not isinstance(prior, (BayesPRType, BayesBType)):
+            raise NotImplementedError(f"prior {type(prior).__name__} for {t.name}: only BayesPR and BayesB are on the accelerated path")
+        df = 4.0                                  # 3 + size(v,1), src/mme.jl:493
+        scale = prior.v * (df - 2.0) / df         # src/mme.jl:501
+        regions = _regions_for(prior, P, t.map, outFolder, t.name)
+        lhs0 = rhs0 = None
+        if t.name in summaryStat:                 # src/mme.jl:316-322
+            m, v = np.asarray(summaryStat[t.name][0], float), np.asarray(summaryStat[t.name][1], float)
+            lhs0 = np.where(np.isinf(1.0 / v), 0.0, 1.0 / v)
+            rhs0 = np.nan_to_num(lhs0 * m)
+        if isinstance(prior, BayesBType):
+            sid = smp.add_marker_set(col0, P, METHOD_BAYESB, df, scale, regions, [prior.v] * P, pi0=prior.pi, estPi=prior.estimatePi,
+                                     lhs0=lhs0, rhs0=rhs0)
+        else:
+            sid = smp.add_marker_set(col0, P, METHOD_BAYESPR, df, scale, regions, [prior.v] * len(regions), lhs0=lhs0, rhs0=rhs0)
+        sets.append(dict(id=sid, name=t.name, col0=col0, P=P, prior=prior, nreg=len(regions)))
+        col0 += P
+    smp.set_y(y)
+    smp.set_schedule(nChain, nBurn, nThin)
+    # header rows (src/mme.jl:543-595)
+    if samples == "text":
+        _out(outFolder, "b", ["(Intercept)"] if intercept else [])
+        _out(outFolder, "varE", ["e"])
+        for s in sets:
+            names = [f"M{i + 1}" for i in range(s["P"])]  # src/prepMatVec.jl:131
+            _out(outFolder, f"beta{s['name']}", names)
+            _out(outFolder, f"delta{s['name']}", names)
+            if isinstance(s["prior"], BayesBType):
+                _out(outFolder, f"pi{s['name']}", ["pi1", "pi2"])
+            _out(outFolder, f"var{s['name']}", [f"reg_{r + 1}" for r in range(s["nreg"])])
+    # the chain (src/samplers.jl:29-105): kept iterations = burnIn+thin : thin : chainLength
+    done = 0
+    if samples == "text":
+        for it in range(nBurn + nThin, nChain + 1, nThin):
+            smp.run(it - done)
+            done = it
+            st = smp.get_state()
+            _out(outFolder, "b", _fmt(st["b"]) if intercept else [])
+            _out(outFolder, "varE", _fmt(st["varE"]))
+            vb_off = 0
+            for k, s in enumerate(sets):
+                sl = slice(s["col0"], s["col0"] + s["P"])
+                _out(outFolder, f"beta{s['name']}", _fmt(st["beta"][sl]))
+                _out(outFolder, f"delta{s['name']}", [str(int(v)) for v in st["delta"][sl]])
+                if isinstance(s["prior"], BayesBType):
+                    _out(outFolder, f"pi{s['name']}", _fmt(st["piHat"][2 * k:2 * k + 2]))
+                _out(outFolder, f"var{s['name']}", _fmt(st["varBeta"][vb_off:vb_off + s["nreg"]]))
+                vb_off += s["nreg"]
+    smp.run(nChain - done)
+    ps = smp.get_posterior_sums()
+    n = max(ps["nKept"], 1)
+    res = dict(nKept=ps["nKept"], b=ps["sum_b"] / n, varE=ps["sum_varE"] / n, sets={})
+    vb_off = 0
+    for k, s in enumerate(sets):
+        sl = slice(s["col0"], s["col0"] + s["P"])
+        res["sets"][s["name"]] = dict(beta=ps["sum_beta"][sl] / n, delta=ps["sum_delta"][sl] / n,
+                                      var=ps["sum_varBeta"][vb_off:vb_off + s["nreg"]] / n, pi=ps["sum_pi"][2 * k:2 * k + 2] / n)
+        vb_off += s["nreg"]
+    res["sampler"] = smp
+    return res

@@ -1,0 +1,143 @@
+# NextGPHIP.jl -- reference-side binding of libnextgp_hip.so (include/nextgp_hip.h) for NextGP.jl.
+#
+# NOT runnable in the build container (no Julia toolchain there, SURVEY.md section 8c); it is the
+# stub a NextGP.jl maintainer adds next to src/samplers.jl.  Two seams, both defined by the reference:
+#
+#   coarse:  replace `samplers.runSampler!(...)` (src/samplers.jl:23, called at src/MCMC.jl:39)
+#            by `NextGPHIP.runSampler!(...)`: the whole chain runs on the GPU, the same *Out files
+#            are written (src/samplers.jl:56-103).
+#   fine:    replace the stored callback `M[set][:funct]` (src/mme.jl:326,333,355, invoked at
+#            src/samplers.jl:52) by `NextGPHIP.sweep!`: fixed / random effects stay in Julia,
+#            only the per-SNP sweep of one marker set runs on the GPU.
+#
+# Ownership: Julia arrays are passed for the duration of the ccall only (GC roots them); the
+# library copies what it keeps.  All status codes != 0 become `error(msg)`, like src/mme.jl:77.
+module NextGPHIP
+
+using DelimitedFiles
+
+const LIB = get(ENV, "NEXTGP_HIP_LIB", "libnextgp_hip")
+
+mutable struct Handle
+    ptr::Ptr{Cvoid}
+end
+
+function check(h::Handle, rc::Integer)
+    rc == 0 && return
+    msg = unsafe_string(ccall((:ngp_last_error, LIB), Cstring, (Ptr{Cvoid},), h.ptr))
+    error("libnextgp_hip ($rc): $msg")
+end
+
+function Handle(; device::Integer=0, seed::Integer=1, chain::Integer=0)
+    out = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:ngp_create, LIB), Int32, (Int32, UInt64, UInt32, Ref{Ptr{Cvoid}}), device, seed, chain, out)
+    rc == 0 || error("ngp_create ($rc): " * unsafe_string(ccall((:ngp_last_error, LIB), Cstring, (Ptr{Cvoid},), C_NULL)))
+    h = Handle(out[])
+    finalizer(x -> ccall((:ngp_destroy, LIB), Int32, (Ptr{Cvoid},), x.ptr), h)
+    return h
+end
+
+# M[set][:data] is the centred Float64 N x P matrix of src/prepMatVec.jl:129-131 (centre = 0)
+set_panel!(h::Handle, data::Matrix{Float64}; centre::Bool=false) =
+    check(h, ccall((:ngp_set_panel_f64, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Int32),
+                   h.ptr, data, size(data, 1), size(data, 2), stride(data, 2), centre))
+
+# regionArray::Vector{UnitRange{Int}} (1-based, src/mme.jl:335-358) -> 0-based [start, stop)
+function add_marker_set!(h::Handle, col0::Integer, ncol::Integer, method::Integer, df::Float64, scale::Float64,
+                         regionArray, varBeta0::Vector{Float64}; pi0::Float64=0.0, estPi::Bool=false,
+                         lhs0=C_NULL, rhs0=C_NULL)
+    rs = Int64[first(r) - 1 for r in regionArray]
+    re = Int64[last(r) for r in regionArray]
+    id = Ref{Int32}(0)
+    check(h, ccall((:ngp_add_marker_set, LIB), Int32,
+                   (Ptr{Cvoid}, Int64, Int64, Int32, Float64, Float64, Ptr{Int64}, Ptr{Int64}, Int64, Ptr{Float64}, Float64, Int32,
+                    Ptr{Float64}, Ptr{Float64}, Ref{Int32}),
+                   h.ptr, col0, ncol, method, df, scale, rs, re, length(rs), varBeta0, pi0, estPi, lhs0, rhs0, id))
+    return id[]
+end
+
+set_y!(h::Handle, y::Vector{Float64}) = check(h, ccall((:ngp_set_y, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64), h.ptr, y, length(y)))
+set_residual_prior!(h::Handle, df, scale) = check(h, ccall((:ngp_set_residual_prior, LIB), Int32, (Ptr{Cvoid}, Float64, Float64), h.ptr, df, scale))
+set_schedule!(h::Handle, n, burn, thin) = check(h, ccall((:ngp_set_schedule, LIB), Int32, (Ptr{Cvoid}, Int64, Int64, Int64), h.ptr, n, burn, thin))
+run!(h::Handle, niter) = check(h, ccall((:ngp_run, LIB), Int32, (Ptr{Cvoid}, Int64), h.ptr, niter))
+
+"""
+    sweep!(h, set_id, mSet, M, beta, delta, ycorr, varE, varBeta)
+
+Fine seam: same argument list as the reference's `sampleBayesPR!/sampleBayesB!(mSet, M, beta, delta, ycorr, varE, varBeta)`
+(src/functions.jl:118,157) plus the handle and the set id.  Mutates `beta[M[mSet].pos]`, `delta[M[mSet].pos]`, `ycorr`,
+`varBeta[mSet]` and, for BayesB, `M[mSet].piHat` / `M[mSet].logPi` in place.
+"""
+function sweep!(h::Handle, set_id::Integer, mSet, M, beta, delta, ycorr::Vector{Float64}, varE::Float64, varBeta)
+    b = vec(beta[M[mSet].pos])                 # 1 x P Matrix{Float64}: vec() shares the memory
+    d = vec(delta[M[mSet].pos])                # 1 x P Matrix{Int64}
+    vb = varBeta[mSet] isa Vector{Float64} ? varBeta[mSet] : Float64.(varBeta[mSet])
+    pih = haskey(M[mSet], :piHat) ? vec(M[mSet].piHat) : Float64[0.0, 0.0]
+    check(h, ccall((:ngp_sweep_set, LIB), Int32,
+                   (Ptr{Cvoid}, Int32, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}),
+                   h.ptr, set_id, varE, ycorr, b, d, vb, pih))
+    varBeta[mSet] isa Vector{Float64} || (varBeta[mSet] .= vb)
+    if haskey(M[mSet], :piHat)
+        M[mSet].piHat .= reshape(pih, size(M[mSet].piHat))
+        M[mSet].logPi .= log.(M[mSet].piHat)  # src/functions.jl:193
+    end
+    return nothing
+end
+
+"""
+    runSampler!(ycorr, nData, E, X, b, Z, u, varU, M, beta, varBeta, delta, chainLength, burnIn, outputFreq, outPut; seed=1)
+
+Coarse seam: drop-in for `samplers.runSampler!` (src/samplers.jl:23) for models made of an intercept and
+Symbol marker sets with BayesPR / BayesB priors.  Anything else falls back to the reference sampler.
+"""
+function runSampler!(ycorr, nData, E, X, b, Z, u, varU, M, beta, varBeta, delta, chainLength, burnIn, outputFreq, outPut;
+                     seed::Integer=1, device::Integer=0)
+    isempty(Z) || error("random effects present: use the fine seam (NextGPHIP.sweep!) instead")
+    (length(X) <= 1 && all(x -> X[x].nCol == 1, keys(X))) || error("only the intercept is supported on the coarse seam")
+    E.str == "I" || error("weighted residuals: use the reference sampler")
+    h = Handle(device=device, seed=seed)
+    sets = collect(keys(M))                       # Dict order, as src/samplers.jl:50
+    panel = hcat((M[s].data for s in sets)...)    # consecutive column ranges of ONE panel
+    set_panel!(h, panel)
+    col0 = 0
+    ids = Dict{Any,Int32}()
+    for s in sets
+        P = M[s].dims[2]
+        method = M[s].method == "BayesB" ? 1 : 0
+        ids[s] = add_marker_set!(h, col0, P, method, Float64(M[s].df), Float64(M[s].scale), M[s].regionArray,
+                                 Float64.(varBeta[s]); pi0 = method == 1 ? M[s].piHat[2] : 0.0,
+                                 estPi = method == 1 ? M[s].estPi : false, lhs0 = Float64.(M[s].lhs), rhs0 = Float64.(M[s].rhs))
+        col0 += P
+    end
+    set_y!(h, Vector{Float64}(ycorr))            # ycorr == y at this point (src/mme.jl:57)
+    set_residual_prior!(h, E.df, E.scale)
+    check(h, ccall((:ngp_set_intercept, LIB), Int32, (Ptr{Cvoid}, Int32), h.ptr, isempty(X) ? 0 : 1))
+    set_schedule!(h, chainLength, burnIn, outputFreq)
+    Ptot = col0
+    bet = Vector{Float64}(undef, Ptot); del = Vector{Int64}(undef, Ptot)
+    nvb = sum(length(varBeta[s]) for s in sets); vb = Vector{Float64}(undef, nvb); pih = Vector{Float64}(undef, 2 * length(sets))
+    ve = Ref{Float64}(0.0); bb = Ref{Float64}(0.0); it = Ref{Int64}(0)
+    done = 0
+    for keep in (burnIn + outputFreq):outputFreq:chainLength      # these2Keep, src/samplers.jl:26
+        run!(h, keep - done); done = keep
+        check(h, ccall((:ngp_get_state, LIB), Int32,
+                       (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}, Ref{Float64}, Ref{Int64}),
+                       h.ptr, ycorr, bet, del, vb, pih, ve, bb, it))
+        open(io -> writedlm(io, [bb[]]'), outPut * "/bOut", "a")          # src/samplers.jl:57
+        open(io -> writedlm(io, ve[]), outPut * "/varEOut", "a")          # src/samplers.jl:58
+        c0 = 0; v0 = 0
+        for (k, s) in enumerate(sets)
+            P = M[s].dims[2]
+            open(io -> writedlm(io, bet[c0+1:c0+P]'), outPut * "/beta$(s)Out", "a")    # :80
+            open(io -> writedlm(io, del[c0+1:c0+P]'), outPut * "/delta$(s)Out", "a")   # :81
+            M[s].method == "BayesB" && open(io -> writedlm(io, pih[2k-1:2k]'), outPut * "/pi$(s)Out", "a")   # :83
+            nr = length(varBeta[s])
+            open(io -> writedlm(io, vb[v0+1:v0+nr]'), outPut * "/var$(s)Out", "a")     # :101-103
+            c0 += P; v0 += nr
+        end
+    end
+    run!(h, chainLength - done)
+    return h
+end
+
+end # module

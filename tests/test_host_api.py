@@ -1,0 +1,87 @@
+"""Host-side mirror of the reference interface: parsing, region building, output files (CPU) and an
+end-to-end runLMEM on the GPU whose files must reproduce the oracle chain."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import make_problem
+
+
+def test_parse_formula(ngp):
+    lhs, ic, snps = ngp.parse_formula('y ~ 1 + SNP(M, "geno.txt")')
+    assert (lhs, ic) == ("y", True) and snps[0].name == "M" and snps[0].path == "geno.txt" and snps[0].map == ""
+    lhs, ic, snps = ngp.parse_formula('pheno ~ 0 + SNP(M1,"a b.txt","map.csv") + SNP(M2, "g2.txt")')
+    assert (lhs, ic) == ("pheno", False) and [s.name for s in snps] == ["M1", "M2"] and snps[0].map == "map.csv"
+    for bad in ("y ~ 1 + x1 + SNP(M,\"g\")", "y ~ 1 + PED(ID) + SNP(M,\"g\")", "y ~ 1 + (1|herd) + SNP(M,\"g\")"):
+        with pytest.raises(NotImplementedError, match="Julia path"):
+            ngp.parse_formula(bad)
+
+
+def test_priors_have_reference_fields(ngp):
+    p = ngp.BayesPR(9999, 0.001)
+    assert (p.r, p.v, p.name) == (9999, 0.001, "BayesPR")          # src/runTime.jl:30-45
+    b = ngp.BayesB(0.05, 0.01, estimatePi=True)
+    assert (b.pi, b.v, b.name, b.estimatePi) == (0.05, 0.01, "BayesB", True)
+    assert ngp.Random("I", 2.0).str == "I"
+
+
+def test_read_genotypes_drops_missing_columns(ngp, tmp_path):
+    f = tmp_path / "g.txt"
+    f.write_text("0 1 2 1\n1 nan 0 2\n2 1 1 0\n")
+    M = ngp.read_genotypes(str(f))
+    assert M.shape == (3, 3) and np.array_equal(M[:, 0], [0, 1, 2]) and np.array_equal(M[:, 1], [2, 0, 1])
+
+
+def test_prep2RegionData(ngp, tmp_path):
+    m = tmp_path / "map.csv"
+    rows = ["snpID,snpOrder,chrID"] + [f"s{i},{i},{1 if i <= 5 else 2}" for i in range(1, 13)]
+    m.write_text("\n".join(rows) + "\n")
+    assert ngp.prep2RegionData(str(tmp_path), "M", str(m), 9999) == [(0, 12)]
+    assert ngp.prep2RegionData(str(tmp_path), "M", str(m), 99) == [(0, 5), (5, 12)]
+    assert ngp.prep2RegionData(str(tmp_path), "M", str(m), 3) == [(0, 3), (3, 5), (5, 8), (8, 11), (11, 12)]
+    gi = (tmp_path / "groupInfo_M.txt").read_text().splitlines()
+    assert gi[0].split("\t") == ["snpID", "snpOrder", "chrID", "groupID"] and len(gi) == 13
+
+
+def test_summaryMCMC_is_column_mean(ngp, tmp_path):
+    (tmp_path / "betaMOut").write_text("M1\tM2\n1.0\t2.0\n3.0\t6.0\n")
+    assert np.allclose(ngp.summaryMCMC("betaM", outFolder=str(tmp_path)), [[2.0, 4.0]])
+
+
+@pytest.mark.gpu
+def test_runLMEM_end_to_end_matches_oracle(ngp, O, tmp_path):
+    N, P1, P2 = 120, 70, 90
+    X, y, bt, v = make_problem(O, N, P1 + P2, seed=3)
+    raw = np.rint(X.astype(np.float64) + X.astype(np.float64).mean(0))  # any integer-ish genotypes; centring is redone
+    X1 = O.generate_panel(N, P1 + P2, seed=5)[0]
+    mu = -X1.astype(np.float64).min(axis=0)
+    G = np.rint(X1.astype(np.float64) + mu)                      # raw 0/1/2 genotypes
+    g1, g2 = tmp_path / "g1.txt", tmp_path / "g2.txt"
+    np.savetxt(g1, G[:, :P1], fmt="%d", delimiter=" ")
+    np.savetxt(g2, G[:, P1:], fmt="%d", delimiter=" ")
+    out = tmp_path / "outMCMC"
+    VCV = {"M1": ngp.BayesPR(9999, v), "M2": ngp.BayesB(0.1, v, estimatePi=True), "e": ngp.Random("I", 0.5 * y.var())}
+    res = ngp.runLMEM(f'y ~ 1 + SNP(M1,"{g1}") + SNP(M2,"{g2}")', {"y": y}, 20, 6, 2, outFolder=str(out), VCV=VCV, seed=9, engine=(1, 3))
+    assert res["nKept"] == 7
+    # the same model on the oracle (reference order)
+    Gc = (G - G.mean(axis=0)).astype(np.float32)
+    o = O.Oracle(0, seed=9, chain=0)
+    o.set_panel_f32(Gc)
+    o.add_marker_set(0, P1, 0, 4.0, v * 0.5, [(0, P1)], [v])
+    o.add_marker_set(P1, P2, 1, 4.0, v * 0.5, [(j, j + 1) for j in range(P2)], [v] * P2, pi0=0.1, estPi=True)
+    o.set_y(y); o.set_residual_prior(4.0, 0.5 * y.var() * 0.5); o.set_schedule(20, 6, 2); o.run(20)
+    ps = o.get_posterior_sums()
+    assert np.abs(res["sets"]["M1"]["beta"] - ps["sum_beta"][:P1] / 7).max() < 1e-9
+    assert np.array_equal(res["sets"]["M2"]["delta"], ps["sum_delta"][P1:] / 7)
+    assert abs(res["varE"] - ps["sum_varE"] / 7) < 1e-9 * res["varE"]
+    # files: header + one row per kept iteration; posterior mean through summaryMCMC == device sums
+    for name, ncol in (("b", 1), ("varE", 1), ("betaM1", P1), ("deltaM1", P1), ("betaM2", P2), ("deltaM2", P2), ("piM2", 2), ("varM1", 1),
+                       ("varM2", P2)):
+        lines = (out / f"{name}Out").read_text().splitlines()
+        assert len(lines) == 8 and len(lines[0].split("\t")) == ncol, name
+    assert np.allclose(ngp.summaryMCMC("betaM1", outFolder=str(out))[0], res["sets"]["M1"]["beta"], rtol=0, atol=1e-12)
+    assert np.allclose(ngp.summaryMCMC("varE", outFolder=str(out))[0, 0], res["varE"])
+    assert (out / "betaM2Out").read_text().splitlines()[0].split("\t")[:2] == ["M1", "M2"]
+    with pytest.raises(FileExistsError):
+        ngp.runLMEM(f'y ~ 1 + SNP(M1,"{g1}")', {"y": y}, 2, 0, 1, outFolder=str(out), VCV=VCV)
