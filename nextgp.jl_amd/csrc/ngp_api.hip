@@ -42,7 +42,7 @@ struct ngp_handle {
     int64_t N = 0, P = 0, R = 0, S = 0, NBLK = 0, Ppad = 0, L = 0;
     size_t lds_step = 0, lds_sweep = 0;
     int mode = 1;      // 1: persistent sweep kernel, 0: one streaming + one recursion launch per block
-    int lag = 4;       // look-ahead D of the persistent sweep (blocks)
+    int lag = 5;       // look-ahead D of the persistent sweep (blocks)
     int D = 1;         // Gram planes stored per block (= lag in mode 1, 1 in mode 0)
     int NG = 1;        // reducer groups = ceil(S/32)
     int NS = 1;        // LDS tile slots of a streamer workgroup
@@ -312,7 +312,7 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
         SweepArgs A;
         A.tiles = h->d_tiles; A.ycorr = h->d_ycorr; A.gramx = h->d_gramx;
         A.D = h->D; A.R = R; A.S = S; A.NG = h->NG; A.NS = h->NS; A.t0 = (int)tb0; A.t1 = (int)tb1;
-        A.beta = h->d_beta; A.delta = h->d_delta; A.c = h->d_c; A.w = h->d_w; A.q = h->d_q; A.T = h->d_T; A.chi = h->d_chi;
+        A.beta = h->d_beta; A.delta = h->d_delta; A.c = h->d_c; A.w = h->d_w; A.q = h->d_q; A.mpm = h->d_mpm; A.chi = h->d_chi;
         A.setof = h->d_setof; A.vbidx = h->d_vbidx; A.sets = h->d_sets; A.varBeta = h->d_varBeta;
         A.part = h->d_cpart; A.gsum = h->d_cgsum; A.dlt = h->d_cdlt;
         A.cnt_part = h->d_ccnt; A.cnt_gs = h->d_ccnt + (size_t)NGP_RING * h->NG * 32;
@@ -334,7 +334,7 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
         if (evs && do_gemv) (void)hipEventRecord(evs[e++], h->stream);
         if (do_gemv)
             hipLaunchKernelGGL(k_recur, dim3(1), dim3(256), 0, h->stream, h->d_part, h->d_gramx, h->D, S, (int)t, h->d_beta, h->d_delta,
-                               h->d_c, h->d_w, h->d_q, h->d_T, h->d_chi, h->d_setof, h->d_vbidx, h->d_sets, h->d_varBeta, h->d_dlt);
+                               h->d_c, h->d_w, h->d_q, h->d_mpm, h->d_chi, h->d_setof, h->d_vbidx, h->d_sets, h->d_varBeta, h->d_dlt);
     }
     h->sweep_launches += 2 * (tb1 - tb0) + 1;
 }
@@ -492,6 +492,13 @@ int32_t ngp_get_gram(ngp_handle *h, int64_t t, double *out) {
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
     REQUIRE(out && t >= 0 && t < h->NBLK, NGP_ERR_ARG, "block index out of range");
     HCHK(hipMemcpy(out, h->d_gramx + (size_t)t * h->D * NGP_BLK * NGP_BLK, NGP_BLK * NGP_BLK * sizeof(double), hipMemcpyDeviceToHost));
+    // the device keeps entry [k][j] for j > k only (plus x'x in mpm); hand back the symmetric block
+    double diag[NGP_BLK];
+    HCHK(hipMemcpy(diag, h->d_mpm + (size_t)t * NGP_BLK, sizeof(diag), hipMemcpyDeviceToHost));
+    for (int k = 0; k < NGP_BLK; k++) {
+        out[k * NGP_BLK + k] = diag[k];
+        for (int j = k + 1; j < NGP_BLK; j++) out[j * NGP_BLK + k] = out[k * NGP_BLK + j];
+    }
     return NGP_OK;
 }
 

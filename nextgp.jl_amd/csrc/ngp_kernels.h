@@ -188,7 +188,8 @@ __global__ __launch_bounds__(256) void k_prep(long long Ppad, const int8_t *__re
         } else {
             st = (0.0 < TT) ? -1.0 : __builtin_huge_val();
         }
-        q[k] = st;
+        // threshold on f = c r instead of r (c > 0 when finite): thr = st c; -1 always, inf never
+        q[k] = (st < 0.0) ? -1.0 : ((st == __builtin_huge_val()) ? st : st * cc);
         T[k] = TT;
         Rng rc = rng_seed(seed, chain, it, NGP_KIND_B_LOCUS_CHI2, key);
         chi[k] = rng_chisq(rc, S.df + 1.0);
@@ -269,7 +270,7 @@ __global__ __launch_bounds__(256) void k_step(const float *__restrict__ tiles, d
 __global__ __launch_bounds__(256) void k_recur(const double *__restrict__ part, const double *__restrict__ gramx, int D, int S, int t,
                                                double *__restrict__ beta, uint8_t *__restrict__ delta,
                                                const double *__restrict__ c, const double *__restrict__ w,
-                                               const double *__restrict__ q, const double *__restrict__ T,
+                                               const double *__restrict__ q, const double *__restrict__ mpm,
                                                const double *__restrict__ chi, const int8_t *__restrict__ setof,
                                                const int32_t *__restrict__ vbidx, DSet *__restrict__ sets,
                                                double *__restrict__ varBeta, double *__restrict__ dlt) {
@@ -291,23 +292,22 @@ __global__ __launch_bounds__(256) void k_recur(const double *__restrict__ part, 
     double Gr[NGP_BLK];
 #pragma unroll
     for (int kk = 0; kk < NGP_BLK; kk++) Gr[kk] = G[kk * NGP_BLK + j];
-    const double gd = G[j * NGP_BLK + j];
+    const double gd = mpm[k];
     const double bo = beta[k], cc = c[k], ww = w[k], st = q[k];
-    double r = __builtin_fma(gd, bo, tot);
-    double dsave = 0.0;
-    int isave = 1;
+    const double r = __builtin_fma(gd, bo, tot);
+    // scaled recursion: e = c r + w (candidate draw), f = c r (inclusion test |f| > thr), H_k = -(c G[.][k])
+    double e = __builtin_fma(r, cc, ww), f = r * cc;
 #pragma unroll
     for (int kk = 0; kk < NGP_BLK; kk++) {
-        int in = __builtin_fabs(r) > st;
-        double d = __builtin_fma(r, cc, ww);
-        double dl = in ? d : -bo;
-        if (j == kk) {
-            dsave = dl;
-            isave = in;
-        }
+        int in = __builtin_fabs(f) > st;
+        double dl = in ? e : -bo;
         double dk = readlane_d(dl, kk);
-        r = __builtin_fma(-Gr[kk], dk, r);
+        double H = -(cc * Gr[kk]);  // -0 for lanes <= kk: their e, f stay frozen at their own step's value
+        e = __builtin_fma(H, dk, e);
+        f = __builtin_fma(H, dk, f);
     }
+    const int isave = __builtin_fabs(f) > st;
+    const double dsave = isave ? e : -bo;
     const double bn = bo + dsave;
     beta[k] = bn;
     delta[k] = (uint8_t)isave;
@@ -495,9 +495,11 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const double *__restrict__ 
         for (int s = s0 + 1; s < s1; s++) v = v + p[(size_t)s * (NGP_BLK * NGP_BLK)];
         tot = (g == 0) ? v : tot + v;
     }
-    gramx[((size_t)(t0 + tb) * D + d) * (NGP_BLK * NGP_BLK) + kj] = tot;
     int k = kj / NGP_BLK, j = kj % NGP_BLK;
     if (d == 0 && k == j) mpm[(size_t)(t0 + tb) * NGP_BLK + k] = tot;
+    // the diagonal block is stored strictly "one-sided": entry [k][j] is kept for j > k only (what step k of the
+    // recursion applies to the later lanes), zero elsewhere, so the chain needs no per-step masking; x'x lives in mpm
+    gramx[((size_t)(t0 + tb) * D + d) * (NGP_BLK * NGP_BLK) + kj] = (d == 0 && j <= k) ? 0.0 : tot;
 }
 
 // synthetic genotypes: per-column mean of g_ij (integer sum), then centred fp32 tiles

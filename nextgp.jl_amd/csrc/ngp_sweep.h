@@ -44,7 +44,7 @@ struct SweepArgs {
     int D, R, S, NG, NS, t0, t1;  // NS: LDS tile slots of a streamer
     double *beta;
     uint8_t *delta;
-    const double *c, *w, *q, *T, *chi;
+    const double *c, *w, *q, *mpm, *chi;
     const int8_t *setof;
     const int32_t *vbidx;
     DSet *sets;
@@ -316,14 +316,15 @@ __device__ inline void role_reducer(const SweepArgs &A, const int g) {
 
 // ------------------------------------------------------------------------------------------
 struct CoefRegs {
-    double bo, cc, ww, st;
+    double bo, cc, ww, st, gd;
 };
 __device__ inline CoefRegs load_coef(const SweepArgs &A, long long k) {
     CoefRegs c;
     c.bo = A.beta[k];
     c.cc = A.c[k];
     c.ww = A.w[k];
-    c.st = A.q[k];  // inclusion threshold: included iff |r| > st (st < 0: always)
+    c.st = A.q[k];  // inclusion threshold on f = c r: included iff |f| > st (st < 0: always)
+    c.gd = A.mpm[k];
     return c;
 }
 
@@ -445,34 +446,36 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
             if (have_far || have_one) tot = tot - cor;
             const double *gdb = Gd + buf * 4096;
             const double bo = cur.bo, cc = cur.cc, ww = cur.ww, st = cur.st;
-            double r = __builtin_fma(gdb[j * NGP_BLK + j], bo, tot);
-            double Gr[NGP_BLK];
+            const double r = __builtin_fma(cur.gd, bo, tot);
+            // scaled recursion: e = c r + w is the candidate draw, f = c r feeds the
+            // inclusion test |f| > thr.  H_k = -(c G[k][.]) is formed off the serial path; the stored diagonal block
+            // is zero for lanes <= k, so a lane's e and f freeze at its own step and nothing has to be captured.
+            // Serial path per step: v_readlane -> ONE fma (BayesPR blocks), + compare / select for BayesB.
+            double H[NGP_BLK];
 #pragma unroll
-            for (int kk = 0; kk < NGP_BLK; kk++) Gr[kk] = gdb[kk * NGP_BLK + j];
-            double dsave = 0.0;
+            for (int kk = 0; kk < NGP_BLK; kk++) H[kk] = -(cc * gdb[kk * NGP_BLK + j]);
+            double e = __builtin_fma(r, cc, ww);
+            double dsave;
             int isave = 1;
             if (__ballot(st >= 0.0) == 0ull) {
-                // every locus of the block is always included (BayesPR): fma -> broadcast -> fma per step
 #pragma unroll
                 for (int kk = 0; kk < NGP_BLK; kk++) {
-                    double d = __builtin_fma(r, cc, ww);
-                    if (j == kk) dsave = d;
-                    double dk = readlane_d(d, kk);
-                    r = __builtin_fma(-Gr[kk], dk, r);
+                    double dk = readlane_d(e, kk);
+                    e = __builtin_fma(H[kk], dk, e);
                 }
+                dsave = e;
             } else {
+                double f = r * cc;
 #pragma unroll
                 for (int kk = 0; kk < NGP_BLK; kk++) {
-                    int in = __builtin_fabs(r) > st;
-                    double d = __builtin_fma(r, cc, ww);
-                    double dlv = in ? d : -bo;
-                    if (j == kk) {
-                        dsave = dlv;
-                        isave = in;
-                    }
+                    int in = __builtin_fabs(f) > st;
+                    double dlv = in ? e : -bo;
                     double dk = readlane_d(dlv, kk);
-                    r = __builtin_fma(-Gr[kk], dk, r);
+                    e = __builtin_fma(H[kk], dk, e);
+                    f = __builtin_fma(H[kk], dk, f);
                 }
+                isave = __builtin_fabs(f) > st;
+                dsave = isave ? e : -bo;
             }
             hist[slot * NGP_BLK + j] = dsave;
             outb[buf * NGP_BLK + j] = bo + dsave;

@@ -679,7 +679,8 @@ static void iter_blocked(ora_t *h) {
                     double st;
                     if (qq < 0.0) { double thr2 = TT / qq; st = (thr2 < 0.0) ? -1.0 : sqrt(thr2); }
                     else st = (0.0 < TT) ? -1.0 : INFINITY;
-                    h->q[k] = st; h->T[k] = TT;
+                    /* threshold on f = c r instead of r (c > 0 when finite): thr = st c; -1 always, inf never */
+                    h->q[k] = (st < 0.0) ? -1.0 : (isinf(st) ? INFINITY : st * c); h->T[k] = TT;
                     rng_seed(&r, h->seed, h->chain, it, KIND_B_LOCUS_CHI2, ((uint64_t)si << 40) | (uint64_t)l);
                     h->chi[k] = rng_chisq(&r, Sx->df + 1.0);
                 }
@@ -743,13 +744,22 @@ static void iter_blocked(ora_t *h) {
             if (have) tot = tot - c;
             rr[j] = __builtin_fma(G[j * BLK + j], h->beta[k0 + j], tot);
         }
+        /* recursion in the scaled variables e_j = c_j r_j + w_j (the candidate draw) and f_j = c_j r_j (for the
+           inclusion test |f_j| > thr_j = st_j c_j): one fma per step on the serial path, H_jk = -(c_j G_jk) */
+        double ee[BLK], ff[BLK];
+        for (int j = 0; j < BLK; j++) {
+            ee[j] = __builtin_fma(rr[j], h->c[k0 + j], h->w[k0 + j]);
+            ff[j] = rr[j] * h->c[k0 + j];
+        }
         for (int k = 0; k < BLK; k++) {
-            double rk = rr[k];
-            int in = fabs(rk) > h->q[k0 + k];
-            double d = __builtin_fma(rk, h->c[k0 + k], h->w[k0 + k]);
-            double dk = in ? d : -h->beta[k0 + k];
+            int in = fabs(ff[k]) > h->q[k0 + k];
+            double dk = in ? ee[k] : -h->beta[k0 + k];
             dlt[k] = dk; inc[k] = in;
-            for (int j = k + 1; j < BLK; j++) rr[j] = __builtin_fma(-G[j * BLK + k], dk, rr[j]);
+            for (int j = k + 1; j < BLK; j++) {
+                double Hjk = -(h->c[k0 + j] * G[j * BLK + k]);
+                ee[j] = __builtin_fma(Hjk, dk, ee[j]);
+                ff[j] = __builtin_fma(Hjk, dk, ff[j]);
+            }
         }
         for (int k = 0; k < BLK; k++) {
             hist[tb * BLK + k] = dlt[k];
