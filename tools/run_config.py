@@ -1,0 +1,34 @@
+"""Runs one of the BASELINE.json configurations end to end and prints a JSON line (diagnostic / report tool).
+   python tools/run_config.py C3|C4|C2 [iters] [warm]"""
+import json, os, sys, time
+import numpy as np
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from ngp_pkg import load_pkg
+ngp = load_pkg()
+cfg = sys.argv[1]
+iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+warm = int(sys.argv[3]) if len(sys.argv) > 3 else 5
+N, P, sets = {"C2": (10000, 100000, [("PR", 100000)]), "C3": (10000, 100000, [("B", 100000)]),
+              "C4": (50000, 600000, [("PR", 200000)] * 3), "C4s": (50000, 60000, [("PR", 20000)] * 3)}[cfg]
+s = ngp.Sampler(device=0, seed=1001, chain=0)
+t0 = time.perf_counter(); s.generate_panel(N, P); setup = time.perf_counter() - t0
+rng = np.random.default_rng(1); bt = np.zeros(P); idx = rng.choice(P, max(10, P // 100), replace=False); bt[idx] = rng.normal(size=len(idx))
+t0 = time.perf_counter(); g = s.xbeta(bt); txb = time.perf_counter() - t0
+y = 10 + g + np.random.default_rng(2).normal(size=N) * np.sqrt(g.var())
+v = 0.5 * y.var() / (s.mpm().sum() / N)
+c0 = 0
+for kind, n in sets:
+    if kind == "PR": s.add_marker_set(c0, n, 0, 4.0, v * 0.5, [(0, n)], [v])
+    else: s.add_marker_set(c0, n, 1, 4.0, v * 0.5, [(j, j + 1) for j in range(n)], np.full(n, v), pi0=0.01, estPi=True)
+    c0 += n
+s.set_y(y); s.set_residual_prior(4.0, 0.25 * y.var()); s.set_schedule(warm + iters, warm, 1)
+s.run(warm)
+t0 = time.perf_counter(); s.run(iters); dt = (time.perf_counter() - t0) / iters
+st = s.get_state(); ps = s.get_posterior_sums()
+resid = y - st["b"] - s.xbeta(st["beta"])
+R, S, nb = s.layout(); mode, lag = s.config()
+corr = float(np.corrcoef(ps["sum_beta"], bt)[0, 1])
+print(json.dumps(dict(config=cfg, N=N, P=P, sets=[k for k, _ in sets], mode=mode, lag=lag, R=R, S=S, nblk=nb, ms_per_iter=dt * 1e3, it_per_s=1 / dt,
+                      GBs=4.0 * N * P / dt / 1e9, frac_of_8TBs=4.0 * N * P / dt / 8e12, setup_s=setup, xbeta_s=txb,
+                      invariant_max=float(np.abs(st["ycorr"] - resid).max()), varE=st["varE"], piHat=list(map(float, st["piHat"])),
+                      included=int(st["delta"].sum()), corr_postmean_true=corr)))
