@@ -1,0 +1,80 @@
+"""Full-size checks on the GPU (BASELINE.json configs[1]/[2] shapes): the CPU oracle cannot run these sizes in
+seconds, so parity is carried by size-independent properties of the sampler."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+N, P = 10000, 100000
+
+
+def _chain(ngp, method, niter, engine=(1, 5), seed=1001, P_=P):
+    s = ngp.Sampler(device=0, seed=seed, chain=0, mode=engine[0], lag=engine[1])
+    s.generate_panel(N, P_)
+    rng = np.random.default_rng(1)
+    bt = np.zeros(P_); idx = rng.choice(P_, P_ // 100, replace=False); bt[idx] = rng.normal(size=len(idx))
+    g = s.xbeta(bt)
+    y = 10.0 + g + np.random.default_rng(2).normal(size=N) * np.sqrt(g.var())
+    v = 0.5 * y.var() / (s.mpm().sum() / N)
+    if method == "PR":
+        s.add_marker_set(0, P_, 0, 4.0, v * 0.5, [(0, P_)], [v])
+    elif method == "B":
+        s.add_marker_set(0, P_, 1, 4.0, v * 0.5, [(j, j + 1) for j in range(P_)], np.full(P_, v), pi0=0.01, estPi=True)
+    else:  # three consecutive sets, like the multi-breed configuration
+        third = P_ // 3
+        s.add_marker_set(0, third, 0, 4.0, v * 0.5, [(0, third)], [v])
+        s.add_marker_set(third, third, 1, 4.0, v * 0.5, [(j, j + 1) for j in range(third)], np.full(third, v), pi0=0.02, estPi=True)
+        s.add_marker_set(2 * third, P_ - 2 * third, 0, 4.0, v * 0.5, [(0, P_ - 2 * third)], [v])
+    s.set_y(y); s.set_residual_prior(4.0, 0.25 * y.var()); s.set_schedule(niter, 0, 1)
+    s.run(niter)
+    return s, y
+
+
+@pytest.mark.parametrize("method", ["PR", "B", "multi"])
+def test_residual_invariant_and_indicator_consistency(ngp, method):
+    s, y = _chain(ngp, method, 12)
+    st = s.get_state()
+    resid = y - st["b"] - s.xbeta(st["beta"])                       # ycorr recomputed from scratch
+    assert np.abs(st["ycorr"] - resid).max() <= 1e-9 * np.abs(y).max()
+    assert np.isfinite(st["beta"]).all() and st["varE"] > 0 and st["iter"] == 12
+    d = st["delta"]
+    assert set(np.unique(d)) <= {0, 1}
+    if method == "PR":
+        assert d.min() == 1 and st["varBeta"][0] > 0
+    if method == "B":                                               # functions.jl:184-186
+        assert np.all(st["beta"][d == 0] == 0.0) and np.all(st["varBeta"][d == 0] == 0.0) and np.all(st["varBeta"][d == 1] > 0.0)
+        assert 0.0 < st["piHat"][1] < 0.2 and abs(st["piHat"].sum() - 1.0) < 1e-15
+    ps = s.get_posterior_sums()
+    assert ps["nKept"] == 12 and np.all(ps["sum_delta"] <= 12) and np.all(ps["sum_beta2"] >= 0)
+
+
+def test_bitwise_reproducible_and_seed_sensitive(ngp):
+    a, _ = _chain(ngp, "B", 6)
+    b, _ = _chain(ngp, "B", 6)
+    c, _ = _chain(ngp, "B", 6, seed=1002)
+    sa, sb, sc = a.get_state(), b.get_state(), c.get_state()
+    for k in ("ycorr", "beta", "delta", "varBeta", "piHat"):
+        assert np.array_equal(sa[k], sb[k]), k
+    assert sa["varE"] == sb["varE"] and not np.array_equal(sa["beta"], sc["beta"])
+
+
+def test_engines_draw_the_same_chain(ngp):
+    """Per-block launches (lag 1) and the persistent sweep (lag 5): identical indicators, floats to 1e-9."""
+    P_ = 20032
+    a, _ = _chain(ngp, "multi", 8, engine=(0, 1), P_=P_)
+    b, _ = _chain(ngp, "multi", 8, engine=(1, 5), P_=P_)
+    sa, sb = a.get_state(), b.get_state()
+    assert np.array_equal(sa["delta"], sb["delta"])
+    assert np.abs(sa["beta"] - sb["beta"]).max() <= 1e-9 * max(1e-3, np.abs(sa["beta"]).max())
+    assert np.abs(sa["ycorr"] - sb["ycorr"]).max() <= 1e-9 * np.abs(sa["ycorr"]).max()
+    assert abs(sa["varE"] - sb["varE"]) <= 1e-9 * sa["varE"]
+
+
+def test_xbeta_is_linear(ngp):
+    s = ngp.Sampler(device=0, seed=1, chain=0)
+    s.generate_panel(N, 4096)
+    rng = np.random.default_rng(0)
+    u, w = rng.normal(size=4096), rng.normal(size=4096)
+    lhs = s.xbeta(2.0 * u - 3.0 * w)
+    rhs = 2.0 * s.xbeta(u) - 3.0 * s.xbeta(w)
+    assert np.abs(lhs - rhs).max() <= 1e-10 * np.abs(lhs).max()
