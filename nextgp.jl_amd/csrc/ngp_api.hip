@@ -67,7 +67,7 @@ struct ngp_handle {
     DReg *d_regs = nullptr;
     long long *d_seg_k0 = nullptr;
     int32_t *d_seg_len = nullptr;
-    double *d_segpart = nullptr;
+    double *d_segpart = nullptr, *d_regchi = nullptr;
     std::vector<DReg> h_regs;
     std::vector<long long> h_seg_k0;
     std::vector<int32_t> h_seg_len;
@@ -290,6 +290,7 @@ int sync_tables(ngp_handle *h) {
     if ((rc = dalloc(h, &h->d_seg_k0, h->h_seg_k0.size()))) return rc;
     if ((rc = dalloc(h, &h->d_seg_len, h->h_seg_len.size()))) return rc;
     if ((rc = dalloc(h, &h->d_segpart, h->h_seg_k0.size()))) return rc;
+    if ((rc = dalloc(h, &h->d_regchi, h->h_regs.size()))) return rc;
     if (!h->h_regs.empty()) {
         HCHK(hipMemcpy(h->d_regs, h->h_regs.data(), h->h_regs.size() * sizeof(DReg), hipMemcpyHostToDevice));
         HCHK(hipMemcpy(h->d_seg_k0, h->h_seg_k0.data(), h->h_seg_k0.size() * sizeof(long long), hipMemcpyHostToDevice));
@@ -354,10 +355,10 @@ int check_abort(ngp_handle *h) {
 void launch_variance(ngp_handle *h, int active_set, uint64_t it) {
     const long long nseg = (long long)h->h_seg_k0.size(), nreg = (long long)h->h_regs.size();
     if (nseg > 0) {
-        hipLaunchKernelGGL(k_regssq, dim3((unsigned)((nseg + 255) / 256)), dim3(256), 0, h->stream, nseg, h->d_seg_k0, h->d_seg_len,
+        hipLaunchKernelGGL(k_regssq, dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, h->stream, nseg, h->d_seg_k0, h->d_seg_len,
                            h->d_beta, h->d_segpart);
         hipLaunchKernelGGL(k_regdraw, dim3((unsigned)((nreg + 63) / 64)), dim3(64), 0, h->stream, nreg, h->d_regs, h->d_segpart,
-                           h->d_sets, h->d_varBeta, active_set, h->seed, (uint64_t)h->chain, it);
+                           h->d_sets, h->d_varBeta, active_set, h->d_regchi);
     }
     hipLaunchKernelGGL(k_pidraw, dim3(1), dim3(64), 0, h->stream, (int)h->sets.size(), h->d_sets, active_set, h->seed,
                        (uint64_t)h->chain, it);
@@ -369,7 +370,7 @@ int one_iteration(ngp_handle *h, int64_t trace_idx, hipEvent_t *evs) {
                        h->e_scale, h->intercept, 1, h->seed, (uint64_t)h->chain, it, h->d_tr_varE, h->d_tr_b, (long long)trace_idx);
     hipLaunchKernelGGL(k_prep, dim3((unsigned)(h->Ppad / 256 + 1)), dim3(256), 0, h->stream, (long long)h->Ppad, h->d_setof, h->d_loc,
                        h->d_vbidx, h->d_sets, h->d_scal, h->d_varBeta, h->d_mpm, h->d_lhs0, h->d_rhs0, h->d_beta, h->d_c, h->d_w,
-                       h->d_q, h->d_T, h->d_chi, -1, h->seed, (uint64_t)h->chain, it);
+                       h->d_q, h->d_T, h->d_chi, -1, h->seed, (uint64_t)h->chain, it, (long long)h->h_regs.size(), h->d_regs, h->d_regchi);
     launch_sweep(h, 0, h->NBLK, evs);
     launch_variance(h, -1, it);
     h->iter += 1;
@@ -430,7 +431,7 @@ int32_t ngp_destroy(ngp_handle *h) {
     dfree(h->d_c); dfree(h->d_w); dfree(h->d_q); dfree(h->d_T); dfree(h->d_chi); dfree(h->d_setof); dfree(h->d_loc);
     dfree(h->d_vbidx); dfree(h->d_delta); dfree(h->d_sum_beta); dfree(h->d_sum_beta2); dfree(h->d_sum_delta);
     dfree(h->d_ycorr); dfree(h->d_part); dfree(h->d_dlt); dfree(h->d_sets); dfree(h->d_scal); dfree(h->d_varBeta);
-    dfree(h->d_sum_varBeta); dfree(h->d_regs); dfree(h->d_seg_k0); dfree(h->d_seg_len); dfree(h->d_segpart);
+    dfree(h->d_sum_varBeta); dfree(h->d_regs); dfree(h->d_seg_k0); dfree(h->d_seg_len); dfree(h->d_segpart); dfree(h->d_regchi);
     dfree(h->d_tr_varE); dfree(h->d_tr_b);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -811,7 +812,7 @@ int32_t ngp_sweep_set(ngp_handle *h, int32_t set_id, double varE, double *ycorr,
     hipLaunchKernelGGL(k_set_varE, dim3(1), dim3(1), 0, h->stream, h->d_scal, varE);
     hipLaunchKernelGGL(k_prep, dim3((unsigned)(h->Ppad / 256 + 1)), dim3(256), 0, h->stream, (long long)h->Ppad, h->d_setof, h->d_loc,
                        h->d_vbidx, h->d_sets, h->d_scal, h->d_varBeta, h->d_mpm, h->d_lhs0, h->d_rhs0, h->d_beta, h->d_c, h->d_w,
-                       h->d_q, h->d_T, h->d_chi, (int)set_id, h->seed, (uint64_t)h->chain, it);
+                       h->d_q, h->d_T, h->d_chi, (int)set_id, h->seed, (uint64_t)h->chain, it, (long long)h->h_regs.size(), h->d_regs, h->d_regchi);
     const int64_t tb0 = hs.col0 / NGP_BLK, tb1 = (hs.col0 + hs.ncol - 1) / NGP_BLK + 1;
     launch_sweep(h, tb0, tb1, nullptr);
     launch_variance(h, (int)set_id, it);

@@ -32,6 +32,12 @@ struct DSet {  // one marker set (src/mme.jl:324-361, 492-520)
     double sum_pi0, sum_pi1;
 };
 
+struct DReg {  // one BayesPR variance region
+    long long seg0;
+    int nseg, set, rg, vb;
+    long long n;
+};
+
 struct DScal {  // chain scalars
     double varE, iVarE, b, db;
     double sum_varE, sum_b;
@@ -131,8 +137,14 @@ __global__ __launch_bounds__(256) void k_prep(long long Ppad, const int8_t *__re
                                               const double *__restrict__ rhs0, const double *__restrict__ beta,
                                               double *__restrict__ c, double *__restrict__ w, double *__restrict__ q,
                                               double *__restrict__ T, double *__restrict__ chi, int active_set, uint64_t seed,
-                                              uint64_t chain, uint64_t it) {
+                                              uint64_t chain, uint64_t it, long long nreg, const DReg *__restrict__ regs,
+                                              double *__restrict__ regchi) {
     long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k < nreg) {  // data-independent draws of the region variances (functions.jl:509-511): off the post-sweep path
+        const DReg Rg = regs[k];
+        Rng rr = rng_seed(seed, chain, it, NGP_KIND_REGION_CHI2, ((uint64_t)Rg.set << 40) | (uint64_t)Rg.rg);
+        regchi[k] = rng_chisq(rr, sets[Rg.set].df + (double)Rg.n);
+    }
     if (k >= Ppad) return;
     int si = setof[k];
     if (si < 0 || (active_set >= 0 && si != active_set)) {
@@ -333,27 +345,28 @@ __global__ __launch_bounds__(256) void k_recur(const double *__restrict__ part, 
 __global__ __launch_bounds__(256) void k_regssq(long long nseg, const long long *__restrict__ seg_k0,
                                                 const int32_t *__restrict__ seg_len, const double *__restrict__ beta,
                                                 double *__restrict__ segpart) {
-    long long sg = (long long)blockIdx.x * 256 + threadIdx.x;
+    // one wave per 256-locus segment: lane l takes loci l, l+64, l+128, l+192 (coalesced), then the xor butterfly
+    const long long sg = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (sg >= nseg) return;
+    const int lane = threadIdx.x & 63;
     const double *b = beta + seg_k0[sg];
-    int n = seg_len[sg];
-    double p = 0.0;
-    for (int i = 0; i < n; i++) {
-        double v = b[i];
-        p = __builtin_fma(v, v, p);
+    const int n = seg_len[sg];
+    double a = 0.0;
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const int i = lane + 64 * m;
+        const double v = b[min(i, n - 1)];
+        if (i < n) a = __builtin_fma(v, v, a);
     }
-    segpart[sg] = p;
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) a = a + __shfl_xor(a, off);
+    if (lane == 0) segpart[sg] = a;
 }
 
-struct DReg {
-    long long seg0;
-    int nseg, set, rg, vb;
-    long long n;
-};
 
 __global__ __launch_bounds__(64) void k_regdraw(long long nreg, const DReg *__restrict__ regs, const double *__restrict__ segpart,
                                                 const DSet *__restrict__ sets, double *__restrict__ varBeta, int active_set,
-                                                uint64_t seed, uint64_t chain, uint64_t it) {
+                                                const double *__restrict__ regchi) {
     long long rg = (long long)blockIdx.x * 64 + threadIdx.x;
     if (rg >= nreg) return;
     const DReg R = regs[rg];
@@ -361,8 +374,7 @@ __global__ __launch_bounds__(64) void k_regdraw(long long nreg, const DReg *__re
     double tot = segpart[R.seg0];
     for (int s = 1; s < R.nseg; s++) tot = tot + segpart[R.seg0 + s];
     const DSet S = sets[R.set];
-    Rng r = rng_seed(seed, chain, it, NGP_KIND_REGION_CHI2, ((uint64_t)R.set << 40) | (uint64_t)R.rg);
-    double ch = rng_chisq(r, S.df + (double)R.n);
+    const double ch = regchi[rg];  // chi-square(df + n_r) of this iteration, drawn ahead of the sweep by k_prep
     double tt = S.scale * S.df;
     tt = tt + tot;
     varBeta[R.vb] = tt / ch;

@@ -777,8 +777,17 @@ static void iter_blocked(ora_t *h) {
                 double tot = 0.0; int first = 1;
                 for (int64_t l0 = Sx->reg_start[rg]; l0 < Sx->reg_stop[rg]; l0 += SEG) {
                     int64_t l1 = l0 + SEG < Sx->reg_stop[rg] ? l0 + SEG : Sx->reg_stop[rg];
-                    double p = 0.0;
-                    for (int64_t l = l0; l < l1; l++) { double bv = h->beta[Sx->col0 + l]; p = __builtin_fma(bv, bv, p); }
+                    /* 256-locus segment on one wave: lane l takes loci l, l+64, l+128, l+192, then the xor butterfly */
+                    double lane[64];
+                    for (int l = 0; l < 64; l++) {
+                        double a = 0.0;
+                        for (int m = 0; m < 4; m++) {
+                            int64_t ll = l0 + l + 64 * m;
+                            if (ll < l1) { double bv = h->beta[Sx->col0 + ll]; a = __builtin_fma(bv, bv, a); }
+                        }
+                        lane[l] = a;
+                    }
+                    double p = wave_butterfly(lane);
                     tot = first ? p : tot + p; first = 0;
                 }
                 rng_seed(&r, h->seed, h->chain, it, KIND_REGION_CHI2, ((uint64_t)si << 40) | (uint64_t)rg);
