@@ -48,7 +48,7 @@ int32_t ngp_destroy(ngp_handle *h);
 const char *ngp_last_error(ngp_handle *h);
 
 /* Sweep engine, to be chosen BEFORE the panel is set (it fixes the tiling and the Gram window):
- * mode 1 (default) = one persistent kernel per iteration with look-ahead `lag` (1..6 blocks of 64 SNPs),
+ * mode 1 (default) = one persistent kernel per iteration with look-ahead `lag` (1..8 blocks of 64 SNPs),
  * mode 0 = one streaming + one recursion launch per 64-SNP block (lag 1).  Both replace the same
  * reference loop (src/functions.jl:124-136) and draw the same chain; only summation order differs. */
 int32_t ngp_configure(ngp_handle *h, int32_t mode, int32_t lag);

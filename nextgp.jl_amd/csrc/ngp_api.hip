@@ -42,7 +42,7 @@ struct ngp_handle {
     int64_t N = 0, P = 0, R = 0, S = 0, NBLK = 0, Ppad = 0, L = 0;
     size_t lds_step = 0, lds_sweep = 0;
     int mode = 1;      // 1: persistent sweep kernel, 0: one streaming + one recursion launch per block
-    int lag = 5;       // look-ahead D of the persistent sweep (blocks)
+    int lag = 6;       // look-ahead D of the persistent sweep (blocks)
     int D = 1;         // Gram planes stored per block (= lag in mode 1, 1 in mode 0)
     int NG = 1;        // reducer groups = ceil(S/32)
     int NS = 1;        // LDS tile slots of a streamer workgroup
@@ -892,7 +892,7 @@ int32_t ngp_configure(ngp_handle *h, int32_t mode, int32_t lag) {
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles == nullptr, NGP_ERR_STATE, "ngp_configure must precede the panel upload");
     REQUIRE(mode == 0 || mode == 1, NGP_ERR_ARG, "mode must be 0 (per-block launches) or 1 (persistent sweep)");
-    REQUIRE(lag >= 1 && lag <= NGP_MAX_LAG, NGP_ERR_ARG, "lag must be in 1..6");
+    REQUIRE(lag >= 1 && lag <= NGP_MAX_LAG, NGP_ERR_ARG, "lag must be in 1..8");
     h->mode = mode; h->lag = lag;
     return NGP_OK;
 }

@@ -27,7 +27,7 @@
 #pragma clang fp contract(off)
 
 #define NGP_RING 16        // slots of every communication ring (>= lag D)
-#define NGP_MAX_LAG 6
+#define NGP_MAX_LAG 8
 #define NGP_SPIN_LIMIT (1u << 21)
 #define NGP_WG 512          // threads per workgroup of the persistent kernel
 #define NGP_DBG_WAVES (1u << 19)   // sampler: 8 words per block, end-of-work stamp of every wave
@@ -305,6 +305,31 @@ __device__ inline void role_reducer(const SweepArgs &A, const int g) {
 #pragma unroll
         for (int s = 1; s < NGP_GRP; s++)
             if (s < gsize) v = v + vals[s];
+        // far look-ahead corrections folded into this group's sum: lags d = 3 + g, 3 + g + NG, ... (< D).  The Gram rows
+        // are requested before dlt of block u-d is awaited, so only the 64 fma follow the hand-off.
+        for (int d = 3 + g; d < A.D; d += A.NG) {
+            const int a = u - d;
+            if (a < 0) continue;
+            const double *gx = A.gramx + ((size_t)(A.t0 + u) * A.D + d) * (NGP_BLK * NGP_BLK) + lane;
+            double gr[NGP_BLK];
+#pragma unroll
+            for (int kk = 0; kk < NGP_BLK; kk++) gr[kk] = gx[kk * NGP_BLK];
+            int okd = 1;
+            if (lane == 0) okd = wait_ge(A.flag_dlt, (unsigned)(a + 1), A.abort_w, 4u) ? 1 : 0;
+            okd = __shfl(okd, 0);
+            if (!okd) return;
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            const double dreg = ld_f64(&A.dlt[(size_t)(a % NGP_RING) * NGP_BLK + lane]);  // lane k holds dlt_k
+            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+            for (int kk = 0; kk < NGP_BLK; kk += 4) {
+                s0 = __builtin_fma(gr[kk + 0], readlane_d(dreg, kk + 0), s0);
+                s1 = __builtin_fma(gr[kk + 1], readlane_d(dreg, kk + 1), s1);
+                s2 = __builtin_fma(gr[kk + 2], readlane_d(dreg, kk + 2), s2);
+                s3 = __builtin_fma(gr[kk + 3], readlane_d(dreg, kk + 3), s3);
+            }
+            v = v - ((s0 + s1) + (s2 + s3));
+        }
         st_f64(&A.gsum[((size_t)slot * A.NG + g) * NGP_BLK + lane], v);
         drain_vm();
         if (lane == 0) {
@@ -543,21 +568,21 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
             NGP_END_OF_BLOCK();
         }
     } else {
-        // far correction waves: lag fx = 2..5; Gram rows of the pair handled in the NEXT block are loaded one block ahead
+        // wave 4: the lag-2 correction (farther lags are folded into the group sums by the reducers); its Gram rows are
+        // loaded one block ahead.  Waves 5-7 only keep the barrier count.
         const int fx = wv - 2;
         double gr[NGP_BLK];
 #pragma unroll
         for (int kk = 0; kk < NGP_BLK; kk++) gr[kk] = 0.0;
         bool have = false;
         for (int u = 0; u < nb; ++u) {
-            if (fx < D) {
+            if (fx == 2 && fx < D) {
                 if (u >= 1 && have) {  // dlt of local block a = u-1, target a + fx
                     const int a = u - 1, upb = a + fx;
                     const double *dp = hist + (a % NGP_RING) * NGP_BLK;
                     double v = gemv4([&](int kk) { return gr[kk]; }, dp);
                     double *va = vacc + (upb % NGP_RING) * NGP_BLK + j;
-                    const bool first = (fx == D - 1) || (a == 0);
-                    *va = first ? v : *va + v;
+                    *va = v;  // the only locally computed far term
                 }
                 have = (u + fx < nb) && (u + 1 < nb);  // rows for the next block: a' = u, target u + fx
                 if (have) {
@@ -591,21 +616,22 @@ __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         case 3: role_streamer<3, T>(A, s, smem); break;        \
         default: role_streamer<4, T>(A, s, smem); break;       \
     }
-        if (tpt <= 1) {
-            switch (A.D) {
-                case 5: role_streamer<5, 1>(A, s, smem); break;
-                case 6: role_streamer<6, 1>(A, s, smem); break;
-                default: NGP_DISPATCH_D(1)
-            }
+#define NGP_DISPATCH_D8(T)                                     \
+    switch (A.D) {                                             \
+        case 5: role_streamer<5, T>(A, s, smem); break;        \
+        case 6: role_streamer<6, T>(A, s, smem); break;        \
+        case 7: role_streamer<7, T>(A, s, smem); break;        \
+        case 8: role_streamer<8, T>(A, s, smem); break;        \
+        default: NGP_DISPATCH_D(T)                             \
+    }
+        if (tpt == 1) {
+            NGP_DISPATCH_D8(1)
         } else if (tpt == 2) {
-            switch (A.D) {
-                case 5: role_streamer<5, 2>(A, s, smem); break;
-                case 6: role_streamer<6, 2>(A, s, smem); break;
-                default: NGP_DISPATCH_D(2)
-            }
+            NGP_DISPATCH_D8(2)
         } else {
             NGP_DISPATCH_D(4)  // host clamps the lag to 4 for tall shards (register budget of the delay line)
         }
+#undef NGP_DISPATCH_D8
 #undef NGP_DISPATCH_D
     }
 }

@@ -730,18 +730,35 @@ static void iter_blocked(ora_t *h) {
         }
         double rr[BLK], dlt[BLK]; int inc[BLK];
         const double *G = h->gram + (size_t)tb * BLK * BLK;
+        const int64_t NGq = (S + GRP - 1) / GRP;
         for (int j = 0; j < BLK; j++) {
-            double tot = group_sum(part + j, S, BLK);
-            /* cross corrections of the not yet applied blocks a = tb-D+1 .. tb-1, ascending */
-            double c = 0.0; int have = 0;
-            for (int64_t a = (tb - D + 1 > 0 ? tb - D + 1 : 0); a < tb; a++) {
-                const double *Gx = h->gramx + (((size_t)tb * D + (tb - a)) * BLK) * BLK;
-                double s4[4] = {0, 0, 0, 0};
-                for (int k = 0; k < BLK; k++) s4[k & 3] = __builtin_fma(Gx[k * BLK + j], hist[a * BLK + k], s4[k & 3]);
-                double v = (s4[0] + s4[1]) + (s4[2] + s4[3]);
-                c = have ? c + v : v; have = 1;
+            /* group sums: shards of a group added in order */
+            double gs[64];
+            for (int64_t g = 0; g < NGq; g++) {
+                int64_t s0 = g * GRP, s1 = s0 + GRP < S ? s0 + GRP : S;
+                double v = part[s0 * BLK + j];
+                for (int64_t s = s0 + 1; s < s1; s++) v = v + part[s * BLK + j];
+                gs[g] = v;
             }
-            if (have) tot = tot - c;
+            /* look-ahead corrections v_d = G[tb, tb-d] dlt_{tb-d} of the blocks whose update the GEMV has not seen.
+               Far lags d = 3 .. D-1 are folded into the group sums (the reducer workgroups compute them): lag d goes
+               to group (d-3) mod NG, ascending d.  Lags 2 and 1 stay with the sampler: cor = v_2 + v_1. */
+            double vd[17]; int hv[17];
+            for (int64_t d = 1; d < D; d++) {
+                hv[d] = (tb - d >= 0);
+                if (!hv[d]) continue;
+                const double *Gx = h->gramx + (((size_t)tb * D + d) * BLK) * BLK;
+                const double *da = hist + (tb - d) * BLK;
+                double s4[4] = {0, 0, 0, 0};
+                for (int k = 0; k < BLK; k++) s4[k & 3] = __builtin_fma(Gx[k * BLK + j], da[k], s4[k & 3]);
+                vd[d] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+            }
+            for (int64_t d = 3; d < D; d++)
+                if (hv[d]) { int64_t g = (d - 3) % NGq; gs[g] = gs[g] - vd[d]; }
+            double tot = gs[0];
+            for (int64_t g = 1; g < NGq; g++) tot = tot + gs[g];
+            if (D >= 3 && hv[2]) { double c = vd[2] + vd[1]; tot = tot - c; }
+            else if (D >= 2 && hv[1]) tot = tot - vd[1];
             rr[j] = __builtin_fma(G[j * BLK + j], h->beta[k0 + j], tot);
         }
         /* recursion in the scaled variables e_j = c_j r_j + w_j (the candidate draw) and f_j = c_j r_j (for the

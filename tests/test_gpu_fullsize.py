@@ -8,7 +8,7 @@ pytestmark = pytest.mark.gpu
 N, P = 10000, 100000
 
 
-def _chain(ngp, method, niter, engine=(1, 5), seed=1001, P_=P):
+def _chain(ngp, method, niter, engine=(1, 6), seed=1001, P_=P):
     s = ngp.Sampler(device=0, seed=seed, chain=0, mode=engine[0], lag=engine[1])
     s.generate_panel(N, P_)
     rng = np.random.default_rng(1)
@@ -62,7 +62,7 @@ def test_engines_draw_the_same_chain(ngp):
     """Per-block launches (lag 1) and the persistent sweep (lag 5): identical indicators, floats to 1e-9."""
     P_ = 20032
     a, _ = _chain(ngp, "multi", 8, engine=(0, 1), P_=P_)
-    b, _ = _chain(ngp, "multi", 8, engine=(1, 5), P_=P_)
+    b, _ = _chain(ngp, "multi", 8, engine=(1, 6), P_=P_)
     sa, sb = a.get_state(), b.get_state()
     assert np.array_equal(sa["delta"], sb["delta"])
     assert np.abs(sa["beta"] - sb["beta"]).max() <= 1e-9 * max(1e-3, np.abs(sa["beta"]).max())

@@ -38,8 +38,8 @@ def test_draws_bit_exact(dev, O, what, p1, p2):
     assert np.array_equal(got, exp)
 
 
-ENGINES = [(0, 1), (1, 1), (1, 2), (1, 3), (1, 4), (1, 6)]   # (mode, lag): per-block launches / persistent sweep
-ENGINE_IDS = ["blocklaunch", "persist_lag1", "persist_lag2", "persist_lag3", "persist_lag4", "persist_lag6"]
+ENGINES = [(0, 1), (1, 1), (1, 2), (1, 3), (1, 4), (1, 6), (1, 8)]   # (mode, lag): per-block launches / persistent sweep
+ENGINE_IDS = ["blocklaunch", "persist_lag1", "persist_lag2", "persist_lag3", "persist_lag4", "persist_lag6", "persist_lag8"]
 
 
 def _pair(ngp, O, X, seed=1001, chain=0, engine=(1, 6)):
