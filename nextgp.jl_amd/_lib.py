@@ -10,7 +10,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libnextgp_hip.so")
+LIB_PATH = os.environ.get("NGP_HIP_LIB") or os.path.join(_HERE, "libnextgp_hip.so")  # override: a library built elsewhere
 
 METHOD_BAYESPR, METHOD_BAYESB = 0, 1
 

@@ -74,6 +74,20 @@ __device__ inline void st_f64(double *p, double v) {
 // XCC (XCD) id of the executing wave: HW_REG_XCC_ID (id 20), bits 3:0
 __device__ inline unsigned xcc_id() { return (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xFu; }
 __device__ inline void drain_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// workgroup barrier that leaves VMEM traffic in flight (__syncthreads() drains vmcnt, which would serialise every
+// LDS-DMA issued just before it); LDS traffic of the wave is complete
+__device__ inline void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+// LDS-DMA of 64 x 16 B (lane l: global gsrc_lane -> LDS lds_base + 16 l), issued from inline asm so that the compiler's
+// wait-count pass does not see an LDS write it would have to drain before the wave's next LDS access; the caller
+// owns every wait (drain_vm / counted vmcnt) before the data is read
+__device__ inline void dma16_lds(const void *gsrc_lane, const void *lds_base_uniform) {
+    const unsigned m = __builtin_amdgcn_readfirstlane((unsigned)(size_t)(__attribute__((address_space(3))) const char *)lds_base_uniform);
+    unsigned keep_m0;  // M0 is read when the instruction issues, so it can be handed back at once
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep_m0)
+                 : "s"(m), "v"(gsrc_lane)
+                 : "memory");
+}
 
 // ONE lane polls ONE word; bounded; false = give up (abort word set by us or by somebody else)
 __device__ inline bool wait_ge(const unsigned *flag, unsigned target, unsigned *abort_w, unsigned code) {
@@ -86,6 +100,14 @@ __device__ inline bool wait_ge(const unsigned *flag, unsigned target, unsigned *
         }
         __builtin_amdgcn_s_sleep(4);
     }
+}
+
+// scalar (SMEM) load that bypasses the scalar cache: lets a wave with LDS-DMA in flight look at a global word
+// without touching vmcnt
+__device__ inline unsigned sld_u32(const unsigned *p) {
+    unsigned v;
+    asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
+    return v;
 }
 
 // gemv4: v_j = sum_k G[k][j] * d[k], four interleaved partial sums, ((s0+s1)+(s2+s3))
@@ -125,6 +147,14 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
     int *sflag = (int *)(dl + 128);
     char *scratch = (char *)(dl + 128) + 64;  // 3 KiB sink of the L2-warming DMA
     double *pp = (double *)(scratch + 3072);  // 8 x R partial sums of the update
+    // diagnostic runs, short shards only (the workgroup's LDS is sized by the sampler then): barrier-arrival stamps of
+    // every wave of streamer 1 for local blocks 800..815, staged in LDS and dumped at the end
+    unsigned long long *fine = (unsigned long long *)(pp + 8 * (size_t)R);
+    const bool fine_on = A.dbg && s == 1 && R <= 64;
+#define NGP_FINE(k)                                                                                          \
+    do {                                                                                                     \
+        if (fine_on && (unsigned)(u - 800) < 16u && j == 0) fine[(((u - 800) * 8 + wv) << 3) + (k)] = wall_clock64(); \
+    } while (0)
     const size_t tile_elems = (size_t)R * NGP_BLK;
     const int nchunk = R >> 2;  // 1 KiB pieces per tile
     const int ntask = (8 * R + NGP_WG - 1) / NGP_WG;
@@ -134,9 +164,7 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
     auto dma_tile = [&](int ub) {  // waves 4..6 copy tile ub into slot ub&1, 1 KiB per wave-instruction
         const char *src = (const char *)(A.tiles + ((size_t)(A.t0 + ub) * S + s) * tile_elems);
         char *dst = ring + (size_t)(ub & 1) * TB;
-        for (int c = wv - 4; c < nchunk; c += 3)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(src + (size_t)c * 1024 + (size_t)j * 16),
-                                             (__attribute__((address_space(3))) void *)(dst + (size_t)c * 1024), 16, 0, 0);
+        for (int c = wv - 4; c < nchunk; c += 3) dma16_lds(src + (size_t)c * 1024 + (size_t)j * 16, dst + (size_t)c * 1024);
     };
     // wave 7: wait for dlt of local block (uu - DT) and stage it in dl[uu & 1]
     auto poll_dlt = [&](int uu) {
@@ -187,24 +215,26 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
             if (u >= nb + DT) break;
             const int a = u - DT;  // block whose update is applied in this iteration (if >= 0); its tile sits in keep[d]
             if (A.dbg) tt0 = wall_clock64();
+            NGP_FINE(0);
             // ---------------- phase A: everything that waits on memory ----------------
             if (wv >= 4 && wv <= 6) {
                 drain_vm();  // tile u (issued one iteration ago) has landed
+                NGP_FINE(7);
                 if (u + 1 < nb) dma_tile(u + 1);
                 if ((u & 7) == 0 && !same_xcd) same_xcd = (ld_u32(A.xcc_w) == my_xcc);
                 if (same_xcd && u + 1 < nb) {  // fire-and-forget: the lines only have to reach this XCD's L2
                     const char *gb = (const char *)(A.gramx + (size_t)(A.t0 + u + 1) * DT * NGP_BLK * NGP_BLK);
                     const size_t lo = (size_t)slice * slice_bytes, hi = min((size_t)(slice + 1) * slice_bytes, gram_bytes);
                     for (size_t off = lo + (size_t)(wv - 4) * 1024; off + 1024 <= hi; off += 3 * 1024)
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gb + off + (size_t)j * 16),
-                                                         (__attribute__((address_space(3))) void *)(scratch + (wv - 4) * 1024), 16, 0, 0);
+                        dma16_lds(gb + off + (size_t)j * 16, scratch + (wv - 4) * 1024);
                 }
             } else if (wv == 7 && A.dbg_mode != 1) {
                 if (DT <= 2 || u == 0) poll_dlt(u);  // lags 1-2 cannot poll ahead: the flag would (transitively, through the
                                                      // sampler's own look-ahead fetch of the next group sums) need this block's partial
             }
             if (A.dbg && (tid == 448 || tid == 256)) accP += wall_clock64() - tt0;  // wave 7 poll / wave 4 DMA drain
-            __syncthreads();
+            NGP_FINE(1);
+            wg_barrier();
             if (!*sflag) return;
             if (A.dbg && tid == 0) { unsigned long long n = wall_clock64(); accA += n - tt0; tt0 = n; }
             // ---------------- phase B: ycorr -= X_a dlt_a (tile a waits in keep[d]) ----------------
@@ -219,19 +249,27 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
                         pp[(size_t)tc[tp] * R + ti[tp]] = p;
                     }
                 }
-                __syncthreads();
+                NGP_FINE(2);
+                wg_barrier();
                 for (int i = tid; i < R; i += NGP_WG) {
                     const double T = ((pp[i] + pp[R + i]) + (pp[2 * R + i] + pp[3 * R + i])) +
                                      ((pp[4 * R + i] + pp[5 * R + i]) + (pp[6 * R + i] + pp[7 * R + i]));
                     ys[i] = ys[i] - T;
                 }
             } else {
-                __syncthreads();
+                wg_barrier();
             }
-            __syncthreads();
+            NGP_FINE(3);
+            wg_barrier();
             if (A.dbg && tid == 0) { unsigned long long n = wall_clock64(); accB += n - tt0; tt0 = n; }
             // ---------------- phase C: partial X_u' ycorr, and tile u into the delay line ----------------
             if (u < nb) {
+                // wave 7, lag >= 3: dlt of the NEXT iteration in two asynchronous steps -- the flag is read while the wave
+                // works on its chain, the 64 values travel while the workgroup crosses the barrier
+                const int pa = u + 1 - DT;
+                const bool pollw = (wv == 7) && (DT >= 3) && (A.dbg_mode != 1) && (pa >= 0) && (u + 1 < nb + DT);
+                unsigned fl = 0;
+                if (pollw) fl = ld_u32(A.flag_dlt);
                 const float *slotp = (const float *)(ring + (size_t)(u & 1) * TB);
 #pragma unroll
                 for (int tp = 0; tp < NGP_TPT; tp++) {
@@ -254,13 +292,34 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
                     }
                     red[wv * 64 + j] = acc;
                 }
-                if (wv == 7 && DT >= 3 && A.dbg_mode != 1) poll_dlt(u + 1);  // next iteration's dlt: the round trips hide behind this phase
-                __syncthreads();
-                if (wv == 0 && A.dbg_mode != 1) {
+                NGP_FINE(4);
+                double dnext = 0.0;
+                bool have_dnext = false;
+                if (pollw) {
+                    int ok = 1;
+                    if (__shfl((int)fl, 0) < pa + 1) {
+                        if (j == 0) {
+                            ok = wait_ge(A.flag_dlt, (unsigned)(pa + 1), A.abort_w, 1u) ? 1 : 0;
+                            if (!ok) *sflag = 0;
+                        }
+                        ok = __shfl(ok, 0);
+                    }
+                    if (A.dbg && s == 0 && j == 0) A.dbg[NGP_DBG_STREAM + 2 * (size_t)(u + 1) + 1] = wall_clock64();
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (ok) {
+                        dnext = ld_f64(&A.dlt[(size_t)(pa % NGP_RING) * NGP_BLK + j]);
+                        have_dnext = true;
+                    }
+                }
+                NGP_FINE(5);
+                wg_barrier();
+                if (have_dnext) dl[((u + 1) & 1) * 64 + j] = dnext;  // read in phase B of the next iteration, two barriers away
+                if (wv == 1 && A.dbg_mode != 1) {
                     const int slot = u % NGP_RING;
                     double p = ((red[j] + red[64 + j]) + (red[128 + j] + red[192 + j])) + ((red[256 + j] + red[320 + j]) + (red[384 + j] + red[448 + j]));
                     st_f64(&A.part[((size_t)slot * S + s) * NGP_BLK + j], p);
-                    drain_vm();
+                    drain_vm();  // (counting the partial a phase later, to take this round trip out of the loop, gains nothing
+                                 // at long lags and costs latency at short ones)
                     if (j == 0) {
                         atomicAdd(&A.cnt_part[((size_t)slot * A.NG + g) * 32], 1u);
                         if (A.dbg && s == 0) A.dbg[NGP_DBG_STREAM + 2 * (size_t)u] = wall_clock64();
@@ -274,11 +333,17 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
             }
             else if (wv == 7 && DT >= 3 && A.dbg_mode != 1) poll_dlt(u + 1);
             if (A.dbg && tid == 0) accC += wall_clock64() - tt0;
+            NGP_FINE(6);
         }
     }
     if (A.dbg && tid == 0) { A.dbg[NGP_DBG_ALL + 4096 + 8 * (size_t)s] = accA; A.dbg[NGP_DBG_ALL + 4096 + 8 * (size_t)s + 1] = accB; A.dbg[NGP_DBG_ALL + 4096 + 8 * (size_t)s + 2] = accC; }
     if (A.dbg && tid == 448) A.dbg[NGP_DBG_ALL + 4096 + 8 * (size_t)s + 3] = accP;
     if (A.dbg && tid == 256) A.dbg[NGP_DBG_ALL + 4096 + 8 * (size_t)s + 4] = accP;
+    if (fine_on && nb > 816) {
+        __syncthreads();
+        for (int i = tid; i < 1024; i += NGP_WG) A.dbg[NGP_DBG_ALL + 8192 + i] = fine[i];
+    }
+#undef NGP_FINE
     __syncthreads();
     for (int i = tid; i < R; i += NGP_WG) yg[i] = ys[i];
 }
@@ -305,9 +370,9 @@ __device__ inline void role_reducer(const SweepArgs &A, const int g) {
 #pragma unroll
         for (int s = 1; s < NGP_GRP; s++)
             if (s < gsize) v = v + vals[s];
-        // far look-ahead corrections folded into this group's sum: lags d = 3 + g, 3 + g + NG, ... (< D).  The Gram rows
+        // far look-ahead corrections folded into this group's sum: lags d = 4 + g, 4 + g + NG, ... (< D).  The Gram rows
         // are requested before dlt of block u-d is awaited, so only the 64 fma follow the hand-off.
-        for (int d = 3 + g; d < A.D; d += A.NG) {
+        for (int d = 4 + g; d < A.D; d += A.NG) {
             const int a = u - d;
             if (a < 0) continue;
             const double *gx = A.gramx + ((size_t)(A.t0 + u) * A.D + d) * (NGP_BLK * NGP_BLK) + lane;
@@ -354,7 +419,6 @@ __device__ inline CoefRegs load_coef(const SweepArgs &A, long long k) {
 }
 
 // workgroup barrier that drains LDS traffic only: global loads issued before it stay in flight
-__device__ inline void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 
 // group sums of local block u -> per-lane total (lane 0 polls, whole wave loads); false on abort
 __device__ inline bool fetch_group_sums(const SweepArgs &A, int u, int j, double *tot_out) {
@@ -413,18 +477,19 @@ __device__ inline void publish_block(const SweepArgs &A, int up, int j, const do
 // LDS: Gd[2][4096] | Gx[2][4096] | hist[RING][64] | vacc[RING][64] | r0[2][64] | outb[2][64] | outi[2][64] | flags
 __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
     const int D = A.D, tid = threadIdx.x, wv = tid >> 6, j = tid & 63;
-    double *Gd = (double *)smem;                // 2 x 4096
-    double *Gx = Gd + 2 * 4096;                 // 2 x 4096 (lag-1 cross block, [k][j])
-    double *hist = Gx + 2 * 4096;               // RING x 64
+    double *Gd = (double *)smem;                // 3 x 4096: diagonal Gram blocks of local blocks u, u+1, u+2
+    double *hist = Gd + 3 * 4096;               // RING x 64
     double *vacc = hist + NGP_RING * NGP_BLK;   // RING x 64
-    double *r0 = vacc + NGP_RING * NGP_BLK;     // 2 x 64
-    double *outb = r0 + 2 * NGP_BLK;            // 2 x 64
+    double *r0 = vacc + NGP_RING * NGP_BLK;     // 4 x 64 (ring over local blocks)
+    double *outb = r0 + 4 * NGP_BLK;            // 2 x 64
     int *outi = (int *)(outb + 2 * NGP_BLK);    // 2 x 64
     int *sabort = outi + 2 * NGP_BLK;
+    int *totflag = sabort + 1;  // local block index + 1 whose corrected total is ready in r0[buf]
     const int nb = A.t1 - A.t0;
     const size_t bsz = NGP_BLK * NGP_BLK;
     if (tid == 0) {
         *sabort = 0;
+        *totflag = 0;
         st_u32(A.xcc_w, xcc_id() + 1u);
         if (A.dbg) { A.dbg[NGP_DBG_ALL - 2] = xcc_id(); A.dbg[NGP_DBG_ALL - 1] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4); }
     }
@@ -432,6 +497,10 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
     {
         const double *gd = A.gramx + ((size_t)A.t0 * D + 0) * bsz;
         for (int idx = tid; idx < 4096; idx += NGP_WG) Gd[idx] = gd[idx];
+        if (nb > 1) {
+            const double *gd1 = A.gramx + ((size_t)(A.t0 + 1) * D + 0) * bsz;
+            for (int idx = tid; idx < 4096; idx += NGP_WG) Gd[4096 + idx] = gd1[idx];
+        }
     }
     __syncthreads();
     if (wv == 2) {
@@ -452,52 +521,58 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
         // ---------------- critical wave: LDS + ALU only ----------------
         CoefRegs cur = load_coef(A, (long long)A.t0 * NGP_BLK + j), nxt = cur;
         for (int u = 0; u < nb; ++u) {
-            const int t = A.t0 + u, buf = u & 1, slot = u % NGP_RING;
+            const int t = A.t0 + u, buf = u & 1, slot = u % NGP_RING, rs = u & 3;
             if (u + 1 < nb) nxt = load_coef(A, (long long)(t + 1) * NGP_BLK + j);
             if (A.dbg && j == 0) A.dbg[4 * (size_t)u] = wall_clock64();
-            double tot = r0[buf * NGP_BLK + j];
-            bool okc = true;
-            if (D == 1 && u >= 1) okc = fetch_group_sums(A, u, j, &tot);  // lag 1: nothing can be fetched ahead
-            if (!okc && j == 0) *sabort = 1;
-            const bool have_far = (D >= 3) && (u >= 2);
-            const bool have_one = (D >= 2) && (u >= 1);
-            double cor = have_far ? vacc[slot * NGP_BLK + j] : 0.0;
-            if (have_one) {
-                const double *gx = Gx + buf * 4096;
-                const double *dp = hist + ((u - 1) % NGP_RING) * NGP_BLK;
-                double v1 = gemv4([&](int kk) { return gx[kk * NGP_BLK + j]; }, dp);
-                cor = have_far ? cor + v1 : v1;
+            double tot;
+            if (D == 1) {  // lag 1: nothing can be fetched or corrected ahead
+                tot = r0[rs * NGP_BLK + j];
+                bool okc = true;
+                if (u >= 1) okc = fetch_group_sums(A, u, j, &tot);
+                if (!okc && j == 0) *sabort = 1;
+            } else {       // wave 5 applies the look-ahead corrections and leaves the final total in r0[buf]
+                while (__hip_atomic_load(totflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != u + 1) __builtin_amdgcn_s_sleep(0);
+                tot = r0[rs * NGP_BLK + j];
             }
-            if (have_far || have_one) tot = tot - cor;
-            const double *gdb = Gd + buf * 4096;
+            const double *gdb = Gd + (u % 3) * 4096 + j;
             const double bo = cur.bo, cc = cur.cc, ww = cur.ww, st = cur.st;
             const double r = __builtin_fma(cur.gd, bo, tot);
             // scaled recursion: e = c r + w is the candidate draw, f = c r feeds the
-            // inclusion test |f| > thr.  H_k = -(c G[k][.]) is formed off the serial path; the stored diagonal block
-            // is zero for lanes <= k, so a lane's e and f freeze at its own step and nothing has to be captured.
-            // Serial path per step: v_readlane -> ONE fma (BayesPR blocks), + compare / select for BayesB.
-            double H[NGP_BLK];
+            // inclusion test |f| > thr.  The stored diagonal block is zero for lanes <= k, so a lane's e and f freeze at
+            // its own step and nothing has to be captured.  H_k = -(c G[k][.]) is formed four steps ahead, in the
+            // latency shadow of the serial path: v_readlane -> ONE fma per step (BayesPR), + compare / select (BayesB).
+            double G[NGP_BLK];
 #pragma unroll
-            for (int kk = 0; kk < NGP_BLK; kk++) H[kk] = -(cc * gdb[kk * NGP_BLK + j]);
+            for (int kk = 0; kk < NGP_BLK; kk++) G[kk] = gdb[kk * NGP_BLK];
             double e = __builtin_fma(r, cc, ww);
             double dsave;
             int isave = 1;
+            double H0 = -(cc * G[0]), H1 = -(cc * G[1]), H2 = -(cc * G[2]), H3 = -(cc * G[3]);
             if (__ballot(st >= 0.0) == 0ull) {
 #pragma unroll
-                for (int kk = 0; kk < NGP_BLK; kk++) {
-                    double dk = readlane_d(e, kk);
-                    e = __builtin_fma(H[kk], dk, e);
+                for (int kk = 0; kk < NGP_BLK; kk += 4) {
+                    double dk;
+                    dk = readlane_d(e, kk + 0); e = __builtin_fma(H0, dk, e); H0 = -(cc * G[(kk + 4) & 63]);
+                    dk = readlane_d(e, kk + 1); e = __builtin_fma(H1, dk, e); H1 = -(cc * G[(kk + 5) & 63]);
+                    dk = readlane_d(e, kk + 2); e = __builtin_fma(H2, dk, e); H2 = -(cc * G[(kk + 6) & 63]);
+                    dk = readlane_d(e, kk + 3); e = __builtin_fma(H3, dk, e); H3 = -(cc * G[(kk + 7) & 63]);
                 }
                 dsave = e;
             } else {
                 double f = r * cc;
 #pragma unroll
-                for (int kk = 0; kk < NGP_BLK; kk++) {
-                    int in = __builtin_fabs(f) > st;
-                    double dlv = in ? e : -bo;
-                    double dk = readlane_d(dlv, kk);
-                    e = __builtin_fma(H[kk], dk, e);
-                    f = __builtin_fma(H[kk], dk, f);
+                for (int kk = 0; kk < NGP_BLK; kk += 4) {
+#define NGP_STEP(HX, KO)                                              \
+    {                                                                 \
+        int in = __builtin_fabs(f) > st;                              \
+        double dlv = in ? e : -bo;                                    \
+        double dk = readlane_d(dlv, kk + KO);                         \
+        e = __builtin_fma(HX, dk, e);                                 \
+        f = __builtin_fma(HX, dk, f);                                 \
+        HX = -(cc * G[(kk + KO + 4) & 63]);                           \
+    }
+                    NGP_STEP(H0, 0) NGP_STEP(H1, 1) NGP_STEP(H2, 2) NGP_STEP(H3, 3)
+#undef NGP_STEP
                 }
                 isave = __builtin_fabs(f) > st;
                 dsave = isave ? e : -bo;
@@ -516,73 +591,142 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
         }
         if (nb >= 1) publish_block(A, nb - 1, j, hist, outb, outi);
     } else if (wv == 2) {
-        // group sums of block u+1 -> r0[next].  The counter of block u+2 is probed (one relaxed load, no spin)
-        // while the loads of block u+1 are in flight, so in steady state each block costs ONE memory round trip.
-        bool ready_next = false;  // counter of local block u+1 already seen complete
-        for (int u = 0; u < nb; ++u) {
-            if (u + 1 < nb && D >= 2) {
-                const int un = u + 1, nslot = un % NGP_RING;
-                const int NG = A.NG;
-                unsigned probe = 0;
-                const bool can_probe = (u + 2 < nb) && (D >= 3);
-                const unsigned *pc = &A.cnt_gs[(size_t)((u + 2) % NGP_RING) * 32];
-                int ok = 1;
-                if (!ready_next) {
-                    if (j == 0) ok = wait_ge(&A.cnt_gs[(size_t)nslot * 32], (unsigned)((un / NGP_RING + 1) * NG), A.abort_w, 3u) ? 1 : 0;
+        // group sums -> r0 ring.  Lag >= 4: two blocks ahead -- the loads of block u+2 (and a probe of the counter of
+        // block u+3) are issued during block u and consumed at the start of block u+1, so the memory round trip of this
+        // busy CU never sits on the block period.  Lags 2-3: one block ahead, blocking.
+        // (A streamer with lag >= 3 polls dlt_{u+1-D} before it publishes partial u, so the group sums of block u+2
+        // exist during block u only when D >= 4.)
+        const int NG = A.NG;
+        if (D >= 4) {
+            double gv[8];
+#pragma unroll
+            for (int g = 0; g < 8; g++) gv[g] = 0.0;
+            auto target_of = [&](int ub) { return (unsigned)((ub / NGP_RING + 1) * NG); };
+            auto issue = [&](int ub) {  // counter of block ub known complete: start the loads
+                const double *gp = A.gsum + (size_t)(ub % NGP_RING) * NG * NGP_BLK + j;
+#pragma unroll
+                for (int g = 0; g < 8; g++) gv[g] = ld_f64(gp + (size_t)min(g, NG - 1) * NGP_BLK);
+            };
+            auto consume = [&](int ub) {
+                double tot = gv[0];
+#pragma unroll
+                for (int g = 1; g < 8; g++)
+                    if (g < NG) tot = tot + gv[g];
+                r0[(ub & 3) * NGP_BLK + j] = tot;
+                if (A.dbg && j == 0) A.dbg[4 * (size_t)ub + 3] = wall_clock64();
+            };
+            int next_fetch = 1;   // first local block whose group sums have not been requested yet
+            bool pend = false;    // loads of block next_fetch - 1 in flight
+            unsigned probe = (nb > 2) ? ld_u32(&A.cnt_gs[(size_t)(2 % NGP_RING) * 32]) : 0u;  // counter of block u + 2, read a block early
+            for (int u = 0; u < nb; ++u) {
+                if (pend) { consume(next_fetch - 1); pend = false; }
+                if (next_fetch == u + 1 && u + 1 < nb) {  // not ahead: the next block needs these sums -> wait for them here
+                    int ok = 1;
+                    if (j == 0) ok = wait_ge(&A.cnt_gs[(size_t)((u + 1) % NGP_RING) * 32], target_of(u + 1), A.abort_w, 3u) ? 1 : 0;
                     ok = __shfl(ok, 0);
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (ok) { issue(u + 1); consume(u + 1); }
+                    else if (j == 0) *sabort = 1;
+                    next_fetch = u + 2;
                 }
-                __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                if (A.dbg && j == 0) A.dbg[4 * (size_t)un + 3] = wall_clock64();
-                if (ok) {
-                    const double *gp = A.gsum + (size_t)nslot * NG * NGP_BLK + j;
-                    double gv[8];
-#pragma unroll
-                    for (int g = 0; g < 8; g++) gv[g] = ld_f64(gp + (size_t)min(g, NG - 1) * NGP_BLK);
-                    if (can_probe) probe = ld_u32(pc);
-                    double tot = gv[0];
-#pragma unroll
-                    for (int g = 1; g < 8; g++)
-                        if (g < NG) tot = tot + gv[g];
-                    r0[((u & 1) ^ 1) * NGP_BLK + j] = tot;
-                    ready_next = can_probe && (__shfl((int)probe, 0) >= (int)(((u + 2) / NGP_RING + 1) * NG));
-                } else if (j == 0) {
-                    *sabort = 1;
+                if (next_fetch == u + 2 && u + 2 < nb) {  // ahead only if the counter was already complete a block ago: never blocks
+                    if (__shfl((int)probe, 0) >= (int)target_of(u + 2)) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        issue(u + 2);
+                        pend = true;
+                        next_fetch = u + 3;
+                    }
                 }
+                if (u + 3 < nb) probe = ld_u32(&A.cnt_gs[(size_t)((u + 3) % NGP_RING) * 32]);
+                NGP_END_OF_BLOCK();
             }
-            NGP_END_OF_BLOCK();
+        } else {
+            for (int u = 0; u < nb; ++u) {
+                if (u + 1 < nb && D >= 2) {
+                    double tot;
+                    if (fetch_group_sums(A, u + 1, j, &tot)) r0[((u + 1) & 3) * NGP_BLK + j] = tot;
+                    else if (j == 0) *sabort = 1;
+                }
+                NGP_END_OF_BLOCK();
+            }
         }
     } else if (wv == 3) {
-        // LDS-DMA (global_load_lds_dwordx4): 2 x 32 KiB in flight, no VGPR staging; drained before the barrier
+        // LDS-DMA (global_load_lds_dwordx4) of the diagonal Gram block of local block u+2 into the 3-slot ring: 32 KiB
+        // issued per block, and only the PREVIOUS block's 32 instructions have to be complete at the barrier
+        // (counted vmcnt), so each transfer has a whole block period to land.  This wave never reads LDS (an LDS read
+        // would make the compiler drain the DMA): it sees an abort through a scalar load of the abort word.
         for (int u = 0; u < nb; ++u) {
-            if (u + 1 < nb) {
-                for (int x = 0; x < 2 && x < D; x++) {
-                    const char *gsrc = (const char *)(A.gramx + ((size_t)(A.t0 + u + 1) * D + x) * bsz) + (size_t)j * 16;
-                    char *gdst = (char *)((x == 0 ? Gd : Gx) + ((u & 1) ^ 1) * 4096);
+            if (u + 2 < nb) {
+                const char *gsrc = (const char *)(A.gramx + ((size_t)(A.t0 + u + 2) * D + 0) * bsz) + (size_t)j * 16;
+                char *gdst = (char *)(Gd + ((u + 2) % 3) * 4096);
 #pragma unroll
-                    for (int i = 0; i < 32; i++)
-                        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + (size_t)i * 1024),
-                                                         (__attribute__((address_space(3))) void *)(gdst + i * 1024), 16, 0, 0);
-                }
+                for (int i = 0; i < 32; i++)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + (size_t)i * 1024),
+                                                     (__attribute__((address_space(3))) void *)(gdst + i * 1024), 16, 0, 0);
+                asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
+            } else {
                 drain_vm();
+            }
+            if (A.dbg && j == 0) A.dbg[NGP_DBG_WAVES + 8 * (size_t)u + wv] = wall_clock64();
+            wg_barrier();
+            if (sld_u32(A.abort_w) != 0u) return;
+        }
+    } else if (wv == 5) {
+        // finishes r0 for the critical wave: total - ((lag-3 + lag-2 terms) + lag-1 term), then raises the LDS flag.
+        // The lag-1 cross Gram block lives in this wave's registers, loaded one block ahead.
+        double gxr[NGP_BLK];
+#pragma unroll
+        for (int kk = 0; kk < NGP_BLK; kk++) gxr[kk] = 0.0;
+        for (int u = 0; u < nb; ++u) {
+            if (D >= 2) {
+                const int slot = u % NGP_RING, rs = u & 3;
+                double tot = r0[rs * NGP_BLK + j];
+                const bool have_far = (D >= 3) && (u >= 2);
+                const bool have_one = (u >= 1);
+                double cor = have_far ? vacc[slot * NGP_BLK + j] : 0.0;
+                if (have_one) {
+                    const double dreg = hist[((u - 1) % NGP_RING) * NGP_BLK + j];  // lane k holds dlt_k of the previous block
+                    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+                    for (int kk = 0; kk < NGP_BLK; kk += 4) {
+                        s0 = __builtin_fma(gxr[kk + 0], readlane_d(dreg, kk + 0), s0);
+                        s1 = __builtin_fma(gxr[kk + 1], readlane_d(dreg, kk + 1), s1);
+                        s2 = __builtin_fma(gxr[kk + 2], readlane_d(dreg, kk + 2), s2);
+                        s3 = __builtin_fma(gxr[kk + 3], readlane_d(dreg, kk + 3), s3);
+                    }
+                    const double v1 = (s0 + s1) + (s2 + s3);
+                    cor = have_far ? cor + v1 : v1;
+                }
+                if (have_far || have_one) tot = tot - cor;
+                r0[rs * NGP_BLK + j] = tot;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (j == 0) __hip_atomic_store(totflag, u + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (u + 1 < nb) {
+                    const double *gx = A.gramx + ((size_t)(A.t0 + u + 1) * D + 1) * bsz + j;
+#pragma unroll
+                    for (int kk = 0; kk < NGP_BLK; kk++) gxr[kk] = gx[kk * NGP_BLK];
+                }
             }
             NGP_END_OF_BLOCK();
         }
     } else {
-        // wave 4: the lag-2 correction (farther lags are folded into the group sums by the reducers); its Gram rows are
-        // loaded one block ahead.  Waves 5-7 only keep the barrier count.
-        const int fx = wv - 2;
+        // waves 4 and 6: the lag-2 and lag-3 corrections (farther lags are folded into the group sums by the reducers);
+        // their Gram rows are loaded one block ahead.  Wave 7 only keeps the barrier count.
+        const int fx = (wv == 4) ? 2 : (wv == 6 ? 3 : 99);
         double gr[NGP_BLK];
 #pragma unroll
         for (int kk = 0; kk < NGP_BLK; kk++) gr[kk] = 0.0;
         bool have = false;
         for (int u = 0; u < nb; ++u) {
-            if (fx == 2 && fx < D) {
+            if (fx < D) {
                 if (u >= 1 && have) {  // dlt of local block a = u-1, target a + fx
                     const int a = u - 1, upb = a + fx;
                     const double *dp = hist + (a % NGP_RING) * NGP_BLK;
                     double v = gemv4([&](int kk) { return gr[kk]; }, dp);
                     double *va = vacc + (upb % NGP_RING) * NGP_BLK + j;
-                    *va = v;  // the only locally computed far term
+                    // lag 3 arrives one block before lag 2 (both by this workgroup, separated by a barrier): (v_3 + v_2)
+                    const bool first = (fx == 3) || (D <= 3) || (a == 0);
+                    *va = first ? v : *va + v;
                 }
                 have = (u + fx < nb) && (u + 1 < nb);  // rows for the next block: a' = u, target u + fx
                 if (have) {

@@ -741,8 +741,8 @@ static void iter_blocked(ora_t *h) {
                 gs[g] = v;
             }
             /* look-ahead corrections v_d = G[tb, tb-d] dlt_{tb-d} of the blocks whose update the GEMV has not seen.
-               Far lags d = 3 .. D-1 are folded into the group sums (the reducer workgroups compute them): lag d goes
-               to group (d-3) mod NG, ascending d.  Lags 2 and 1 stay with the sampler: cor = v_2 + v_1. */
+               Far lags d = 4 .. D-1 are folded into the group sums (the reducer workgroups compute them): lag d goes
+               to group (d-4) mod NG, ascending d.  Lags 3, 2 and 1 stay with the sampler. */
             double vd[17]; int hv[17];
             for (int64_t d = 1; d < D; d++) {
                 hv[d] = (tb - d >= 0);
@@ -753,12 +753,16 @@ static void iter_blocked(ora_t *h) {
                 for (int k = 0; k < BLK; k++) s4[k & 3] = __builtin_fma(Gx[k * BLK + j], da[k], s4[k & 3]);
                 vd[d] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
             }
-            for (int64_t d = 3; d < D; d++)
-                if (hv[d]) { int64_t g = (d - 3) % NGq; gs[g] = gs[g] - vd[d]; }
+            for (int64_t d = 4; d < D; d++)
+                if (hv[d]) { int64_t g = (d - 4) % NGq; gs[g] = gs[g] - vd[d]; }
             double tot = gs[0];
             for (int64_t g = 1; g < NGq; g++) tot = tot + gs[g];
-            if (D >= 3 && hv[2]) { double c = vd[2] + vd[1]; tot = tot - c; }
-            else if (D >= 2 && hv[1]) tot = tot - vd[1];
+            {   /* near lags stay with the sampler: cor = (v_3 + v_2) + v_1 over the terms that exist */
+                double c = 0.0; int have = 0;
+                for (int64_t d = (D - 1 < 3 ? D - 1 : 3); d >= 1; d--)
+                    if (hv[d]) { c = have ? c + vd[d] : vd[d]; have = 1; }
+                if (have) tot = tot - c;
+            }
             rr[j] = __builtin_fma(G[j * BLK + j], h->beta[k0 + j], tot);
         }
         /* recursion in the scaled variables e_j = c_j r_j + w_j (the candidate draw) and f_j = c_j r_j (for the
