@@ -187,6 +187,7 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "traffic_source": traffic_src,
+                "algorithmic_bytes_per_launch": prof["bytes_per_launch"],
                 "launch_avg_ms": prof["avg_ms"],
                 "launches_per_iteration": prof["launches"],
                 "iteration_achieved": bytes_iter * (K / dt) / 1e9,
