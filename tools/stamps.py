@@ -33,7 +33,10 @@ print("streamer0 loop period us:", np.median(np.diff(T[u_lo:u_hi,0]))/100.0)
 
 W = d[(1<<19):(1<<19)+8*nb].reshape(nb,8)
 for w in range(8):
-    print(f"wave {w} end-of-work after block start us:", np.median(W[u,w]-S[u,0])/100.0)
+    ue, uo = u[u % 2 == 0], u[u % 2 == 1]
+    print(f"wave {w} end-of-work after block start us:", np.median(W[u,w]-S[u,0])/100.0,
+          " even blocks", np.median(W[ue,w]-S[ue,0])/100.0, " odd blocks", np.median(W[uo,w]-S[uo,0])/100.0)
+print("slowest wave per block (histogram):", np.bincount(np.argmax(W[u], axis=1), minlength=8))
 
 Rd = d[(3<<18):(3<<18)+2*nb].reshape(nb,2)
 print("reducer0: counter complete for block u, relative to sampler start(u) us:", np.median(Rd[u,0]-S[u,0])/100.0)
