@@ -50,7 +50,6 @@ struct ngp_handle {
     double *d_cpart = nullptr, *d_cgsum = nullptr, *d_cdlt = nullptr;
     unsigned *d_ccnt = nullptr, *d_abort = nullptr;
     unsigned long long *d_dbg = nullptr;
-    double *d_hd = nullptr;  // scaled diagonal blocks of the persistent sweep (k_hscale)
     size_t ccnt_words = 0;
     float *d_tiles = nullptr;
     double *d_gramx = nullptr, *d_mpm = nullptr, *d_lhs0 = nullptr, *d_rhs0 = nullptr, *d_beta = nullptr;
@@ -216,7 +215,6 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
         h->ccnt_words = (size_t)NGP_RING * h->NG * 32 + (size_t)NGP_RING * 32 + 32;
         if ((rc = dalloc(h, &h->d_ccnt, h->ccnt_words))) return rc;
         if ((rc = dalloc(h, &h->d_abort, 32))) return rc;
-        if ((rc = dalloc(h, &h->d_hd, (size_t)h->NBLK * NGP_BLK * NGP_BLK))) return rc;
     }
     HCHK(hipStreamSynchronize(h->stream));
     return NGP_OK;
@@ -313,18 +311,13 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
     if (h->mode == 1) {
         (void)hipMemsetAsync(h->d_ccnt, 0, h->ccnt_words * sizeof(unsigned), h->stream);
         SweepArgs A;
-        A.tiles = h->d_tiles; A.ycorr = h->d_ycorr; A.gramx = h->d_gramx; A.hd = h->d_hd;
+        A.tiles = h->d_tiles; A.ycorr = h->d_ycorr; A.gramx = h->d_gramx;
         A.D = h->D; A.R = R; A.S = S; A.NG = h->NG; A.NS = h->NS; A.t0 = (int)tb0; A.t1 = (int)tb1;
         A.beta = h->d_beta; A.delta = h->d_delta; A.c = h->d_c; A.w = h->d_w; A.q = h->d_q; A.mpm = h->d_mpm; A.chi = h->d_chi;
         A.setof = h->d_setof; A.vbidx = h->d_vbidx; A.sets = h->d_sets; A.varBeta = h->d_varBeta;
         A.part = h->d_cpart; A.gsum = h->d_cgsum; A.dlt = h->d_cdlt;
         A.cnt_part = h->d_ccnt; A.cnt_gs = h->d_ccnt + (size_t)NGP_RING * h->NG * 32;
         A.flag_dlt = A.cnt_gs + (size_t)NGP_RING * 32; A.abort_w = h->d_abort; A.xcc_w = h->d_abort + 16;
-        {
-            const long long ne = (long long)(tb1 - tb0) * NGP_BLK * NGP_BLK;
-            hipLaunchKernelGGL(k_hscale, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, h->stream, h->d_gramx, h->d_c, h->d_hd, h->D,
-                               (int)tb0, (int)(tb1 - tb0));
-        }
         if (evs) (void)hipEventRecord(evs[0], h->stream);
         A.dbg = h->d_dbg;
         { const char *e = getenv("NGP_DEBUG_MODE"); A.dbg_mode = e ? atoi(e) : 0; }
@@ -434,7 +427,7 @@ int32_t ngp_destroy(ngp_handle *h) {
     if (!h) return NGP_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    dfree(h->d_tiles); dfree(h->d_gramx); dfree(h->d_cpart); dfree(h->d_cgsum); dfree(h->d_cdlt); dfree(h->d_ccnt); dfree(h->d_abort); dfree(h->d_dbg); dfree(h->d_hd); dfree(h->d_mpm); dfree(h->d_lhs0); dfree(h->d_rhs0); dfree(h->d_beta);
+    dfree(h->d_tiles); dfree(h->d_gramx); dfree(h->d_cpart); dfree(h->d_cgsum); dfree(h->d_cdlt); dfree(h->d_ccnt); dfree(h->d_abort); dfree(h->d_dbg); dfree(h->d_mpm); dfree(h->d_lhs0); dfree(h->d_rhs0); dfree(h->d_beta);
     dfree(h->d_c); dfree(h->d_w); dfree(h->d_q); dfree(h->d_T); dfree(h->d_chi); dfree(h->d_setof); dfree(h->d_loc);
     dfree(h->d_vbidx); dfree(h->d_delta); dfree(h->d_sum_beta); dfree(h->d_sum_beta2); dfree(h->d_sum_delta);
     dfree(h->d_ycorr); dfree(h->d_part); dfree(h->d_dlt); dfree(h->d_sets); dfree(h->d_scal); dfree(h->d_varBeta);

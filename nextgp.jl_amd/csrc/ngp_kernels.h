@@ -511,20 +511,7 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const double *__restrict__ 
     if (d == 0 && k == j) mpm[(size_t)(t0 + tb) * NGP_BLK + k] = tot;
     // the diagonal block is stored strictly "one-sided": entry [k][j] is kept for j > k only (what step k of the
     // recursion applies to the later lanes), zero elsewhere, so the chain needs no per-step masking; x'x lives in mpm
-    // cross blocks (d >= 1): row pairs interleaved, element (k, j) at ((k >> 1) * 64 + j) * 2 + (k & 1) (ngp_sweep.h)
-    const size_t off = (d == 0) ? (size_t)kj : ((size_t)(k >> 1) * NGP_BLK + j) * 2 + (k & 1);
-    gramx[((size_t)(t0 + tb) * D + d) * (NGP_BLK * NGP_BLK) + off] = (d == 0 && j <= k) ? 0.0 : tot;
-}
-
-// H[t][k][j] = -(c_j G_t[k][j]): the scaled one-sided diagonal block the recursion multiplies with (DESIGN.md section 2,
-// step 5); c changes every iteration, so this runs before every persistent sweep (2 x 32 KiB of traffic per block)
-__global__ __launch_bounds__(256) void k_hscale(const double *__restrict__ gramx, const double *__restrict__ c, double *__restrict__ hd,
-                                                int D, int t0, int nb) {
-    const long long e = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (e >= (long long)nb * NGP_BLK * NGP_BLK) return;
-    const int tb = (int)(e / (NGP_BLK * NGP_BLK)), kj = (int)(e % (NGP_BLK * NGP_BLK));
-    const size_t t = (size_t)(t0 + tb);
-    hd[t * (NGP_BLK * NGP_BLK) + kj] = -(c[t * NGP_BLK + (kj & (NGP_BLK - 1))] * gramx[(t * D + 0) * (NGP_BLK * NGP_BLK) + kj]);
+    gramx[((size_t)(t0 + tb) * D + d) * (NGP_BLK * NGP_BLK) + kj] = (d == 0 && j <= k) ? 0.0 : tot;
 }
 
 // synthetic genotypes: per-column mean of g_ij (integer sum), then centred fp32 tiles

@@ -40,8 +40,7 @@ namespace ngp {
 struct SweepArgs {
     const float *tiles;
     double *ycorr;
-    const double *gramx;  // [block][lag d < D][64][64]: d = 0 one-sided diagonal block (natural order), d >= 1 cross blocks, row pairs interleaved
-    const double *hd;     // [block][64][64]: H = -(c G) of the diagonal block, rebuilt before every sweep (k_hscale)
+    const double *gramx;
     int D, R, S, NG, NS, t0, t1;  // NS: LDS tile slots of a streamer
     double *beta;
     uint8_t *delta;
@@ -101,20 +100,6 @@ __device__ inline bool wait_ge(const unsigned *flag, unsigned target, unsigned *
             return false;
         }
         __builtin_amdgcn_s_sleep(4);
-    }
-}
-
-// cross Gram blocks (lag d >= 1) are stored with row pairs interleaved -- element (k, j) at ((k >> 1) * 64 + j) * 2 + (k & 1)
-// -- so that a lane fetches its column of two rows with one 16-byte load: 32 loads per block instead of 64 (a wave can
-// keep only 63 loads in flight)
-__device__ inline size_t gram_pair_index(int k, int j) { return ((size_t)(k >> 1) * NGP_BLK + j) * 2 + (k & 1); }
-__device__ inline void load_rows_pair(const double *blk, int j, double (&out)[NGP_BLK]) {
-    const double2 *p = (const double2 *)blk + j;
-#pragma unroll
-    for (int k2 = 0; k2 < NGP_BLK / 2; k2++) {
-        const double2 v = p[k2 * NGP_BLK];
-        out[2 * k2] = v.x;
-        out[2 * k2 + 1] = v.y;
     }
 }
 
@@ -391,8 +376,10 @@ __device__ inline void role_reducer(const SweepArgs &A, const int g) {
         for (int d = 4 + g; d < A.D; d += A.NG) {
             const int a = u - d;
             if (a < 0) continue;
+            const double *gx = A.gramx + ((size_t)(A.t0 + u) * A.D + d) * (NGP_BLK * NGP_BLK) + lane;
             double gr[NGP_BLK];
-            load_rows_pair(A.gramx + ((size_t)(A.t0 + u) * A.D + d) * (NGP_BLK * NGP_BLK), lane, gr);
+#pragma unroll
+            for (int kk = 0; kk < NGP_BLK; kk++) gr[kk] = gx[kk * NGP_BLK];
             int okd = 1;
             if (lane == 0) okd = (A.dbg_mode == 3 || wait_ge(A.flag_dlt, (unsigned)(a + 1), A.abort_w, 4u)) ? 1 : 0;
             okd = __shfl(okd, 0);
@@ -482,62 +469,45 @@ __device__ inline void publish_block(const SweepArgs &A, int up, int j, const do
     }
 }
 
-// sampler (8 waves), one raw barrier per block; every wave runs its own block loop (own register budget):
-//   wave 0    serial chain of block u (LDS + ALU only).  Every 8 steps it drops the dlt values finished so far into LDS
-//             and advances a progress word, so the lag-1 correction of the NEXT block is accumulated while the chain runs.
-//   wave 1    publishes block u-1 (dlt -> streamers, beta / delta / varBeta)
-//   wave 2    group sums, up to two blocks ahead -> r0 ring
-//   wave 3    LDS-DMA of the scaled diagonal Gram block H = -(c G) of block u+2 (k_hscale builds H before the sweep)
-//   wave 4,6  lag-2 / lag-3 corrections G[t',a] dlt_a, Gram rows loaded one block ahead into registers
-//   wave 5,7  followers (even / odd blocks): 8 steps behind the chain of block u they accumulate G[u+1,u] dlt_u, then
-//             finish r0[u+1] = group sums - ((lag 3 + lag 2) + lag 1) and raise totflag; in their idle block they load
-//             the cross Gram rows of their next block
-// LDS: Hd[3][4096] | hist[RING][64] | vacc[RING][64] | r0[4][64] | outb[2][64] | outi[2][64] | flags
-__device__ inline int lds_ld(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ inline void lds_st(int *p, int v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-// LDS instructions of one wave execute in order; this only stops the compiler from moving them
-#define NGP_LDS_ORDER() asm volatile("" ::: "memory")
-// chain steps after which the critical wave reports progress: coarse first (fewer LDS writes in the chain), fine at the
-// end (the follower's work after the last report is what the next block waits for)
-#define NGP_NSEG 5
-__device__ constexpr int ngp_seg_end(int sg) { return sg == 0 ? 16 : sg == 1 ? 32 : sg == 2 ? 48 : sg == 3 ? 56 : 64; }
-__device__ constexpr int ngp_seg_begin(int sg) { return sg == 0 ? 0 : ngp_seg_end(sg - 1); }
-
+// sampler (8 waves), one raw barrier per block:
+//   wave 0   serial chain of block u (LDS + ALU only; coefficients prefetched one block ahead)
+//   wave 1   publishes block u-1 (dlt -> streamers, beta/delta/varBeta)
+//   wave 2   fetches the group sums of block u+1 into LDS
+//   wave 3   LDS-DMA of the diagonal and lag-1 Gram blocks of block u+1
+//   wave 4-7 far corrections G[t',a] dlt_a, lag x = 2..5, Gram rows loaded one block ahead into registers
+// LDS: Gd[2][4096] | Gx[2][4096] | hist[RING][64] | vacc[RING][64] | r0[2][64] | outb[2][64] | outi[2][64] | flags
 __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
     const int D = A.D, tid = threadIdx.x, wv = tid >> 6, j = tid & 63;
-    double *Hd = (double *)smem;                // 3 x 4096: scaled diagonal blocks of local blocks u, u+1, u+2
-    double *hist = Hd + 3 * 4096;               // RING x 64
+    double *Gd = (double *)smem;                // 3 x 4096: diagonal Gram blocks of local blocks u, u+1, u+2
+    double *hist = Gd + 3 * 4096;               // RING x 64
     double *vacc = hist + NGP_RING * NGP_BLK;   // RING x 64
     double *r0 = vacc + NGP_RING * NGP_BLK;     // 4 x 64 (ring over local blocks)
     double *outb = r0 + 4 * NGP_BLK;            // 2 x 64
     int *outi = (int *)(outb + 2 * NGP_BLK);    // 2 x 64
     int *sabort = outi + 2 * NGP_BLK;
-    int *totflag = sabort + 1;  // b + 1: r0[b & 3] holds the final total of local block b
-    int *prog = sabort + 2;     // 64 u + (chain steps of local block u whose dlt is in hist)
-    int *vflag = sabort + 3;    // b + 1: vacc of local block b is complete (lags 2-3)
-    int *r0flag = sabort + 4;   // b + 1: r0[b & 3] holds the group sums of local block b
+    int *totflag = sabort + 1;  // local block index + 1 whose corrected total is ready in r0[buf]
     const int nb = A.t1 - A.t0;
     const size_t bsz = NGP_BLK * NGP_BLK;
     if (tid == 0) {
         *sabort = 0;
         *totflag = 0;
-        *prog = 0;
-        *vflag = 0;
-        *r0flag = 0;
         st_u32(A.xcc_w, xcc_id() + 1u);
         if (A.dbg) { A.dbg[NGP_DBG_ALL - 2] = xcc_id(); A.dbg[NGP_DBG_ALL - 1] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4); }
     }
-    // prologue: scaled diagonal blocks of local blocks 0 and 1 (all waves), group sums of block 0 (wave 2)
-    for (int b = 0; b < 2 && b < nb; b++) {
-        const double *hb = A.hd + (size_t)(A.t0 + b) * bsz;
-        for (int idx = tid; idx < 4096; idx += NGP_WG) Hd[b * 4096 + idx] = hb[idx];
+    // prologue: diagonal Gram block of local block 0 (all waves) and its group sums (wave 2)
+    {
+        const double *gd = A.gramx + ((size_t)A.t0 * D + 0) * bsz;
+        for (int idx = tid; idx < 4096; idx += NGP_WG) Gd[idx] = gd[idx];
+        if (nb > 1) {
+            const double *gd1 = A.gramx + ((size_t)(A.t0 + 1) * D + 0) * bsz;
+            for (int idx = tid; idx < 4096; idx += NGP_WG) Gd[4096 + idx] = gd1[idx];
+        }
     }
     __syncthreads();
     if (wv == 2) {
         double tot;
         if (fetch_group_sums(A, 0, j, &tot)) r0[j] = tot;
         else if (j == 0) *sabort = 1;
-        if (j == 0) { *totflag = 1; *r0flag = 1; }
     }
     __syncthreads();
     if (*sabort) return;
@@ -547,15 +517,7 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
         wg_barrier();                                                                            \
         if (*sabort) return;                                                                     \
     } while (0)
-// LDS spin of one wave on a monotone word; gives up when the workgroup aborts (every global wait is bounded)
-#define NGP_LDS_WAIT(word, target)                                               \
-    do {                                                                         \
-        while (__builtin_amdgcn_readfirstlane(lds_ld(word)) < (target)) {        \
-            if (__builtin_amdgcn_readfirstlane(lds_ld(sabort))) break;           \
-            __builtin_amdgcn_s_sleep(0);                                         \
-        }                                                                        \
-        NGP_LDS_ORDER();                                                         \
-    } while (0)
+    // every role runs its own block loop (own register budget); all meet at ONE raw barrier per block
     if (wv == 0) {
         // ---------------- critical wave: LDS + ALU only ----------------
         CoefRegs cur = load_coef(A, (long long)A.t0 * NGP_BLK + j), nxt = cur;
@@ -563,64 +525,60 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
             const int t = A.t0 + u, buf = u & 1, slot = u % NGP_RING, rs = u & 3;
             if (u + 1 < nb) nxt = load_coef(A, (long long)(t + 1) * NGP_BLK + j);
             if (A.dbg && j == 0) A.dbg[4 * (size_t)u] = wall_clock64();
-            // H_k = -(c G[k][.]) arrived by DMA during the last two blocks: the 64 LDS reads fly while the total is awaited
-            const double *hdb = Hd + (u % 3) * 4096 + j;
-            double H[NGP_BLK];
-#pragma unroll
-            for (int kk = 0; kk < NGP_BLK; kk++) H[kk] = hdb[kk * NGP_BLK];
             double tot;
             if (D == 1) {  // lag 1: nothing can be fetched or corrected ahead
                 tot = r0[rs * NGP_BLK + j];
                 bool okc = true;
                 if (u >= 1) okc = fetch_group_sums(A, u, j, &tot);
                 if (!okc && j == 0) *sabort = 1;
-            } else {       // the follower of block u-1 left the corrected total in r0
-                NGP_LDS_WAIT(totflag, u + 1);
+            } else {       // wave 5 applies the look-ahead corrections and leaves the final total in r0[buf]
+                while (__hip_atomic_load(totflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != u + 1) __builtin_amdgcn_s_sleep(0);
                 tot = r0[rs * NGP_BLK + j];
             }
+            const double *gdb = Gd + (u % 3) * 4096 + j;
             const double bo = cur.bo, cc = cur.cc, ww = cur.ww, st = cur.st;
             const double r = __builtin_fma(cur.gd, bo, tot);
             // scaled recursion: e = c r + w is the candidate draw, f = c r feeds the
             // inclusion test |f| > thr.  The stored diagonal block is zero for lanes <= k, so a lane's e and f freeze at
-            // its own step and nothing has to be captured: v_readlane -> ONE fma per step (BayesPR), + compare / select
-            // (BayesB).  After every NGP_FOLLOW steps the finished values go to hist (later lanes hold unfinished values that
-            // nobody reads) and prog tells the follower how far it may go.
-            double *hrow = hist + slot * NGP_BLK + j;
+            // its own step and nothing has to be captured.  H_k = -(c G[k][.]) is formed four steps ahead, in the
+            // latency shadow of the serial path: v_readlane -> ONE fma per step (BayesPR), + compare / select (BayesB).
+            double G[NGP_BLK];
+#pragma unroll
+            for (int kk = 0; kk < NGP_BLK; kk++) G[kk] = gdb[kk * NGP_BLK];
             double e = __builtin_fma(r, cc, ww);
             double dsave;
             int isave = 1;
+            double H0 = -(cc * G[0]), H1 = -(cc * G[1]), H2 = -(cc * G[2]), H3 = -(cc * G[3]);
             if (__ballot(st >= 0.0) == 0ull) {
 #pragma unroll
-                for (int sg = 0; sg < NGP_NSEG; sg++) {
-#pragma unroll
-                    for (int kk = ngp_seg_begin(sg); kk < ngp_seg_end(sg); kk++) {
-                        const double dk = readlane_d(e, kk);
-                        e = __builtin_fma(H[kk], dk, e);
-                    }
-                    *hrow = e;
-                    NGP_LDS_ORDER();
-                    if (j == 0) lds_st(prog, u * 64 + ngp_seg_end(sg));
+                for (int kk = 0; kk < NGP_BLK; kk += 4) {
+                    double dk;
+                    dk = readlane_d(e, kk + 0); e = __builtin_fma(H0, dk, e); H0 = -(cc * G[(kk + 4) & 63]);
+                    dk = readlane_d(e, kk + 1); e = __builtin_fma(H1, dk, e); H1 = -(cc * G[(kk + 5) & 63]);
+                    dk = readlane_d(e, kk + 2); e = __builtin_fma(H2, dk, e); H2 = -(cc * G[(kk + 6) & 63]);
+                    dk = readlane_d(e, kk + 3); e = __builtin_fma(H3, dk, e); H3 = -(cc * G[(kk + 7) & 63]);
                 }
                 dsave = e;
             } else {
                 double f = r * cc;
 #pragma unroll
-                for (int sg = 0; sg < NGP_NSEG; sg++) {
-#pragma unroll
-                    for (int kk = ngp_seg_begin(sg); kk < ngp_seg_end(sg); kk++) {
-                        const int in = __builtin_fabs(f) > st;
-                        const double dlv = in ? e : -bo;
-                        const double dk = readlane_d(dlv, kk);
-                        e = __builtin_fma(H[kk], dk, e);
-                        f = __builtin_fma(H[kk], dk, f);
-                    }
-                    *hrow = (__builtin_fabs(f) > st) ? e : -bo;
-                    NGP_LDS_ORDER();
-                    if (j == 0) lds_st(prog, u * 64 + ngp_seg_end(sg));
+                for (int kk = 0; kk < NGP_BLK; kk += 4) {
+#define NGP_STEP(HX, KO)                                              \
+    {                                                                 \
+        int in = __builtin_fabs(f) > st;                              \
+        double dlv = in ? e : -bo;                                    \
+        double dk = readlane_d(dlv, kk + KO);                         \
+        e = __builtin_fma(HX, dk, e);                                 \
+        f = __builtin_fma(HX, dk, f);                                 \
+        HX = -(cc * G[(kk + KO + 4) & 63]);                           \
+    }
+                    NGP_STEP(H0, 0) NGP_STEP(H1, 1) NGP_STEP(H2, 2) NGP_STEP(H3, 3)
+#undef NGP_STEP
                 }
                 isave = __builtin_fabs(f) > st;
                 dsave = isave ? e : -bo;
             }
+            hist[slot * NGP_BLK + j] = dsave;
             outb[buf * NGP_BLK + j] = bo + dsave;
             outi[buf * NGP_BLK + j] = isave;
             if (A.dbg && j == 0) A.dbg[4 * (size_t)u + 1] = wall_clock64();
@@ -634,11 +592,11 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
         }
         if (nb >= 1) publish_block(A, nb - 1, j, hist, outb, outi);
     } else if (wv == 2) {
-        // group sums -> r0 ring.  Lag >= 4: up to two blocks ahead -- the loads of block u+2 are issued during block u,
-        // when its counter was already complete a block ago, and consumed at the start of block u+1, so the memory round
-        // trip of this busy CU does not sit on the block period; otherwise one block ahead, blocking.
+        // group sums -> r0 ring.  Lag >= 4: two blocks ahead -- the loads of block u+2 (and a probe of the counter of
+        // block u+3) are issued during block u and consumed at the start of block u+1, so the memory round trip of this
+        // busy CU never sits on the block period.  Lags 2-3: one block ahead, blocking.
         // (A streamer with lag >= 3 polls dlt_{u+1-D} before it publishes partial u, so the group sums of block u+2
-        // can exist during block u only when D >= 4.)
+        // exist during block u only when D >= 4.)
         const int NG = A.NG;
         if (D >= 4) {
             double gv[8];
@@ -656,8 +614,6 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
                 for (int g = 1; g < 8; g++)
                     if (g < NG) tot = tot + gv[g];
                 r0[(ub & 3) * NGP_BLK + j] = tot;
-                NGP_LDS_ORDER();
-                if (j == 0) lds_st(r0flag, ub + 1);
                 if (A.dbg && j == 0) A.dbg[4 * (size_t)ub + 3] = wall_clock64();
             };
             int next_fetch = 1;   // first local block whose group sums have not been requested yet
@@ -693,109 +649,75 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
             for (int u = 0; u < nb; ++u) {
                 if (u + 1 < nb && D >= 2) {
                     double tot;
-                    if (fetch_group_sums(A, u + 1, j, &tot)) {
-                        r0[((u + 1) & 3) * NGP_BLK + j] = tot;
-                        NGP_LDS_ORDER();
-                        if (j == 0) lds_st(r0flag, u + 2);
-                    } else if (j == 0) {
-                        *sabort = 1;
-                    }
+                    if (fetch_group_sums(A, u + 1, j, &tot)) r0[((u + 1) & 3) * NGP_BLK + j] = tot;
+                    else if (j == 0) *sabort = 1;
                 }
                 NGP_END_OF_BLOCK();
             }
         }
     } else if (wv == 3) {
-        // LDS-DMA of the scaled diagonal block H of local block u+2 into the 3-slot ring: 32 KiB issued per block, and only
-        // the PREVIOUS block's 32 instructions have to be complete at the barrier (counted vmcnt), so each transfer has a
-        // whole block period to land
+        // LDS-DMA (global_load_lds_dwordx4) of the diagonal Gram block of local block u+2 into the 3-slot ring: 32 KiB
+        // issued per block, and only the PREVIOUS block's 32 instructions have to be complete at the barrier
+        // (counted vmcnt), so each transfer has a whole block period to land.  This wave never reads LDS (an LDS read
+        // would make the compiler drain the DMA): it sees an abort through a scalar load of the abort word.
         for (int u = 0; u < nb; ++u) {
             if (u + 2 < nb) {
-                const char *gsrc = (const char *)(A.hd + (size_t)(A.t0 + u + 2) * bsz) + (size_t)j * 16;
-                char *gdst = (char *)(Hd + ((u + 2) % 3) * 4096);  // slot of block u-1, whose chain is over
+                const char *gsrc = (const char *)(A.gramx + ((size_t)(A.t0 + u + 2) * D + 0) * bsz) + (size_t)j * 16;
+                char *gdst = (char *)(Gd + ((u + 2) % 3) * 4096);
 #pragma unroll
-                for (int i = 0; i < 32; i++) dma16_lds(gsrc + (size_t)i * 1024, gdst + i * 1024);
+                for (int i = 0; i < 32; i++)
+                    __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void *)(gsrc + (size_t)i * 1024),
+                                                     (__attribute__((address_space(3))) void *)(gdst + i * 1024), 16, 0, 0);
                 asm volatile("s_waitcnt vmcnt(32)" ::: "memory");
             } else {
                 drain_vm();
             }
-            NGP_END_OF_BLOCK();
+            if (A.dbg && j == 0) A.dbg[NGP_DBG_WAVES + 8 * (size_t)u + wv] = wall_clock64();
+            wg_barrier();
+            if (sld_u32(A.abort_w) != 0u) return;
         }
-    } else if (wv == 5 || wv == 7) {
-        // Straight-line pairs (follow block u, load during block u+1): the 64 cross rows have ONE definition and ONE use
-        // per pair, which keeps them in registers.
-        const int par = (wv == 7) ? 1 : 0;
+    } else if (wv == 5) {
+        // finishes r0 for the critical wave: total - ((lag-3 + lag-2 terms) + lag-1 term), then raises the LDS flag.
+        // The lag-1 cross Gram block lives in this wave's registers, loaded one block ahead.
         double gxr[NGP_BLK];
-        auto load_cross = [&](int ub) {  // rows of G[ub, ub-1]; ub is clamped so that the loads are always legal
-            load_rows_pair(A.gramx + ((size_t)(A.t0 + min(ub, nb - 1)) * D + min(1, D - 1)) * bsz, j, gxr);
-        };
-        auto follow = [&](int u) {  // lag-1 correction of block u+1 behind the chain of block u, then the final total
-            typedef const __attribute__((address_space(3))) double *lds_cdp;
-            const lds_cdp hk = (lds_cdp)(hist + (u % NGP_RING) * NGP_BLK);  // same address in every lane: broadcast reads
-            double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-            const int un = u + 1;
-            const bool have_far = (D >= 3) && (un >= 2);
-            double tot = 0.0, far = 0.0;
 #pragma unroll
-            for (int sg = 0; sg < NGP_NSEG; sg++) {
-                if (sg == NGP_NSEG - 1) {  // everything but the lag-1 term is fetched before the last report is awaited
-                    NGP_LDS_WAIT(r0flag, un + 1);
-                    if (have_far) NGP_LDS_WAIT(vflag, un + 1);
-                    tot = r0[(un & 3) * NGP_BLK + j];
-                    far = have_far ? vacc[(un % NGP_RING) * NGP_BLK + j] : 0.0;
-                }
-                while (__builtin_amdgcn_readfirstlane(lds_ld(prog)) < u * 64 + ngp_seg_end(sg)) {
-                    if (__builtin_amdgcn_readfirstlane(lds_ld(sabort))) break;
-                    __builtin_amdgcn_s_sleep(1);
-                }
-                NGP_LDS_ORDER();
-                constexpr int NV = 16;
-                double dv[NV];
+        for (int kk = 0; kk < NGP_BLK; kk++) gxr[kk] = 0.0;
+        for (int u = 0; u < nb; ++u) {
+            if (D >= 2) {
+                const int slot = u % NGP_RING, rs = u & 3;
+                double tot = r0[rs * NGP_BLK + j];
+                const bool have_far = (D >= 3) && (u >= 2);
+                const bool have_one = (u >= 1);
+                double cor = have_far ? vacc[slot * NGP_BLK + j] : 0.0;
+                if (have_one) {
+                    const double dreg = hist[((u - 1) % NGP_RING) * NGP_BLK + j];  // lane k holds dlt_k of the previous block
+                    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-                for (int i = 0; i < NV; i++)
-                    if (ngp_seg_begin(sg) + i < ngp_seg_end(sg)) dv[i] = hk[ngp_seg_begin(sg) + i];
-#pragma unroll
-                for (int i = 0; i < NV; i += 4) {
-                    if (ngp_seg_begin(sg) + i < ngp_seg_end(sg)) {
-                        const int kk = ngp_seg_begin(sg) + i;
-                        s0 = __builtin_fma(gxr[kk + 0], dv[i + 0], s0);
-                        s1 = __builtin_fma(gxr[kk + 1], dv[i + 1], s1);
-                        s2 = __builtin_fma(gxr[kk + 2], dv[i + 2], s2);
-                        s3 = __builtin_fma(gxr[kk + 3], dv[i + 3], s3);
+                    for (int kk = 0; kk < NGP_BLK; kk += 4) {
+                        s0 = __builtin_fma(gxr[kk + 0], readlane_d(dreg, kk + 0), s0);
+                        s1 = __builtin_fma(gxr[kk + 1], readlane_d(dreg, kk + 1), s1);
+                        s2 = __builtin_fma(gxr[kk + 2], readlane_d(dreg, kk + 2), s2);
+                        s3 = __builtin_fma(gxr[kk + 3], readlane_d(dreg, kk + 3), s3);
                     }
+                    const double v1 = (s0 + s1) + (s2 + s3);
+                    cor = have_far ? cor + v1 : v1;
                 }
-                // the sums are "used" here, so the fma stay in this segment (the optimiser would sink them to the end and
-                // hold every segment's dlt values in registers)
-                asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));
+                if (have_far || have_one) tot = tot - cor;
+                r0[rs * NGP_BLK + j] = tot;
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                if (j == 0) __hip_atomic_store(totflag, u + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (u + 1 < nb) {
+                    const double *gx = A.gramx + ((size_t)(A.t0 + u + 1) * D + 1) * bsz + j;
+#pragma unroll
+                    for (int kk = 0; kk < NGP_BLK; kk++) gxr[kk] = gx[kk * NGP_BLK];
+                }
             }
-            const double v1 = (s0 + s1) + (s2 + s3);
-            const double cor = have_far ? far + v1 : v1;
-            tot = tot - cor;
-            r0[(un & 3) * NGP_BLK + j] = tot;
-            NGP_LDS_ORDER();
-            if (j == 0) lds_st(totflag, un + 1);
-        };
-        int u = 0;
-        if (par == 1) {  // the odd follower idles through block 0
-            load_cross(2);
             NGP_END_OF_BLOCK();
-            u = 1;
-        } else {
-            load_cross(1);
-        }
-        for (; u < nb; u += 2) {
-            if (D >= 2 && u + 1 < nb) follow(u);
-            NGP_END_OF_BLOCK();
-            if (u + 1 < nb) {
-                load_cross(u + 3);  // rows for block u+2, the next chain this wave follows
-                ++u;
-                NGP_END_OF_BLOCK();
-                --u;
-            }
         }
     } else {
         // waves 4 and 6: the lag-2 and lag-3 corrections (farther lags are folded into the group sums by the reducers);
-        // their Gram rows are loaded one block ahead
-        const int fx = (wv == 4) ? 2 : 3;
+        // their Gram rows are loaded one block ahead.  Wave 7 only keeps the barrier count.
+        const int fx = (wv == 4) ? 2 : (wv == 6 ? 3 : 99);
         double gr[NGP_BLK];
 #pragma unroll
         for (int kk = 0; kk < NGP_BLK; kk++) gr[kk] = 0.0;
@@ -810,18 +732,17 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
                     // lag 3 arrives one block before lag 2 (both by this workgroup, separated by a barrier): (v_3 + v_2)
                     const bool first = (fx == 3) || (D <= 3) || (a == 0);
                     *va = first ? v : *va + v;
-                    NGP_LDS_ORDER();
-                    if (fx == 2 && j == 0) lds_st(vflag, upb + 1);  // the lag-2 term is the last one of its target
                 }
                 have = (u + fx < nb) && (u + 1 < nb);  // rows for the next block: a' = u, target u + fx
                 if (have) {
-                    load_rows_pair(A.gramx + ((size_t)(A.t0 + u + fx) * D + fx) * bsz, j, gr);
+                    const double *gx = A.gramx + ((size_t)(A.t0 + u + fx) * D + fx) * bsz;
+#pragma unroll
+                    for (int kk = 0; kk < NGP_BLK; kk++) gr[kk] = gx[kk * NGP_BLK + j];
                 }
             }
             NGP_END_OF_BLOCK();
         }
     }
-#undef NGP_LDS_WAIT
 #undef NGP_END_OF_BLOCK
 }
 
