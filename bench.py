@@ -90,8 +90,8 @@ def main():
     ap.add_argument("--P", type=int, default=100000)
     ap.add_argument("--method", default="BayesPR", choices=["BayesPR", "BayesB"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-cols", type=int, default=8000)
-    ap.add_argument("--cpu-iters", type=int, default=12)
+    ap.add_argument("--cpu-cols", type=int, default=16000)
+    ap.add_argument("--cpu-iters", type=int, default=100)
     args = ap.parse_args()
 
     import torch
