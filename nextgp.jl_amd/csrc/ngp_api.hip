@@ -160,7 +160,7 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
     if (h->mode == 0) choose_layout(N, 256, &h->R, &h->S);
     h->NG = (int)((h->S + NGP_GRP - 1) / NGP_GRP);
     h->D = (h->mode == 1) ? h->lag : 1;
-    if (h->mode == 1 && h->R > 128 && h->D > 4) h->D = 4;  // tall shards: the register delay line holds 4 tiles at most
+    if (h->mode == 1 && h->R > 128 && h->D > 5) h->D = 5;  // tall shards: the register delay line holds 5 tiles at most
     h->NBLK = (P + NGP_BLK - 1) / NGP_BLK;
     h->Ppad = h->NBLK * NGP_BLK;
     h->L = h->R * h->S;

@@ -181,14 +181,12 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (ok) dl[(uu & 1) * 64 + j] = ld_f64(&A.dlt[(size_t)(aa % NGP_RING) * NGP_BLK + j]);
     };
-    // the update tasks of this thread (fixed for the whole sweep): q -> (c, i); surplus lanes redo the last task
-    int tc[NGP_TPT], ti[NGP_TPT];
-#pragma unroll
-    for (int tp = 0; tp < NGP_TPT; tp++) {
-        const int q = min(tp * NGP_WG + tid, 8 * R - 1);
-        tc[tp] = q / R;
-        ti[tp] = q - tc[tp] * R;
-    }
+    // the update task of this thread (fixed for the whole sweep): 8-column chain tcc of the NGP_TPT consecutive rows
+    // [ti0, ti0 + NGP_TPT) -- one 4 / 8 / 16-byte LDS read per column instead of NGP_TPT 4-byte reads (tall shards are bound
+    // by LDS instruction issue, not by arithmetic); surplus threads redo the last task
+    const int gpc = R / NGP_TPT;  // row groups per chain (R is a multiple of 4)
+    const int tq_ = min(tid, 8 * gpc - 1);
+    const int tcc = tq_ / gpc, ti0 = (tq_ - tcc * gpc) * NGP_TPT;
     float keep[DT][NGP_TPT][8];
 #pragma unroll
     for (int d = 0; d < DT; d++)
@@ -240,15 +238,22 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
             if (A.dbg && tid == 0) { unsigned long long n = wall_clock64(); accA += n - tt0; tt0 = n; }
             // ---------------- phase B: ycorr -= X_a dlt_a (tile a waits in keep[d]) ----------------
             if (a >= 0 && A.dbg_mode != 1) {
+                {
+                    const double *dq = dl + (u & 1) * 64 + 8 * tcc;
+                    double dqv[8];
 #pragma unroll
-                for (int tp = 0; tp < NGP_TPT; tp++) {
-                    if (tp < ntask) {
-                        const double *dq = dl + (u & 1) * 64 + 8 * tc[tp];
+                    for (int jj = 0; jj < 8; jj++) dqv[jj] = dq[jj];
+                    double pv[NGP_TPT];
+#pragma unroll
+                    for (int tp = 0; tp < NGP_TPT; tp++) {
                         double p = 0.0;
 #pragma unroll
-                        for (int jj = 0; jj < 8; jj++) p = __builtin_fma((double)keep[d][tp][jj], dq[jj], p);
-                        pp[(size_t)tc[tp] * R + ti[tp]] = p;
+                        for (int jj = 0; jj < 8; jj++) p = __builtin_fma((double)keep[d][tp][jj], dqv[jj], p);
+                        pv[tp] = p;
                     }
+                    double *ppw = pp + (size_t)tcc * R + ti0;
+#pragma unroll
+                    for (int tp = 0; tp < NGP_TPT; tp++) ppw[tp] = pv[tp];
                 }
                 NGP_FINE(2);
                 wg_barrier();
@@ -272,12 +277,19 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
                 unsigned fl = 0;
                 if (pollw) fl = ld_u32(A.flag_dlt);
                 const float *slotp = (const float *)(ring + (size_t)(u & 1) * TB);
+                {
+                    const float *tq = slotp + (size_t)(8 * tcc) * R + ti0;
 #pragma unroll
-                for (int tp = 0; tp < NGP_TPT; tp++) {
-                    if (tp < ntask) {
-                        const float *tq = slotp + (size_t)(8 * tc[tp]) * R + ti[tp];
-#pragma unroll
-                        for (int jj = 0; jj < 8; jj++) keep[d][tp][jj] = tq[jj * R];
+                    for (int jj = 0; jj < 8; jj++) {
+                        if (NGP_TPT == 4) {
+                            const float4 v = *(const float4 *)(tq + jj * R);
+                            keep[d][0][jj] = v.x; keep[d][1 % NGP_TPT][jj] = v.y; keep[d][2 % NGP_TPT][jj] = v.z; keep[d][3 % NGP_TPT][jj] = v.w;
+                        } else if (NGP_TPT == 2) {
+                            const float2 v = *(const float2 *)(tq + jj * R);
+                            keep[d][0][jj] = v.x; keep[d][1 % NGP_TPT][jj] = v.y;
+                        } else {
+                            keep[d][0][jj] = tq[jj * R];
+                        }
                     }
                 }
                 {   // chain wv: row quads wv, wv+8, ... (lane = column)
@@ -779,7 +791,10 @@ __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         } else if (tpt == 2) {
             NGP_DISPATCH_D8(2)
         } else {
-            NGP_DISPATCH_D(4)  // host clamps the lag to 4 for tall shards (register budget of the delay line)
+            switch (A.D) {  // host clamps the lag to 5 for tall shards (register budget of the delay line: 32 VGPRs per lag)
+                case 5: role_streamer<5, 4>(A, s, smem); break;
+                default: NGP_DISPATCH_D(4)
+            }
         }
 #undef NGP_DISPATCH_D8
 #undef NGP_DISPATCH_D
