@@ -204,7 +204,7 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
         const size_t lds_sampler = (size_t)(3 * 4096 + 2 * NGP_RING * NGP_BLK + 6 * NGP_BLK) * sizeof(double) + 2 * NGP_BLK * sizeof(int) + 64;
         const size_t lds_max = 160 * 1024;
         const size_t misc = (size_t)h->R * 8 + 4096 + 2 * 512 + 128 + 3072 + (size_t)h->R * 64;
-        const size_t TB = (size_t)h->R * 256;
+        const size_t TB = (size_t)(h->R / 4) * NGP_QS;  // LDS footprint of one tile (quads NGP_QS bytes apart)
         h->NS = 2;
         h->lds_sweep = std::max(2 * TB + misc, lds_sampler);
         if (h->lds_sweep > lds_max) return fail(h, NGP_ERR_ARG, "panel too tall for the persistent sweep (LDS)");
@@ -271,7 +271,7 @@ int set_panel_host(ngp_handle *h, const TIn *M, int64_t N, int64_t P, int64_t ld
                 double v = (double)col[i];
                 if (!std::isfinite(v)) return fail(h, NGP_ERR_ARG, "non-finite genotype value in panel");
                 int64_t s = i / R, ii = i - s * R;
-                buf[((size_t)s * NGP_BLK + jj) * R + ii] = (float)(v - mu);
+                buf[(size_t)s * NGP_BLK * R + tile_off((int)ii, jj)] = (float)(v - mu);
             }
         }
         HCHK(hipMemcpy(h->d_tiles + (size_t)t * blk_elems, buf.data(), blk_elems * sizeof(float), hipMemcpyHostToDevice));

@@ -215,6 +215,12 @@ __global__ __launch_bounds__(256) void k_prep(long long Ppad, const int8_t *__re
 // ------------------------------------------------------------------------------------------
 // streaming step of block t: (U) ycorr -= X_{t-1} dlt_{t-1}  then  (G) partial r = X_t' ycorr.
 // grid = S shards, 256 threads; tile (t,s) = [64 columns][R rows] fp32, contiguous.
+// Tile (t, s) = R rows x 64 columns of fp32, stored QUAD-MAJOR: element (row i, column j) sits at
+// (i >> 2) * 256 + j * 4 + (i & 3).  One quad (rows 4p..4p+3 of all 64 columns) is 1 KiB contiguous -- the unit of the
+// LDS-DMA, of the GEMV's 16-byte reads (lane = column: consecutive lanes, consecutive 16 bytes) and of the streamers'
+// row-half pipelining.
+__host__ __device__ inline size_t tile_off(int i, int j) { return ((size_t)(i >> 2) << 8) + (size_t)(j << 2) + (size_t)(i & 3); }
+
 // dynamic LDS: R*256 (tile) + R*8 (ycorr shard) + 4096 (chain partials)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_step(const float *__restrict__ tiles, double *__restrict__ ycorr,
@@ -236,7 +242,7 @@ __global__ __launch_bounds__(256) void k_step(const float *__restrict__ tiles, d
             for (int c = 0; c < 8; c++) {
                 double p = 0.0;
 #pragma unroll
-                for (int jj = 0; jj < 8; jj++) p = __builtin_fma((double)tp[(size_t)(8 * c + jj) * R + i], dlt[8 * c + jj], p);
+                for (int jj = 0; jj < 8; jj++) p = __builtin_fma((double)tp[tile_off(i, 8 * c + jj)], dlt[8 * c + jj], p);
                 p8[c] = p;
             }
             double T = ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
@@ -253,13 +259,13 @@ __global__ __launch_bounds__(256) void k_step(const float *__restrict__ tiles, d
     for (int idx = tid; idx < R * 16; idx += 256) dst[idx] = src[idx];
     __syncthreads();
     const int wv = tid >> 6, j = tid & 63;
-    const float *col = tl + (size_t)j * R;
+    const float *col = tl + 4 * j;  // quad qd of column j: tl + 256 qd + 4 j
     // 8 chains over strided row quads (chain c: quads c, c+8, ...); this 4-wave kernel runs chains wv and wv+4
 #pragma unroll
     for (int h = 0; h < 2; h++) {
         double acc = 0.0;
         for (int qd = wv + 4 * h; qd < (R >> 2); qd += 8) {
-            float4 x = *(const float4 *)(col + 4 * qd);
+            float4 x = *(const float4 *)(col + 256 * qd);
             const double *yq = ys + 4 * qd;
             acc = __builtin_fma((double)x.x, yq[0], acc);
             acc = __builtin_fma((double)x.y, yq[1], acc);
@@ -440,11 +446,12 @@ __global__ __launch_bounds__(256) void k_accum(long long P, long long nvb, int n
 // ------------------------------------------------------------------------------------------
 // shard partial of Gx[t][d][k][j] = x_{t-d,k}' x_{t,j} (d = 0: the symmetric diagonal block): 256 threads,
 // thread (tk,tj) owns a 4x4 sub-block; rows ascending; both tiles staged through LDS in chunks of RC rows
-#define NGP_GRAM_RC 128
+#define NGP_GRAM_RC 112
+#define NGP_GRAM_LD (NGP_GRAM_RC + 4)  // padded row stride of the staging tiles (bank spread of the transposing writes)
 __global__ __launch_bounds__(256) void k_gram_part(const float *__restrict__ tiles, double *__restrict__ gpart, int R, int S, int t0,
                                                    int d) {
-    __shared__ __attribute__((aligned(16))) float ta[NGP_BLK * NGP_GRAM_RC];
-    __shared__ __attribute__((aligned(16))) float tt[NGP_BLK * NGP_GRAM_RC];
+    __shared__ __attribute__((aligned(16))) float ta[NGP_BLK * NGP_GRAM_LD];
+    __shared__ __attribute__((aligned(16))) float tt[NGP_BLK * NGP_GRAM_LD];
     const int s = blockIdx.x, tb = blockIdx.y, tid = threadIdx.x;
     const int t = t0 + tb;
     const size_t tile_elems = (size_t)R * NGP_BLK;
@@ -460,18 +467,18 @@ __global__ __launch_bounds__(256) void k_gram_part(const float *__restrict__ til
     for (int i0 = 0; i0 < R; i0 += NGP_GRAM_RC) {
         const int rc = min(NGP_GRAM_RC, R - i0);  // multiple of 4
         __syncthreads();
-        for (int idx = tid; idx < NGP_BLK * (rc >> 2); idx += 256) {
-            int j = idx / (rc >> 2), q4 = idx - j * (rc >> 2);
-            *(float4 *)(tt + j * NGP_GRAM_RC + 4 * q4) = *(const float4 *)(src_t + (size_t)j * R + i0 + 4 * q4);
-            *(float4 *)(ta + j * NGP_GRAM_RC + 4 * q4) = *(const float4 *)(src_a + (size_t)j * R + i0 + 4 * q4);
+        for (int idx = tid; idx < NGP_BLK * (rc >> 2); idx += 256) {  // quad-major source: lanes run over the columns
+            const int j = idx & (NGP_BLK - 1), q4 = idx >> 6;
+            *(float4 *)(tt + j * NGP_GRAM_LD + 4 * q4) = *(const float4 *)(src_t + (size_t)((i0 >> 2) + q4) * 256 + 4 * j);
+            *(float4 *)(ta + j * NGP_GRAM_LD + 4 * q4) = *(const float4 *)(src_a + (size_t)((i0 >> 2) + q4) * 256 + 4 * j);
         }
         __syncthreads();
         for (int i = 0; i < rc; i += 4) {
             float4 xk[4], xj[4];
 #pragma unroll
             for (int a = 0; a < 4; a++) {
-                xk[a] = *(const float4 *)(ta + (4 * tk + a) * NGP_GRAM_RC + i);
-                xj[a] = *(const float4 *)(tt + (4 * tj + a) * NGP_GRAM_RC + i);
+                xk[a] = *(const float4 *)(ta + (4 * tk + a) * NGP_GRAM_LD + i);
+                xj[a] = *(const float4 *)(tt + (4 * tj + a) * NGP_GRAM_LD + i);
             }
 #pragma unroll
             for (int a = 0; a < 4; a++)
@@ -541,7 +548,7 @@ __global__ __launch_bounds__(256) void k_gen_fill(float *__restrict__ tiles, lon
     const long long t = blockIdx.y;
     float *tp = tiles + ((size_t)t * S + s) * ((size_t)R * NGP_BLK);
     for (int idx = threadIdx.x; idx < R * NGP_BLK; idx += 256) {
-        int jj = idx / R, ii = idx - jj * R;
+        const int ii = ((idx >> 8) << 2) + (idx & 3), jj = (idx >> 2) & (NGP_BLK - 1);  // idx is the quad-major offset
         long long i = (long long)s * R + ii, j = t * NGP_BLK + jj;
         float v = 0.0f;
         if (i < N && j < P) {
@@ -560,7 +567,7 @@ __global__ __launch_bounds__(256) void k_xbeta(const float *__restrict__ tiles, 
         double acc = 0.0;
         for (long long t = 0; t < NBLK; t++) {
             const float *tp = tiles + ((size_t)t * S + s) * ((size_t)R * NGP_BLK);
-            for (int j = 0; j < NGP_BLK; j++) acc = __builtin_fma((double)tp[(size_t)j * R + i], beta[t * NGP_BLK + j], acc);
+            for (int j = 0; j < NGP_BLK; j++) acc = __builtin_fma((double)tp[tile_off(i, j)], beta[t * NGP_BLK + j], acc);
         }
         out[(size_t)s * R + i] = acc;
     }

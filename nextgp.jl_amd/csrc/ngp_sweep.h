@@ -33,6 +33,9 @@
 #define NGP_DBG_WAVES (1u << 19)   // sampler: 8 words per block, end-of-work stamp of every wave
 #define NGP_DBG_RED (3u << 18)     // reducer 0: 2 words per block (counter complete, group sum published)
 #define NGP_DBG_ALL (7u << 17)     // every streamer: publish time of local block 800 and its XCC id
+// LDS distance of two quads of a tile: 1 KiB of data + 16 B, so that the update tasks (lanes = consecutive quads, same
+// columns) read conflict-free
+#define NGP_QS 1040
 #define NGP_DBG_STREAM (1u << 20)  // offset of streamer 0's stamps in the debug buffer
 
 namespace ngp {
@@ -140,9 +143,10 @@ template <int DT, int NGP_TPT>
 __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem) {
     const int R = A.R, S = A.S, tid = threadIdx.x;
     const int wv = tid >> 6, j = tid & 63;
-    const size_t TB = (size_t)R * 256;  // tile bytes (a multiple of 1 KiB)
-    char *ring = smem;                  // 2 slots of TB bytes
-    double *ys = (double *)(smem + 2 * TB);
+    const size_t TB = (size_t)R * 256;               // tile bytes in HBM: R/4 quads of 1 KiB (quad-major, ngp_kernels.h)
+    const size_t TBL = (size_t)(R >> 2) * NGP_QS;    // the same tile in LDS: quads NGP_QS bytes apart
+    char *ring = smem;                               // 2 slots of TBL bytes
+    double *ys = (double *)(smem + 2 * TBL);
     double *red = ys + R;                     // 8 x 64 chain partials
     double *dl = red + 512;                   // 2 x 64: dlt of the block being applied, double-buffered by iteration parity
     int *sflag = (int *)(dl + 128);
@@ -164,8 +168,8 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
     const int nb = A.t1 - A.t0;
     auto dma_tile = [&](int ub) {  // waves 4..6 copy tile ub into slot ub&1, 1 KiB per wave-instruction
         const char *src = (const char *)(A.tiles + ((size_t)(A.t0 + ub) * S + s) * tile_elems);
-        char *dst = ring + (size_t)(ub & 1) * TB;
-        for (int c = wv - 4; c < nchunk; c += 3) dma16_lds(src + (size_t)c * 1024 + (size_t)j * 16, dst + (size_t)c * 1024);
+        char *dst = ring + (size_t)(ub & 1) * TBL;
+        for (int c = wv - 4; c < nchunk; c += 3) dma16_lds(src + (size_t)c * 1024 + (size_t)j * 16, dst + (size_t)c * NGP_QS);
     };
     // wave 7: wait for dlt of local block (uu - DT) and stage it in dl[uu & 1]
     auto poll_dlt = [&](int uu) {
@@ -276,27 +280,28 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
                 const bool pollw = (wv == 7) && (DT >= 3) && (A.dbg_mode != 1) && (pa >= 0) && (u + 1 < nb + DT);
                 unsigned fl = 0;
                 if (pollw) fl = ld_u32(A.flag_dlt);
-                const float *slotp = (const float *)(ring + (size_t)(u & 1) * TB);
+                const float *slotp = (const float *)(ring + (size_t)(u & 1) * TBL);
                 {
-                    const float *tq = slotp + (size_t)(8 * tcc) * R + ti0;
+                    // rows ti0.. of columns 8 tcc + jj: quad ti0 >> 2, NGP_QS / 4 floats per quad, 4 floats per column
+                    const float *tq = slotp + (size_t)(ti0 >> 2) * (NGP_QS / 4) + 32 * tcc + (ti0 & 3);
 #pragma unroll
                     for (int jj = 0; jj < 8; jj++) {
                         if (NGP_TPT == 4) {
-                            const float4 v = *(const float4 *)(tq + jj * R);
+                            const float4 v = *(const float4 *)(tq + 4 * jj);
                             keep[d][0][jj] = v.x; keep[d][1 % NGP_TPT][jj] = v.y; keep[d][2 % NGP_TPT][jj] = v.z; keep[d][3 % NGP_TPT][jj] = v.w;
                         } else if (NGP_TPT == 2) {
-                            const float2 v = *(const float2 *)(tq + jj * R);
+                            const float2 v = *(const float2 *)(tq + 4 * jj);
                             keep[d][0][jj] = v.x; keep[d][1 % NGP_TPT][jj] = v.y;
                         } else {
-                            keep[d][0][jj] = tq[jj * R];
+                            keep[d][0][jj] = tq[4 * jj];
                         }
                     }
                 }
                 {   // chain wv: row quads wv, wv+8, ... (lane = column)
-                    const float *col = slotp + (size_t)j * R;
+                    const float *col = slotp + 4 * j;  // quad qd of column j: NGP_QS qd + 16 j bytes -- consecutive lanes, consecutive 16 B
                     double acc = 0.0;
                     for (int qd = wv; qd < (R >> 2); qd += 8) {
-                        float4 x = *(const float4 *)(col + 4 * qd);
+                        float4 x = *(const float4 *)(col + (size_t)qd * (NGP_QS / 4));
                         const double *yq = ys + 4 * qd;
                         acc = __builtin_fma((double)x.x, yq[0], acc);
                         acc = __builtin_fma((double)x.y, yq[1], acc);
