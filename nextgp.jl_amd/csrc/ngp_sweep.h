@@ -63,7 +63,7 @@ struct SweepArgs {
     unsigned *xcc_w;     // sampler's XCC id + 1 (speed only: same-XCD streamers warm the L2 with Gram blocks)
     unsigned long long *dbg;  // optional time stamps (diagnostic runs only), else nullptr
     int dbg_mode;             // diagnostic timing runs, results invalid: 1 = streamers only move tiles, 2 = sampler alone
-                              // (never waits), 3 = streamers + reducers alone (never wait for dlt)
+                              // (never waits), 3 = streamers + reducers alone (never wait for dlt), 4 = as 3 without the tile DMA
 };
 
 __device__ inline unsigned ld_u32(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -167,6 +167,7 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
     const int g = s / NGP_GRP;
     const int nb = A.t1 - A.t0;
     auto dma_tile = [&](int ub) {  // waves 4..6 copy tile ub into slot ub&1, 1 KiB per wave-instruction
+        if (A.dbg_mode == 4) return;  // timing experiment: the compute phases without the stream
         const char *src = (const char *)(A.tiles + ((size_t)(A.t0 + ub) * S + s) * tile_elems);
         char *dst = ring + (size_t)(ub & 1) * TBL;
         for (int c = wv - 4; c < nchunk; c += 3) dma16_lds(src + (size_t)c * 1024 + (size_t)j * 16, dst + (size_t)c * NGP_QS);
@@ -177,7 +178,7 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
         if (aa < 0 || uu >= nb + DT) return;
         int ok = 1;
         if (j == 0) {
-            ok = (A.dbg_mode == 3 || wait_ge(A.flag_dlt, (unsigned)(aa + 1), A.abort_w, 1u)) ? 1 : 0;
+            ok = (A.dbg_mode >= 3 || wait_ge(A.flag_dlt, (unsigned)(aa + 1), A.abort_w, 1u)) ? 1 : 0;
             if (A.dbg && s == 0) A.dbg[NGP_DBG_STREAM + 2 * (size_t)uu + 1] = wall_clock64();
             if (!ok) *sflag = 0;
         }
@@ -201,8 +202,9 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
     for (int i = tid; i < R; i += NGP_WG) ys[i] = yg[i];
     if (tid == 0) *sflag = 1;
     if (wv >= 4 && wv <= 6 && nb > 0) dma_tile(0);
-    // speed only: streamers that share the sampler's XCD pull the Gram blocks of the block after their own
-    // into that XCD's L2, so the sampler CU (one CU, latency-bound on HBM) finds them there
+    // speed only, but worth 25 % at 10k x 100k (3.35 -> 4.43 ms/iteration without it): streamers that share the sampler's
+    // XCD pull the Gram blocks of the block after their own into that XCD's L2, so the sampler CU (one CU, latency-bound)
+    // finds them there
     const unsigned my_xcc = xcc_id() + 1u;
     const int nslice = max(1, S / 8);
     const int slice = (s / 8) % nslice;
@@ -315,7 +317,7 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
                 bool have_dnext = false;
                 if (pollw) {
                     int ok = 1;
-                    if (__shfl((int)fl, 0) < pa + 1 && A.dbg_mode != 3) {
+                    if (__shfl((int)fl, 0) < pa + 1 && A.dbg_mode < 3) {
                         if (j == 0) {
                             ok = wait_ge(A.flag_dlt, (unsigned)(pa + 1), A.abort_w, 1u) ? 1 : 0;
                             if (!ok) *sflag = 0;
@@ -398,7 +400,7 @@ __device__ inline void role_reducer(const SweepArgs &A, const int g) {
 #pragma unroll
             for (int kk = 0; kk < NGP_BLK; kk++) gr[kk] = gx[kk * NGP_BLK];
             int okd = 1;
-            if (lane == 0) okd = (A.dbg_mode == 3 || wait_ge(A.flag_dlt, (unsigned)(a + 1), A.abort_w, 4u)) ? 1 : 0;
+            if (lane == 0) okd = (A.dbg_mode >= 3 || wait_ge(A.flag_dlt, (unsigned)(a + 1), A.abort_w, 4u)) ? 1 : 0;
             okd = __shfl(okd, 0);
             if (!okd) return;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -768,7 +770,7 @@ __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x;
     if (A.dbg_mode == 1 && b <= A.NG) return;
-    if ((A.dbg_mode == 2 && b != 0) || (A.dbg_mode == 3 && b == 0)) return;
+    if ((A.dbg_mode == 2 && b != 0) || ((A.dbg_mode == 3 || A.dbg_mode == 4) && b == 0)) return;
     if (b == 0)
         role_sampler(A, smem);
     else if (b <= A.NG)
