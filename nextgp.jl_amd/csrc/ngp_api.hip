@@ -207,6 +207,7 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
         const size_t TB = (size_t)(h->R / 4) * NGP_QS;  // LDS footprint of one tile (quads NGP_QS bytes apart)
         h->NS = 2;
         h->lds_sweep = std::max(2 * TB + misc, lds_sampler);
+        if (2 * TB + misc + 8192 <= lds_max) h->lds_sweep = std::max(h->lds_sweep, 2 * TB + misc + 8192);  // room for the diagnostic timeline
         if (h->lds_sweep > lds_max) return fail(h, NGP_ERR_ARG, "panel too tall for the persistent sweep (LDS)");
         HCHK(hipFuncSetAttribute((const void *)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_sweep));
         if ((rc = dalloc(h, &h->d_cpart, (size_t)NGP_RING * h->S * NGP_BLK))) return rc;
@@ -320,6 +321,7 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
         A.flag_dlt = A.cnt_gs + (size_t)NGP_RING * 32; A.abort_w = h->d_abort; A.xcc_w = h->d_abort + 16;
         if (evs) (void)hipEventRecord(evs[0], h->stream);
         A.dbg = h->d_dbg;
+        A.NS = ((size_t)2 * (R / 4) * NGP_QS + (size_t)R * 72 + 8320 + 8192 <= h->lds_sweep) ? 1 : 0;  // diagnostic timeline fits in LDS
         { const char *e = getenv("NGP_DEBUG_MODE"); A.dbg_mode = e ? atoi(e) : 0; }
         hipLaunchKernelGGL(k_sweep, dim3((unsigned)(1 + h->NG + S)), dim3(NGP_WG), h->lds_sweep, h->stream, A);
         if (evs) (void)hipEventRecord(evs[1], h->stream);
