@@ -35,6 +35,7 @@ extern "C" {
 
 #define NGP_METHOD_BAYESPR 0 /* src/runTime.jl:30-45 */
 #define NGP_METHOD_BAYESB 1  /* src/runTime.jl:48-61 */
+#define NGP_METHOD_BAYESC 2  /* src/runTime.jl:64-77, sampler src/functions.jl:197-235 */
 
 typedef struct ngp_handle ngp_handle;
 
@@ -79,7 +80,8 @@ int32_t ngp_xbeta(ngp_handle *h, const double *beta, int64_t P, double *out, int
  * method NGP_METHOD_*; df, scale as computed at src/mme.jl:493,501; regions are 0-based
  * [reg_start[r], reg_stop[r]) relative to the set (M[set][:regionArray], src/mme.jl:335-358);
  * varBeta0 holds nreg initial variances (src/mme.jl:516); BayesB needs nreg == ncol (one region
- * per locus, src/mme.jl:356), pi0 = prior inclusion probability, estPi (src/mme.jl:359);
+ * per locus, src/mme.jl:356), pi0 = prior inclusion probability, estPi (src/mme.jl:359); BayesC has nreg == 1 (one
+ * variance for the whole set, src/functions.jl:205,231) and, like the reference, ignores rhs0 (src/functions.jl:220);
  * lhs0/rhs0 (ncol each or NULL) are the summary-statistics terms (src/mme.jl:314-322). */
 int32_t ngp_add_marker_set(ngp_handle *h, int64_t col0, int64_t ncol, int32_t method, double df, double scale,
                            const int64_t *reg_start, const int64_t *reg_stop, int64_t nreg, const double *varBeta0,

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NGP_HIP_LIB") or os.path.join(_HERE, "libnextgp_hip.so")  # override: a library built elsewhere
 
-METHOD_BAYESPR, METHOD_BAYESB = 0, 1
+METHOD_BAYESPR, METHOD_BAYESB, METHOD_BAYESC = 0, 1, 2
 
 # every symbol include/nextgp_hip.h declares
 SYMBOLS = [

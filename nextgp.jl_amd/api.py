@@ -22,9 +22,9 @@ from typing import Optional
 
 import numpy as np
 
-from ._lib import METHOD_BAYESB, METHOD_BAYESPR, Sampler
+from ._lib import METHOD_BAYESB, METHOD_BAYESC, METHOD_BAYESPR, Sampler
 
-__all__ = ["BayesPR", "BayesB", "Random", "SNP", "runLMEM", "summaryMCMC", "read_genotypes", "prep2RegionData", "parse_formula"]
+__all__ = ["BayesPR", "BayesB", "BayesC", "Random", "SNP", "runLMEM", "summaryMCMC", "read_genotypes", "prep2RegionData", "parse_formula"]
 
 
 # ----------------------------------------------------------------------------------------------
@@ -42,6 +42,14 @@ class BayesBType:  # src/runTime.jl:48-61
     pi: float
     v: float
     name: str = "BayesB"
+    estimatePi: bool = False
+
+
+@dataclass
+class BayesCType:  # src/runTime.jl:64-77
+    pi: float
+    v: float
+    name: str = "BayesC"
     estimatePi: bool = False
 
 
@@ -65,6 +73,10 @@ def BayesPR(r, v, name="BayesPR"):
 
 def BayesB(pi, v, name="BayesB", estimatePi=False):
     return BayesBType(float(pi), float(v), name, bool(estimatePi))
+
+
+def BayesC(pi, v, name="BayesC", estimatePi=False):
+    return BayesCType(float(pi), float(v), name, bool(estimatePi))
 
 
 def Random(str, v, type=1):
@@ -178,6 +190,8 @@ def _regions_for(prior, P, map_path, out_folder, set_name):
     """M[set][:regionArray] (src/mme.jl:324-358)."""
     if isinstance(prior, BayesBType):
         return [(j, j + 1) for j in range(P)]
+    if isinstance(prior, BayesCType):  # one variance for the set (nVarCov = 1, src/mme.jl:370)
+        return [(0, P)]
     if not map_path:
         if prior.r == 1:
             return [(j, j + 1) for j in range(P)]
@@ -256,8 +270,8 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
         prior = VCV.get(t.name)
         if prior is None:  # src/mme.jl:324-329, 504, 518
             prior = BayesPR(9999, 0.05)
-        if not isinstance(prior, (BayesPRType, BayesBType)):
-            raise NotImplementedError(f"prior {type(prior).__name__} for {t.name}: only BayesPR and BayesB are on the accelerated path")
+        if not isinstance(prior, (BayesPRType, BayesBType, BayesCType)):
+            raise NotImplementedError(f"prior {type(prior).__name__} for {t.name}: only BayesPR, BayesB and BayesC are on the accelerated path")
         df = 4.0                                  # 3 + size(v,1), src/mme.jl:493
         scale = prior.v * (df - 2.0) / df         # src/mme.jl:501
         regions = _regions_for(prior, P, t.map, outFolder, t.name)
@@ -268,6 +282,9 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
             rhs0 = np.nan_to_num(lhs0 * m)
         if isinstance(prior, BayesBType):
             sid = smp.add_marker_set(col0, P, METHOD_BAYESB, df, scale, regions, [prior.v] * P, pi0=prior.pi, estPi=prior.estimatePi,
+                                     lhs0=lhs0, rhs0=rhs0)
+        elif isinstance(prior, BayesCType):
+            sid = smp.add_marker_set(col0, P, METHOD_BAYESC, df, scale, regions, [prior.v], pi0=prior.pi, estPi=prior.estimatePi,
                                      lhs0=lhs0, rhs0=rhs0)
         else:
             sid = smp.add_marker_set(col0, P, METHOD_BAYESPR, df, scale, regions, [prior.v] * len(regions), lhs0=lhs0, rhs0=rhs0)
@@ -283,7 +300,7 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
             names = [f"M{i + 1}" for i in range(s["P"])]  # src/prepMatVec.jl:131
             _out(outFolder, f"beta{s['name']}", names)
             _out(outFolder, f"delta{s['name']}", names)
-            if isinstance(s["prior"], BayesBType):
+            if isinstance(s["prior"], (BayesBType, BayesCType)):  # src/samplers.jl:80-82
                 _out(outFolder, f"pi{s['name']}", ["pi1", "pi2"])
             _out(outFolder, f"var{s['name']}", [f"reg_{r + 1}" for r in range(s["nreg"])])
     # the chain (src/samplers.jl:29-105): kept iterations = burnIn+thin : thin : chainLength
@@ -300,7 +317,7 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
                 sl = slice(s["col0"], s["col0"] + s["P"])
                 _out(outFolder, f"beta{s['name']}", _fmt(st["beta"][sl]))
                 _out(outFolder, f"delta{s['name']}", [str(int(v)) for v in st["delta"][sl]])
-                if isinstance(s["prior"], BayesBType):
+                if isinstance(s["prior"], (BayesBType, BayesCType)):
                     _out(outFolder, f"pi{s['name']}", _fmt(st["piHat"][2 * k:2 * k + 2]))
                 _out(outFolder, f"var{s['name']}", _fmt(st["varBeta"][vb_off:vb_off + s["nreg"]]))
                 vb_off += s["nreg"]

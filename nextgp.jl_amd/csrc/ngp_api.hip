@@ -360,7 +360,7 @@ void launch_variance(ngp_handle *h, int active_set, uint64_t it) {
         hipLaunchKernelGGL(k_regssq, dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, h->stream, nseg, h->d_seg_k0, h->d_seg_len,
                            h->d_beta, h->d_segpart);
         hipLaunchKernelGGL(k_regdraw, dim3((unsigned)((nreg + 63) / 64)), dim3(64), 0, h->stream, nreg, h->d_regs, h->d_segpart,
-                           h->d_sets, h->d_varBeta, active_set, h->d_regchi);
+                           h->d_sets, h->d_varBeta, active_set, h->d_regchi, h->seed, (uint64_t)h->chain, it);
     }
     hipLaunchKernelGGL(k_pidraw, dim3(1), dim3(64), 0, h->stream, (int)h->sets.size(), h->d_sets, active_set, h->seed,
                        (uint64_t)h->chain, it);
@@ -531,13 +531,18 @@ int32_t ngp_add_marker_set(ngp_handle *h, int64_t col0, int64_t ncol, int32_t me
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
     REQUIRE(h->sets.size() < 16, NGP_ERR_ARG, "at most 16 marker sets");
     REQUIRE(col0 >= 0 && ncol > 0 && col0 + ncol <= h->P, NGP_ERR_ARG, "marker set outside the panel");
-    REQUIRE(method == NGP_METHOD_BAYESPR || method == NGP_METHOD_BAYESB, NGP_ERR_ARG, "unknown method");
+    REQUIRE(method == NGP_METHOD_BAYESPR || method == NGP_METHOD_BAYESB || method == NGP_METHOD_BAYESC, NGP_ERR_ARG, "unknown method");
     REQUIRE(reg_start && reg_stop && varBeta0 && nreg > 0, NGP_ERR_ARG, "regions / varBeta0 missing");
     REQUIRE(std::isfinite(df) && std::isfinite(scale) && df > 0, NGP_ERR_ARG, "df/scale must be finite, df > 0");
     for (int64_t k = col0; k < col0 + ncol; k++) REQUIRE(h->h_setof[k] < 0, NGP_ERR_ARG, "marker sets overlap");
     if (method == NGP_METHOD_BAYESB) {
         REQUIRE(nreg == ncol, NGP_ERR_ARG, "BayesB needs one region per locus (src/mme.jl:356)");
         REQUIRE(pi0 > 0.0 && pi0 < 1.0, NGP_ERR_ARG, "BayesB pi must be in (0,1)");
+    }
+    if (method == NGP_METHOD_BAYESC) {
+        REQUIRE(nreg == 1, NGP_ERR_ARG, "BayesC has one variance for the whole set (src/functions.jl:205)");
+        REQUIRE(pi0 > 0.0 && pi0 < 1.0, NGP_ERR_ARG, "BayesC pi must be in (0,1)");
+        REQUIRE(varBeta0[0] > 0.0, NGP_ERR_ARG, "BayesC varBeta0 must be positive");
     }
     // regions must tile [0,ncol) in order (regionArray of UnitRanges, src/mme.jl:335-347)
     int64_t expect = 0;
@@ -572,7 +577,7 @@ int32_t ngp_add_marker_set(ngp_handle *h, int64_t col0, int64_t ncol, int32_t me
             h->h_loc[k] = (int32_t)l;
             h->h_vbidx[k] = (int32_t)(h->nvb + (method == NGP_METHOD_BAYESB ? l : r));
         }
-    if (method == NGP_METHOD_BAYESPR) {
+    if (method == NGP_METHOD_BAYESPR || method == NGP_METHOD_BAYESC) {  // sets whose variance comes from a sum of squares
         for (int64_t r = 0; r < nreg; r++) {
             DReg dr;
             dr.seg0 = (long long)h->h_seg_k0.size();
@@ -803,13 +808,13 @@ int32_t ngp_sweep_set(ngp_handle *h, int32_t set_id, double varE, double *ycorr,
     if ((rc = sync_tables(h))) return rc;
     HSet &hs = h->sets[set_id];
     for (int64_t r = 0; r < hs.nreg; r++) REQUIRE(std::isfinite(varBeta[r]) && varBeta[r] >= 0.0, NGP_ERR_ARG, "varBeta must be finite, >= 0");
-    if (hs.method == NGP_METHOD_BAYESB) REQUIRE(piHat != nullptr, NGP_ERR_ARG, "BayesB needs piHat");
+    if (hs.method != NGP_METHOD_BAYESPR) REQUIRE(piHat != nullptr, NGP_ERR_ARG, "BayesB / BayesC need piHat");
     const uint64_t it = ++hs.fine_calls;
     HCHK(hipMemsetAsync(h->d_ycorr, 0, (size_t)h->L * sizeof(double), h->stream));
     HCHK(hipMemcpyAsync(h->d_ycorr, ycorr, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HCHK(hipMemcpyAsync(h->d_beta + hs.col0, beta, (size_t)hs.ncol * sizeof(double), hipMemcpyHostToDevice, h->stream));
     HCHK(hipMemcpyAsync(h->d_varBeta + hs.vb_off, varBeta, (size_t)hs.nreg * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if (hs.method == NGP_METHOD_BAYESB)
+    if (hs.method != NGP_METHOD_BAYESPR)
         hipLaunchKernelGGL(k_set_pi, dim3(1), dim3(1), 0, h->stream, h->d_sets, (int)set_id, piHat[0], piHat[1]);
     hipLaunchKernelGGL(k_set_varE, dim3(1), dim3(1), 0, h->stream, h->d_scal, varE);
     hipLaunchKernelGGL(k_prep, dim3((unsigned)(h->Ppad / 256 + 1)), dim3(256), 0, h->stream, (long long)h->Ppad, h->d_setof, h->d_loc,

@@ -142,8 +142,10 @@ __global__ __launch_bounds__(256) void k_prep(long long Ppad, const int8_t *__re
     long long k = (long long)blockIdx.x * 256 + threadIdx.x;
     if (k < nreg) {  // data-independent draws of the region variances (functions.jl:509-511): off the post-sweep path
         const DReg Rg = regs[k];
-        Rng rr = rng_seed(seed, chain, it, NGP_KIND_REGION_CHI2, ((uint64_t)Rg.set << 40) | (uint64_t)Rg.rg);
-        regchi[k] = rng_chisq(rr, sets[Rg.set].df + (double)Rg.n);
+        if (sets[Rg.set].method == 0) {  // BayesC's degrees of freedom depend on the sweep: drawn in k_regdraw
+            Rng rr = rng_seed(seed, chain, it, NGP_KIND_REGION_CHI2, ((uint64_t)Rg.set << 40) | (uint64_t)Rg.rg);
+            regchi[k] = rng_chisq(rr, sets[Rg.set].df + (double)Rg.n);
+        }
     }
     if (k >= Ppad) return;
     int si = setof[k];
@@ -171,11 +173,11 @@ __global__ __launch_bounds__(256) void k_prep(long long Ppad, const int8_t *__re
     Rng r = rng_seed(seed, chain, it, NGP_KIND_BETA_NORMAL, key);
     double z = rng_normal(r);
     double sz = s * z;
-    double tw = rhs0[k] * ilhs;
+    double tw = (S.method == 2) ? 0.0 : rhs0[k] * ilhs;  // BayesC drops M.rhs (src/functions.jl:220)
     tw = tw + sz;
     c[k] = cc;
     w[k] = tw - beta[k];
-    if (S.method == 1) {
+    if (S.method >= 1) {  // BayesB / BayesC inclusion step (src/functions.jl:169-174, 210-217)
         double v0 = m * varE;
         double m2 = m * m;
         m2 = m2 * vbk;
@@ -203,8 +205,12 @@ __global__ __launch_bounds__(256) void k_prep(long long Ppad, const int8_t *__re
         // threshold on f = c r instead of r (c > 0 when finite): thr = st c; -1 always, inf never
         q[k] = (st < 0.0) ? -1.0 : ((st == __builtin_huge_val()) ? st : st * cc);
         T[k] = TT;
-        Rng rc = rng_seed(seed, chain, it, NGP_KIND_B_LOCUS_CHI2, key);
-        chi[k] = rng_chisq(rc, S.df + 1.0);
+        if (S.method == 1) {
+            Rng rc = rng_seed(seed, chain, it, NGP_KIND_B_LOCUS_CHI2, key);
+            chi[k] = rng_chisq(rc, S.df + 1.0);
+        } else {
+            chi[k] = 1.0;
+        }
     } else {
         q[k] = -1.0;  // BayesPR: always included
         T[k] = 1.0;
@@ -341,6 +347,8 @@ __global__ __launch_bounds__(256) void k_recur(const double *__restrict__ part, 
             atomicAdd(&sets[si].nloci, 1);
         }
         varBeta[vbidx[k]] = vb;
+    } else if (si >= 0 && sets[si].method == 2) {
+        if (isave) atomicAdd(&sets[si].nloci, 1);  // BayesC: one variance per set, drawn after the sweep
     }
 }
 
@@ -372,7 +380,7 @@ __global__ __launch_bounds__(256) void k_regssq(long long nseg, const long long 
 
 __global__ __launch_bounds__(64) void k_regdraw(long long nreg, const DReg *__restrict__ regs, const double *__restrict__ segpart,
                                                 const DSet *__restrict__ sets, double *__restrict__ varBeta, int active_set,
-                                                const double *__restrict__ regchi) {
+                                                const double *__restrict__ regchi, uint64_t seed, uint64_t chain, uint64_t it) {
     long long rg = (long long)blockIdx.x * 64 + threadIdx.x;
     if (rg >= nreg) return;
     const DReg R = regs[rg];
@@ -380,7 +388,11 @@ __global__ __launch_bounds__(64) void k_regdraw(long long nreg, const DReg *__re
     double tot = segpart[R.seg0];
     for (int s = 1; s < R.nseg; s++) tot = tot + segpart[R.seg0 + s];
     const DSet S = sets[R.set];
-    const double ch = regchi[rg];  // chi-square(df + n_r) of this iteration, drawn ahead of the sweep by k_prep
+    double ch = regchi[rg];  // chi-square(df + n_r) of this iteration, drawn ahead of the sweep by k_prep
+    if (S.method == 2) {     // BayesC (src/functions.jl:231): df + number of loci the sweep has just included
+        Rng rr = rng_seed(seed, chain, it, NGP_KIND_REGION_CHI2, ((uint64_t)R.set << 40) | (uint64_t)R.rg);
+        ch = rng_chisq(rr, S.df + (double)S.nloci);
+    }
     double tt = S.scale * S.df;
     tt = tt + tot;
     varBeta[R.vb] = tt / ch;
@@ -392,7 +404,7 @@ __global__ void k_pidraw(int nsets, DSet *__restrict__ sets, int active_set, uin
     if (si >= nsets) return;
     if (active_set >= 0 && si != active_set) return;
     DSet *S = &sets[si];
-    if (S->method == 1 && S->estPi) {
+    if (S->method >= 1 && S->estPi) {
         int nLoci = S->nloci;
         Rng r = rng_seed(seed, chain, it, NGP_KIND_PI_BETA, (uint64_t)si);
         double piIn = rng_beta(r, (double)nLoci + 1.0, (double)(S->ncol - nLoci) + 1.0);

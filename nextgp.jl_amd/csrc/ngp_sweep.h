@@ -485,6 +485,8 @@ __device__ inline void publish_block(const SweepArgs &A, int up, int j, const do
             atomicAdd(&A.sets[si].nloci, 1);
         }
         A.varBeta[A.vbidx[k]] = vb;
+    } else if (si >= 0 && A.sets[si].method == 2) {
+        if (isave) atomicAdd(&A.sets[si].nloci, 1);  // BayesC: one variance per set, drawn after the sweep
     }
 }
 

@@ -64,9 +64,9 @@ run!(h::Handle, niter) = check(h, ccall((:ngp_run, LIB), Int32, (Ptr{Cvoid}, Int
 """
     sweep!(h, set_id, mSet, M, beta, delta, ycorr, varE, varBeta)
 
-Fine seam: same argument list as the reference's `sampleBayesPR!/sampleBayesB!(mSet, M, beta, delta, ycorr, varE, varBeta)`
-(src/functions.jl:118,157) plus the handle and the set id.  Mutates `beta[M[mSet].pos]`, `delta[M[mSet].pos]`, `ycorr`,
-`varBeta[mSet]` and, for BayesB, `M[mSet].piHat` / `M[mSet].logPi` in place.
+Fine seam: same argument list as the reference's `sampleBayesPR!/sampleBayesB!/sampleBayesC!(mSet, M, beta, delta, ycorr,
+varE, varBeta)` (src/functions.jl:118,157,197) plus the handle and the set id.  Mutates `beta[M[mSet].pos]`, `delta[M[mSet].pos]`, `ycorr`,
+`varBeta[mSet]` and, for BayesB / BayesC, `M[mSet].piHat` / `M[mSet].logPi` in place.
 """
 function sweep!(h::Handle, set_id::Integer, mSet, M, beta, delta, ycorr::Vector{Float64}, varE::Float64, varBeta)
     b = vec(beta[M[mSet].pos])                 # 1 x P Matrix{Float64}: vec() shares the memory
@@ -88,7 +88,7 @@ end
     runSampler!(ycorr, nData, E, X, b, Z, u, varU, M, beta, varBeta, delta, chainLength, burnIn, outputFreq, outPut; seed=1)
 
 Coarse seam: drop-in for `samplers.runSampler!` (src/samplers.jl:23) for models made of an intercept and
-Symbol marker sets with BayesPR / BayesB priors.  Anything else falls back to the reference sampler.
+Symbol marker sets with BayesPR / BayesB / BayesC priors.  Anything else falls back to the reference sampler.
 """
 function runSampler!(ycorr, nData, E, X, b, Z, u, varU, M, beta, varBeta, delta, chainLength, burnIn, outputFreq, outPut;
                      seed::Integer=1, device::Integer=0)
@@ -103,10 +103,12 @@ function runSampler!(ycorr, nData, E, X, b, Z, u, varU, M, beta, varBeta, delta,
     ids = Dict{Any,Int32}()
     for s in sets
         P = M[s].dims[2]
-        method = M[s].method == "BayesB" ? 1 : 0
-        ids[s] = add_marker_set!(h, col0, P, method, Float64(M[s].df), Float64(M[s].scale), M[s].regionArray,
-                                 Float64.(varBeta[s]); pi0 = method == 1 ? M[s].piHat[2] : 0.0,
-                                 estPi = method == 1 ? M[s].estPi : false, lhs0 = Float64.(M[s].lhs), rhs0 = Float64.(M[s].rhs))
+        method = M[s].method == "BayesB" ? 1 : (M[s].method == "BayesC" ? 2 : 0)
+        # BayesC loops over one-locus ranges but has ONE variance (nVarCov = 1, src/mme.jl:370): a single region for the library
+        regions = method == 2 ? [1:P] : M[s].regionArray
+        ids[s] = add_marker_set!(h, col0, P, method, Float64(M[s].df), Float64(M[s].scale), regions,
+                                 Float64.(varBeta[s]); pi0 = method >= 1 ? M[s].piHat[2] : 0.0,
+                                 estPi = method >= 1 ? M[s].estPi : false, lhs0 = Float64.(M[s].lhs), rhs0 = Float64.(M[s].rhs))
         col0 += P
     end
     set_y!(h, Vector{Float64}(ycorr))            # ycorr == y at this point (src/mme.jl:57)
@@ -130,7 +132,7 @@ function runSampler!(ycorr, nData, E, X, b, Z, u, varU, M, beta, varBeta, delta,
             P = M[s].dims[2]
             open(io -> writedlm(io, bet[c0+1:c0+P]'), outPut * "/beta$(s)Out", "a")    # :80
             open(io -> writedlm(io, del[c0+1:c0+P]'), outPut * "/delta$(s)Out", "a")   # :81
-            M[s].method == "BayesB" && open(io -> writedlm(io, pih[2k-1:2k]'), outPut * "/pi$(s)Out", "a")   # :83
+            M[s].method in ("BayesB", "BayesC") && open(io -> writedlm(io, pih[2k-1:2k]'), outPut * "/pi$(s)Out", "a")   # :80-82
             nr = length(varBeta[s])
             open(io -> writedlm(io, vb[v0+1:v0+nr]'), outPut * "/var$(s)Out", "a")     # :101-103
             c0 += P; v0 += nr

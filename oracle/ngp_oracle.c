@@ -58,6 +58,7 @@
 
 #define METHOD_PR 0
 #define METHOD_B 1
+#define METHOD_C 2 /* BayesC: src/functions.jl:197-235 */
 
 #define BLK 64
 #define SEG 256
@@ -555,6 +556,46 @@ static void iter_ref(ora_t *h) {
                 double n_r = (double)(S->reg_stop[rg] - S->reg_start[rg]);
                 vb[rg] = (S->scale * S->df + ssq) / rng_chisq(&r, S->df + n_r);         /* :135, :509-511 */
             }
+        } else if (S->method == METHOD_C) {
+            /* functions.jl:197-235: BayesC = BayesB's inclusion step with ONE variance for the whole set, redrawn after the
+               sweep from all effects (excluded ones are 0) with nLoci included loci (:231, :509-511).  Note the
+               reference's rhs omits M.rhs here (:220, commented out) while lhs keeps M.lhs (:221). */
+            int64_t nLoci = 0;
+            const double iVarBeta = 1.0 / vb[0];                                          /* :205 */
+            double ssq = 0.0;
+            for (int64_t l = 0; l < S->ncol; l++) {
+                int64_t j = S->col0 + l;
+                const double *col = h->data + j * N, *mp = h->Mp + j * N;
+                axpy(h->beta[j], col, h->ycorr, N);                                       /* :208 */
+                double rrr = dot8(col, h->ycorr, N);                                      /* :209 */
+                double v0 = h->mpm[j] * varE;                                             /* :210 */
+                double v1 = (h->mpm[j] * h->mpm[j]) * vb[0] + v0;                         /* :211 */
+                double logDelta0 = -0.5 * (log(v0) + (rrr * rrr) / v0) + S->logPi[0];    /* :213 */
+                double logDelta1 = -0.5 * (log(v1) + (rrr * rrr) / v1) + S->logPi[1];    /* :214 */
+                double probDelta1 = 1.0 / (1.0 + exp(logDelta0 - logDelta1));            /* :216 */
+                rng_seed(&r, h->seed, h->chain, it, KIND_B_UNIFORM, ((uint64_t)si << 40) | (uint64_t)l);
+                double u = rng_uniform(&r);
+                if (u < probDelta1) {                                                     /* :217 */
+                    h->delta[j] = 1; nLoci++;
+                    double rhs = dot8(mp, h->ycorr, N) * iVarE;                           /* :220 */
+                    double lhs = h->mpm[j] * iVarE + h->lhs0[j] + iVarBeta;               /* :221 */
+                    double mean = rhs / lhs;
+                    rng_seed(&r, h->seed, h->chain, it, KIND_BETA_NORMAL, ((uint64_t)si << 40) | (uint64_t)l);
+                    h->beta[j] = mean + sqrt(1.0 / lhs) * rng_normal(&r);                 /* :223 */
+                    axpy(-1.0 * h->beta[j], col, h->ycorr, N);                            /* :224 */
+                } else {
+                    h->beta[j] = 0.0; h->delta[j] = 0;                                    /* :226-227 */
+                }
+                ssq = __builtin_fma(h->beta[j], h->beta[j], ssq);
+            }
+            rng_seed(&r, h->seed, h->chain, it, KIND_REGION_CHI2, ((uint64_t)si << 40));
+            vb[0] = (S->scale * S->df + ssq) / rng_chisq(&r, S->df + (double)nLoci);     /* :231 */
+            if (S->estPi) {                                                               /* :232-236 */
+                rng_seed(&r, h->seed, h->chain, it, KIND_PI_BETA, (uint64_t)si);
+                double piIn = rng_beta(&r, (double)nLoci + 1.0, (double)(S->ncol - nLoci) + 1.0);
+                S->piHat[0] = 1.0 - piIn; S->piHat[1] = piIn;
+                S->logPi[0] = log(1.0 - piIn); S->logPi[1] = log(piIn);
+            }
         } else {
             /* functions.jl:157-195; one region per locus (mme.jl:356-358) */
             int64_t nLoci = 0;
@@ -660,9 +701,10 @@ static void iter_blocked(ora_t *h) {
                 rng_seed(&r, h->seed, h->chain, it, KIND_BETA_NORMAL, ((uint64_t)si << 40) | (uint64_t)l);
                 double z = rng_normal(&r);
                 double sz = s * z;
-                double tw = h->rhs0[k] * ilhs; tw = tw + sz;
+                double tw = (Sx->method == METHOD_C) ? 0.0 : h->rhs0[k] * ilhs; /* BayesC drops M.rhs (functions.jl:220) */
+                tw = tw + sz;
                 h->c[k] = c; h->w[k] = tw - h->beta[k];
-                if (Sx->method == METHOD_B) {
+                if (Sx->method == METHOD_B || Sx->method == METHOD_C) {
                     double v0 = mpm * varE;
                     double m2 = mpm * mpm; m2 = m2 * vbk; double v1 = m2 + v0;
                     double i1 = 1.0 / v1, i0 = 1.0 / v0; double dq = i1 - i0;
@@ -681,8 +723,10 @@ static void iter_blocked(ora_t *h) {
                     else st = (0.0 < TT) ? -1.0 : INFINITY;
                     /* threshold on f = c r instead of r (c > 0 when finite): thr = st c; -1 always, inf never */
                     h->q[k] = (st < 0.0) ? -1.0 : (isinf(st) ? INFINITY : st * c); h->T[k] = TT;
-                    rng_seed(&r, h->seed, h->chain, it, KIND_B_LOCUS_CHI2, ((uint64_t)si << 40) | (uint64_t)l);
-                    h->chi[k] = rng_chisq(&r, Sx->df + 1.0);
+                    if (Sx->method == METHOD_B) {
+                        rng_seed(&r, h->seed, h->chain, it, KIND_B_LOCUS_CHI2, ((uint64_t)si << 40) | (uint64_t)l);
+                        h->chi[k] = rng_chisq(&r, Sx->df + 1.0);
+                    }
                 }
             }
     }
@@ -793,7 +837,10 @@ static void iter_blocked(ora_t *h) {
     for (int si = 0; si < h->nsets; si++) {
         oset_t *Sx = &h->sets[si];
         double *vb = h->varBeta + Sx->vb_off;
-        if (Sx->method == METHOD_PR) {
+        if (Sx->method == METHOD_PR || Sx->method == METHOD_C) {
+            int64_t nLoci = 0;
+            if (Sx->method == METHOD_C)
+                for (int64_t l = 0; l < Sx->ncol; l++) nLoci += h->delta[Sx->col0 + l] ? 1 : 0;
             for (int64_t rg = 0; rg < Sx->nreg; rg++) {
                 double tot = 0.0; int first = 1;
                 for (int64_t l0 = Sx->reg_start[rg]; l0 < Sx->reg_stop[rg]; l0 += SEG) {
@@ -812,10 +859,16 @@ static void iter_blocked(ora_t *h) {
                     tot = first ? p : tot + p; first = 0;
                 }
                 rng_seed(&r, h->seed, h->chain, it, KIND_REGION_CHI2, ((uint64_t)si << 40) | (uint64_t)rg);
-                double n_r = (double)(Sx->reg_stop[rg] - Sx->reg_start[rg]);
+                double n_r = (Sx->method == METHOD_C) ? (double)nLoci : (double)(Sx->reg_stop[rg] - Sx->reg_start[rg]);
                 double ch = rng_chisq(&r, Sx->df + n_r);
                 double tt = Sx->scale * Sx->df; tt = tt + tot;
                 vb[rg] = tt / ch;
+            }
+            if (Sx->method == METHOD_C && Sx->estPi) {
+                rng_seed(&r, h->seed, h->chain, it, KIND_PI_BETA, (uint64_t)si);
+                double piIn = rng_beta(&r, (double)nLoci + 1.0, (double)(Sx->ncol - nLoci) + 1.0);
+                Sx->piHat[0] = 1.0 - piIn; Sx->piHat[1] = piIn;
+                Sx->logPi[0] = det_log(Sx->piHat[0]); Sx->logPi[1] = det_log(piIn);
             }
         } else {
             int64_t nLoci = 0;

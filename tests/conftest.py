@@ -43,7 +43,7 @@ def make_problem(O, N, P, seed=1, ncausal=10, h2=0.5, panel_seed=20250509):
 
 
 def add_sets(m, spec, v):
-    """spec: list of (col0, ncol, 'PR'|'B'|'PR1'|('PRw', width)); same calls on oracle and product."""
+    """spec: list of (col0, ncol, 'PR'|'B'|'Bfix'|'C'|'Cfix'|'PR1'|('PRw', width)); same calls on oracle and product."""
     df = 4.0
     for col0, ncol, kind in spec:
         if kind == "PR":
@@ -60,5 +60,9 @@ def add_sets(m, spec, v):
         elif kind == "Bfix":
             m.add_marker_set(col0, ncol, 1, df, v * (df - 2) / df, [(j, j + 1) for j in range(ncol)], [v] * ncol, pi0=0.2,
                              estPi=False)
+        elif kind == "C":
+            m.add_marker_set(col0, ncol, 2, df, v * (df - 2) / df, [(0, ncol)], [v], pi0=0.05, estPi=True)
+        elif kind == "Cfix":
+            m.add_marker_set(col0, ncol, 2, df, v * (df - 2) / df, [(0, ncol)], [v], pi0=0.3, estPi=False)
         else:
             raise ValueError(kind)

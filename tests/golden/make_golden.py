@@ -15,7 +15,7 @@ from oracle import oracle as O  # noqa: E402
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
-for name, kind in (("pr_50x200", "PR"), ("b_50x200", "B")):
+for name, kind in (("pr_50x200", "PR"), ("b_50x200", "B"), ("c_50x200", "C")):
     N, P = 50, 200
     X, y, bt, v = make_problem(O, N, P, seed=12)
     e_scale = 0.25 * y.var()

@@ -83,6 +83,8 @@ CASES = [
     ("b_single", 500, 600, [(0, 600, "B")]),
     ("b_fixpi", 300, 128, [(0, 128, "Bfix")]),
     ("multi", 400, 450, [(0, 150, "PR"), (150, 170, "B"), (320, 130, "PR")]),   # sets straddle 64-blocks
+    ("c_single", 400, 520, [(0, 520, "C")]),
+    ("c_fixpi_multi", 300, 330, [(0, 100, "Cfix"), (100, 90, "B"), (190, 140, "C")]),
     ("tiny", 7, 3, [(0, 3, "PR")]),
 ]
 

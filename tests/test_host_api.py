@@ -85,3 +85,31 @@ def test_runLMEM_end_to_end_matches_oracle(ngp, O, tmp_path):
     assert (out / "betaM2Out").read_text().splitlines()[0].split("\t")[:2] == ["M1", "M2"]
     with pytest.raises(FileExistsError):
         ngp.runLMEM(f'y ~ 1 + SNP(M1,"{g1}")', {"y": y}, 2, 0, 1, outFolder=str(out), VCV=VCV)
+
+
+@pytest.mark.gpu
+def test_runLMEM_bayesc_matches_oracle(ngp, O, tmp_path):
+    """BayesC through the reference's interface (src/runTime.jl:64-77, src/mme.jl:362-373): one variance for the set, pi file."""
+    N, P = 100, 150
+    X, y, bt, v = make_problem(O, N, P, seed=4)
+    X1 = O.generate_panel(N, P, seed=6)[0]
+    G = np.rint(X1.astype(np.float64) - X1.astype(np.float64).min(axis=0))
+    g = tmp_path / "g.txt"
+    np.savetxt(g, G, fmt="%d", delimiter=" ")
+    out = tmp_path / "outC"
+    VCV = {"M": ngp.BayesC(0.2, v, estimatePi=True), "e": ngp.Random("I", 0.5 * y.var())}
+    res = ngp.runLMEM(f'y ~ 1 + SNP(M,"{g}")', {"y": y}, 16, 4, 3, outFolder=str(out), VCV=VCV, seed=5, engine=(1, 4))
+    assert res["nKept"] == 4
+    Gc = (G - G.mean(axis=0)).astype(np.float32)
+    o = O.Oracle(0, seed=5, chain=0)
+    o.set_panel_f32(Gc)
+    o.add_marker_set(0, P, 2, 4.0, v * 0.5, [(0, P)], [v], pi0=0.2, estPi=True)
+    o.set_y(y); o.set_residual_prior(4.0, 0.5 * y.var() * 0.5); o.set_schedule(16, 4, 3); o.run(16)
+    ps = o.get_posterior_sums()
+    assert np.array_equal(res["sets"]["M"]["delta"], ps["sum_delta"] / 4)
+    assert np.abs(res["sets"]["M"]["beta"] - ps["sum_beta"] / 4).max() < 1e-9
+    assert abs(res["sets"]["M"]["var"][0] - ps["sum_varBeta"][0] / 4) < 1e-9 * res["sets"]["M"]["var"][0]
+    assert np.abs(res["sets"]["M"]["pi"] - ps["sum_pi"] / 4).max() < 1e-12
+    for name, ncol in (("betaM", P), ("deltaM", P), ("piM", 2), ("varM", 1)):
+        lines = (out / f"{name}Out").read_text().splitlines()
+        assert len(lines) == 5 and len(lines[0].split("\t")) == ncol, name

@@ -103,8 +103,9 @@ def test_ridge_limit(O):
     assert abs(ps["sum_b"] / ps["nKept"] - y.mean()) < 0.05
 
 
-@pytest.mark.parametrize("spec", [[(0, 300, "PR")], [(0, 300, "B")], [(0, 100, "PR"), (100, 120, "B"), (220, 80, ("PRw", 17))]],
-                         ids=["PR", "B", "multi"])
+@pytest.mark.parametrize("spec", [[(0, 300, "PR")], [(0, 300, "B")], [(0, 300, "C")], [(0, 300, "Cfix")],
+                                  [(0, 100, "PR"), (100, 120, "B"), (220, 80, ("PRw", 17))], [(0, 140, "C"), (140, 160, "B")]],
+                         ids=["PR", "B", "C", "Cfix", "multi", "multiC"])
 def test_blocked_order_equals_reference_order(O, spec):
     N, P = 257, 300
     X, y, bt, v = make_problem(O, N, P, seed=6)
@@ -150,6 +151,30 @@ def test_bayesb_quirk_excluded_locus_has_zero_variance(O):
         assert np.all(s["beta"][out] == 0.0) and np.all(s["varBeta"][out] == 0.0) and np.all(s["varBeta"][~out] > 0.0)
 
 
+def test_bayesc_one_variance_and_inclusion_count(O):
+    """functions.jl:197-235: BayesC keeps ONE variance per set; excluded loci have beta = 0; with pi fixed and a long chain
+    the mean of varBeta follows its conditional (scale df + sum beta^2) / chisq(df + nLoci) -- checked through the identity
+    E[(scale df + ssq) / varBeta] = df + nLoci on the kept draws (both sides are known per iteration)."""
+    N, P = 120, 48
+    X, y, bt, v = make_problem(O, N, P, seed=9)
+    for order, kw in ((0, {}), (1, dict(R=8, S=15))):
+        o = O.Oracle(order, seed=11, chain=0); o.set_panel_f32(X, **kw)
+        add_sets(o, [(0, P, "Cfix")], v); o.set_y(y); o.set_residual_prior(4.0, 1.0)
+        ratios = []
+        for _ in range(400):
+            o.run(1)
+            s = o.get_state()
+            assert s["varBeta"].shape == (1,) and s["varBeta"][0] > 0
+            out = s["delta"] == 0
+            assert np.all(s["beta"][out] == 0.0)
+            nl = int((~out).sum())
+            df = 4.0
+            ratios.append(((v * (df - 2) / df) * df + float(s["beta"] @ s["beta"])) / s["varBeta"][0] - (df + nl))
+        ratios = np.array(ratios)
+        # chi-square(nu) - nu has mean 0 and variance 2 nu (nu ~ 4 + nLoci <= 52)
+        assert abs(ratios.mean()) < 5 * math.sqrt(2 * 52 / len(ratios))
+
+
 def test_schedule_keeps_reference_iterations(O):
     """samplers.jl:26: kept = (burnIn+thin):thin:chainLength."""
     X, y, bt, v = make_problem(O, 40, 8, seed=1)
@@ -158,14 +183,14 @@ def test_schedule_keeps_reference_iterations(O):
     assert o.get_posterior_sums()["nKept"] == len(range(5 + 4, 23 + 1, 4))
 
 
-@pytest.mark.parametrize("name", ["pr_50x200", "b_50x200"])
+@pytest.mark.parametrize("name", ["pr_50x200", "b_50x200", "c_50x200"])
 def test_golden_vectors(O, name):
     """Committed fixtures generated by tests/golden/make_golden.py from the reference-order oracle."""
     g = np.load(os.path.join(GOLD, name + ".npz"))
     X = np.asfortranarray(g["X"])
     for order, kw, tol in ((0, {}, 0.0), (1, dict(R=4, S=13), 1e-11)):
         o = O.Oracle(order, seed=int(g["seed"]), chain=int(g["chain"])); o.set_panel_f32(X, **kw)
-        kind = "PR" if name.startswith("pr") else "B"
+        kind = {"pr": "PR", "b_": "B", "c_": "C"}[name[:2]]
         add_sets(o, [(0, X.shape[1], kind)], float(g["v"])); o.set_y(g["y"]); o.set_residual_prior(4.0, float(g["e_scale"]))
         done = 0
         for it in (1, 2, 10):

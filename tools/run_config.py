@@ -1,5 +1,5 @@
 """Runs one of the BASELINE.json configurations end to end and prints a JSON line (diagnostic / report tool).
-   python tools/run_config.py C3|C4|C2 [iters] [warm]"""
+   python tools/run_config.py C2|C3|C3c|C4|C4s [iters] [warm]   (C3c = C3 with BayesC)"""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,7 +8,7 @@ ngp = load_pkg()
 cfg = sys.argv[1]
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 warm = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-N, P, sets = {"C2": (10000, 100000, [("PR", 100000)]), "C3": (10000, 100000, [("B", 100000)]),
+N, P, sets = {"C2": (10000, 100000, [("PR", 100000)]), "C3": (10000, 100000, [("B", 100000)]), "C3c": (10000, 100000, [("C", 100000)]),
               "C4": (50000, 600000, [("PR", 200000)] * 3), "C4s": (50000, 60000, [("PR", 20000)] * 3)}[cfg]
 s = ngp.Sampler(device=0, seed=1001, chain=0)
 t0 = time.perf_counter(); s.generate_panel(N, P); setup = time.perf_counter() - t0
@@ -19,6 +19,7 @@ v = 0.5 * y.var() / (s.mpm().sum() / N)
 c0 = 0
 for kind, n in sets:
     if kind == "PR": s.add_marker_set(c0, n, 0, 4.0, v * 0.5, [(0, n)], [v])
+    elif kind == "C": s.add_marker_set(c0, n, 2, 4.0, v * 0.5, [(0, n)], [v], pi0=0.01, estPi=True)
     else: s.add_marker_set(c0, n, 1, 4.0, v * 0.5, [(j, j + 1) for j in range(n)], np.full(n, v), pi0=0.01, estPi=True)
     c0 += n
 s.set_y(y); s.set_residual_prior(4.0, 0.25 * y.var()); s.set_schedule(warm + iters, warm, 1)
