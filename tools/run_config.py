@@ -29,7 +29,30 @@ st = s.get_state(); ps = s.get_posterior_sums()
 resid = y - st["b"] - s.xbeta(st["beta"])
 R, S, nb = s.layout(); mode, lag = s.config()
 corr = float(np.corrcoef(ps["sum_beta"], bt)[0, 1])
+
+
+def ess_geyer(x):
+    """Effective sample size by Geyer's initial positive sequence estimator (SURVEY.md section 8 d)."""
+    x = np.asarray(x, float) - np.mean(x)
+    n = len(x)
+    if n < 8 or not np.any(x):
+        return float(n)
+    f = np.fft.rfft(x, 2 * n)
+    acf = np.fft.irfft(f * np.conj(f))[:n] / (x @ x)
+    tau, k = -1.0, 0
+    while k + 1 < n:
+        pair = acf[k] + acf[k + 1]
+        if pair <= 0:
+            break
+        tau += 2.0 * pair
+        k += 2
+    return float(n / max(tau, 1e-12))
+
+
+tr = s.get_trace(iters)
+ess_varE = ess_geyer(tr["varE"])
 print(json.dumps(dict(config=cfg, N=N, P=P, sets=[k for k, _ in sets], mode=mode, lag=lag, R=R, S=S, nblk=nb, ms_per_iter=dt * 1e3, it_per_s=1 / dt,
                       GBs=4.0 * N * P / dt / 1e9, frac_of_8TBs=4.0 * N * P / dt / 8e12, setup_s=setup, xbeta_s=txb,
                       invariant_max=float(np.abs(st["ycorr"] - resid).max()), varE=st["varE"], piHat=list(map(float, st["piHat"])),
-                      included=int(st["delta"].sum()), corr_postmean_true=corr)))
+                      included=int(st["delta"].sum()), corr_postmean_true=corr,
+                      ess_varE=ess_varE, ess_varE_per_s=ess_varE / (dt * iters))))
