@@ -61,23 +61,33 @@ def cpu_baseline(N, P, sample_cols, sample_iters):
     g = X.astype(np.float64) @ bt
     y = 10.0 + g + np.random.default_rng(2).normal(size=N) * np.sqrt(g.var())
     v = 0.5 * y.var() / float((mu * (1 - mu / 2)).sum())
-    o = O.Oracle(order=0, seed=1001, chain=0)
-    o.set_panel_f32(X)
-    o.add_marker_set(0, sample_cols, 0, 4.0, v * 0.5, [(0, sample_cols)], [v])
-    o.set_y(y)
-    o.set_residual_prior(4.0, 0.25 * y.var())
-    o.run(1)  # warm-up
-    t0 = time.time()
-    o.run(sample_iters)
-    dt = time.time() - t0
-    its_sample = sample_iters / dt
+    def timed(threads, iters):
+        O.set_threads(threads)
+        o = O.Oracle(order=0, seed=1001, chain=0)
+        o.set_panel_f32(X)
+        o.add_marker_set(0, sample_cols, 0, 4.0, v * 0.5, [(0, sample_cols)], [v])
+        o.set_y(y)
+        o.set_residual_prior(4.0, 0.25 * y.var())
+        o.run(1)  # warm-up
+        t0 = time.time()
+        o.run(iters)
+        dt = time.time() - t0
+        O.set_threads(1)
+        return iters / dt, dt
+
+    # (i) one thread, (ii) all cores of the box (threaded daxpy / ddot, as OpenBLAS would run them)
+    ncores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    its1, dt1 = timed(1, sample_iters)
+    itsn, dtn = (its1, dt1) if ncores <= 1 else timed(ncores, max(1, sample_iters // 2))
+    best, cores = (itsn, ncores) if itsn > its1 else (its1, 1)
     return {
-        "value": its_sample * sample_cols / P,
+        "value": best * sample_cols / P,
         "unit": "it/s",
-        "cores": 1,
+        "cores": cores,
         "kind": "port",
-        "sample": f"{sample_iters} iterations of N={N} x P={sample_cols} ({dt:.1f} s), it/s scaled by {sample_cols}/{P} "
-                  "(per-SNP cost is independent of P); reference-order C restatement, 24*N bytes of DRAM traffic per SNP",
+        "sample": f"N={N} x P={sample_cols} columns of the workload, it/s scaled by {sample_cols}/{P} (per-SNP cost is independent of P); "
+                  f"reference-order C restatement (24*N bytes of DRAM traffic per SNP): 1 thread {its1 * sample_cols / P:.3f} it/s "
+                  f"({sample_iters} iterations, {dt1:.1f} s), {ncores} threads {itsn * sample_cols / P:.3f} it/s ({dtn:.1f} s); the better is reported",
     }
 
 

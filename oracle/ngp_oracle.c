@@ -494,7 +494,14 @@ static void accumulate(ora_t *h) {
 /* ------------------------------------------------------------------ */
 /* order 0: reference order                                             */
 /* ------------------------------------------------------------------ */
-static inline double dot8(const double *a, const double *b, int64_t n) {
+/* Threads of the reference-order BLAS-1 calls (the reference runs OpenBLAS, whose ddot / daxpy are multi-threaded for
+   long vectors).  1 (default) = the deterministic sequences every test uses; T > 1 (bench.py's all-core baseline only):
+   T contiguous chunks, partial dots added in chunk order. */
+static int g_threads = 1;
+void ora_set_threads(int t) { g_threads = t < 1 ? 1 : t; }
+int ora_get_threads(void) { return g_threads; }
+
+static inline double dot8_1(const double *a, const double *b, int64_t n) {
     double acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
     int64_t i = 0;
     for (; i + 8 <= n; i += 8)
@@ -503,7 +510,26 @@ static inline double dot8(const double *a, const double *b, int64_t n) {
     for (; i < n; i++) tail = __builtin_fma(a[i], b[i], tail);
     return ((acc[0] + acc[1]) + (acc[2] + acc[3])) + ((acc[4] + acc[5]) + (acc[6] + acc[7])) + tail;
 }
+static inline double dot8(const double *a, const double *b, int64_t n) {
+    if (g_threads <= 1) return dot8_1(a, b, n);
+    double part[64];
+    const int T = g_threads > 64 ? 64 : g_threads;
+    const int64_t chunk = ((n + T - 1) / T + 7) & ~(int64_t)7;
+#pragma omp parallel for num_threads(T) schedule(static, 1)
+    for (int t = 0; t < T; t++) {
+        int64_t lo = t * chunk, hi = lo + chunk < n ? lo + chunk : n;
+        part[t] = lo < hi ? dot8_1(a + lo, b + lo, hi - lo) : 0.0;
+    }
+    double tot = 0.0;
+    for (int t = 0; t < T; t++) tot += part[t];
+    return tot;
+}
 static inline void axpy(double a, const double *x, double *y, int64_t n) {
+    if (g_threads <= 1) {
+        for (int64_t i = 0; i < n; i++) y[i] = __builtin_fma(a, x[i], y[i]);
+        return;
+    }
+#pragma omp parallel for num_threads(g_threads) schedule(static)
     for (int64_t i = 0; i < n; i++) y[i] = __builtin_fma(a, x[i], y[i]);
 }
 

@@ -46,6 +46,11 @@ def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
 
 
+def set_threads(t):
+    """Threads of the reference-order BLAS-1 calls (bench.py's all-core baseline only; every test runs with 1)."""
+    lib().ora_set_threads(int(t))
+
+
 def det_log(x):
     return lib().ora_det_log(float(x))
 
