@@ -63,6 +63,10 @@ int32_t ngp_debug_stamps(ngp_handle *h, int32_t enable, uint64_t *out, int64_t n
  * centre != 0: subtract the column mean first (src/prepMatVec.jl:129).  Stored as fp32, re-tiled. */
 int32_t ngp_set_panel_f64(ngp_handle *h, const double *M, int64_t N, int64_t P, int64_t ld, int32_t centre);
 int32_t ngp_set_panel_f32(ngp_handle *h, const float *M, int64_t N, int64_t P, int64_t ld, int32_t centre);
+/* Same panel from one byte per genotype (0/1/2 allele counts, or any value 0..255): a quarter of the fp32 host footprint and
+ * of the PCIe transfer; centring and the fp32 conversion happen on the device and give bit for bit the tiles of
+ * ngp_set_panel_f64 on the same values (integer column sum / N). */
+int32_t ngp_set_panel_u8(ngp_handle *h, const uint8_t *G, int64_t N, int64_t P, int64_t ld, int32_t centre);
 /* Synthetic panel generated on the device: g_ij ~ Binomial(2,p_j), p_j ~ U(maf_lo,maf_hi). */
 int32_t ngp_generate_panel(ngp_handle *h, int64_t N, int64_t P, double maf_lo, double maf_hi, uint64_t panel_seed);
 /* Device tiling chosen for the panel: rows per shard R, shards S, 64-SNP blocks NBLK (the blocked

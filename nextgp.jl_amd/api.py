@@ -134,8 +134,14 @@ def parse_formula(formula):
 # ----------------------------------------------------------------------------------------------
 def read_genotypes(path):
     """Space-delimited text, one row per individual, no header (prepMatVec.jl:116); columns holding a missing
-    value are dropped (prepMatVec.jl:118).  Returns a float64 (N, P) Fortran-ordered matrix, NOT centred."""
+    value are dropped (prepMatVec.jl:118).  Returns a float64 (N, P) Fortran-ordered matrix, NOT centred.
+    Beyond the reference: an (N, P) array, or a `.npy` file (memory-mapped), is taken as it is -- uint8 allele counts stay
+    uint8 (one byte per genotype; at 50k x 600k the text parse alone would take hours)."""
+    if isinstance(path, (str, os.PathLike)) and str(path).endswith(".npy"):
+        path = np.load(path, mmap_mode="r")
     if isinstance(path, np.ndarray):
+        if path.dtype == np.uint8:
+            return np.asfortranarray(path)
         M = np.asarray(path, dtype=np.float64)
     else:
         M = np.genfromtxt(path, delimiter=" ", dtype=np.float64)
@@ -252,6 +258,8 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
     for M in mats:
         if M.shape[0] != len(y):
             raise ValueError("genotype rows must match the phenotype records (marker files are ordered as the data, runTime.jl:23)")
+    if not all(M.dtype == np.uint8 for M in mats):  # one byte per genotype only when every set comes that way
+        mats = [np.asarray(M, dtype=np.float64) for M in mats]
     panel = np.asfortranarray(np.concatenate(mats, axis=1))
     smp = Sampler(device=device, seed=seed, chain=chain, **(dict(mode=engine[0], lag=engine[1]) if engine else {}))
     smp.set_panel(panel, centre=True)  # centring: src/prepMatVec.jl:129

@@ -451,6 +451,38 @@ int32_t ngp_set_panel_f32(ngp_handle *h, const float *M, int64_t N, int64_t P, i
     return set_panel_host<float>(h, M, N, P, ld, centre);
 }
 
+int32_t ngp_set_panel_u8(ngp_handle *h, const uint8_t *G, int64_t N, int64_t P, int64_t ld, int32_t centre) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(G != nullptr, NGP_ERR_ARG, "null panel pointer");
+    REQUIRE(ld >= N, NGP_ERR_ARG, "leading dimension smaller than N");
+    if ((rc = alloc_panel(h, N, P))) return rc;
+    // staged through the device in chunks of whole 64-column blocks (about 64 MiB of genotypes at a time)
+    const int64_t blk_bytes = (int64_t)NGP_BLK * ld;
+    const int64_t nb_chunk = std::max<int64_t>(1, std::min<int64_t>(h->NBLK, ((int64_t)64 << 20) / blk_bytes));
+    uint8_t *d_g = nullptr;
+    double *d_mu = nullptr;
+    if (hipMalloc((void **)&d_g, (size_t)nb_chunk * blk_bytes) != hipSuccess) return fail(h, NGP_ERR_NOMEM, "staging buffer");
+    if ((rc = dalloc(h, &d_mu, (size_t)nb_chunk * NGP_BLK))) { (void)hipFree(d_g); return rc; }
+    hipError_t e = hipSuccess;
+    for (int64_t t0 = 0; t0 < h->NBLK && e == hipSuccess; t0 += nb_chunk) {
+        const int64_t nb = std::min<int64_t>(nb_chunk, h->NBLK - t0);
+        const int64_t c0 = t0 * NGP_BLK, ncols = std::min<int64_t>(nb * NGP_BLK, P - c0);
+        // the last column may be shorter than ld in the caller's buffer: copy ncols-1 full columns + N bytes
+        const size_t bytes = (size_t)(ncols - 1) * ld + (size_t)N;
+        e = hipMemcpyAsync(d_g, G + (size_t)c0 * ld, bytes, hipMemcpyHostToDevice, h->stream);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(k_u8_colmean, dim3((unsigned)ncols), dim3(256), 0, h->stream, d_g, (long long)N, (long long)ld, (int)centre, d_mu);
+        hipLaunchKernelGGL(k_u8_fill, dim3((unsigned)h->S, (unsigned)nb), dim3(256), 0, h->stream, h->d_tiles, d_g, (long long)N,
+                           (long long)ld, (long long)ncols, (int)h->R, (int)h->S, (long long)t0, d_mu);
+        e = hipStreamSynchronize(h->stream);  // the staging buffer is reused by the next chunk
+    }
+    (void)hipFree(d_g);
+    dfree(d_mu);
+    if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("set_panel_u8: ") + hipGetErrorString(e));
+    return build_gram(h);
+}
+
 int32_t ngp_generate_panel(ngp_handle *h, int64_t N, int64_t P, double maf_lo, double maf_hi, uint64_t panel_seed) {
     int rc;
     if ((rc = enter(h))) return rc;

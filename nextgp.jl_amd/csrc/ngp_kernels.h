@@ -571,6 +571,35 @@ __global__ __launch_bounds__(256) void k_gen_fill(float *__restrict__ tiles, lon
     }
 }
 
+// compact genotype input (one byte per genotype, column-major staging chunk of ncols columns, leading dimension ld):
+// integer column sums -> mean = sum / N exactly as the host path computes it, then centred fp32 quad-major tiles
+__global__ __launch_bounds__(256) void k_u8_colmean(const uint8_t *__restrict__ G, long long N, long long ld, int centre,
+                                                    double *__restrict__ mu) {
+    __shared__ unsigned long long wsum[4];
+    const long long jc = blockIdx.x;  // column of the chunk
+    const uint8_t *col = G + (size_t)jc * ld;
+    unsigned long long sum = 0;
+    for (long long i = threadIdx.x; i < N; i += 256) sum += col[i];
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) sum += __shfl_xor(sum, off);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) mu[jc] = centre ? (double)(wsum[0] + wsum[1] + wsum[2] + wsum[3]) / (double)N : 0.0;
+}
+__global__ __launch_bounds__(256) void k_u8_fill(float *__restrict__ tiles, const uint8_t *__restrict__ G, long long N, long long ld,
+                                                 long long ncols, int R, int S, long long t0, const double *__restrict__ mu) {
+    const int s = blockIdx.x;
+    const long long tb = blockIdx.y;  // block of the chunk
+    float *tp = tiles + ((size_t)(t0 + tb) * S + s) * ((size_t)R * NGP_BLK);
+    for (int idx = threadIdx.x; idx < R * NGP_BLK; idx += 256) {
+        const int ii = ((idx >> 8) << 2) + (idx & 3), jj = (idx >> 2) & (NGP_BLK - 1);  // idx is the quad-major offset
+        const long long i = (long long)s * R + ii, jc = tb * NGP_BLK + jj;
+        float v = 0.0f;
+        if (i < N && jc < ncols) v = (float)((double)G[(size_t)jc * ld + i] - mu[jc]);
+        tp[idx] = v;
+    }
+}
+
 // out_i = sum_k x_ik beta_k, k ascending (utility, not on the hot path)
 __global__ __launch_bounds__(256) void k_xbeta(const float *__restrict__ tiles, const double *__restrict__ beta,
                                                double *__restrict__ out, int R, int S, long long NBLK) {

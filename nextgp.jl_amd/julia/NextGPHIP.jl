@@ -42,6 +42,11 @@ set_panel!(h::Handle, data::Matrix{Float64}; centre::Bool=false) =
     check(h, ccall((:ngp_set_panel_f64, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Int32),
                    h.ptr, data, size(data, 1), size(data, 2), stride(data, 2), centre))
 
+# one byte per genotype (raw allele counts, e.g. read from a binary file instead of src/prepMatVec.jl:116): centred on the device
+set_panel!(h::Handle, data::Matrix{UInt8}; centre::Bool=true) =
+    check(h, ccall((:ngp_set_panel_u8, LIB), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Int64, Int64, Int64, Int32),
+                   h.ptr, data, size(data, 1), size(data, 2), stride(data, 2), centre))
+
 # regionArray::Vector{UnitRange{Int}} (1-based, src/mme.jl:335-358) -> 0-based [start, stop)
 function add_marker_set!(h::Handle, col0::Integer, ncol::Integer, method::Integer, df::Float64, scale::Float64,
                          regionArray, varBeta0::Vector{Float64}; pi0::Float64=0.0, estPi::Bool=false,

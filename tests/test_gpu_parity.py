@@ -195,3 +195,29 @@ def test_errors_are_reported_not_thrown(ngp):
         s.add_marker_set(0, 5, 0, 4.0, 0.1, [(0, 5)], [0.1])
     with pytest.raises(ngp.NextGPHipError, match="no marker set"):
         s.set_y(np.zeros(4)); s.run(1)
+
+
+def test_u8_panel_equals_f64_panel(ngp, O):
+    """ngp_set_panel_u8: one byte per genotype, centred and converted on the device -- bit for bit the chain of the same
+    values handed over as Float64 (src/prepMatVec.jl:129 centring)."""
+    N, P = 333, 210
+    X1 = O.generate_panel(N, P, seed=8)[0]
+    G = np.rint(X1.astype(np.float64) - X1.astype(np.float64).min(axis=0)).astype(np.uint8)
+    assert set(np.unique(G)) <= {0, 1, 2}
+    y = np.random.default_rng(4).normal(size=N) + G[:, 3] - G[:, 77]
+    out = []
+    for panel in (G, G.astype(np.float64)):
+        s = ngp.Sampler(device=0, seed=3, chain=0)
+        s.set_panel(np.asfortranarray(panel), centre=True)
+        s.add_marker_set(0, P, 0, 4.0, 0.01, [(0, P)], [0.02])
+        s.set_y(y); s.set_residual_prior(4.0, 0.5)
+        s.run(5)
+        out.append((s.mpm(), s.get_state()))
+    assert np.array_equal(out[0][0], out[1][0])
+    for k in ("beta", "ycorr", "varBeta"):
+        assert np.array_equal(out[0][1][k], out[1][1][k]), k
+    assert out[0][1]["varE"] == out[1][1]["varE"]
+    # not centred: the values themselves
+    s = ngp.Sampler(device=0, seed=3, chain=0)
+    s.set_panel(np.asfortranarray(G), centre=False)
+    assert np.allclose(s.mpm(), (G.astype(np.float64) ** 2).sum(axis=0))
