@@ -63,7 +63,8 @@ struct SweepArgs {
     unsigned *xcc_w;     // sampler's XCC id + 1 (speed only: same-XCD streamers warm the L2 with Gram blocks)
     unsigned long long *dbg;  // optional time stamps (diagnostic runs only), else nullptr
     int dbg_mode;             // diagnostic timing runs, results invalid: 1 = streamers only move tiles, 2 = sampler alone
-                              // (never waits), 3 = streamers + reducers alone (never wait for dlt), 4 = as 3 without the tile DMA
+                              // (never waits), 3 = streamers + reducers alone (never wait for dlt), 4 = as 3 without the tile DMA,
+                              // 5 = whole pipeline, BayesPR blocks without the recursion
 };
 
 __device__ inline unsigned ld_u32(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -178,7 +179,7 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
         if (aa < 0 || uu >= nb + DT) return;
         int ok = 1;
         if (j == 0) {
-            ok = (A.dbg_mode >= 3 || wait_ge(A.flag_dlt, (unsigned)(aa + 1), A.abort_w, 1u)) ? 1 : 0;
+            ok = (A.dbg_mode == 3 || A.dbg_mode == 4 || wait_ge(A.flag_dlt, (unsigned)(aa + 1), A.abort_w, 1u)) ? 1 : 0;
             if (A.dbg && s == 0) A.dbg[NGP_DBG_STREAM + 2 * (size_t)uu + 1] = wall_clock64();
             if (!ok) *sflag = 0;
         }
@@ -317,7 +318,7 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
                 bool have_dnext = false;
                 if (pollw) {
                     int ok = 1;
-                    if (__shfl((int)fl, 0) < pa + 1 && A.dbg_mode < 3) {
+                    if (__shfl((int)fl, 0) < pa + 1 && A.dbg_mode != 3 && A.dbg_mode != 4) {
                         if (j == 0) {
                             ok = wait_ge(A.flag_dlt, (unsigned)(pa + 1), A.abort_w, 1u) ? 1 : 0;
                             if (!ok) *sflag = 0;
@@ -400,7 +401,7 @@ __device__ inline void role_reducer(const SweepArgs &A, const int g) {
 #pragma unroll
             for (int kk = 0; kk < NGP_BLK; kk++) gr[kk] = gx[kk * NGP_BLK];
             int okd = 1;
-            if (lane == 0) okd = (A.dbg_mode >= 3 || wait_ge(A.flag_dlt, (unsigned)(a + 1), A.abort_w, 4u)) ? 1 : 0;
+            if (lane == 0) okd = (A.dbg_mode == 3 || A.dbg_mode == 4 || wait_ge(A.flag_dlt, (unsigned)(a + 1), A.abort_w, 4u)) ? 1 : 0;
             okd = __shfl(okd, 0);
             if (!okd) return;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -570,7 +571,9 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
             double dsave;
             int isave = 1;
             double H0 = -(cc * G[0]), H1 = -(cc * G[1]), H2 = -(cc * G[2]), H3 = -(cc * G[3]);
-            if (__ballot(st >= 0.0) == 0ull) {
+            if (A.dbg_mode == 5 && __ballot(st >= 0.0) == 0ull) {
+                dsave = e;  // timing experiment: BayesPR blocks without the 64-step recursion
+            } else if (__ballot(st >= 0.0) == 0ull) {
 #pragma unroll
                 for (int kk = 0; kk < NGP_BLK; kk += 4) {
                     double dk;
