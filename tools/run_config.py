@@ -1,5 +1,5 @@
 """Runs one of the BASELINE.json configurations end to end and prints a JSON line (diagnostic / report tool).
-   python tools/run_config.py C2|C3|C3c|C4|C4s [iters] [warm]   (C3c = C3 with BayesC)"""
+   python tools/run_config.py C1|C2|C3|C3c|C4|C4s [iters] [warm]   (C3c = C3 with BayesC)"""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -8,7 +8,7 @@ ngp = load_pkg()
 cfg = sys.argv[1]
 iters = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 warm = int(sys.argv[3]) if len(sys.argv) > 3 else 5
-N, P, sets = {"C2": (10000, 100000, [("PR", 100000)]), "C3": (10000, 100000, [("B", 100000)]), "C3c": (10000, 100000, [("C", 100000)]),
+N, P, sets = {"C1": (500, 5000, [("PR", 5000)]), "C2": (10000, 100000, [("PR", 100000)]), "C3": (10000, 100000, [("B", 100000)]), "C3c": (10000, 100000, [("C", 100000)]),
               "C4": (50000, 600000, [("PR", 200000)] * 3), "C4s": (50000, 60000, [("PR", 20000)] * 3)}[cfg]
 s = ngp.Sampler(device=0, seed=1001, chain=0)
 t0 = time.perf_counter(); s.generate_panel(N, P); setup = time.perf_counter() - t0
@@ -49,10 +49,21 @@ def ess_geyer(x):
     return float(n / max(tau, 1e-12))
 
 
+cpu = None
+if cfg == "C1":  # the reference's own CPU-runnable case: the reference-order oracle timed beside it (same model, same seeds)
+    from oracle import oracle as O
+    X, mu = O.generate_panel(N, P)
+    o = O.Oracle(0, seed=1001, chain=0); o.set_panel_f32(X)
+    o.add_marker_set(0, P, 0, 4.0, v * 0.5, [(0, P)], [v]); o.set_y(y); o.set_residual_prior(4.0, 0.25 * y.var())
+    o.run(warm)
+    t0 = time.perf_counter(); o.run(iters); cdt = (time.perf_counter() - t0) / iters
+    so = o.get_state()
+    cpu = dict(ms_per_iter=cdt * 1e3, it_per_s=1 / cdt, cores=1, kind="reference-order C port",
+               max_abs_dbeta_vs_gpu=float(np.abs(so["beta"] - st["beta"]).max()), varE=so["varE"])
 tr = s.get_trace(iters)
 ess_varE = ess_geyer(tr["varE"])
 print(json.dumps(dict(config=cfg, N=N, P=P, sets=[k for k, _ in sets], mode=mode, lag=lag, R=R, S=S, nblk=nb, ms_per_iter=dt * 1e3, it_per_s=1 / dt,
                       GBs=4.0 * N * P / dt / 1e9, frac_of_8TBs=4.0 * N * P / dt / 8e12, setup_s=setup, xbeta_s=txb,
                       invariant_max=float(np.abs(st["ycorr"] - resid).max()), varE=st["varE"], piHat=list(map(float, st["piHat"])),
                       included=int(st["delta"].sum()), corr_postmean_true=corr,
-                      ess_varE=ess_varE, ess_varE_per_s=ess_varE / (dt * iters))))
+                      ess_varE=ess_varE, ess_varE_per_s=ess_varE / (dt * iters), cpu_oracle=cpu)))
