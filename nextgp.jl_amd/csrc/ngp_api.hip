@@ -45,7 +45,6 @@ struct ngp_handle {
     int lag = 6;       // look-ahead D of the persistent sweep (blocks)
     int D = 1;         // Gram planes stored per block (= lag in mode 1, 1 in mode 0)
     int NG = 1;        // reducer groups = ceil(S/32)
-    int NS = 1;        // LDS tile slots of a streamer workgroup
     int cu_count = 256;
     double *d_cpart = nullptr, *d_cgsum = nullptr, *d_cdlt = nullptr;
     unsigned *d_ccnt = nullptr, *d_abort = nullptr;
@@ -205,7 +204,6 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
         const size_t lds_max = 160 * 1024;
         const size_t misc = (size_t)h->R * 8 + 4096 + 2 * 512 + 128 + 3072 + (size_t)h->R * 64;
         const size_t TB = (size_t)(h->R / 4) * NGP_QS;  // LDS footprint of one tile (quads NGP_QS bytes apart)
-        h->NS = 2;
         h->lds_sweep = std::max(2 * TB + misc, lds_sampler);
         if (2 * TB + misc + 8192 <= lds_max) h->lds_sweep = std::max(h->lds_sweep, 2 * TB + misc + 8192);  // room for the diagnostic timeline
         if (h->lds_sweep > lds_max) return fail(h, NGP_ERR_ARG, "panel too tall for the persistent sweep (LDS)");
@@ -313,7 +311,7 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
         (void)hipMemsetAsync(h->d_ccnt, 0, h->ccnt_words * sizeof(unsigned), h->stream);
         SweepArgs A;
         A.tiles = h->d_tiles; A.ycorr = h->d_ycorr; A.gramx = h->d_gramx;
-        A.D = h->D; A.R = R; A.S = S; A.NG = h->NG; A.NS = h->NS; A.t0 = (int)tb0; A.t1 = (int)tb1;
+        A.D = h->D; A.R = R; A.S = S; A.NG = h->NG; A.fine_ok = 0; A.t0 = (int)tb0; A.t1 = (int)tb1;
         A.beta = h->d_beta; A.delta = h->d_delta; A.c = h->d_c; A.w = h->d_w; A.q = h->d_q; A.mpm = h->d_mpm; A.chi = h->d_chi;
         A.setof = h->d_setof; A.vbidx = h->d_vbidx; A.sets = h->d_sets; A.varBeta = h->d_varBeta;
         A.part = h->d_cpart; A.gsum = h->d_cgsum; A.dlt = h->d_cdlt;
@@ -321,7 +319,7 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
         A.flag_dlt = A.cnt_gs + (size_t)NGP_RING * 32; A.abort_w = h->d_abort; A.xcc_w = h->d_abort + 16;
         if (evs) (void)hipEventRecord(evs[0], h->stream);
         A.dbg = h->d_dbg;
-        A.NS = ((size_t)2 * (R / 4) * NGP_QS + (size_t)R * 72 + 8320 + 8192 <= h->lds_sweep) ? 1 : 0;  // diagnostic timeline fits in LDS
+        A.fine_ok = ((size_t)2 * (R / 4) * NGP_QS + (size_t)R * 72 + 8320 + 8192 <= h->lds_sweep) ? 1 : 0;  // diagnostic timeline fits in LDS
         { const char *e = getenv("NGP_DEBUG_MODE"); A.dbg_mode = e ? atoi(e) : 0; }
         hipLaunchKernelGGL(k_sweep, dim3((unsigned)(1 + h->NG + S)), dim3(NGP_WG), h->lds_sweep, h->stream, A);
         if (evs) (void)hipEventRecord(evs[1], h->stream);

@@ -44,7 +44,7 @@ struct SweepArgs {
     const float *tiles;
     double *ycorr;
     const double *gramx;
-    int D, R, S, NG, NS, t0, t1;  // NS: 1 = the streamers' LDS has room for the diagnostic timeline
+    int D, R, S, NG, fine_ok, t0, t1;  // fine_ok: the streamers' LDS has room for the diagnostic timeline
     double *beta;
     uint8_t *delta;
     const double *c, *w, *q, *mpm, *chi;
@@ -156,7 +156,7 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
     // diagnostic runs, short shards only (the workgroup's LDS is sized by the sampler then): barrier-arrival stamps of
     // every wave of streamer 1 for local blocks 800..815, staged in LDS and dumped at the end
     unsigned long long *fine = (unsigned long long *)(pp + 8 * (size_t)R);
-    const bool fine_on = A.dbg && s == 1 && A.NS == 1;
+    const bool fine_on = A.dbg && s == 1 && A.fine_ok == 1;
 #define NGP_FINE(k)                                                                                          \
     do {                                                                                                     \
         if (fine_on && (unsigned)(u - 800) < 16u && j == 0) fine[(((u - 800) * 8 + wv) << 3) + (k)] = wall_clock64(); \
