@@ -20,6 +20,8 @@ def _chain(ngp, method, niter, engine=(1, 6), seed=1001, P_=P):
         s.add_marker_set(0, P_, 0, 4.0, v * 0.5, [(0, P_)], [v])
     elif method == "B":
         s.add_marker_set(0, P_, 1, 4.0, v * 0.5, [(j, j + 1) for j in range(P_)], np.full(P_, v), pi0=0.01, estPi=True)
+    elif method == "C":
+        s.add_marker_set(0, P_, 2, 4.0, v * 0.5, [(0, P_)], [v], pi0=0.01, estPi=True)
     else:  # three consecutive sets, like the multi-breed configuration
         third = P_ // 3
         s.add_marker_set(0, third, 0, 4.0, v * 0.5, [(0, third)], [v])
@@ -30,7 +32,7 @@ def _chain(ngp, method, niter, engine=(1, 6), seed=1001, P_=P):
     return s, y
 
 
-@pytest.mark.parametrize("method", ["PR", "B", "multi"])
+@pytest.mark.parametrize("method", ["PR", "B", "C", "multi"])
 def test_residual_invariant_and_indicator_consistency(ngp, method):
     s, y = _chain(ngp, method, 12)
     st = s.get_state()
@@ -43,6 +45,9 @@ def test_residual_invariant_and_indicator_consistency(ngp, method):
         assert d.min() == 1 and st["varBeta"][0] > 0
     if method == "B":                                               # functions.jl:184-186
         assert np.all(st["beta"][d == 0] == 0.0) and np.all(st["varBeta"][d == 0] == 0.0) and np.all(st["varBeta"][d == 1] > 0.0)
+        assert 0.0 < st["piHat"][1] < 0.2 and abs(st["piHat"].sum() - 1.0) < 1e-15
+    if method == "C":                                               # functions.jl:226-231: one variance, excluded effects are 0
+        assert np.all(st["beta"][d == 0] == 0.0) and st["varBeta"].shape == (1,) and st["varBeta"][0] > 0.0
         assert 0.0 < st["piHat"][1] < 0.2 and abs(st["piHat"].sum() - 1.0) < 1e-15
     ps = s.get_posterior_sums()
     assert ps["nKept"] == 12 and np.all(ps["sum_delta"] <= 12) and np.all(ps["sum_beta2"] >= 0)

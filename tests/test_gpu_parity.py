@@ -119,7 +119,7 @@ def test_chain_bit_exact_vs_blocked_oracle(ngp, O, name, N, P, spec, engine):
 
 
 @pytest.mark.parametrize("engine", [(0, 1), (1, 6)], ids=["blocklaunch", "persist_lag6"])
-@pytest.mark.parametrize("kind", ["PR", "B"])
+@pytest.mark.parametrize("kind", ["PR", "B", "C"])
 def test_chain_vs_reference_order_oracle(ngp, O, kind, engine):
     """Same Markov chain, reference summation order: indicators identical, floats within 1e-9 relative."""
     N, P = 500, 1000
