@@ -54,6 +54,11 @@ const char *ngp_last_error(ngp_handle *h);
  * reference loop (src/functions.jl:124-136) and draw the same chain; only summation order differs. */
 int32_t ngp_configure(ngp_handle *h, int32_t mode, int32_t lag);
 int32_t ngp_get_config(ngp_handle *h, int32_t *mode, int32_t *lag);
+/* Persistent sweep only: look-ahead lags 1..near are corrected inside the sampler workgroup, lags near+1..lag-1 by the
+ * reducer workgroups (another summation order, which the blocked oracle needs to know).  0 = automatic (3, or 4 for shards
+ * taller than 128 rows); to be chosen before the panel is set.  ngp_get_near_lags reports the value in force. */
+int32_t ngp_set_near_lags(ngp_handle *h, int32_t near);
+int32_t ngp_get_near_lags(ngp_handle *h, int32_t *near);
 /* Diagnostic only: enable != 0 makes the persistent kernel write 100 MHz time stamps (sampler: 4 words per
  * block at [4u..4u+3]; streamer 0: 2 words per block from word 2^20); out/n copies the first n words back. */
 int32_t ngp_debug_stamps(ngp_handle *h, int32_t enable, uint64_t *out, int64_t n);

@@ -20,7 +20,7 @@ SYMBOLS = [
     "ngp_generate_panel", "ngp_get_layout", "ngp_get_mpm", "ngp_get_gram", "ngp_xbeta", "ngp_add_marker_set", "ngp_set_y",
     "ngp_set_residual_prior", "ngp_set_intercept", "ngp_set_schedule", "ngp_run", "ngp_get_state", "ngp_set_state",
     "ngp_get_trace", "ngp_get_posterior_sums", "ngp_posterior_len", "ngp_export_posterior_device", "ngp_sweep_set",
-    "ngp_get_timing", "ngp_profile_iteration", "ngp_draws_indexed", "ngp_eval_math", "ngp_configure", "ngp_get_config", "ngp_debug_stamps",
+    "ngp_get_timing", "ngp_profile_iteration", "ngp_draws_indexed", "ngp_eval_math", "ngp_configure", "ngp_get_config", "ngp_debug_stamps", "ngp_set_near_lags", "ngp_get_near_lags",
 ]
 
 _lib = None
@@ -65,6 +65,14 @@ class Sampler:
 
     def configure(self, mode, lag):
         self._chk(self.L.ngp_configure(self.h, C.c_int32(mode), C.c_int32(lag)))
+
+    def set_near(self, near):
+        self._chk(self.L.ngp_set_near_lags(self.h, C.c_int32(near)))
+
+    def near(self):
+        n = C.c_int32()
+        self._chk(self.L.ngp_get_near_lags(self.h, C.byref(n)))
+        return n.value
 
     def config(self):
         m, l = C.c_int32(), C.c_int32()

@@ -43,6 +43,8 @@ struct ngp_handle {
     size_t lds_step = 0, lds_sweep = 0;
     int mode = 1;      // 1: persistent sweep kernel, 0: one streaming + one recursion launch per block
     int lag = 6;       // look-ahead D of the persistent sweep (blocks)
+    int near_req = 0;  // near lags requested (0 = automatic)
+    int near = 3;      // look-ahead lags 1..near corrected by the sampler itself, farther ones by the reducers
     int D = 1;         // Gram planes stored per block (= lag in mode 1, 1 in mode 0)
     int NG = 1;        // reducer groups = ceil(S/32)
     int cu_count = 256;
@@ -160,6 +162,10 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
     h->NG = (int)((h->S + NGP_GRP - 1) / NGP_GRP);
     h->D = (h->mode == 1) ? h->lag : 1;
     if (h->mode == 1 && h->R > 128 && h->D > 5) h->D = 5;  // tall shards: the register delay line holds 5 tiles at most
+    // the far path (sampler -> reducer -> sampler, about 7 us) has `near` block periods to complete: 3 blocks of 2.1 us at
+    // short shards (a fourth near lag overloads the sampler CU there: +17 % time), 4 blocks for tall shards, where with
+    // lag 5 nothing is left for the reducers (-8 % time)
+    h->near = h->near_req ? h->near_req : ((h->mode == 1 && h->R > 128) ? 4 : 3);
     h->NBLK = (P + NGP_BLK - 1) / NGP_BLK;
     h->Ppad = h->NBLK * NGP_BLK;
     h->L = h->R * h->S;
@@ -311,7 +317,7 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
         (void)hipMemsetAsync(h->d_ccnt, 0, h->ccnt_words * sizeof(unsigned), h->stream);
         SweepArgs A;
         A.tiles = h->d_tiles; A.ycorr = h->d_ycorr; A.gramx = h->d_gramx;
-        A.D = h->D; A.R = R; A.S = S; A.NG = h->NG; A.fine_ok = 0; A.t0 = (int)tb0; A.t1 = (int)tb1;
+        A.D = h->D; A.R = R; A.S = S; A.NG = h->NG; A.near = h->near; A.fine_ok = 0; A.t0 = (int)tb0; A.t1 = (int)tb1;
         A.beta = h->d_beta; A.delta = h->d_delta; A.c = h->d_c; A.w = h->d_w; A.q = h->d_q; A.mpm = h->d_mpm; A.chi = h->d_chi;
         A.setof = h->d_setof; A.vbidx = h->d_vbidx; A.sets = h->d_sets; A.varBeta = h->d_varBeta;
         A.part = h->d_cpart; A.gsum = h->d_cgsum; A.dlt = h->d_cdlt;
@@ -931,6 +937,22 @@ int32_t ngp_configure(ngp_handle *h, int32_t mode, int32_t lag) {
     REQUIRE(mode == 0 || mode == 1, NGP_ERR_ARG, "mode must be 0 (per-block launches) or 1 (persistent sweep)");
     REQUIRE(lag >= 1 && lag <= NGP_MAX_LAG, NGP_ERR_ARG, "lag must be in 1..8");
     h->mode = mode; h->lag = lag;
+    return NGP_OK;
+}
+
+int32_t ngp_set_near_lags(ngp_handle *h, int32_t near) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(h->d_tiles == nullptr, NGP_ERR_STATE, "ngp_set_near_lags must precede the panel upload");
+    REQUIRE(near == 0 || near == 3 || near == 4, NGP_ERR_ARG, "near lags: 0 (automatic), 3 or 4");
+    h->near_req = near;
+    return NGP_OK;
+}
+
+int32_t ngp_get_near_lags(ngp_handle *h, int32_t *near) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    if (near) *near = h->near;
     return NGP_OK;
 }
 

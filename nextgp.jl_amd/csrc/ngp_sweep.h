@@ -44,7 +44,8 @@ struct SweepArgs {
     const float *tiles;
     double *ycorr;
     const double *gramx;
-    int D, R, S, NG, fine_ok, t0, t1;  // fine_ok: the streamers' LDS has room for the diagnostic timeline
+    int D, R, S, NG, near, fine_ok, t0, t1;  // near: look-ahead lags 1..near are corrected by the sampler, farther ones by the reducers
+     // fine_ok: the streamers' LDS has room for the diagnostic timeline
     double *beta;
     uint8_t *delta;
     const double *c, *w, *q, *mpm, *chi;
@@ -391,9 +392,9 @@ __device__ inline void role_reducer(const SweepArgs &A, const int g) {
 #pragma unroll
         for (int s = 1; s < NGP_GRP; s++)
             if (s < gsize) v = v + vals[s];
-        // far look-ahead corrections folded into this group's sum: lags d = 4 + g, 4 + g + NG, ... (< D).  The Gram rows
+        // far look-ahead corrections folded into this group's sum: lags d = near + 1 + g, + NG, ... (< D).  The Gram rows
         // are requested before dlt of block u-d is awaited, so only the 64 fma follow the hand-off.
-        for (int d = 4 + g; d < A.D; d += A.NG) {
+        for (int d = A.near + 1 + g; d < A.D; d += A.NG) {
             const int a = u - d;
             if (a < 0) continue;
             const double *gx = A.gramx + ((size_t)(A.t0 + u) * A.D + d) * (NGP_BLK * NGP_BLK) + lane;
@@ -739,9 +740,11 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
             NGP_END_OF_BLOCK();
         }
     } else {
-        // waves 4 and 6: the lag-2 and lag-3 corrections (farther lags are folded into the group sums by the reducers);
-        // their Gram rows are loaded one block ahead.  Wave 7 only keeps the barrier count.
-        const int fx = (wv == 4) ? 2 : (wv == 6 ? 3 : 99);
+        // waves 4, 6 and 7: the lag-2, lag-3 and lag-4 corrections (farther lags are folded into the group sums by the
+        // reducers -- a loop sampler -> reducer -> sampler of about 7 us that must fit into `near` block periods);
+        // their Gram rows are loaded one block ahead.
+        const int fx = (wv == 4) ? 2 : (wv == 6 ? 3 : (wv == 7 && A.near >= 4 ? 4 : 99));
+        const int top = min(A.near, D - 1);  // highest lag corrected here: its term opens the sum of a target
         double gr[NGP_BLK];
 #pragma unroll
         for (int kk = 0; kk < NGP_BLK; kk++) gr[kk] = 0.0;
@@ -753,8 +756,8 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
                     const double *dp = hist + (a % NGP_RING) * NGP_BLK;
                     double v = gemv4([&](int kk) { return gr[kk]; }, dp);
                     double *va = vacc + (upb % NGP_RING) * NGP_BLK + j;
-                    // lag 3 arrives one block before lag 2 (both by this workgroup, separated by a barrier): (v_3 + v_2)
-                    const bool first = (fx == 3) || (D <= 3) || (a == 0);
+                    // higher lags arrive first, one block apart (all by this workgroup, separated by barriers): ((v_4 + v_3) + v_2)
+                    const bool first = (fx == top) || (a == 0);
                     *va = first ? v : *va + v;
                 }
                 have = (u + fx < nb) && (u + 1 < nb);  // rows for the next block: a' = u, target u + fx

@@ -280,6 +280,7 @@ typedef struct {
     /* blocked order storage */
     int64_t R, S, NBLK, Ppad; /* rows per shard, shards, blocks */
     int64_t D;                /* lag of the pipelined sweep (1 = no look-ahead) */
+    int64_t near;             /* look-ahead lags 1..near corrected by the sampler, farther ones folded into the group sums */
     double *gramx;            /* [t][d][k][j], d = 1..D-1: x_{t-d,k}' x_{t,j} */
     float *tiles;             /* [s][t][j][i] */
     double *gram;             /* [t][64][64] */
@@ -316,7 +317,13 @@ int ora_create(int order, uint64_t seed, uint32_t chain, ora_t **out) {
     h->order = order; h->seed = seed; h->chain = chain;
     h->e_df = 4.0; h->e_scale = 0.0005; h->intercept = 1;
     h->chainLength = 0; h->burnIn = 0; h->thin = 1;
+    h->near = 3;
     *out = h; return ORA_OK;
+}
+/* which look-ahead lags the sampler corrects itself (the library reports its choice: ngp_get_near_lags) */
+int ora_set_near(ora_t *h, int64_t near) {
+    if (near < 1 || near > 8) { snprintf(h->err, 256, "near lags out of range"); return ORA_ERR; }
+    h->near = near; return ORA_OK;
 }
 static void free_sets(ora_t *h) {
     for (int s = 0; s < h->nsets; s++) { free(h->sets[s].reg_start); free(h->sets[s].reg_stop); }
@@ -811,8 +818,8 @@ static void iter_blocked(ora_t *h) {
                 gs[g] = v;
             }
             /* look-ahead corrections v_d = G[tb, tb-d] dlt_{tb-d} of the blocks whose update the GEMV has not seen.
-               Far lags d = 4 .. D-1 are folded into the group sums (the reducer workgroups compute them): lag d goes
-               to group (d-4) mod NG, ascending d.  Lags 3, 2 and 1 stay with the sampler. */
+               Far lags d = h->near+1 .. D-1 are folded into the group sums (the reducer workgroups compute them):
+               lag d goes to group (d-h->near-1) mod NG, ascending d.  Lags h->near .. 1 stay with the sampler. */
             double vd[17]; int hv[17];
             for (int64_t d = 1; d < D; d++) {
                 hv[d] = (tb - d >= 0);
@@ -823,13 +830,13 @@ static void iter_blocked(ora_t *h) {
                 for (int k = 0; k < BLK; k++) s4[k & 3] = __builtin_fma(Gx[k * BLK + j], da[k], s4[k & 3]);
                 vd[d] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
             }
-            for (int64_t d = 4; d < D; d++)
-                if (hv[d]) { int64_t g = (d - 4) % NGq; gs[g] = gs[g] - vd[d]; }
+            for (int64_t d = h->near + 1; d < D; d++)
+                if (hv[d]) { int64_t g = (d - h->near - 1) % NGq; gs[g] = gs[g] - vd[d]; }
             double tot = gs[0];
             for (int64_t g = 1; g < NGq; g++) tot = tot + gs[g];
-            {   /* near lags stay with the sampler: cor = (v_3 + v_2) + v_1 over the terms that exist */
+            {   /* near lags stay with the sampler: cor = (((v_near + ...) + v_2) + v_1) over the terms that exist */
                 double c = 0.0; int have = 0;
-                for (int64_t d = (D - 1 < 3 ? D - 1 : 3); d >= 1; d--)
+                for (int64_t d = (D - 1 < h->near ? D - 1 : h->near); d >= 1; d--)
                     if (hv[d]) { c = have ? c + vd[d] : vd[d]; have = 1; }
                 if (have) tot = tot - c;
             }

@@ -38,18 +38,24 @@ def test_draws_bit_exact(dev, O, what, p1, p2):
     assert np.array_equal(got, exp)
 
 
-ENGINES = [(0, 1), (1, 1), (1, 2), (1, 3), (1, 4), (1, 6), (1, 8)]   # (mode, lag): per-block launches / persistent sweep
-ENGINE_IDS = ["blocklaunch", "persist_lag1", "persist_lag2", "persist_lag3", "persist_lag4", "persist_lag6", "persist_lag8"]
+# (mode, lag[, near lags]): per-block launches / persistent sweep; near = 4 is what tall shards (R > 128) run with
+ENGINES = [(0, 1), (1, 1), (1, 2), (1, 3), (1, 4), (1, 6), (1, 8), (1, 5, 4), (1, 8, 4)]
+ENGINE_IDS = ["blocklaunch", "persist_lag1", "persist_lag2", "persist_lag3", "persist_lag4", "persist_lag6", "persist_lag8",
+              "persist_lag5_near4", "persist_lag8_near4"]
 
 
 def _pair(ngp, O, X, seed=1001, chain=0, engine=(1, 6)):
+    """engine = (mode, lag) or (mode, lag, near lags)."""
     s = ngp.Sampler(device=0, seed=seed, chain=chain, mode=engine[0], lag=engine[1])
+    if len(engine) > 2:
+        s.set_near(engine[2])
     s.set_panel(X)
     R, S, nblk = s.layout()
     mode, D = s.config()
     assert mode == engine[0] and D == (engine[1] if mode == 1 else 1)
+    assert s.near() == (engine[2] if len(engine) > 2 else 3)   # short shards: 3 unless asked otherwise
     o = O.Oracle(order=1, seed=seed, chain=chain)
-    o.set_panel_f32(X, R=R, S=S, D=D)
+    o.set_panel_f32(X, R=R, S=S, D=D, near=s.near())
     return s, o
 
 

@@ -124,6 +124,22 @@ def test_blocked_order_equals_reference_order(O, spec):
     assert a.get_posterior_sums()["nKept"] == b.get_posterior_sums()["nKept"] == 10
 
 
+@pytest.mark.parametrize("D,near", [(2, 3), (4, 3), (6, 3), (8, 3), (5, 4), (8, 4)])
+def test_look_ahead_is_the_same_chain(O, D, near):
+    """Lag D with the corrections split between sampler (lags 1..near) and reducers (the rest): same chain as the reference
+    order, whatever the split."""
+    N, P = 130, 64 * 11 + 5
+    X, y, bt, v = make_problem(O, N, P, seed=13)
+    a = O.Oracle(0, seed=5, chain=2); a.set_panel_f32(X)
+    b = O.Oracle(1, seed=5, chain=2); b.set_panel_f32(X, R=8, S=17, D=D, near=near)
+    for m in (a, b):
+        add_sets(m, [(0, 400, "PR"), (400, P - 400, "B")], v); m.set_y(y); m.set_residual_prior(4.0, 0.25 * y.var()); m.run(12)
+    sa, sb = a.get_state(), b.get_state()
+    assert np.array_equal(sa["delta"], sb["delta"])
+    assert np.abs(sa["beta"] - sb["beta"]).max() <= 1e-10 * max(1e-3, np.abs(sa["beta"]).max())
+    assert np.abs(sa["ycorr"] - sb["ycorr"]).max() <= 1e-10 * np.abs(sa["ycorr"]).max()
+
+
 def test_layout_independence_of_blocked_order(O):
     """Different shard layouts change only the summation tree: results agree to rounding, indicators exactly."""
     N, P = 200, 128
