@@ -135,14 +135,15 @@ void dfree(T *&p) {
     if (p) { (void)hipFree(p); p = nullptr; }
 }
 
-// rows per shard R = 4*odd (conflict-free ds_read_b128 in both read patterns), S = ceil(N/R)
-void choose_layout(int64_t N, int64_t max_shards, int64_t *R, int64_t *S) {
+// rows per shard R: a multiple of 4, 4*odd where that fits under the cap (the layouts of the first versions, kept so that
+// results stay comparable; with quad-major tiles any multiple of 4 reads conflict-free), S = ceil(N/R)
+void choose_layout(int64_t N, int64_t max_shards, int64_t r_cap, int64_t *R, int64_t *S) {
     int64_t r0 = (N + max_shards - 1) / max_shards;
     int64_t m = (r0 + 3) / 4;
     if (m < 1) m = 1;
-    if ((m & 1) == 0) m += 1;
+    if ((m & 1) == 0 && 4 * (m + 1) <= r_cap) m += 1;
     int64_t r = 4 * m;
-    if (r > 508) r = 508;  // LDS bound of the streaming kernel: R*264 + 2048 <= 160 KiB
+    if (r > r_cap) r = r_cap;
     *R = r;
     *S = (N + r - 1) / r;
 }
@@ -156,15 +157,14 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
     if (h->mode == 1) {
         max_shards = h->cu_count - 1 - (h->cu_count + NGP_GRP - 1) / NGP_GRP;
         if (N > max_shards * 256) h->mode = 0;  // too many rows for one resident wave of streamers (2 LDS tile slots + partials)
-        else choose_layout(N, max_shards, &h->R, &h->S);
+        else choose_layout(N, max_shards, 256, &h->R, &h->S);  // 8 R / 4 update tasks <= 512 threads, two 1040 R / 4 byte LDS slots
     }
-    if (h->mode == 0) choose_layout(N, 256, &h->R, &h->S);
+    if (h->mode == 0) choose_layout(N, 256, 508, &h->R, &h->S);  // LDS bound of k_step: R*264 + 4096 <= 160 KiB
     h->NG = (int)((h->S + NGP_GRP - 1) / NGP_GRP);
     h->D = (h->mode == 1) ? h->lag : 1;
     if (h->mode == 1 && h->R > 128 && h->D > 5) h->D = 5;  // tall shards: the register delay line holds 5 tiles at most
-    // the far path (sampler -> reducer -> sampler, about 7 us) has `near` block periods to complete: 3 blocks of 2.1 us at
-    // short shards (a fourth near lag overloads the sampler CU there: +17 % time), 4 blocks for tall shards, where with
-    // lag 5 nothing is left for the reducers (-8 % time)
+    // a fourth near lag overloads the sampler CU at short shards (+17 % time at 10k x 100k); at tall shards, where with lag 5
+    // nothing is left for the reducers then, it saves 8 %
     h->near = h->near_req ? h->near_req : ((h->mode == 1 && h->R > 128) ? 4 : 3);
     h->NBLK = (P + NGP_BLK - 1) / NGP_BLK;
     h->Ppad = h->NBLK * NGP_BLK;

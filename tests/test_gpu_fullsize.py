@@ -83,3 +83,24 @@ def test_xbeta_is_linear(ngp):
     lhs = s.xbeta(2.0 * u - 3.0 * w)
     rhs = 2.0 * s.xbeta(u) - 3.0 * s.xbeta(w)
     assert np.abs(lhs - rhs).max() <= 1e-10 * np.abs(lhs).max()
+
+
+@pytest.mark.parametrize("N_,P_,mode_", [(63000, 700, 1), (63232, 400, 1), (63300, 300, 0)], ids=["R256", "R256_full", "fallback"])
+def test_tallest_shards_and_fallback(ngp, N_, P_, mode_):
+    """The persistent sweep holds shards of at most 256 rows (247 streamers -> N <= 63232); beyond that the per-block engine
+    takes over.  (A layout rule that preferred 4*odd rows once produced 260-row shards here and dropped update tasks.)"""
+    s = ngp.Sampler(device=0, seed=5, chain=0)
+    s.generate_panel(N_, P_)
+    R, S, nblk = s.layout()
+    assert s.config()[0] == mode_ and (R <= 256 if mode_ == 1 else True) and R * S >= N_
+    rng = np.random.default_rng(1)
+    bt = np.zeros(P_); bt[rng.choice(P_, 10, replace=False)] = rng.normal(size=10)
+    g = s.xbeta(bt)
+    y = 3.0 + g + np.random.default_rng(2).normal(size=N_) * np.sqrt(g.var())
+    v = 0.5 * y.var() / (s.mpm().sum() / N_)
+    h = P_ // 2
+    s.add_marker_set(0, h, 0, 4.0, v * 0.5, [(0, h)], [v])
+    s.add_marker_set(h, P_ - h, 1, 4.0, v * 0.5, [(j, j + 1) for j in range(P_ - h)], np.full(P_ - h, v), pi0=0.1, estPi=True)
+    s.set_y(y); s.set_residual_prior(4.0, 0.25 * y.var()); s.run(6)
+    st = s.get_state()
+    assert np.abs(st["ycorr"] - (y - st["b"] - s.xbeta(st["beta"]))).max() < 1e-9
