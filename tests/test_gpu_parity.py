@@ -227,3 +227,30 @@ def test_u8_panel_equals_f64_panel(ngp, O):
     s = ngp.Sampler(device=0, seed=3, chain=0)
     s.set_panel(np.asfortranarray(G), centre=False)
     assert np.allclose(s.mpm(), (G.astype(np.float64) ** 2).sum(axis=0))
+
+
+@pytest.mark.parametrize("N", [14700, 16000, 30400, 31700, 62000, 63232], ids=["R60", "R68", "R124", "R132", "R252", "R256"])
+def test_shard_height_boundaries_bit_exact(ngp, O, N):
+    """Rows per shard at the boundaries of the update-task mappings (1, 2, 4 rows per thread), of the lag / near-lag
+    rules for tall shards and of the LDS budget: bit-exact against the blocked oracle with the layout the library reports."""
+    P = 448 + 17
+    X = O.generate_panel(N, P, seed=3)[0]
+    rng = np.random.default_rng(2)
+    y = 1.0 + X[:, :5].astype(np.float64) @ rng.normal(size=5) + rng.normal(size=N)
+    s = ngp.Sampler(device=0, seed=21, chain=0)
+    s.set_panel(X)
+    R, S, nblk = s.layout()
+    mode, D = s.config()
+    assert mode == 1 and R == {14700: 60, 16000: 68, 30400: 124, 31700: 132, 62000: 252, 63232: 256}[N]
+    assert (D, s.near()) == ((6, 3) if R <= 128 else (5, 4))
+    o = O.Oracle(order=1, seed=21, chain=0)
+    o.set_panel_f32(X, R=R, S=S, D=D, near=s.near())
+    v = 0.01
+    for m in (s, o):
+        add_sets(m, [(0, 300, "PR"), (300, P - 300, "B")], v)
+        m.set_y(y); m.set_residual_prior(4.0, 0.5); m.run(4)
+    a, b = s.get_state(), o.get_state()
+    assert np.array_equal(a["delta"], b["delta"])
+    for k in ("beta", "ycorr", "varBeta", "piHat"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["varE"] == b["varE"] and a["b"] == b["b"]
