@@ -254,3 +254,31 @@ def test_shard_height_boundaries_bit_exact(ngp, O, N):
     for k in ("beta", "ycorr", "varBeta", "piHat"):
         assert np.array_equal(a[k], b[k]), k
     assert a["varE"] == b["varE"] and a["b"] == b["b"]
+
+
+@pytest.mark.parametrize("engine", [(0, 1), (1, 6), (1, 8, 4)], ids=["blocklaunch", "persist_lag6", "persist_lag8_near4"])
+def test_summary_stat_terms_no_intercept_long_regions(ngp, O, engine):
+    """M.lhs / M.rhs of summary statistics (src/mme.jl:314-322; BayesC drops M.rhs, src/functions.jl:220), a model without
+    intercept (src/functions.jl:41-47 skipped) and variance regions longer than one 256-locus segment."""
+    N, P = 300, 1500
+    X, y, bt, v = make_problem(O, N, P, seed=21)
+    rng = np.random.default_rng(5)
+    s, o = _pair(ngp, O, X, seed=31, chain=2, engine=engine)
+    ro = O.Oracle(order=0, seed=31, chain=2); ro.set_panel_f32(X)
+    df = 4.0
+    sets = [(0, 700, 0, [(0, 300), (300, 650), (650, 700)], None), (700, 400, 1, [(j, j + 1) for j in range(400)], 0.1),
+            (1100, 400, 2, [(0, 400)], 0.2)]
+    for m in (s, o, ro):
+        for col0, ncol, method, regs, pi0 in sets:
+            lhs0 = np.abs(np.random.default_rng(col0).normal(size=ncol)) * 0.3
+            rhs0 = np.random.default_rng(col0 + 1).normal(size=ncol) * 0.2
+            m.add_marker_set(col0, ncol, method, df, v * (df - 2) / df, regs, [v] * len(regs), pi0=pi0 or 0.0, estPi=bool(pi0),
+                             lhs0=lhs0, rhs0=rhs0)
+        m.set_y(y); m.set_intercept(False); m.set_residual_prior(4.0, 0.25 * y.var()); m.run(10)
+    a, b, c = s.get_state(), o.get_state(), ro.get_state()
+    assert a["b"] == 0.0 and b["b"] == 0.0
+    assert np.array_equal(a["delta"], b["delta"]) and np.array_equal(a["delta"], c["delta"])
+    for k in ("beta", "ycorr", "varBeta", "piHat"):
+        assert np.array_equal(a[k], b[k]), k
+        assert np.abs(a[k] - c[k]).max() <= 1e-9 * max(1e-6, np.abs(c[k]).max()), k
+    assert a["varE"] == b["varE"]
