@@ -282,3 +282,44 @@ def test_summary_stat_terms_no_intercept_long_regions(ngp, O, engine):
         assert np.array_equal(a[k], b[k]), k
         assert np.abs(a[k] - c[k]).max() <= 1e-9 * max(1e-6, np.abs(c[k]).max()), k
     assert a["varE"] == b["varE"]
+
+
+def test_fine_seam_bayesc_and_second_set(ngp, O):
+    """Fine seam (src/samplers.jl:52) for a BayesC set that does not start at column 0: the sweep covers only the blocks of
+    that set; ycorr, beta, delta, the single variance and piHat come back; the other set's columns are untouched."""
+    N, P = 250, 400
+    X, y, bt, v = make_problem(O, N, P, seed=14)
+    s = ngp.Sampler(device=0, seed=8, chain=0)
+    s.set_panel(X)
+    s.add_marker_set(0, 150, 0, 4.0, v * 0.5, [(0, 150)], [v])
+    s.add_marker_set(150, 250, 2, 4.0, v * 0.5, [(0, 250)], [v], pi0=0.3, estPi=True)
+    ycorr = y - y.mean()
+    beta = np.zeros(250); vb = np.array([v]); pi = np.array([0.7, 0.3])
+    for it in range(4):
+        d = s.sweep_set(1, 0.9, ycorr, beta, vb, pi)
+        assert set(np.unique(d)) <= {0, 1} and np.all(beta[d == 0] == 0.0) and vb[0] > 0 and abs(pi.sum() - 1.0) < 1e-15
+        full = np.zeros(P); full[150:] = beta
+        assert np.abs(ycorr - ((y - y.mean()) - s.xbeta(full))).max() < 1e-10
+    assert 0.0 < pi[1] < 1.0 and pi[1] != 0.3
+
+
+def test_monomorphic_columns(ngp, O):
+    """Columns without variation (x'x = 0 after centring): the reference's arithmetic gives lhs = 1/varBeta for BayesPR and an
+    inclusion probability of NaN, i.e. never included, for BayesB / BayesC (log 0, 0/0 in src/functions.jl:169-173).  Oracle
+    (both orders) and device agree."""
+    N, P = 120, 192
+    X, y, bt, v = make_problem(O, N, P, seed=15)
+    X = np.asfortranarray(X)
+    X[:, [3, 70, 100, 150, 191]] = 0.0
+    s, o = _pair(ngp, O, X, seed=12, chain=0, engine=(1, 3))
+    ro = O.Oracle(order=0, seed=12, chain=0); ro.set_panel_f32(X)
+    for m in (s, o, ro):
+        add_sets(m, [(0, 64, "PR"), (64, 64, "Bfix"), (128, 64, "Cfix")], v)
+        m.set_y(y); m.set_residual_prior(4.0, 0.25 * y.var()); m.run(6)
+    a, b, c = s.get_state(), o.get_state(), ro.get_state()
+    assert np.array_equal(a["delta"], b["delta"]) and np.array_equal(a["delta"], c["delta"])
+    assert a["delta"][70] == 0 and a["delta"][100] == 0 and a["delta"][150] == 0 and a["delta"][191] == 0 and a["delta"][3] == 1
+    for k in ("beta", "ycorr", "varBeta"):
+        assert np.array_equal(a[k], b[k]), k
+        assert np.all(np.isfinite(a[k]))
+        assert np.abs(a[k] - c[k]).max() <= 1e-9 * max(1e-6, np.abs(c[k]).max()), k
