@@ -35,6 +35,7 @@
 #define NGP_DBG_ALL (7u << 17)     // every streamer: publish time of local block 800 and its XCC id
 // LDS distance of two quads of a tile: 1 KiB of data + 16 B, so that the update tasks (lanes = consecutive quads, same
 // columns) read conflict-free
+#define NGP_SPARSE_MAX 16  // BayesB / BayesC blocks with at most this many active lanes take the sparse chain
 #define NGP_QS 1040
 #define NGP_DBG_STREAM (1u << 20)  // offset of streamer 0's stamps in the debug buffer
 
@@ -566,15 +567,16 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
             // its own step and nothing has to be captured.  H_k = -(c G[k][.]) is formed four steps ahead, in the
             // latency shadow of the serial path: v_readlane -> ONE fma per step (BayesPR), + compare / select (BayesB).
             double G[NGP_BLK];
-#pragma unroll
-            for (int kk = 0; kk < NGP_BLK; kk++) G[kk] = gdb[kk * NGP_BLK];
+#define NGP_LOAD_G()                                                           \
+    _Pragma("unroll") for (int kk = 0; kk < NGP_BLK; kk++) G[kk] = gdb[kk * NGP_BLK]; \
+    double H0 = -(cc * G[0]), H1 = -(cc * G[1]), H2 = -(cc * G[2]), H3 = -(cc * G[3]);
             double e = __builtin_fma(r, cc, ww);
             double dsave;
             int isave = 1;
-            double H0 = -(cc * G[0]), H1 = -(cc * G[1]), H2 = -(cc * G[2]), H3 = -(cc * G[3]);
             if (A.dbg_mode == 5 && __ballot(st >= 0.0) == 0ull) {
                 dsave = e;  // timing experiment: BayesPR blocks without the 64-step recursion
             } else if (__ballot(st >= 0.0) == 0ull) {
+                NGP_LOAD_G()
 #pragma unroll
                 for (int kk = 0; kk < NGP_BLK; kk += 4) {
                     double dk;
@@ -584,7 +586,29 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
                     dk = readlane_d(e, kk + 3); e = __builtin_fma(H3, dk, e); H3 = -(cc * G[(kk + 7) & 63]);
                 }
                 dsave = e;
+            } else if (__popcll(__ballot((__builtin_fabs(r * cc) > st) || (bo != 0.0))) <= NGP_SPARSE_MAX) {
+                // Sparse BayesB / BayesC block: a step k changes something only if locus k is included (|f_k| > thr_k) or
+                // carries an old effect to take out (beta_k != 0); every other step multiplies by dlt_k = -0 and leaves all e, f
+                // as they are, bit for bit.  So the chain visits only the lanes of that mask, which is rebuilt after every
+                // visited step (f has changed for the later lanes).  With pi around 1 % that is a handful of steps, not 64.
+                double f = r * cc;
+                const double nbo = -bo;
+                unsigned long long todo = __ballot((__builtin_fabs(f) > st) || (bo != 0.0));
+                while (todo) {
+                    const int k = __builtin_ctzll(todo);
+                    const double Hk = -(cc * gdb[k * NGP_BLK]);  // row k of the one-sided block: 0 for lanes <= k
+                    const unsigned long long inm = __ballot(__builtin_fabs(f) > st);
+                    const double ek = readlane_d(e, k), nk = readlane_d(nbo, k);
+                    const double dk = ((inm >> k) & 1ull) ? ek : nk;
+                    e = __builtin_fma(Hk, dk, e);
+                    f = __builtin_fma(Hk, dk, f);
+                    const unsigned long long later = (k == 63) ? 0ull : (~0ull << (k + 1));
+                    todo = __ballot((__builtin_fabs(f) > st) || (bo != 0.0)) & later;
+                }
+                isave = __builtin_fabs(f) > st;
+                dsave = isave ? e : -bo;
             } else {
+                NGP_LOAD_G()
                 double f = r * cc;
 #pragma unroll
                 for (int kk = 0; kk < NGP_BLK; kk += 4) {
@@ -603,6 +627,7 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
                 isave = __builtin_fabs(f) > st;
                 dsave = isave ? e : -bo;
             }
+#undef NGP_LOAD_G
             hist[slot * NGP_BLK + j] = dsave;
             outb[buf * NGP_BLK + j] = bo + dsave;
             outi[buf * NGP_BLK + j] = isave;
