@@ -206,7 +206,7 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
     h->have_y = false; h->iter = 0;
     HCHK(hipFuncSetAttribute((const void *)k_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_step));
     if (h->mode == 1) {
-        const size_t lds_sampler = (size_t)(3 * 4096 + 2 * NGP_RING * NGP_BLK + 6 * NGP_BLK) * sizeof(double) + 2 * NGP_BLK * sizeof(int) + 64;
+        const size_t lds_sampler = (size_t)(3 * 4096 + 2 * NGP_RING * NGP_BLK + 6 * NGP_BLK) * sizeof(double) + 2 * NGP_BLK * sizeof(int) + 256;
         const size_t lds_max = 160 * 1024;
         const size_t misc = (size_t)h->R * 8 + 4096 + 2 * 512 + 128 + 3072 + (size_t)h->R * 64;
         const size_t TB = (size_t)(h->R / 4) * NGP_QS;  // LDS footprint of one tile (quads NGP_QS bytes apart)

@@ -464,9 +464,15 @@ __device__ inline bool fetch_group_sums(const SweepArgs &A, int u, int j, double
 }
 
 // results of a finished block: dlt first (sc1 + drain + flag: the streamers are waiting), then beta / delta / varBeta
-__device__ inline void publish_block(const SweepArgs &A, int up, int j, const double *hist, const double *outb, const int *outi) {
+__device__ inline void publish_block(const SweepArgs &A, int up, int j, const double *hist, const double *outb, const int *outi,
+                                     const int *smeth, const double *ssdf) {
     const int pslot = up % NGP_RING, pbuf = up & 1;
     const long long k = (long long)(A.t0 + up) * NGP_BLK + j;
+    // what the variance bookkeeping of BayesB needs is requested first, so that it travels while the store is acknowledged
+    // (three dependent round trips here made the publisher the slowest wave of BayesB sweeps)
+    const int si = A.setof[k];
+    const double chik = A.chi[k];
+    const int vbi = A.vbidx[k];
     st_f64(&A.dlt[(size_t)pslot * NGP_BLK + j], hist[pslot * NGP_BLK + j]);
     drain_vm();
     if (j == 0) {
@@ -477,18 +483,18 @@ __device__ inline void publish_block(const SweepArgs &A, int up, int j, const do
     const int isave = outi[pbuf * NGP_BLK + j];
     A.beta[k] = bn;
     A.delta[k] = (uint8_t)isave;
-    const int si = A.setof[k];
-    if (si >= 0 && A.sets[si].method == 1) {
+    const int meth = (si >= 0) ? smeth[si] : -1;  // per-set constants live in LDS
+    if (meth == 1) {
         double vb = 0.0;
         if (isave) {
-            double tt = A.sets[si].sdf;
+            double tt = ssdf[si];
             double b2 = bn * bn;
             tt = tt + b2;
-            vb = tt / A.chi[k];
+            vb = tt / chik;
             atomicAdd(&A.sets[si].nloci, 1);
         }
-        A.varBeta[A.vbidx[k]] = vb;
-    } else if (si >= 0 && A.sets[si].method == 2) {
+        A.varBeta[vbi] = vb;
+    } else if (meth == 2) {
         if (isave) atomicAdd(&A.sets[si].nloci, 1);  // BayesC: one variance per set, drawn after the sweep
     }
 }
@@ -510,8 +516,14 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
     int *outi = (int *)(outb + 2 * NGP_BLK);    // 2 x 64
     int *sabort = outi + 2 * NGP_BLK;
     int *totflag = sabort + 1;  // local block index + 1 whose corrected total is ready in r0[buf]
+    int *smeth = sabort + 4;                     // method of each of the (at most 16) marker sets
+    double *ssdf = (double *)(sabort + 20);      // scale * df of each set
     const int nb = A.t1 - A.t0;
     const size_t bsz = NGP_BLK * NGP_BLK;
+    if (tid < 16) {
+        smeth[tid] = A.sets[tid].method;
+        ssdf[tid] = A.sets[tid].sdf;
+    }
     if (tid == 0) {
         *sabort = 0;
         *totflag = 0;
@@ -637,10 +649,10 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
         }
     } else if (wv == 1) {
         for (int u = 0; u < nb; ++u) {
-            if (u >= 1) publish_block(A, u - 1, j, hist, outb, outi);
+            if (u >= 1) publish_block(A, u - 1, j, hist, outb, outi, smeth, ssdf);
             NGP_END_OF_BLOCK();
         }
-        if (nb >= 1) publish_block(A, nb - 1, j, hist, outb, outi);
+        if (nb >= 1) publish_block(A, nb - 1, j, hist, outb, outi, smeth, ssdf);
     } else if (wv == 2) {
         // group sums -> r0 ring.  Lag >= 4: two blocks ahead -- the loads of block u+2 (and a probe of the counter of
         // block u+3) are issued during block u and consumed at the start of block u+1, so the memory round trip of this
