@@ -752,14 +752,26 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
                 const bool have_one = (u >= 1);
                 double cor = have_far ? vacc[slot * NGP_BLK + j] : 0.0;
                 if (have_one) {
-                    const double dreg = hist[((u - 1) % NGP_RING) * NGP_BLK + j];  // lane k holds dlt_k of the previous block
+                    // dlt of the previous block by broadcast reads from LDS (every lane reads the same 16 bytes): 32 LDS
+                    // instructions instead of 128 v_readlane in front of the 64 fma -- this wave is what the chain waits for
+                    typedef const __attribute__((address_space(3))) double *lds_cdp;
+                    const lds_cdp dk = (lds_cdp)(hist + ((u - 1) % NGP_RING) * NGP_BLK);
                     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-                    for (int kk = 0; kk < NGP_BLK; kk += 4) {
-                        s0 = __builtin_fma(gxr[kk + 0], readlane_d(dreg, kk + 0), s0);
-                        s1 = __builtin_fma(gxr[kk + 1], readlane_d(dreg, kk + 1), s1);
-                        s2 = __builtin_fma(gxr[kk + 2], readlane_d(dreg, kk + 2), s2);
-                        s3 = __builtin_fma(gxr[kk + 3], readlane_d(dreg, kk + 3), s3);
+                    for (int kk = 0; kk < NGP_BLK; kk += 16) {
+                        double dv[16];
+#pragma unroll
+                        for (int i = 0; i < 16; i++) dv[i] = dk[kk + i];
+#pragma unroll
+                        for (int i = 0; i < 16; i += 4) {
+                            s0 = __builtin_fma(gxr[kk + i + 0], dv[i + 0], s0);
+                            s1 = __builtin_fma(gxr[kk + i + 1], dv[i + 1], s1);
+                            s2 = __builtin_fma(gxr[kk + i + 2], dv[i + 2], s2);
+                            s3 = __builtin_fma(gxr[kk + i + 3], dv[i + 3], s3);
+                        }
+                        // the sums are "used" here so that the 16 fma stay with their chunk (all 64 dlt values in registers
+                        // next to the 64 Gram rows would not fit)
+                        asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));
                     }
                     const double v1 = (s0 + s1) + (s2 + s3);
                     cor = have_far ? cor + v1 : v1;
