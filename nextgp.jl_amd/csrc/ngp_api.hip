@@ -208,7 +208,7 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
     if (h->mode == 1) {
         const size_t lds_sampler = (size_t)(3 * 4096 + 2 * NGP_RING * NGP_BLK + 6 * NGP_BLK) * sizeof(double) + 2 * NGP_BLK * sizeof(int) + 256;
         const size_t lds_max = 160 * 1024;
-        const size_t misc = (size_t)h->R * 8 + 4096 + 2 * 512 + 128 + 3072 + (size_t)h->R * 64;
+        const size_t misc = (size_t)h->R * 16 + 4096 + 2 * 512 + 128 + 3072 + (size_t)h->R * 64;
         const size_t TB = (size_t)(h->R / 4) * NGP_QS;  // LDS footprint of one tile (quads NGP_QS bytes apart)
         h->lds_sweep = std::max(2 * TB + misc, lds_sampler);
         if (2 * TB + misc + 8192 <= lds_max) h->lds_sweep = std::max(h->lds_sweep, 2 * TB + misc + 8192);  // room for the diagnostic timeline
@@ -325,7 +325,7 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
         A.flag_dlt = A.cnt_gs + (size_t)NGP_RING * 32; A.abort_w = h->d_abort; A.xcc_w = h->d_abort + 16;
         if (evs) (void)hipEventRecord(evs[0], h->stream);
         A.dbg = h->d_dbg;
-        A.fine_ok = ((size_t)2 * (R / 4) * NGP_QS + (size_t)R * 72 + 8320 + 8192 <= h->lds_sweep) ? 1 : 0;  // diagnostic timeline fits in LDS
+        A.fine_ok = ((size_t)2 * (R / 4) * NGP_QS + (size_t)R * 80 + 8320 + 8192 <= h->lds_sweep) ? 1 : 0;  // diagnostic timeline fits in LDS
         { const char *e = getenv("NGP_DEBUG_MODE"); A.dbg_mode = e ? atoi(e) : 0; }
         hipLaunchKernelGGL(k_sweep, dim3((unsigned)(1 + h->NG + S)), dim3(NGP_WG), h->lds_sweep, h->stream, A);
         if (evs) (void)hipEventRecord(evs[1], h->stream);

@@ -149,8 +149,13 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
     const size_t TB = (size_t)R * 256;               // tile bytes in HBM: R/4 quads of 1 KiB (quad-major, ngp_kernels.h)
     const size_t TBL = (size_t)(R >> 2) * NGP_QS;    // the same tile in LDS: quads NGP_QS bytes apart
     char *ring = smem;                               // 2 slots of TBL bytes
-    double *ys = (double *)(smem + 2 * TBL);
-    double *red = ys + R;                     // 8 x 64 chain partials
+    // Short shards (R <= 64, one update task per thread): a shard fits into the lanes of one wave, so every wave forms the
+    // updated shard itself at the start of phase C (lane i: tree of the 8 chain partials of row i, y_i - T) and reads its
+    // quads' rows with v_readlane -- the separate pass over the shard and its barrier are gone.  The shard is double
+    // buffered in LDS by iteration parity (wave 0 writes the new one while the others may still read the old one).
+    constexpr bool FUSE1 = (NGP_TPT == 1);
+    double *ys = (double *)(smem + 2 * TBL);  // FUSE1: 2 x R (parity), else R
+    double *red = ys + 2 * R;                 // 8 x 64 chain partials
     double *dl = red + 512;                   // 2 x 64: dlt of the block being applied, double-buffered by iteration parity
     int *sflag = (int *)(dl + 128);
     char *scratch = (char *)(dl + 128) + 64;  // 3 KiB sink of the L2-warming DMA
@@ -266,16 +271,32 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
                 }
                 NGP_FINE(2);
                 wg_barrier();
-                for (int i = tid; i < R; i += NGP_WG) {
-                    const double T = ((pp[i] + pp[R + i]) + (pp[2 * R + i] + pp[3 * R + i])) +
-                                     ((pp[4 * R + i] + pp[5 * R + i]) + (pp[6 * R + i] + pp[7 * R + i]));
-                    ys[i] = ys[i] - T;
+                if (!FUSE1) {
+                    for (int i = tid; i < R; i += NGP_WG) {
+                        const double T = ((pp[i] + pp[R + i]) + (pp[2 * R + i] + pp[3 * R + i])) +
+                                         ((pp[4 * R + i] + pp[5 * R + i]) + (pp[6 * R + i] + pp[7 * R + i]));
+                        ys[i] = ys[i] - T;
+                    }
                 }
-            } else {
+            } else if (!FUSE1) {
                 wg_barrier();
             }
             NGP_FINE(3);
-            wg_barrier();
+            if (!FUSE1) wg_barrier();
+            // FUSE1: lane i < R of EVERY wave holds the updated y_i of this iteration; wave 0 stores it for the next one
+            double yn = 0.0;
+            if (FUSE1) {
+                const double *yc = ys + (size_t)(u & 1) * R;
+                if (j < R) {
+                    yn = yc[j];
+                    if (a >= 0 && A.dbg_mode != 1) {
+                        const double T = ((pp[j] + pp[R + j]) + (pp[2 * R + j] + pp[3 * R + j])) +
+                                         ((pp[4 * R + j] + pp[5 * R + j]) + (pp[6 * R + j] + pp[7 * R + j]));
+                        yn = yn - T;
+                    }
+                    if (wv == 0) ys[(size_t)((u & 1) ^ 1) * R + j] = yn;
+                }
+            }
             if (A.dbg && tid == 0) { unsigned long long n = wall_clock64(); accB += n - tt0; tt0 = n; }
             // ---------------- phase C: partial X_u' ycorr, and tile u into the delay line ----------------
             if (u < nb) {
@@ -305,13 +326,20 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
                 {   // chain wv: row quads wv, wv+8, ... (lane = column)
                     const float *col = slotp + 4 * j;  // quad qd of column j: NGP_QS qd + 16 j bytes -- consecutive lanes, consecutive 16 B
                     double acc = 0.0;
-                    for (int qd = wv; qd < (R >> 2); qd += 8) {
+                    for (int qd = __builtin_amdgcn_readfirstlane(wv); qd < (R >> 2); qd += 8) {  // (uniform: it indexes v_readlane)
                         float4 x = *(const float4 *)(col + (size_t)qd * (NGP_QS / 4));
-                        const double *yq = ys + 4 * qd;
-                        acc = __builtin_fma((double)x.x, yq[0], acc);
-                        acc = __builtin_fma((double)x.y, yq[1], acc);
-                        acc = __builtin_fma((double)x.z, yq[2], acc);
-                        acc = __builtin_fma((double)x.w, yq[3], acc);
+                        double y0, y1, y2, y3;
+                        if (FUSE1) {
+                            y0 = readlane_d(yn, 4 * qd); y1 = readlane_d(yn, 4 * qd + 1);
+                            y2 = readlane_d(yn, 4 * qd + 2); y3 = readlane_d(yn, 4 * qd + 3);
+                        } else {
+                            const double *yq = ys + 4 * qd;
+                            y0 = yq[0]; y1 = yq[1]; y2 = yq[2]; y3 = yq[3];
+                        }
+                        acc = __builtin_fma((double)x.x, y0, acc);
+                        acc = __builtin_fma((double)x.y, y1, acc);
+                        acc = __builtin_fma((double)x.z, y2, acc);
+                        acc = __builtin_fma((double)x.w, y3, acc);
                     }
                     red[wv * 64 + j] = acc;
                 }
@@ -368,7 +396,10 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
     }
 #undef NGP_FINE
     __syncthreads();
-    for (int i = tid; i < R; i += NGP_WG) yg[i] = ys[i];
+    {   // FUSE1: the last iteration (index nb + DT - 1) wrote the buffer of parity nb + DT
+        const double *yfin = FUSE1 ? ys + (size_t)((nb + DT) & 1) * R : ys;
+        for (int i = tid; i < R; i += NGP_WG) yg[i] = yfin[i];
+    }
 }
 
 // ------------------------------------------------------------------------------------------
