@@ -113,6 +113,8 @@ def main():
     ap.add_argument("--P", type=int, default=100000)
     ap.add_argument("--method", default="BayesPR", choices=["BayesPR", "BayesB"])
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on one GPU)")
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
     ap.add_argument("--cpu-cols", type=int, default=16000)
     ap.add_argument("--cpu-iters", type=int, default=100)
     args = ap.parse_args()
@@ -127,10 +129,15 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: libnextgp_hip has no CPU fallback")
+    if args.same_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend=args.backend)
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
 
     def barrier():
