@@ -107,8 +107,8 @@ def cpu_baseline(N, P, sample_cols, sample_iters):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=30)
-    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--N", type=int, default=10000)
     ap.add_argument("--P", type=int, default=100000)
     ap.add_argument("--method", default="BayesPR", choices=["BayesPR", "BayesB"])
