@@ -1,9 +1,11 @@
 // ngp_sweep.h -- the persistent sweep kernel ("stage B"): ONE launch per Gibbs iteration walks all
 // 64-SNP blocks.  Workgroups take fixed roles, one workgroup per CU:
 //
-//   sampler  (1)   wave 0 runs the serial 64-step recursion of every block; waves 1-3 prefetch the
-//                  Gram blocks into LDS and compute the look-ahead corrections G[t,a] * dlt_a.
-//   reducers (NG)  reducer g sums the partial X_t'y of shards 32g..32g+31 (fixed order).
+//   sampler  (1)   wave 0 runs the serial recursion of every block; the other waves publish the previous block, fetch
+//                  group sums and Gram blocks ahead, and compute the near look-ahead corrections G[t,a] * dlt_a
+//                  (see role_sampler).
+//   reducers (NG)  reducer g sums the partial X_t'y of shards 32g..32g+31 (fixed order) and folds in the far
+//                  look-ahead corrections.
 //   streamers (S)  streamer s owns rows [sR,(s+1)R) of ycorr (resident in LDS for the whole sweep):
 //                  for every block t it applies the update of block t-D, then streams tile (t,s)
 //                  through LDS and publishes its 64 partial dot products.
@@ -33,9 +35,9 @@
 #define NGP_DBG_WAVES (1u << 19)   // sampler: 8 words per block, end-of-work stamp of every wave
 #define NGP_DBG_RED (3u << 18)     // reducer 0: 2 words per block (counter complete, group sum published)
 #define NGP_DBG_ALL (7u << 17)     // every streamer: publish time of local block 800 and its XCC id
+#define NGP_SPARSE_MAX 16  // BayesB / BayesC blocks with at most this many active lanes take the sparse chain
 // LDS distance of two quads of a tile: 1 KiB of data + 16 B, so that the update tasks (lanes = consecutive quads, same
 // columns) read conflict-free
-#define NGP_SPARSE_MAX 16  // BayesB / BayesC blocks with at most this many active lanes take the sparse chain
 #define NGP_QS 1040
 #define NGP_DBG_STREAM (1u << 20)  // offset of streamer 0's stamps in the debug buffer
 
@@ -531,12 +533,13 @@ __device__ inline void publish_block(const SweepArgs &A, int up, int j, const do
 }
 
 // sampler (8 waves), one raw barrier per block:
-//   wave 0   serial chain of block u (LDS + ALU only; coefficients prefetched one block ahead)
+//   wave 0   serial chain of block u (LDS + ALU only; coefficients prefetched one block ahead); sparse for BayesB / BayesC
 //   wave 1   publishes block u-1 (dlt -> streamers, beta/delta/varBeta)
-//   wave 2   fetches the group sums of block u+1 into LDS
-//   wave 3   LDS-DMA of the diagonal and lag-1 Gram blocks of block u+1
-//   wave 4-7 far corrections G[t',a] dlt_a, lag x = 2..5, Gram rows loaded one block ahead into registers
-// LDS: Gd[2][4096] | Gx[2][4096] | hist[RING][64] | vacc[RING][64] | r0[2][64] | outb[2][64] | outi[2][64] | flags
+//   wave 2   fetches group sums up to two blocks ahead into the r0 ring
+//   wave 3   LDS-DMA of the diagonal Gram block of block u+2 (3 slots, counted vmcnt)
+//   wave 5   lag-1 correction (cross block in registers, loaded one block ahead), final total, LDS flag for wave 0
+//   wave 4, 6, 7   lag-2, lag-3 and (near = 4) lag-4 corrections, Gram rows loaded one block ahead into registers
+// LDS: Gd[3][4096] | hist[RING][64] | vacc[RING][64] | r0[4][64] | outb[2][64] | outi[2][64] | flags, per-set constants
 __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
     const int D = A.D, tid = threadIdx.x, wv = tid >> 6, j = tid & 63;
     double *Gd = (double *)smem;                // 3 x 4096: diagonal Gram blocks of local blocks u, u+1, u+2
