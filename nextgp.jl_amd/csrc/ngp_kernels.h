@@ -530,7 +530,9 @@ __global__ __launch_bounds__(256) void k_gram_reduce(const double *__restrict__ 
     if (d == 0 && k == j) mpm[(size_t)(t0 + tb) * NGP_BLK + k] = tot;
     // the diagonal block is stored strictly "one-sided": entry [k][j] is kept for j > k only (what step k of the
     // recursion applies to the later lanes), zero elsewhere, so the chain needs no per-step masking; x'x lives in mpm
-    gramx[((size_t)(t0 + tb) * D + d) * (NGP_BLK * NGP_BLK) + kj] = (d == 0 && j <= k) ? 0.0 : tot;
+    // cross blocks (d >= 1): row pairs interleaved, element (k, j) at ((k >> 1) * 64 + j) * 2 + (k & 1) (ngp_sweep.h)
+    const size_t off = (d == 0) ? (size_t)kj : ((size_t)(k >> 1) * NGP_BLK + j) * 2 + (k & 1);
+    gramx[((size_t)(t0 + tb) * D + d) * (NGP_BLK * NGP_BLK) + off] = (d == 0 && j <= k) ? 0.0 : tot;
 }
 
 // synthetic genotypes: per-column mean of g_ij (integer sum), then centred fp32 tiles

@@ -46,7 +46,8 @@ namespace ngp {
 struct SweepArgs {
     const float *tiles;
     double *ycorr;
-    const double *gramx;
+    const double *gramx;  // [block][lag d < D][64][64]: d = 0 one-sided diagonal block (natural order), d >= 1 cross blocks with
+                          // row pairs interleaved (gram_pair_index)
     int D, R, S, NG, near, fine_ok, t0, t1;  // near: look-ahead lags 1..near are corrected by the sampler, farther ones by the reducers
      // fine_ok: the streamers' LDS has room for the diagnostic timeline
     double *beta;
@@ -108,6 +109,20 @@ __device__ inline bool wait_ge(const unsigned *flag, unsigned target, unsigned *
             return false;
         }
         __builtin_amdgcn_s_sleep(4);
+    }
+}
+
+// Cross Gram blocks (lag d >= 1) are stored with row pairs interleaved -- element (k, j) at ((k >> 1) * 64 + j) * 2 + (k & 1)
+// -- so that a lane fetches its column of two rows with one 16-byte load: 32 loads per block instead of 64.  A wave can keep
+// only 63 loads in flight (vmcnt has 6 bits): the 64th load of a block used to stall its wave for a full memory round trip,
+// which made the lag-2 / lag-3 waves the last ones at the sampler's barrier.
+__device__ inline void load_rows_pair(const double *blk, int j, double (&out)[NGP_BLK]) {
+    const double2 *p = (const double2 *)blk + j;
+#pragma unroll
+    for (int k2 = 0; k2 < NGP_BLK / 2; k2++) {
+        const double2 v = p[k2 * NGP_BLK];
+        out[2 * k2] = v.x;
+        out[2 * k2 + 1] = v.y;
     }
 }
 
@@ -431,10 +446,8 @@ __device__ inline void role_reducer(const SweepArgs &A, const int g) {
         for (int d = A.near + 1 + g; d < A.D; d += A.NG) {
             const int a = u - d;
             if (a < 0) continue;
-            const double *gx = A.gramx + ((size_t)(A.t0 + u) * A.D + d) * (NGP_BLK * NGP_BLK) + lane;
             double gr[NGP_BLK];
-#pragma unroll
-            for (int kk = 0; kk < NGP_BLK; kk++) gr[kk] = gx[kk * NGP_BLK];
+            load_rows_pair(A.gramx + ((size_t)(A.t0 + u) * A.D + d) * (NGP_BLK * NGP_BLK), lane, gr);
             int okd = 1;
             if (lane == 0) okd = (A.dbg_mode == 3 || A.dbg_mode == 4 || wait_ge(A.flag_dlt, (unsigned)(a + 1), A.abort_w, 4u)) ? 1 : 0;
             okd = __shfl(okd, 0);
@@ -815,9 +828,7 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (j == 0) __hip_atomic_store(totflag, u + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
                 if (u + 1 < nb) {
-                    const double *gx = A.gramx + ((size_t)(A.t0 + u + 1) * D + 1) * bsz + j;
-#pragma unroll
-                    for (int kk = 0; kk < NGP_BLK; kk++) gxr[kk] = gx[kk * NGP_BLK];
+                    load_rows_pair(A.gramx + ((size_t)(A.t0 + u + 1) * D + 1) * bsz, j, gxr);
                 }
             }
             NGP_END_OF_BLOCK();
@@ -845,9 +856,7 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
                 }
                 have = (u + fx < nb) && (u + 1 < nb);  // rows for the next block: a' = u, target u + fx
                 if (have) {
-                    const double *gx = A.gramx + ((size_t)(A.t0 + u + fx) * D + fx) * bsz;
-#pragma unroll
-                    for (int kk = 0; kk < NGP_BLK; kk++) gr[kk] = gx[kk * NGP_BLK + j];
+                    load_rows_pair(A.gramx + ((size_t)(A.t0 + u + fx) * D + fx) * bsz, j, gr);
                 }
             }
             NGP_END_OF_BLOCK();
