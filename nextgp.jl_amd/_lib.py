@@ -61,7 +61,7 @@ class Sampler:
         self.nsets = 0
         self.set_shapes = []  # (ncol, nreg) per set
         if mode is not None or lag is not None:
-            self.configure(1 if mode is None else mode, 6 if lag is None else lag)
+            self.configure(1 if mode is None else mode, 8 if lag is None else lag)
 
     def configure(self, mode, lag):
         self._chk(self.L.ngp_configure(self.h, C.c_int32(mode), C.c_int32(lag)))

@@ -42,7 +42,7 @@ struct ngp_handle {
     int64_t N = 0, P = 0, R = 0, S = 0, NBLK = 0, Ppad = 0, L = 0;
     size_t lds_step = 0, lds_sweep = 0;
     int mode = 1;      // 1: persistent sweep kernel, 0: one streaming + one recursion launch per block
-    int lag = 6;       // look-ahead D of the persistent sweep (blocks)
+    int lag = 8;       // look-ahead D of the persistent sweep (blocks); shards taller than 128 rows are capped at 5
     int near_req = 0;  // near lags requested (0 = automatic)
     int near = 3;      // look-ahead lags 1..near corrected by the sampler itself, farther ones by the reducers
     int D = 1;         // Gram planes stored per block (= lag in mode 1, 1 in mode 0)

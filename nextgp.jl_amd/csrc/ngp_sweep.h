@@ -38,6 +38,9 @@
 #define NGP_SPARSE_MAX 16  // BayesB / BayesC blocks with at most this many active lanes take the sparse chain
 // LDS distance of two quads of a tile: 1 KiB of data + 16 B, so that the update tasks (lanes = consecutive quads, same
 // columns) read conflict-free
+#ifndef NGP_LAZY_LAG
+#define NGP_LAZY_LAG 7  // streamers count their partials lazily from this lag on
+#endif
 #define NGP_QS 1040
 #define NGP_DBG_STREAM (1u << 20)  // offset of streamer 0's stamps in the debug buffer
 
@@ -236,6 +239,20 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
     const size_t gram_bytes = (size_t)DT * NGP_BLK * NGP_BLK * sizeof(double);
     const size_t slice_bytes = ((gram_bytes / nslice + 1023) / 1024) * 1024;
     bool same_xcd = false;
+    // Lag >= NGP_LAZY_LAG (long lags have the slack for a slightly later hand-off): the publisher (wave 1) does not sit out
+    // the round trip of its partial-sum store (store -> acknowledgement, about 1.4 us, then the counter).  It looks at its
+    // own VM_CNT (HW_REG_IB_STS) whenever it passes a phase boundary and counts the partial at the first boundary where the
+    // store has been acknowledged; it only blocks right before the next partial is stored.  Pays since the sampler stopped
+    // being the slower stage: 3.09 -> 2.86 ms at 10k x 100k, lag 8; at lags <= 6 the later hand-off costs more than it saves.
+    constexpr bool LAZY = (DT >= NGP_LAZY_LAG);
+    int sig_pending = -1;  // ring slot of the stored, not yet counted partial
+    auto try_signal = [&](bool force) {
+        if (!LAZY || wv != 1 || sig_pending < 0) return;
+        if (force) drain_vm();
+        else if ((__builtin_amdgcn_s_getreg((23 << 11) | 7) & 0xC0000Fu) != 0u) return;  // VM_CNT [3:0] and [23:22]
+        if (j == 0) atomicAdd(&A.cnt_part[((size_t)sig_pending * A.NG + g) * 32], 1u);
+        sig_pending = -1;
+    };
     unsigned long long accA = 0, accB = 0, accC = 0, accP = 0, tt0 = 0;
     __syncthreads();
     for (int u0 = 0; u0 < nb + DT; u0 += DT) {
@@ -264,6 +281,7 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
             }
             if (A.dbg && (tid == 448 || tid == 256)) accP += wall_clock64() - tt0;  // wave 7 poll / wave 4 DMA drain
             NGP_FINE(1);
+            try_signal(false);
             wg_barrier();
             if (!*sflag) return;
             if (A.dbg && tid == 0) { unsigned long long n = wall_clock64(); accA += n - tt0; tt0 = n; }
@@ -287,7 +305,9 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
                     for (int tp = 0; tp < NGP_TPT; tp++) ppw[tp] = pv[tp];
                 }
                 NGP_FINE(2);
+                try_signal(false);
                 wg_barrier();
+                try_signal(false);
                 if (!FUSE1) {
                     for (int i = tid; i < R; i += NGP_WG) {
                         const double T = ((pp[i] + pp[R + i]) + (pp[2 * R + i] + pp[3 * R + i])) +
@@ -380,16 +400,21 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
                     }
                 }
                 NGP_FINE(5);
+                try_signal(false);
                 wg_barrier();
                 if (have_dnext) dl[((u + 1) & 1) * 64 + j] = dnext;  // read in phase B of the next iteration, two barriers away
                 if (wv == 1 && A.dbg_mode != 1) {
                     const int slot = u % NGP_RING;
                     double p = ((red[j] + red[64 + j]) + (red[128 + j] + red[192 + j])) + ((red[256 + j] + red[320 + j]) + (red[384 + j] + red[448 + j]));
+                    try_signal(true);  // the previous partial, if its store was still under way at every boundary
                     st_f64(&A.part[((size_t)slot * S + s) * NGP_BLK + j], p);
-                    drain_vm();  // (counting the partial a phase later, to take this round trip out of the loop, gains nothing
-                                 // at long lags and costs latency at short ones)
+                    if (LAZY) {
+                        sig_pending = slot;
+                    } else {
+                        drain_vm();
+                        if (j == 0) atomicAdd(&A.cnt_part[((size_t)slot * A.NG + g) * 32], 1u);
+                    }
                     if (j == 0) {
-                        atomicAdd(&A.cnt_part[((size_t)slot * A.NG + g) * 32], 1u);
                         if (A.dbg && s == 0) A.dbg[NGP_DBG_STREAM + 2 * (size_t)u] = wall_clock64();
                         if (A.dbg && (u == 800 || u == 1200)) {
                             A.dbg[NGP_DBG_ALL + 4 * (size_t)s + (u == 800 ? 0 : 2)] = wall_clock64();
@@ -404,6 +429,7 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
             NGP_FINE(6);
         }
     }
+    try_signal(true);
     if (A.dbg && tid == 0) { A.dbg[NGP_DBG_ALL + 4096 + 8 * (size_t)s] = accA; A.dbg[NGP_DBG_ALL + 4096 + 8 * (size_t)s + 1] = accB; A.dbg[NGP_DBG_ALL + 4096 + 8 * (size_t)s + 2] = accC; }
     if (A.dbg && tid == 448) A.dbg[NGP_DBG_ALL + 4096 + 8 * (size_t)s + 3] = accP;
     if (A.dbg && tid == 256) A.dbg[NGP_DBG_ALL + 4096 + 8 * (size_t)s + 4] = accP;

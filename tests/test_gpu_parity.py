@@ -242,7 +242,7 @@ def test_shard_height_boundaries_bit_exact(ngp, O, N):
     R, S, nblk = s.layout()
     mode, D = s.config()
     assert mode == 1 and R == {14700: 60, 16000: 68, 30400: 124, 31700: 132, 62000: 252, 63232: 256}[N]
-    assert (D, s.near()) == ((6, 3) if R <= 128 else (5, 4))
+    assert (D, s.near()) == ((8, 3) if R <= 128 else (5, 4))
     o = O.Oracle(order=1, seed=21, chain=0)
     o.set_panel_f32(X, R=R, S=S, D=D, near=s.near())
     v = 0.01
