@@ -72,7 +72,7 @@ struct SweepArgs {
     unsigned long long *dbg;  // optional time stamps (diagnostic runs only), else nullptr
     int dbg_mode;             // diagnostic timing runs, results invalid: 1 = streamers only move tiles, 2 = sampler alone
                               // (never waits), 3 = streamers + reducers alone (never wait for dlt), 4 = as 3 without the tile DMA,
-                              // 5 = whole pipeline, BayesPR blocks without the recursion
+                              // 5 = whole pipeline, BayesPR blocks without the recursion, 6 = whole pipeline, reducers never wait for dlt
 };
 
 __device__ inline unsigned ld_u32(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -475,7 +475,7 @@ __device__ inline void role_reducer(const SweepArgs &A, const int g) {
             double gr[NGP_BLK];
             load_rows_pair(A.gramx + ((size_t)(A.t0 + u) * A.D + d) * (NGP_BLK * NGP_BLK), lane, gr);
             int okd = 1;
-            if (lane == 0) okd = (A.dbg_mode == 3 || A.dbg_mode == 4 || wait_ge(A.flag_dlt, (unsigned)(a + 1), A.abort_w, 4u)) ? 1 : 0;
+            if (lane == 0) okd = (A.dbg_mode == 3 || A.dbg_mode == 4 || A.dbg_mode == 6 || wait_ge(A.flag_dlt, (unsigned)(a + 1), A.abort_w, 4u)) ? 1 : 0;
             okd = __shfl(okd, 0);
             if (!okd) return;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
