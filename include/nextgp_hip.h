@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define NGP_ABI_VERSION 1
+#define NGP_ABI_VERSION 2
 
 #define NGP_OK 0
 #define NGP_ERR_ARG (-1)     /* bad argument (null, size mismatch, non-finite value) */
@@ -32,6 +32,7 @@ extern "C" {
 #define NGP_ERR_HIP (-3)     /* HIP runtime error (message carries hipGetErrorString) */
 #define NGP_ERR_NOMEM (-4)
 #define NGP_ERR_NODEVICE (-5) /* no usable gfx950 device: the library has NO CPU fallback */
+#define NGP_ERR_DEBUG (-6)    /* the call ran in a diagnostic timing mode (ngp_debug_set_mode): its results are invalid */
 
 #define NGP_METHOD_BAYESPR 0 /* src/runTime.jl:30-45 */
 #define NGP_METHOD_BAYESB 1  /* src/runTime.jl:48-61 */
@@ -96,7 +97,8 @@ int32_t ngp_add_marker_set(ngp_handle *h, int64_t col0, int64_t ncol, int32_t me
                            const int64_t *reg_start, const int64_t *reg_stop, int64_t nreg, const double *varBeta0,
                            double pi0, int32_t estPi, const double *lhs0, const double *rhs0, int32_t *set_id);
 
-/* Phenotypes; resets the chain state: ycorr = y (src/mme.jl:57), b = 0, beta = 0, delta = 1, iter = 0. */
+/* Phenotypes; resets the chain: ycorr = y (src/mme.jl:57), b = 0, beta = 0, delta = 1, iter = 0, every variance and pi back to
+ * the values given to ngp_add_marker_set (src/mme.jl:351-360, 516), all posterior sums and nKept zero. */
 int32_t ngp_set_y(ngp_handle *h, const double *y, int64_t N);
 /* E.df, E.scale (src/mme.jl:87-94). */
 int32_t ngp_set_residual_prior(ngp_handle *h, double df, double scale);
@@ -133,8 +135,9 @@ int32_t ngp_export_posterior_device(ngp_handle *h, void *device_ptr, int64_t len
 int32_t ngp_sweep_set(ngp_handle *h, int32_t set_id, double varE, double *ycorr, double *beta, int64_t *delta, double *varBeta,
                       double *piHat);
 
-/* Device time of the sweep kernels accumulated since the last call (HIP events on the handle's stream). */
-int32_t ngp_get_timing(ngp_handle *h, double *sweep_ms, int64_t *sweep_launches, double *iter_ms, int64_t *iters);
+/* Device time of the iterations of ngp_run (HIP events on the handle's stream) and the number of sweep-kernel launches,
+ * both accumulated since the last call. */
+int32_t ngp_get_timing(ngp_handle *h, int64_t *sweep_launches, double *iter_ms, int64_t *iters);
 /* Runs ONE extra iteration with a HIP event pair around every sweep-kernel launch and returns the
  * average launch duration of the dominant (panel-streaming) kernel, its launch count and the
  * algorithmic bytes one launch streams (bench.py roofline). */
@@ -146,6 +149,45 @@ int32_t ngp_draws_indexed(ngp_handle *h, uint64_t iter, uint64_t kind, uint64_t 
                           int64_t n, double *out);
 /* det_log / ppnd16 evaluated on the device (bit-parity probe), n inputs -> n outputs. */
 int32_t ngp_eval_math(ngp_handle *h, int32_t which, const double *in, int64_t n, double *out);
+
+/* ---- streamer variants of the persistent sweep (before the panel is set) ----
+ * 0 = automatic, 1 = phase streamer (every shard height), 2 = row-owning waves + loader wave (shards of at most 224 rows,
+ * lags 3..6; the default for shards taller than 128 rows).  Both replace the loop of src/functions.jl:124-136; they differ in
+ * the summation order of the shard partial of X_t'ycorr only: ngp_get_streamer reports the variant in force and the number of
+ * GEMV chains per partial (8 or 7), which the blocked oracle needs like R, S, lag and near lags. */
+int32_t ngp_set_streamer(ngp_handle *h, int32_t variant);
+int32_t ngp_get_streamer(ngp_handle *h, int32_t *variant, int32_t *gemv_chains);
+
+/* Diagnostic timing modes of the persistent kernel (1..6: parts of the pipeline switched off, ngp_sweep.h).  They are an
+ * explicit, per-handle setting -- never read from the environment -- and while one is active ngp_run / ngp_sweep_set do
+ * their launches and then return NGP_ERR_DEBUG: the chain they leave behind is invalid.  0 = off. */
+int32_t ngp_debug_set_mode(ngp_handle *h, int32_t mode);
+/* Tuning knob of the row-owning streamer: bits 2:0 = row-owning waves that help the loader wave issue the LDS-DMA requests
+ * (0..5, default 2).  Changes timing only, never results. */
+int32_t ngp_debug_set_knob(ngp_handle *h, int32_t knob);
+
+/* Resume support, second half: overwrite the posterior sums (same shapes as ngp_get_posterior_sums).  With ngp_set_state a
+ * resumed run then reproduces the posterior means of the uninterrupted one -- the role of the reference's append-only *Out
+ * files (src/outFiles.jl:17-21, rows written at src/samplers.jl:56-104). */
+int32_t ngp_set_posterior_sums(ngp_handle *h, const double *sum_beta, const double *sum_beta2, const double *sum_delta,
+                               const double *sum_varBeta, const double *sum_pi, double sum_varE, double sum_b, int64_t nKept);
+/* Binary snapshot of chain state + posterior sums + draw-stream identity (seed, chain) in one file (written to path.tmp, then
+ * renamed).  ngp_load_snapshot needs the same model (panel, sets, y) built first and verifies N, P, variance components and
+ * sets; afterwards ngp_run continues the interrupted chain bit for bit. */
+int32_t ngp_save_snapshot(ngp_handle *h, const char *path);
+int32_t ngp_load_snapshot(ngp_handle *h, const char *path);
+
+/* Per-iteration traces beyond varE / b (ngp_get_trace): effects of up to 4096 chosen loci (0-based panel columns), the first
+ * n_varBeta variance components and pi of every set, recorded for every iteration of the following ngp_run calls (what
+ * the reference writes as rows of beta<set>Out / var<set>Out / pi<set>Out, src/samplers.jl:80-84, for these columns).
+ * ngp_get_trace_ext copies the first n iterations of the last ngp_run: beta_tr[n][nloci], varBeta_tr[n][n_varBeta], pi_tr[n][nsets]. */
+int32_t ngp_set_trace_loci(ngp_handle *h, const int64_t *loci, int64_t n, int64_t n_varBeta);
+int32_t ngp_get_trace_ext(ngp_handle *h, double *beta_tr, double *varBeta_tr, double *pi_tr, int64_t n);
+
+/* Posterior sums pooled over n chains (one handle per chain, src/samplers.jl:23 runs one chain per Julia task): afterwards
+ * every handle holds the sums over all chains.  Handles on different devices: ONE RCCL all-reduce (fp64 sum) over xGMI, RCCL
+ * loaded on first use; handles sharing a device are added on the device.  Errors are reported on hs[0]. */
+int32_t ngp_allreduce_posterior(ngp_handle **hs, int32_t n);
 
 #ifdef __cplusplus
 }

@@ -21,6 +21,8 @@ SYMBOLS = [
     "ngp_set_residual_prior", "ngp_set_intercept", "ngp_set_schedule", "ngp_run", "ngp_get_state", "ngp_set_state",
     "ngp_get_trace", "ngp_get_posterior_sums", "ngp_posterior_len", "ngp_export_posterior_device", "ngp_sweep_set",
     "ngp_get_timing", "ngp_profile_iteration", "ngp_draws_indexed", "ngp_eval_math", "ngp_configure", "ngp_get_config", "ngp_debug_stamps", "ngp_set_near_lags", "ngp_get_near_lags",
+    "ngp_set_streamer", "ngp_get_streamer", "ngp_debug_set_mode", "ngp_debug_set_knob", "ngp_set_posterior_sums", "ngp_save_snapshot", "ngp_load_snapshot",
+    "ngp_set_trace_loci", "ngp_get_trace_ext", "ngp_allreduce_posterior",
 ]
 
 _lib = None
@@ -52,7 +54,7 @@ def _p(a, t):
 class Sampler:
     """One chain on one device == one `ngp_handle` (reference: one Julia task running runSampler!)."""
 
-    def __init__(self, device=0, seed=1, chain=0, mode=None, lag=None):
+    def __init__(self, device=0, seed=1, chain=0, mode=None, lag=None, streamer=None):
         self.L = load()
         self.h = C.c_void_p()
         rc = self.L.ngp_create(C.c_int32(device), C.c_uint64(seed), C.c_uint32(chain), C.byref(self.h))
@@ -60,8 +62,12 @@ class Sampler:
             raise NextGPHipError(f"ngp_create failed ({rc}): " + (self.L.ngp_last_error(None) or b"").decode())
         self.nsets = 0
         self.set_shapes = []  # (ncol, nreg) per set
+        self.ntl = 0
+        self.ntvb = 0
         if mode is not None or lag is not None:
             self.configure(1 if mode is None else mode, 8 if lag is None else lag)
+        if streamer is not None:
+            self.set_streamer(streamer)
 
     def configure(self, mode, lag):
         self._chk(self.L.ngp_configure(self.h, C.c_int32(mode), C.c_int32(lag)))
@@ -73,6 +79,21 @@ class Sampler:
         n = C.c_int32()
         self._chk(self.L.ngp_get_near_lags(self.h, C.byref(n)))
         return n.value
+
+    def set_streamer(self, variant):
+        self._chk(self.L.ngp_set_streamer(self.h, C.c_int32(variant)))
+
+    def streamer(self):
+        """(variant in force, GEMV chains per shard partial)"""
+        v, n = C.c_int32(), C.c_int32()
+        self._chk(self.L.ngp_get_streamer(self.h, C.byref(v), C.byref(n)))
+        return v.value, n.value
+
+    def debug_set_knob(self, knob):
+        self._chk(self.L.ngp_debug_set_knob(self.h, C.c_int32(knob)))
+
+    def debug_set_mode(self, mode):
+        self._chk(self.L.ngp_debug_set_mode(self.h, C.c_int32(mode)))
 
     def config(self):
         m, l = C.c_int32(), C.c_int32()
@@ -225,10 +246,39 @@ class Sampler:
         return delta
 
     def get_timing(self):
-        sm, it = C.c_double(), C.c_double()
+        it = C.c_double()
         sl, ni = C.c_int64(), C.c_int64()
-        self._chk(self.L.ngp_get_timing(self.h, C.byref(sm), C.byref(sl), C.byref(it), C.byref(ni)))
-        return dict(sweep_ms=sm.value, sweep_launches=sl.value, iter_ms=it.value, iters=ni.value)
+        self._chk(self.L.ngp_get_timing(self.h, C.byref(sl), C.byref(it), C.byref(ni)))
+        return dict(sweep_launches=sl.value, iter_ms=it.value, iters=ni.value)
+
+    def set_posterior_sums(self, ps):
+        a = {k: np.ascontiguousarray(ps[k], dtype=np.float64) for k in ("sum_beta", "sum_beta2", "sum_delta", "sum_varBeta", "sum_pi")}
+        self._chk(self.L.ngp_set_posterior_sums(self.h, _p(a["sum_beta"], C.c_double), _p(a["sum_beta2"], C.c_double),
+                                                _p(a["sum_delta"], C.c_double), _p(a["sum_varBeta"], C.c_double), _p(a["sum_pi"], C.c_double),
+                                                C.c_double(ps["sum_varE"]), C.c_double(ps["sum_b"]), C.c_int64(ps["nKept"])))
+
+    def save_snapshot(self, path):
+        self._chk(self.L.ngp_save_snapshot(self.h, os.fsencode(path)))
+
+    def load_snapshot(self, path):
+        self._chk(self.L.ngp_load_snapshot(self.h, os.fsencode(path)))
+
+    def set_trace_loci(self, loci, n_varBeta=0):
+        loci = np.ascontiguousarray(loci, dtype=np.int64)
+        self._chk(self.L.ngp_set_trace_loci(self.h, _p(loci, C.c_int64) if len(loci) else None, C.c_int64(len(loci)), C.c_int64(n_varBeta)))
+        self.ntl, self.ntvb = len(loci), n_varBeta
+
+    def get_trace_ext(self, n):
+        bt = np.empty((n, max(self.ntl, 1))); vt = np.empty((n, max(self.ntvb, 1))); pt = np.empty((n, max(self.nsets, 1)))
+        self._chk(self.L.ngp_get_trace_ext(self.h, _p(bt, C.c_double), _p(vt, C.c_double), _p(pt, C.c_double), C.c_int64(n)))
+        return dict(beta=bt[:, :self.ntl], varBeta=vt[:, :self.ntvb], pi=pt[:, :self.nsets])
+
+    @staticmethod
+    def allreduce_posterior(samplers):
+        """Pooled posterior sums over the chains of `samplers` (ngp_allreduce_posterior): every sampler then holds them."""
+        L = samplers[0].L
+        arr = (C.c_void_p * len(samplers))(*[s.h for s in samplers])
+        samplers[0]._chk(L.ngp_allreduce_posterior(arr, C.c_int32(len(samplers))))
 
     def profile_iteration(self):
         ms, by = C.c_double(), C.c_double()

@@ -4,6 +4,8 @@
 // without a usable device every entry point fails with NGP_ERR_NODEVICE / NGP_ERR_HIP.
 #include <hip/hip_runtime.h>
 
+#include <dlfcn.h>
+
 #include <algorithm>
 #include <cmath>
 #include <cstdio>
@@ -28,6 +30,8 @@ struct HSet {
     int64_t vb_off;
     int estPi;
     uint64_t fine_calls;
+    double pi0;               // prior inclusion probability (src/mme.jl:351,360): what ngp_set_y goes back to
+    std::vector<double> vb0;  // initial variances (src/mme.jl:516)
 };
 
 std::string g_create_err;
@@ -40,11 +44,15 @@ struct ngp_handle {
     uint32_t chain = 0;
     hipStream_t stream = nullptr;
     int64_t N = 0, P = 0, R = 0, S = 0, NBLK = 0, Ppad = 0, L = 0;
-    size_t lds_step = 0, lds_sweep = 0;
+    size_t lds_step = 0, lds_sweep = 0, lds_rows = 0;
     int mode = 1;      // 1: persistent sweep kernel, 0: one streaming + one recursion launch per block
     int lag = 8;       // look-ahead D of the persistent sweep (blocks); shards taller than 128 rows are capped at 5
+    bool lag_auto = true;  // lag not chosen by the caller (ngp_configure): tall shards then take the measured best
     int near_req = 0;  // near lags requested (0 = automatic)
     int near = 3;      // look-ahead lags 1..near corrected by the sampler itself, farther ones by the reducers
+    int streamer_req = 0;  // streamer variant requested: 0 automatic, 1 phase streamer, 2 row-owning waves + loader wave
+    int streamer = 1;      // variant in force (persistent sweep only)
+    int nchain = 8;        // GEMV chains per shard partial: 8 (phase streamer, per-block engine) or 7 (row-owning waves)
     int D = 1;         // Gram planes stored per block (= lag in mode 1, 1 in mode 0)
     int NG = 1;        // reducer groups = ceil(S/32)
     int cu_count = 256;
@@ -90,8 +98,16 @@ struct ngp_handle {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     double iter_ms = 0.0;
     int64_t iters_timed = 0;
-    double sweep_ms = 0.0;
     int64_t sweep_launches = 0;
+    // diagnostics (ngp_debug_set_mode): != 0 makes every chain invalid, ngp_run / ngp_sweep_set then return NGP_ERR_DEBUG
+    int dbg_mode = 0;
+    int knob = 2;  // helper issuers of the row-owning streamer (ngp_debug_set_knob)
+    bool poisoned = false;  // a sweep gave up half-way (abort word): the chain state is unusable until ngp_set_y / ngp_set_state
+    // optional per-iteration traces of selected effects, variances and pi (ngp_set_trace_loci)
+    int64_t *d_trace_loci = nullptr;
+    int64_t ntl = 0, ntvb = 0;
+    double *d_tr_beta = nullptr, *d_tr_vb = nullptr, *d_tr_pi = nullptr;
+    int64_t trace_ext_cap = 0;
     std::string err;
 };
 
@@ -162,7 +178,15 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
     if (h->mode == 0) choose_layout(N, 256, 508, &h->R, &h->S);  // LDS bound of k_step: R*264 + 4096 <= 160 KiB
     h->NG = (int)((h->S + NGP_GRP - 1) / NGP_GRP);
     h->D = (h->mode == 1) ? h->lag : 1;
-    if (h->mode == 1 && h->R > 128 && h->D > 5) h->D = 5;  // tall shards: the register delay line holds 5 tiles at most
+    // streamer variant (ngp_sweep.h): the row-owning waves serve shards of up to NGP_ROWS_MAX_R rows at lags 3..6 and are the
+    // default where the phase streamer is bound by its barriers (shards taller than 128 rows)
+    h->streamer = 1;
+    if (h->mode == 1 && h->R <= NGP_ROWS_MAX_R && h->lag >= 3 && (h->streamer_req == 2 || (h->streamer_req == 0 && h->R > 128))) h->streamer = 2;
+    h->nchain = (h->streamer == 2) ? NGP_ROWS_NW : 8;
+    if (h->streamer == 2) {
+        if (h->D > 6) h->D = 6;  // register delay line: 32 VGPRs per lag
+        if (h->R > 128 && h->lag_auto && h->D > 5) h->D = 5;
+    } else if (h->mode == 1 && h->R > 128 && h->D > 5) h->D = 5;  // tall shards: the register delay line holds 5 tiles at most
     // a fourth near lag overloads the sampler CU at short shards (+17 % time at 10k x 100k); at tall shards, where with lag 5
     // nothing is left for the reducers then, it saves 8 %
     h->near = h->near_req ? h->near_req : ((h->mode == 1 && h->R > 128) ? 4 : 3);
@@ -212,8 +236,23 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
         const size_t TB = (size_t)(h->R / 4) * NGP_QS;  // LDS footprint of one tile (quads NGP_QS bytes apart)
         h->lds_sweep = std::max(2 * TB + misc, lds_sampler);
         if (2 * TB + misc + 8192 <= lds_max) h->lds_sweep = std::max(h->lds_sweep, 2 * TB + misc + 8192);  // room for the diagnostic timeline
+        if (h->streamer == 2) {  // ring of 2 NQ + H quads | shard | 2 x 7 x 64 chain partials | 2 x 64 dlt | flags | 1 KiB sink
+            const size_t nq = (size_t)h->R / 4, hq = std::min<size_t>(NGP_ROWS_HMAX, (nq + 1) / 2);
+            const size_t need = (2 * nq + hq) * NGP_QS + (size_t)((h->R + 7) & ~7) * 8 + 2 * NGP_ROWS_NW * NGP_BLK * 8 + 2 * NGP_BLK * 8 + 64 + 1024;
+            h->lds_rows = need;
+            h->lds_sweep = std::max(need, lds_sampler);
+            if (need + 8192 <= lds_max) h->lds_sweep = std::max(h->lds_sweep, need + 8192);
+        }
         if (h->lds_sweep > lds_max) return fail(h, NGP_ERR_ARG, "panel too tall for the persistent sweep (LDS)");
-        HCHK(hipFuncSetAttribute((const void *)k_sweep, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_sweep));
+        HCHK(hipFuncSetAttribute((const void *)k_sweep<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_sweep));
+        HCHK(hipFuncSetAttribute((const void *)k_sweep<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_sweep));
+        // every workgroup of the persistent kernel waits for others: the whole grid must be resident at once, one workgroup
+        // per CU.  Checked here, not assumed (a grid that does not fit would only show up as a spin timeout).
+        int wg_per_cu = 0;
+        HCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, (const void *)k_sweep<false>, NGP_WG, h->lds_sweep));
+        if (wg_per_cu < 1 || 1 + h->NG + h->S > (int64_t)wg_per_cu * h->cu_count)
+            return fail(h, NGP_ERR_STATE, "persistent sweep: grid of " + std::to_string(1 + h->NG + h->S) + " workgroups cannot be co-resident (" +
+                                              std::to_string(wg_per_cu) + " per CU x " + std::to_string(h->cu_count) + " CUs); use ngp_configure(mode 0)");
         if ((rc = dalloc(h, &h->d_cpart, (size_t)NGP_RING * h->S * NGP_BLK))) return rc;
         if ((rc = dalloc(h, &h->d_cgsum, (size_t)NGP_RING * h->NG * NGP_BLK))) return rc;
         if ((rc = dalloc(h, &h->d_cdlt, (size_t)NGP_RING * NGP_BLK))) return rc;
@@ -326,8 +365,13 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
         if (evs) (void)hipEventRecord(evs[0], h->stream);
         A.dbg = h->d_dbg;
         A.fine_ok = ((size_t)2 * (R / 4) * NGP_QS + (size_t)R * 80 + 8320 + 8192 <= h->lds_sweep) ? 1 : 0;  // diagnostic timeline fits in LDS
-        { const char *e = getenv("NGP_DEBUG_MODE"); A.dbg_mode = e ? atoi(e) : 0; }
-        hipLaunchKernelGGL(k_sweep, dim3((unsigned)(1 + h->NG + S)), dim3(NGP_WG), h->lds_sweep, h->stream, A);
+        A.variant = h->streamer; A.knob = h->knob;
+        if (h->streamer == 2) A.fine_ok = (h->lds_rows + 8192 <= h->lds_sweep) ? 1 : 0;
+        A.dbg_mode = h->dbg_mode;
+        if (h->d_dbg || h->dbg_mode)  // diagnostic instantiation: stamps and timing modes exist only there
+            hipLaunchKernelGGL(k_sweep<true>, dim3((unsigned)(1 + h->NG + S)), dim3(NGP_WG), h->lds_sweep, h->stream, A);
+        else
+            hipLaunchKernelGGL(k_sweep<false>, dim3((unsigned)(1 + h->NG + S)), dim3(NGP_WG), h->lds_sweep, h->stream, A);
         if (evs) (void)hipEventRecord(evs[1], h->stream);
         h->sweep_launches += 1;
         return;
@@ -352,8 +396,10 @@ int check_abort(ngp_handle *h) {
     HCHK(hipMemcpy(&code, h->d_abort, sizeof(unsigned), hipMemcpyDeviceToHost));
     if (code != 0) {
         (void)hipMemset(h->d_abort, 0, sizeof(unsigned));
+        h->poisoned = true;  // ycorr / beta were left half-way through a sweep
         return fail(h, NGP_ERR_HIP, "persistent sweep kernel gave up waiting (role code " + std::to_string(code) +
-                                        "): workgroups not co-resident or a hand-off was lost");
+                                        "): workgroups not co-resident (another kernel holding CUs?) or a hand-off was lost; the chain "
+                                        "state is invalid until ngp_set_y / ngp_set_state");
     }
     return NGP_OK;
 }
@@ -380,6 +426,11 @@ int one_iteration(ngp_handle *h, int64_t trace_idx, hipEvent_t *evs) {
     launch_sweep(h, 0, h->NBLK, evs);
     launch_variance(h, -1, it);
     h->iter += 1;
+    if (h->d_trace_loci && trace_idx < h->trace_ext_cap) {
+        const long long nt = std::max<long long>(std::max<long long>(h->ntl, h->ntvb), (long long)h->sets.size());
+        hipLaunchKernelGGL(k_trace, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->stream, (long long)h->ntl, (const long long *)h->d_trace_loci, (long long)h->ntvb,
+                           (int)h->sets.size(), h->d_beta, h->d_varBeta, h->d_sets, h->d_tr_beta, h->d_tr_vb, h->d_tr_pi, (long long)trace_idx);
+    }
     if (is_kept(h, h->iter)) {
         long long n = std::max<long long>(std::max<long long>(h->P, h->nvb), 16);
         hipLaunchKernelGGL(k_accum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (long long)h->P, (long long)h->nvb,
@@ -438,7 +489,7 @@ int32_t ngp_destroy(ngp_handle *h) {
     dfree(h->d_vbidx); dfree(h->d_delta); dfree(h->d_sum_beta); dfree(h->d_sum_beta2); dfree(h->d_sum_delta);
     dfree(h->d_ycorr); dfree(h->d_part); dfree(h->d_dlt); dfree(h->d_sets); dfree(h->d_scal); dfree(h->d_varBeta);
     dfree(h->d_sum_varBeta); dfree(h->d_regs); dfree(h->d_seg_k0); dfree(h->d_seg_len); dfree(h->d_segpart); dfree(h->d_regchi);
-    dfree(h->d_tr_varE); dfree(h->d_tr_b);
+    dfree(h->d_tr_varE); dfree(h->d_tr_b); dfree(h->d_trace_loci); dfree(h->d_tr_beta); dfree(h->d_tr_vb); dfree(h->d_tr_pi);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     if (h->stream) (void)hipStreamDestroy(h->stream);
@@ -589,7 +640,7 @@ int32_t ngp_add_marker_set(ngp_handle *h, int64_t col0, int64_t ncol, int32_t me
     }
     REQUIRE(expect == ncol, NGP_ERR_ARG, "regions must cover the whole set");
     const int si = (int)h->sets.size();
-    HSet hs{col0, ncol, method, df, scale, nreg, h->nvb, estPi, 0};
+    HSet hs{col0, ncol, method, df, scale, nreg, h->nvb, estPi, 0, pi0, std::vector<double>(varBeta0, varBeta0 + nreg)};
     // grow varBeta storage
     const int64_t new_nvb = h->nvb + nreg;
     if (new_nvb > h->vb_cap) {
@@ -659,8 +710,17 @@ int32_t ngp_set_y(ngp_handle *h, const double *y, int64_t N) {
     HCHK(hipMemsetAsync(h->d_sum_beta, 0, (size_t)h->Ppad * sizeof(double), h->stream));
     HCHK(hipMemsetAsync(h->d_sum_beta2, 0, (size_t)h->Ppad * sizeof(double), h->stream));
     HCHK(hipMemsetAsync(h->d_sum_delta, 0, (size_t)h->Ppad * sizeof(double), h->stream));
+    // a second chain on the same handle starts from the priors, with empty posterior sums (src/mme.jl:351-360, 516)
+    if (h->nvb > 0) HCHK(hipMemsetAsync(h->d_sum_varBeta, 0, (size_t)h->nvb * sizeof(double), h->stream));
+    for (size_t si = 0; si < h->sets.size(); si++) {
+        const HSet &hs = h->sets[si];
+        HCHK(hipMemcpyAsync(h->d_varBeta + hs.vb_off, hs.vb0.data(), hs.vb0.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        hipLaunchKernelGGL(k_set_pi, dim3(1), dim3(1), 0, h->stream, h->d_sets, (int)si, 1.0 - hs.pi0, hs.pi0);
+        hipLaunchKernelGGL(k_set_sum_pi, dim3(1), dim3(1), 0, h->stream, h->d_sets, (int)si, 0.0, 0.0);
+    }
     HCHK(hipStreamSynchronize(h->stream));
-    h->iter = 0; h->have_y = true;
+    h->iter = 0; h->have_y = true; h->poisoned = false; h->ntrace = 0;
+    for (auto &hs : h->sets) hs.fine_calls = 0;
     return NGP_OK;
 }
 
@@ -690,6 +750,14 @@ int32_t ngp_run(ngp_handle *h, int64_t niter) {
     if ((rc = enter(h))) return rc;
     if ((rc = ready(h))) return rc;
     REQUIRE(niter >= 0, NGP_ERR_ARG, "niter must be >= 0");
+    REQUIRE(!h->poisoned, NGP_ERR_STATE, "an earlier sweep was abandoned half-way: set the state again (ngp_set_y / ngp_set_state)");
+    REQUIRE(h->ntvb <= h->nvb, NGP_ERR_STATE, "more variance traces requested than the model has variance components");
+    if (h->ntl + h->ntvb + (int64_t)h->sets.size() > 0 && h->d_trace_loci && niter > h->trace_ext_cap) {
+        if ((rc = dalloc(h, &h->d_tr_beta, (size_t)niter * std::max<int64_t>(h->ntl, 1)))) return rc;
+        if ((rc = dalloc(h, &h->d_tr_vb, (size_t)niter * std::max<int64_t>(h->ntvb, 1)))) return rc;
+        if ((rc = dalloc(h, &h->d_tr_pi, (size_t)niter * std::max<size_t>(h->sets.size(), 1)))) return rc;
+        h->trace_ext_cap = niter;
+    }
     if (niter > h->trace_cap) {
         if ((rc = dalloc(h, &h->d_tr_varE, (size_t)niter))) return rc;
         if ((rc = dalloc(h, &h->d_tr_b, (size_t)niter))) return rc;
@@ -711,6 +779,7 @@ int32_t ngp_run(ngp_handle *h, int64_t niter) {
     float ms = 0.f;
     HCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->iter_ms += ms; h->iters_timed += niter;
+    if (h->dbg_mode != 0) return fail(h, NGP_ERR_DEBUG, "diagnostic timing mode " + std::to_string(h->dbg_mode) + " is active: the chain is invalid (ngp_debug_set_mode(h, 0) ends it)");
     return NGP_OK;
 }
 
@@ -764,6 +833,7 @@ int32_t ngp_set_state(ngp_handle *h, const double *ycorr, const double *beta, co
     HCHK(hipMemcpy(h->d_scal, &sc, sizeof(DScal), hipMemcpyHostToDevice));
     HCHK(hipStreamSynchronize(h->stream));
     h->iter = iter;
+    if (ycorr && beta) h->poisoned = false;
     return NGP_OK;
 }
 
@@ -865,6 +935,7 @@ int32_t ngp_sweep_set(ngp_handle *h, int32_t set_id, double varE, double *ycorr,
     HCHK(hipStreamSynchronize(h->stream));
     HCHK(hipGetLastError());
     if ((rc = check_abort(h))) return rc;
+    if (h->dbg_mode != 0) return fail(h, NGP_ERR_DEBUG, "diagnostic timing mode is active: the sweep is invalid");
     if (delta) {
         std::vector<uint8_t> d((size_t)hs.ncol);
         HCHK(hipMemcpy(d.data(), h->d_delta + hs.col0, (size_t)hs.ncol, hipMemcpyDeviceToHost));
@@ -878,14 +949,13 @@ int32_t ngp_sweep_set(ngp_handle *h, int32_t set_id, double varE, double *ycorr,
     return NGP_OK;
 }
 
-int32_t ngp_get_timing(ngp_handle *h, double *sweep_ms, int64_t *sweep_launches, double *iter_ms, int64_t *iters) {
+int32_t ngp_get_timing(ngp_handle *h, int64_t *sweep_launches, double *iter_ms, int64_t *iters) {
     int rc;
     if ((rc = enter(h))) return rc;
-    if (sweep_ms) *sweep_ms = h->sweep_ms;
     if (sweep_launches) *sweep_launches = h->sweep_launches;
     if (iter_ms) *iter_ms = h->iter_ms;
     if (iters) *iters = h->iters_timed;
-    h->sweep_ms = 0; h->sweep_launches = 0; h->iter_ms = 0; h->iters_timed = 0;
+    h->sweep_launches = 0; h->iter_ms = 0; h->iters_timed = 0;
     return NGP_OK;
 }
 
@@ -936,7 +1006,7 @@ int32_t ngp_configure(ngp_handle *h, int32_t mode, int32_t lag) {
     REQUIRE(h->d_tiles == nullptr, NGP_ERR_STATE, "ngp_configure must precede the panel upload");
     REQUIRE(mode == 0 || mode == 1, NGP_ERR_ARG, "mode must be 0 (per-block launches) or 1 (persistent sweep)");
     REQUIRE(lag >= 1 && lag <= NGP_MAX_LAG, NGP_ERR_ARG, "lag must be in 1..8");
-    h->mode = mode; h->lag = lag;
+    h->mode = mode; h->lag = lag; h->lag_auto = false;
     return NGP_OK;
 }
 
@@ -993,6 +1063,292 @@ int32_t ngp_eval_math(ngp_handle *h, int32_t which, const double *in, int64_t n,
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
     dfree(di); dfree(dout);
     if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("eval_math: ") + hipGetErrorString(e));
+    return NGP_OK;
+}
+
+
+/* ------------------------------------------------------------------------------------------------
+ * round 2 additions: diagnostics out of the environment, posterior-sum restore, snapshots, traces,
+ * streamer variants, pooled posterior sums
+ * ---------------------------------------------------------------------------------------------- */
+int32_t ngp_debug_set_mode(ngp_handle *h, int32_t mode) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(mode >= 0 && mode <= 6, NGP_ERR_ARG, "diagnostic mode must be in 0..6");
+    h->dbg_mode = mode;
+    return NGP_OK;
+}
+
+int32_t ngp_debug_set_knob(ngp_handle *h, int32_t knob) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    h->knob = knob;
+    return NGP_OK;
+}
+
+int32_t ngp_set_streamer(ngp_handle *h, int32_t variant) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(h->d_tiles == nullptr, NGP_ERR_STATE, "ngp_set_streamer must precede the panel upload");
+    REQUIRE(variant >= 0 && variant <= 2, NGP_ERR_ARG, "streamer variant: 0 (automatic), 1 (phase streamer) or 2 (row-owning waves)");
+    h->streamer_req = variant;
+    return NGP_OK;
+}
+
+int32_t ngp_get_streamer(ngp_handle *h, int32_t *variant, int32_t *gemv_chains) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    if (variant) *variant = (h->mode == 1) ? h->streamer : 0;
+    if (gemv_chains) *gemv_chains = h->nchain;
+    return NGP_OK;
+}
+
+int32_t ngp_set_posterior_sums(ngp_handle *h, const double *sum_beta, const double *sum_beta2, const double *sum_delta,
+                               const double *sum_varBeta, const double *sum_pi, double sum_varE, double sum_b, int64_t nKept) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(h->d_tiles != nullptr && h->have_y, NGP_ERR_STATE, "panel / y not set");
+    REQUIRE(sum_beta && sum_beta2 && sum_delta && nKept >= 0 && std::isfinite(sum_varE) && std::isfinite(sum_b), NGP_ERR_ARG, "bad posterior sums");
+    REQUIRE(h->nvb == 0 || sum_varBeta, NGP_ERR_ARG, "sum_varBeta missing");
+    REQUIRE(h->sets.empty() || sum_pi, NGP_ERR_ARG, "sum_pi missing");
+    HCHK(hipStreamSynchronize(h->stream));
+    const size_t pb = (size_t)h->P * sizeof(double);
+    HCHK(hipMemcpy(h->d_sum_beta, sum_beta, pb, hipMemcpyHostToDevice));
+    HCHK(hipMemcpy(h->d_sum_beta2, sum_beta2, pb, hipMemcpyHostToDevice));
+    HCHK(hipMemcpy(h->d_sum_delta, sum_delta, pb, hipMemcpyHostToDevice));
+    if (h->nvb) HCHK(hipMemcpy(h->d_sum_varBeta, sum_varBeta, (size_t)h->nvb * sizeof(double), hipMemcpyHostToDevice));
+    for (size_t si = 0; si < h->sets.size(); si++)
+        hipLaunchKernelGGL(k_set_sum_pi, dim3(1), dim3(1), 0, h->stream, h->d_sets, (int)si, sum_pi[2 * si], sum_pi[2 * si + 1]);
+    HCHK(hipStreamSynchronize(h->stream));
+    DScal sc;
+    HCHK(hipMemcpy(&sc, h->d_scal, sizeof(DScal), hipMemcpyDeviceToHost));
+    sc.sum_varE = sum_varE; sc.sum_b = sum_b; sc.nKept = nKept;
+    HCHK(hipMemcpy(h->d_scal, &sc, sizeof(DScal), hipMemcpyHostToDevice));
+    return NGP_OK;
+}
+
+/* Snapshot file: the chain state and the posterior sums, little-endian, no padding:
+ *   char[8] "NGPSNAP1" | int64 N, P, nvb, nsets, iter, nKept | uint64 seed | uint64 chain |
+ *   double varE, b, sum_varE, sum_b | ycorr[N] | beta[P] | delta[P] (uint8) | varBeta[nvb] | piHat[2 nsets] |
+ *   sum_beta[P] | sum_beta2[P] | sum_delta[P] | sum_varBeta[nvb] | sum_pi[2 nsets] | fine_calls[nsets] (uint64)
+ * It plays the role of the reference's append-only *Out files for a resumed run (src/outFiles.jl:17-21): what was kept
+ * before the interruption is not lost. */
+int32_t ngp_save_snapshot(ngp_handle *h, const char *path) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(h->d_tiles != nullptr && h->have_y, NGP_ERR_STATE, "panel / y not set");
+    REQUIRE(path != nullptr, NGP_ERR_ARG, "null path");
+    REQUIRE(!h->poisoned, NGP_ERR_STATE, "the chain state is invalid (abandoned sweep)");
+    const size_t N = (size_t)h->N, P = (size_t)h->P, nvb = (size_t)h->nvb, ns = h->sets.size();
+    std::vector<double> yc(N), be(P), vb(std::max<size_t>(nvb, 1)), pi(2 * std::max<size_t>(ns, 1)), sb(P), sb2(P), sd(P), sv(std::max<size_t>(nvb, 1)),
+        sp(2 * std::max<size_t>(ns, 1));
+    std::vector<int64_t> de(P);
+    double varE = 0, b = 0, svE = 0, sbb = 0;
+    int64_t iter = 0, nk = 0;
+    if ((rc = ngp_get_state(h, yc.data(), be.data(), de.data(), vb.data(), pi.data(), &varE, &b, &iter))) return rc;
+    if ((rc = ngp_get_posterior_sums(h, sb.data(), sb2.data(), sd.data(), sv.data(), sp.data(), &svE, &sbb, &nk))) return rc;
+    std::vector<uint8_t> d8(P);
+    for (size_t k = 0; k < P; k++) d8[k] = (uint8_t)(de[k] != 0);
+    const std::string tmp = std::string(path) + ".tmp";
+    FILE *f = fopen(tmp.c_str(), "wb");
+    if (!f) return fail(h, NGP_ERR_ARG, "cannot open " + tmp + " for writing");
+    bool ok = true;
+    auto W = [&](const void *p, size_t n) { if (n && fwrite(p, 1, n, f) != n) ok = false; };
+    const int64_t hdr[6] = {h->N, h->P, h->nvb, (int64_t)ns, iter, nk};
+    const uint64_t ids[2] = {h->seed, (uint64_t)h->chain};
+    const double scal[4] = {varE, b, svE, sbb};
+    W("NGPSNAP1", 8); W(hdr, sizeof(hdr)); W(ids, sizeof(ids)); W(scal, sizeof(scal));
+    W(yc.data(), N * 8); W(be.data(), P * 8); W(d8.data(), P); W(vb.data(), nvb * 8); W(pi.data(), 2 * ns * 8);
+    W(sb.data(), P * 8); W(sb2.data(), P * 8); W(sd.data(), P * 8); W(sv.data(), nvb * 8); W(sp.data(), 2 * ns * 8);
+    for (auto &hs : h->sets) W(&hs.fine_calls, 8);
+    if (fclose(f) != 0) ok = false;
+    if (!ok || rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); return fail(h, NGP_ERR_ARG, std::string("writing the snapshot failed: ") + path); }
+    return NGP_OK;
+}
+
+int32_t ngp_load_snapshot(ngp_handle *h, const char *path) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(h->d_tiles != nullptr && h->have_y, NGP_ERR_STATE, "panel / y not set (build the model first, then load the snapshot)");
+    REQUIRE(path != nullptr, NGP_ERR_ARG, "null path");
+    FILE *f = fopen(path, "rb");
+    if (!f) return fail(h, NGP_ERR_ARG, std::string("cannot open snapshot ") + path);
+    bool ok = true;
+    auto Rd = [&](void *p, size_t n) { if (n && fread(p, 1, n, f) != n) ok = false; };
+    char magic[8]; int64_t hdr[6] = {0, 0, 0, 0, 0, 0}; uint64_t ids[2] = {0, 0}; double scal[4] = {0, 0, 0, 0};
+    Rd(magic, 8); Rd(hdr, sizeof(hdr)); Rd(ids, sizeof(ids)); Rd(scal, sizeof(scal));
+    if (!ok || memcmp(magic, "NGPSNAP1", 8) != 0) { fclose(f); return fail(h, NGP_ERR_ARG, "not a snapshot file (bad magic or truncated header)"); }
+    if (hdr[0] != h->N || hdr[1] != h->P || hdr[2] != h->nvb || hdr[3] != (int64_t)h->sets.size() || hdr[4] < 0 || hdr[5] < 0) {
+        fclose(f);
+        return fail(h, NGP_ERR_ARG, "snapshot does not match the model of this handle (N, P, variance components or marker sets differ)");
+    }
+    const size_t N = (size_t)h->N, P = (size_t)h->P, nvb = (size_t)h->nvb, ns = h->sets.size();
+    std::vector<double> yc(N), be(P), vb(std::max<size_t>(nvb, 1)), pi(2 * std::max<size_t>(ns, 1)), sb(P), sb2(P), sd(P), sv(std::max<size_t>(nvb, 1)),
+        sp(2 * std::max<size_t>(ns, 1));
+    std::vector<uint8_t> d8(P);
+    std::vector<uint64_t> fc(std::max<size_t>(ns, 1));
+    Rd(yc.data(), N * 8); Rd(be.data(), P * 8); Rd(d8.data(), P); Rd(vb.data(), nvb * 8); Rd(pi.data(), 2 * ns * 8);
+    Rd(sb.data(), P * 8); Rd(sb2.data(), P * 8); Rd(sd.data(), P * 8); Rd(sv.data(), nvb * 8); Rd(sp.data(), 2 * ns * 8); Rd(fc.data(), ns * 8);
+    char extra;
+    const bool at_end = fread(&extra, 1, 1, f) == 0;
+    fclose(f);
+    if (!ok || !at_end) return fail(h, NGP_ERR_ARG, "snapshot file is truncated or has trailing bytes");
+    std::vector<int64_t> de(P);
+    for (size_t k = 0; k < P; k++) de[k] = d8[k];
+    if ((rc = ngp_set_state(h, yc.data(), be.data(), de.data(), vb.data(), pi.data(), scal[0], scal[1], hdr[4]))) return rc;
+    if ((rc = ngp_set_posterior_sums(h, sb.data(), sb2.data(), sd.data(), sv.data(), sp.data(), scal[2], scal[3], hdr[5]))) return rc;
+    for (size_t si = 0; si < ns; si++) h->sets[si].fine_calls = fc[si];
+    h->seed = ids[0]; h->chain = (uint32_t)ids[1];  // the draws continue the interrupted chain's streams
+    return NGP_OK;
+}
+
+int32_t ngp_set_trace_loci(ngp_handle *h, const int64_t *loci, int64_t n, int64_t n_varBeta) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
+    REQUIRE(n >= 0 && n <= 4096 && (n == 0 || loci) && n_varBeta >= 0, NGP_ERR_ARG, "at most 4096 traced loci");
+    for (int64_t i = 0; i < n; i++) REQUIRE(loci[i] >= 0 && loci[i] < h->P, NGP_ERR_ARG, "traced locus outside the panel");
+    HCHK(hipStreamSynchronize(h->stream));
+    dfree(h->d_trace_loci); dfree(h->d_tr_beta); dfree(h->d_tr_vb); dfree(h->d_tr_pi);
+    h->trace_ext_cap = 0; h->ntl = n; h->ntvb = n_varBeta;
+    if (n == 0 && n_varBeta == 0) return NGP_OK;
+    if ((rc = dalloc(h, &h->d_trace_loci, (size_t)std::max<int64_t>(n, 1)))) return rc;
+    if (n) HCHK(hipMemcpy(h->d_trace_loci, loci, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice));
+    return NGP_OK;
+}
+
+int32_t ngp_get_trace_ext(ngp_handle *h, double *beta_tr, double *varBeta_tr, double *pi_tr, int64_t n) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(h->d_trace_loci != nullptr, NGP_ERR_STATE, "no traces requested (ngp_set_trace_loci)");
+    n = std::min(n, std::min(h->ntrace, h->trace_ext_cap));
+    if (n <= 0) return NGP_OK;
+    HCHK(hipStreamSynchronize(h->stream));
+    const int64_t ntvb = std::min<int64_t>(h->ntvb, h->nvb);
+    REQUIRE(ntvb == h->ntvb, NGP_ERR_STATE, "more variance traces requested than the model has variance components");
+    if (beta_tr && h->ntl) HCHK(hipMemcpy(beta_tr, h->d_tr_beta, (size_t)(n * h->ntl) * sizeof(double), hipMemcpyDeviceToHost));
+    if (varBeta_tr && h->ntvb) HCHK(hipMemcpy(varBeta_tr, h->d_tr_vb, (size_t)(n * h->ntvb) * sizeof(double), hipMemcpyDeviceToHost));
+    if (pi_tr && !h->sets.empty()) HCHK(hipMemcpy(pi_tr, h->d_tr_pi, (size_t)n * h->sets.size() * sizeof(double), hipMemcpyDeviceToHost));
+    return NGP_OK;
+}
+
+
+/* Pooled posterior sums of n independent chains (one handle each): afterwards every handle holds the sums over all chains
+ * (nKept included), so posterior means come from any of them.  Handles on DIFFERENT devices are reduced by ONE RCCL
+ * all-reduce (ncclSum, fp64) over xGMI -- RCCL is loaded on first use (dlopen), the library has no link-time dependency on
+ * it; handles that SHARE a device are added on that device first.  Single-process form of the end-of-run exchange
+ * (SURVEY.md section 8 e); bench.py's multi-process form uses torch.distributed on the same packed buffer. */
+namespace {
+struct Rccl {
+    void *lib = nullptr;
+    int (*CommInitAll)(void **, int, const int *) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    std::string err;
+    bool load() {
+        if (lib) return true;
+        const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+        for (const char *nm : names) { lib = dlopen(nm, RTLD_NOW | RTLD_LOCAL); if (lib) break; }
+        if (!lib) { err = std::string("cannot load RCCL: ") + (dlerror() ? dlerror() : "?"); return false; }
+        CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll");
+        AllReduce = (decltype(AllReduce))dlsym(lib, "ncclAllReduce");
+        GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
+        CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+        GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+        if (!CommInitAll || !AllReduce || !GroupStart || !GroupEnd || !CommDestroy) { err = "RCCL symbols missing"; dlclose(lib); lib = nullptr; return false; }
+        return true;
+    }
+} g_rccl;
+
+int import_posterior_device(ngp_handle *h, const double *o) {  // inverse of ngp_export_posterior_device
+    const size_t pb = (size_t)h->P * sizeof(double);
+    HCHK(hipMemcpyAsync(h->d_sum_beta, o, pb, hipMemcpyDeviceToDevice, h->stream));
+    HCHK(hipMemcpyAsync(h->d_sum_beta2, o + h->P, pb, hipMemcpyDeviceToDevice, h->stream));
+    HCHK(hipMemcpyAsync(h->d_sum_delta, o + 2 * h->P, pb, hipMemcpyDeviceToDevice, h->stream));
+    if (h->nvb) HCHK(hipMemcpyAsync(h->d_sum_varBeta, o + 3 * h->P, (size_t)h->nvb * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    std::vector<double> tail(2 * h->sets.size() + 3);
+    HCHK(hipMemcpyAsync(tail.data(), o + 3 * h->P + h->nvb, tail.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
+    HCHK(hipStreamSynchronize(h->stream));
+    for (size_t si = 0; si < h->sets.size(); si++)
+        hipLaunchKernelGGL(k_set_sum_pi, dim3(1), dim3(1), 0, h->stream, h->d_sets, (int)si, tail[2 * si], tail[2 * si + 1]);
+    DScal sc;
+    HCHK(hipMemcpy(&sc, h->d_scal, sizeof(DScal), hipMemcpyDeviceToHost));
+    const size_t t0 = 2 * h->sets.size();
+    sc.sum_varE = tail[t0]; sc.sum_b = tail[t0 + 1]; sc.nKept = (long long)std::llround(tail[t0 + 2]);
+    HCHK(hipMemcpy(h->d_scal, &sc, sizeof(DScal), hipMemcpyHostToDevice));
+    HCHK(hipStreamSynchronize(h->stream));
+    return NGP_OK;
+}
+}  // namespace
+
+int32_t ngp_allreduce_posterior(ngp_handle **hs, int32_t n) {
+    if (!hs || n < 1) return fail(nullptr, NGP_ERR_ARG, "ngp_allreduce_posterior: no handles");
+    for (int i = 0; i < n; i++)
+        if (!hs[i]) return fail(nullptr, NGP_ERR_ARG, "ngp_allreduce_posterior: null handle");
+    ngp_handle *h = hs[0];  // errors are reported on the first handle
+    int rc;
+    int64_t len = 0;
+    if ((rc = ngp_posterior_len(h, &len))) return rc;
+    for (int i = 0; i < n; i++) {
+        REQUIRE(hs[i]->d_tiles != nullptr, NGP_ERR_STATE, "ngp_allreduce_posterior: a handle has no panel");
+        REQUIRE(hs[i]->P == h->P && hs[i]->nvb == h->nvb && hs[i]->sets.size() == h->sets.size(), NGP_ERR_ARG,
+                "ngp_allreduce_posterior: the chains do not share one model");
+        for (int k = 0; k < i; k++) REQUIRE(hs[k] != hs[i], NGP_ERR_ARG, "ngp_allreduce_posterior: a handle is listed twice");
+    }
+    std::vector<double *> buf((size_t)n, nullptr);
+    auto cleanup = [&]() { for (int i = 0; i < n; i++) if (buf[i]) { (void)hipSetDevice(hs[i]->device); (void)hipFree(buf[i]); } };
+    for (int i = 0; i < n; i++) {
+        if ((rc = enter(hs[i]))) { cleanup(); return rc; }
+        if (hipMalloc((void **)&buf[i], (size_t)len * sizeof(double)) != hipSuccess) { cleanup(); return fail(h, NGP_ERR_NOMEM, "posterior buffer"); }
+        if ((rc = ngp_export_posterior_device(hs[i], buf[i], len))) { if (hs[i] != h) h->err = hs[i]->err; cleanup(); return rc; }
+    }
+    // leaders: the first handle of every device; the others are added into their leader on the device
+    std::vector<int> leader((size_t)n);
+    std::vector<int> leaders;
+    for (int i = 0; i < n; i++) {
+        leader[i] = i;
+        for (int k = 0; k < i; k++) if (hs[k]->device == hs[i]->device) { leader[i] = leader[k]; break; }
+        if (leader[i] == i) leaders.push_back(i);
+    }
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < n && e == hipSuccess; i++)
+        if (leader[i] != i) {
+            ngp_handle *L = hs[leader[i]];
+            (void)hipSetDevice(L->device);
+            hipLaunchKernelGGL(k_add_inplace, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, L->stream, buf[leader[i]], buf[i], (long long)len);
+            e = hipStreamSynchronize(L->stream);
+        }
+    if (e != hipSuccess) { cleanup(); return fail(h, NGP_ERR_HIP, std::string("pooling on one device: ") + hipGetErrorString(e)); }
+    if (leaders.size() > 1) {
+        if (!g_rccl.load()) { cleanup(); return fail(h, NGP_ERR_HIP, g_rccl.err); }
+        const int nl = (int)leaders.size();
+        std::vector<void *> comms((size_t)nl, nullptr);
+        std::vector<int> devs((size_t)nl);
+        for (int i = 0; i < nl; i++) devs[i] = hs[leaders[i]]->device;
+        int r = g_rccl.CommInitAll(comms.data(), nl, devs.data());
+        if (r == 0) {
+            g_rccl.GroupStart();
+            for (int i = 0; i < nl && r == 0; i++) {
+                ngp_handle *L = hs[leaders[i]];
+                (void)hipSetDevice(L->device);
+                r = g_rccl.AllReduce(buf[leaders[i]], buf[leaders[i]], (size_t)len, /*ncclDouble*/ 8, /*ncclSum*/ 0, comms[i], L->stream);
+            }
+            const int r2 = g_rccl.GroupEnd();
+            if (r == 0) r = r2;
+            for (int i = 0; i < nl; i++) { (void)hipSetDevice(devs[i]); (void)hipStreamSynchronize(hs[leaders[i]]->stream); }
+        }
+        for (int i = 0; i < nl; i++) if (comms[i]) g_rccl.CommDestroy(comms[i]);
+        if (r != 0) { cleanup(); return fail(h, NGP_ERR_HIP, std::string("RCCL all-reduce failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?")); }
+    }
+    for (int i = 0; i < n; i++) {
+        (void)hipSetDevice(hs[i]->device);
+        if ((rc = import_posterior_device(hs[i], buf[leader[i]]))) { if (hs[i] != h) h->err = hs[i]->err; cleanup(); return rc; }
+    }
+    cleanup();
     return NGP_OK;
 }
 

@@ -423,6 +423,25 @@ __global__ void k_set_pi(DSet *__restrict__ sets, int si, double p0, double p1) 
     sets[si].logPi1 = det_log(p1);
     sets[si].nloci = 0;
 }
+__global__ void k_set_sum_pi(DSet *__restrict__ sets, int si, double s0, double s1) {
+    sets[si].sum_pi0 = s0;
+    sets[si].sum_pi1 = s1;
+}
+// per-iteration traces of selected effects, the first ntvb variances and pi of every set (bench.py: effective sample sizes)
+__global__ __launch_bounds__(256) void k_trace(long long ntl, const long long *__restrict__ loci, long long ntvb, int nsets,
+                                               const double *__restrict__ beta, const double *__restrict__ varBeta,
+                                               const DSet *__restrict__ sets, double *__restrict__ tr_beta,
+                                               double *__restrict__ tr_vb, double *__restrict__ tr_pi, long long idx) {
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k < ntl) tr_beta[idx * ntl + k] = beta[loci[k]];
+    if (k < ntvb) tr_vb[idx * ntvb + k] = varBeta[k];
+    if (k < nsets) tr_pi[idx * nsets + k] = sets[k].piHat1;
+}
+// out += in (pooling of posterior sums of handles that share a device)
+__global__ __launch_bounds__(256) void k_add_inplace(double *__restrict__ out, const double *__restrict__ in, long long n) {
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (k < n) out[k] = out[k] + in[k];
+}
 __global__ void k_set_varE(DScal *__restrict__ sc, double varE) {
     sc->varE = varE;
     sc->iVarE = 1.0 / varE;

@@ -51,6 +51,8 @@ struct SweepArgs {
     double *ycorr;
     const double *gramx;  // [block][lag d < D][64][64]: d = 0 one-sided diagonal block (natural order), d >= 1 cross blocks with
                           // row pairs interleaved (gram_pair_index)
+    int knob;     // tuning knob of the streamers (ngp_debug_set_knob), see role_streamer_rows
+    int variant;  // streamer variant: 1 = phase streamer (role_streamer), 2 = row-owning waves + loader wave (role_streamer_rows)
     int D, R, S, NG, near, fine_ok, t0, t1;  // near: look-ahead lags 1..near are corrected by the sampler, farther ones by the reducers
      // fine_ok: the streamers' LDS has room for the diagnostic timeline
     double *beta;
@@ -74,6 +76,13 @@ struct SweepArgs {
                               // (never waits), 3 = streamers + reducers alone (never wait for dlt), 4 = as 3 without the tile DMA,
                               // 5 = whole pipeline, BayesPR blocks without the recursion, 6 = whole pipeline, reducers never wait for dlt
 };
+
+// The diagnostic build of the kernel (k_sweep<true>: time stamps, timing modes) is a separate instantiation; in the production
+// kernel (k_sweep<false>) every stamp and every mode test folds away at compile time.
+#define NGP_DBG_LOCALS                                                   \
+    unsigned long long *const dbg = DBG ? A.dbg : nullptr;               \
+    const int dbg_mode = DBG ? A.dbg_mode : 0;                           \
+    (void)dbg; (void)dbg_mode;
 
 __device__ inline unsigned ld_u32(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline void st_u32(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -99,6 +108,19 @@ __device__ inline void dma16_lds(const void *gsrc_lane, const void *lds_base_uni
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, off\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep_m0)
                  : "s"(m), "v"(gsrc_lane)
+                 : "memory");
+}
+
+// Lean form for a wave that does nothing but request tiles: LDS address and the 64-bit global base are wave-uniform (SGPRs),
+// the per-lane part is one 32-bit VGPR offset (lane * 16), so a request costs a handful of scalar instructions.  With
+// per-lane 64-bit addresses and a v_readfirstlane per request (dma16_lds) ONE wave issues about 18 KiB per us, below a CU's
+// share of the stream; in this form it keeps up (tools/microbench/dma_bench.hip: 2.69 -> 2.16 us per 51 KiB tile, every CU
+// streaming; a second issuing wave would give 2.04).
+__device__ inline void dma16_s(unsigned lds_addr_uniform, const void *gbase_uniform, unsigned voff) {
+    unsigned keep_m0;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep_m0)
+                 : "s"(lds_addr_uniform), "v"(voff), "s"(gbase_uniform)
                  : "memory");
 }
 
@@ -162,8 +184,9 @@ __device__ inline double gemv4(GLoad G, const double *d) {
 //   waves 0-3  GEMV (lane = column, strided row quads); wave 0 publishes the 64 partial sums
 //   all waves  update tasks (c, i): 8-column chain c of row i
 // TPT = update tasks per thread: 8*R <= TPT * NGP_WG (R <= 64 / 128 / 256 for TPT = 1 / 2 / 4)
-template <int DT, int NGP_TPT>
+template <bool DBG, int DT, int NGP_TPT>
 __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem) {
+    NGP_DBG_LOCALS
     const int R = A.R, S = A.S, tid = threadIdx.x;
     const int wv = tid >> 6, j = tid & 63;
     const size_t TB = (size_t)R * 256;               // tile bytes in HBM: R/4 quads of 1 KiB (quad-major, ngp_kernels.h)
@@ -183,7 +206,7 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
     // diagnostic runs, short shards only (the workgroup's LDS is sized by the sampler then): barrier-arrival stamps of
     // every wave of streamer 1 for local blocks 800..815, staged in LDS and dumped at the end
     unsigned long long *fine = (unsigned long long *)(pp + 8 * (size_t)R);
-    const bool fine_on = A.dbg && s == 1 && A.fine_ok == 1;
+    const bool fine_on = dbg && s == 1 && A.fine_ok == 1;
 #define NGP_FINE(k)                                                                                          \
     do {                                                                                                     \
         if (fine_on && (unsigned)(u - 800) < 16u && j == 0) fine[(((u - 800) * 8 + wv) << 3) + (k)] = wall_clock64(); \
@@ -195,7 +218,7 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
     const int g = s / NGP_GRP;
     const int nb = A.t1 - A.t0;
     auto dma_tile = [&](int ub) {  // waves 4..6 copy tile ub into slot ub&1, 1 KiB per wave-instruction
-        if (A.dbg_mode == 4) return;  // timing experiment: the compute phases without the stream
+        if (dbg_mode == 4) return;  // timing experiment: the compute phases without the stream
         const char *src = (const char *)(A.tiles + ((size_t)(A.t0 + ub) * S + s) * tile_elems);
         char *dst = ring + (size_t)(ub & 1) * TBL;
         for (int c = wv - 4; c < nchunk; c += 3) dma16_lds(src + (size_t)c * 1024 + (size_t)j * 16, dst + (size_t)c * NGP_QS);
@@ -206,8 +229,8 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
         if (aa < 0 || uu >= nb + DT) return;
         int ok = 1;
         if (j == 0) {
-            ok = (A.dbg_mode == 3 || A.dbg_mode == 4 || wait_ge(A.flag_dlt, (unsigned)(aa + 1), A.abort_w, 1u)) ? 1 : 0;
-            if (A.dbg && s == 0) A.dbg[NGP_DBG_STREAM + 2 * (size_t)uu + 1] = wall_clock64();
+            ok = (dbg_mode == 3 || dbg_mode == 4 || wait_ge(A.flag_dlt, (unsigned)(aa + 1), A.abort_w, 1u)) ? 1 : 0;
+            if (dbg && s == 0) dbg[NGP_DBG_STREAM + 2 * (size_t)uu + 1] = wall_clock64();
             if (!ok) *sflag = 0;
         }
         ok = __shfl(ok, 0);
@@ -261,7 +284,7 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
             const int u = u0 + d;
             if (u >= nb + DT) break;
             const int a = u - DT;  // block whose update is applied in this iteration (if >= 0); its tile sits in keep[d]
-            if (A.dbg) tt0 = wall_clock64();
+            if (dbg) tt0 = wall_clock64();
             NGP_FINE(0);
             // ---------------- phase A: everything that waits on memory ----------------
             if (wv >= 4 && wv <= 6) {
@@ -275,18 +298,18 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
                     for (size_t off = lo + (size_t)(wv - 4) * 1024; off + 1024 <= hi; off += 3 * 1024)
                         dma16_lds(gb + off + (size_t)j * 16, scratch + (wv - 4) * 1024);
                 }
-            } else if (wv == 7 && A.dbg_mode != 1) {
+            } else if (wv == 7 && dbg_mode != 1) {
                 if (DT <= 2 || u == 0) poll_dlt(u);  // lags 1-2 cannot poll ahead: the flag would (transitively, through the
                                                      // sampler's own look-ahead fetch of the next group sums) need this block's partial
             }
-            if (A.dbg && (tid == 448 || tid == 256)) accP += wall_clock64() - tt0;  // wave 7 poll / wave 4 DMA drain
+            if (dbg && (tid == 448 || tid == 256)) accP += wall_clock64() - tt0;  // wave 7 poll / wave 4 DMA drain
             NGP_FINE(1);
             try_signal(false);
             wg_barrier();
             if (!*sflag) return;
-            if (A.dbg && tid == 0) { unsigned long long n = wall_clock64(); accA += n - tt0; tt0 = n; }
+            if (dbg && tid == 0) { unsigned long long n = wall_clock64(); accA += n - tt0; tt0 = n; }
             // ---------------- phase B: ycorr -= X_a dlt_a (tile a waits in keep[d]) ----------------
-            if (a >= 0 && A.dbg_mode != 1) {
+            if (a >= 0 && dbg_mode != 1) {
                 {
                     const double *dq = dl + (u & 1) * 64 + 8 * tcc;
                     double dqv[8];
@@ -326,7 +349,7 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
                 const double *yc = ys + (size_t)(u & 1) * R;
                 if (j < R) {
                     yn = yc[j];
-                    if (a >= 0 && A.dbg_mode != 1) {
+                    if (a >= 0 && dbg_mode != 1) {
                         const double T = ((pp[j] + pp[R + j]) + (pp[2 * R + j] + pp[3 * R + j])) +
                                          ((pp[4 * R + j] + pp[5 * R + j]) + (pp[6 * R + j] + pp[7 * R + j]));
                         yn = yn - T;
@@ -334,13 +357,13 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
                     if (wv == 0) ys[(size_t)((u & 1) ^ 1) * R + j] = yn;
                 }
             }
-            if (A.dbg && tid == 0) { unsigned long long n = wall_clock64(); accB += n - tt0; tt0 = n; }
+            if (dbg && tid == 0) { unsigned long long n = wall_clock64(); accB += n - tt0; tt0 = n; }
             // ---------------- phase C: partial X_u' ycorr, and tile u into the delay line ----------------
             if (u < nb) {
                 // wave 7, lag >= 3: dlt of the NEXT iteration in two asynchronous steps -- the flag is read while the wave
                 // works on its chain, the 64 values travel while the workgroup crosses the barrier
                 const int pa = u + 1 - DT;
-                const bool pollw = (wv == 7) && (DT >= 3) && (A.dbg_mode != 1) && (pa >= 0) && (u + 1 < nb + DT);
+                const bool pollw = (wv == 7) && (DT >= 3) && (dbg_mode != 1) && (pa >= 0) && (u + 1 < nb + DT);
                 unsigned fl = 0;
                 if (pollw) fl = ld_u32(A.flag_dlt);
                 const float *slotp = (const float *)(ring + (size_t)(u & 1) * TBL);
@@ -385,14 +408,14 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
                 bool have_dnext = false;
                 if (pollw) {
                     int ok = 1;
-                    if (__shfl((int)fl, 0) < pa + 1 && A.dbg_mode != 3 && A.dbg_mode != 4) {
+                    if (__shfl((int)fl, 0) < pa + 1 && dbg_mode != 3 && dbg_mode != 4) {
                         if (j == 0) {
                             ok = wait_ge(A.flag_dlt, (unsigned)(pa + 1), A.abort_w, 1u) ? 1 : 0;
                             if (!ok) *sflag = 0;
                         }
                         ok = __shfl(ok, 0);
                     }
-                    if (A.dbg && s == 0 && j == 0) A.dbg[NGP_DBG_STREAM + 2 * (size_t)(u + 1) + 1] = wall_clock64();
+                    if (dbg && s == 0 && j == 0) dbg[NGP_DBG_STREAM + 2 * (size_t)(u + 1) + 1] = wall_clock64();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     if (ok) {
                         dnext = ld_f64(&A.dlt[(size_t)(pa % NGP_RING) * NGP_BLK + j]);
@@ -403,7 +426,7 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
                 try_signal(false);
                 wg_barrier();
                 if (have_dnext) dl[((u + 1) & 1) * 64 + j] = dnext;  // read in phase B of the next iteration, two barriers away
-                if (wv == 1 && A.dbg_mode != 1) {
+                if (wv == 1 && dbg_mode != 1) {
                     const int slot = u % NGP_RING;
                     double p = ((red[j] + red[64 + j]) + (red[128 + j] + red[192 + j])) + ((red[256 + j] + red[320 + j]) + (red[384 + j] + red[448 + j]));
                     try_signal(true);  // the previous partial, if its store was still under way at every boundary
@@ -415,27 +438,27 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
                         if (j == 0) atomicAdd(&A.cnt_part[((size_t)slot * A.NG + g) * 32], 1u);
                     }
                     if (j == 0) {
-                        if (A.dbg && s == 0) A.dbg[NGP_DBG_STREAM + 2 * (size_t)u] = wall_clock64();
-                        if (A.dbg && (u == 800 || u == 1200)) {
-                            A.dbg[NGP_DBG_ALL + 4 * (size_t)s + (u == 800 ? 0 : 2)] = wall_clock64();
-                            A.dbg[NGP_DBG_ALL + 4 * (size_t)s + 1] = my_xcc;
-                            A.dbg[NGP_DBG_ALL + 4 * (size_t)s + 3] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+                        if (dbg && s == 0) dbg[NGP_DBG_STREAM + 2 * (size_t)u] = wall_clock64();
+                        if (dbg && (u == 800 || u == 1200)) {
+                            dbg[NGP_DBG_ALL + 4 * (size_t)s + (u == 800 ? 0 : 2)] = wall_clock64();
+                            dbg[NGP_DBG_ALL + 4 * (size_t)s + 1] = my_xcc;
+                            dbg[NGP_DBG_ALL + 4 * (size_t)s + 3] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
                         }
                     }
                 }
             }
-            else if (wv == 7 && DT >= 3 && A.dbg_mode != 1) poll_dlt(u + 1);
-            if (A.dbg && tid == 0) accC += wall_clock64() - tt0;
+            else if (wv == 7 && DT >= 3 && dbg_mode != 1) poll_dlt(u + 1);
+            if (dbg && tid == 0) accC += wall_clock64() - tt0;
             NGP_FINE(6);
         }
     }
     try_signal(true);
-    if (A.dbg && tid == 0) { A.dbg[NGP_DBG_ALL + 4096 + 8 * (size_t)s] = accA; A.dbg[NGP_DBG_ALL + 4096 + 8 * (size_t)s + 1] = accB; A.dbg[NGP_DBG_ALL + 4096 + 8 * (size_t)s + 2] = accC; }
-    if (A.dbg && tid == 448) A.dbg[NGP_DBG_ALL + 4096 + 8 * (size_t)s + 3] = accP;
-    if (A.dbg && tid == 256) A.dbg[NGP_DBG_ALL + 4096 + 8 * (size_t)s + 4] = accP;
+    if (dbg && tid == 0) { dbg[NGP_DBG_ALL + 4096 + 8 * (size_t)s] = accA; dbg[NGP_DBG_ALL + 4096 + 8 * (size_t)s + 1] = accB; dbg[NGP_DBG_ALL + 4096 + 8 * (size_t)s + 2] = accC; }
+    if (dbg && tid == 448) dbg[NGP_DBG_ALL + 4096 + 8 * (size_t)s + 3] = accP;
+    if (dbg && tid == 256) dbg[NGP_DBG_ALL + 4096 + 8 * (size_t)s + 4] = accP;
     if (fine_on && nb > 816) {
         __syncthreads();
-        for (int i = tid; i < 1024; i += NGP_WG) A.dbg[NGP_DBG_ALL + 8192 + i] = fine[i];
+        for (int i = tid; i < 1024; i += NGP_WG) dbg[NGP_DBG_ALL + 8192 + i] = fine[i];
     }
 #undef NGP_FINE
     __syncthreads();
@@ -445,9 +468,299 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// Streamer, variant 2 ("row-owning waves"), shards of up to NGP_ROWS_MAX_R rows, lags 3..6.
+//
+// What bounded the phase streamer above on tall shards (50k x 600k: 2.96 us per block against 2.20 us for the bare
+// stream) was not arithmetic: four workgroup barriers per block, with the three DMA waves sitting 1.3 us in the issue of
+// the next tile (the CU's memory pipeline admits new requests at the rate data returns) and the publisher wave 1.5 us in
+// the acknowledgement of its store, while the other waves waited at the barrier behind them.  Here
+//
+//   wave 7     is the loader and nothing else: it keeps the LDS-DMA queue of the CU full (tile u+1 and the first H quads
+//              of tile u+2 are requested during block u, into a ring of 2 NQ + H quad slots) and joins the ONE barrier of
+//              the block after a counted vmcnt wait that leaves those H requests in flight;
+//   waves 0-6  own rows: wave w holds quads w, w+7, w+14, ... of the shard (a quad = 4 rows).  It forms the GEMV chain of
+//              exactly those quads (lane = column) and applies the update to exactly those rows (lane = (quad, 8-column
+//              chain), the 8 chain partials of a row meet in a DPP tree inside the wave), so ycorr never crosses a wave:
+//              no barrier between the update and the GEMV, no partial-sum array, one LDS read of the shard per quad.
+//   wave 2     also publishes the 64 partial dot products of the previous block right after the barrier and counts them
+//              when its own VM_CNT shows the store acknowledged (it has no other memory traffic);
+//   wave 6     also fetches dlt of the block to be applied next (flag requested at the start of the block, read after its
+//              arithmetic).
+//
+// Summation order (DESIGN.md section 2, step 3'): 7 GEMV chains instead of 8 -- chain w runs over quads w, w+7, ... (4
+// sequential fma per quad), p = ((a0+a1)+(a2+a3))+((a4+a5)+a6); the update is unchanged (8 chains of 8 columns, pairwise
+// tree).  The blocked oracle takes the chain count as a layout parameter (ngp_get_streamer).
+#define NGP_ROWS_MAX_R 224
+#define NGP_ROWS_NW 7       // row-owning waves
+#define NGP_ROWS_HMAX 24    // quads of tile u+2 requested during block u (the counted wait keeps them in flight)
+#define NGP_ROWS_PUBW 2
+#define NGP_ROWS_POLLW 6
+
+__device__ inline double dpp_f64(double v, const int ctrl_sel) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    if (ctrl_sel == 0) {  // quad_perm [1,0,3,2]: lane ^ 1
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0xB1, 0xF, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(hi, hi, 0xB1, 0xF, 0xF, false);
+    } else if (ctrl_sel == 1) {  // quad_perm [2,3,0,1]: lane ^ 2
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false);
+    } else {  // row_half_mirror: lane i of each group of 8 reads lane 7 - i (the other group of four)
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, 0xF, false);
+    }
+    return __hiloint2double(hi, lo);
+}
+
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n in 0..NGP_ROWS_HMAX (the instruction takes an immediate)
+__device__ inline void wait_vmcnt_le(int n) {
+#define NGP_VMC(i) case i: asm volatile("s_waitcnt vmcnt(" #i ")" ::: "memory"); break;
+    switch (n) {
+        NGP_VMC(1) NGP_VMC(2) NGP_VMC(3) NGP_VMC(4) NGP_VMC(5) NGP_VMC(6) NGP_VMC(7) NGP_VMC(8) NGP_VMC(9) NGP_VMC(10) NGP_VMC(11)
+        NGP_VMC(12) NGP_VMC(13) NGP_VMC(14) NGP_VMC(15) NGP_VMC(16) NGP_VMC(17) NGP_VMC(18) NGP_VMC(19) NGP_VMC(20) NGP_VMC(21)
+        NGP_VMC(22) NGP_VMC(23) NGP_VMC(24)
+        default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
+    }
+#undef NGP_VMC
+}
+
+template <bool DBG, int DT>
+__device__ inline void role_streamer_rows(const SweepArgs &A, const int s, char *smem) {
+    NGP_DBG_LOCALS
+    const int R = A.R, S = A.S, tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int NQ = R >> 2;                                   // quads per tile
+    const int H = min(NGP_ROWS_HMAX, (NQ + 1) >> 1);         // quads of a tile requested one block earlier than the rest
+    const int RQ = 2 * NQ + H;                               // ring slots: tile u in use, tile u+1 complete, H quads of tile u+2
+    char *ring = smem;
+    double *ys = (double *)(smem + (size_t)RQ * NGP_QS);     // the shard of ycorr, resident for the whole sweep
+    double *red = ys + ((R + 7) & ~7);                       // 2 (block parity) x 7 chains x 64 columns
+    double *dl = red + 2 * NGP_ROWS_NW * NGP_BLK;            // 2 (block parity) x 64: dlt of the block being applied
+    int *sflag = (int *)(dl + 2 * NGP_BLK);
+    char *scratch = (char *)(dl + 2 * NGP_BLK) + 64;         // 1 KiB sink of the L2-warming DMA
+    unsigned long long *fine = (unsigned long long *)(scratch + 1024);  // diagnostic timeline (DBG only, if it fits)
+    const bool fine_on = DBG && dbg && s == 1 && A.fine_ok == 1;
+#define NGP_FINE(k)                                                                                              \
+    do {                                                                                                         \
+        if (fine_on && (unsigned)(u - 800) < 16u && lane == 0) fine[(((u - 800) * 8 + wv) << 3) + (k)] = wall_clock64(); \
+    } while (0)
+    const size_t tile_elems = (size_t)R * NGP_BLK;
+    double *yg = A.ycorr + (size_t)s * R;
+    const int g = s / NGP_GRP;
+    const int nb = A.t1 - A.t0;
+    for (int i = tid; i < R; i += NGP_WG) ys[i] = yg[i];
+    if (tid == 0) *sflag = 1;
+    int base = 0;  // ring slot of quad 0 of tile u
+    auto wrap = [&](int p) { return p >= RQ ? p - RQ : p; };
+    if (wv == NGP_ROWS_NW) {
+        // ------------------------------ loader ------------------------------
+        const unsigned ring0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)ring;
+        const unsigned scratch0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)scratch;
+        const unsigned voff = (unsigned)lane * 16u;
+        const bool no_dma = DBG && dbg_mode == 4;  // timing experiment: the arithmetic without the stream
+        // quads [q0, q1) of local tile `tile` into ring slots tbase + q (everything wave-uniform: scalar registers only)
+        auto dma_quads = [&](int tile, int q0, int q1, int tbase) {
+            if (no_dma || q0 >= q1) return 0;
+            const char *g = (const char *)(A.tiles + ((size_t)(A.t0 + tile) * S + s) * tile_elems) + (size_t)q0 * 1024;
+            int p = wrap(tbase + q0);
+            for (int q = q0; q < q1; ++q) {
+                dma16_s(ring0 + (unsigned)p * NGP_QS, g, voff);
+                g += 1024;
+                if (++p == RQ) p = 0;
+            }
+            return q1 - q0;
+        };
+        const unsigned my_xcc = xcc_id() + 1u;
+        const int nslice = max(1, S / 8);
+        const int slice = (s / 8) % nslice;
+        const size_t gram_bytes = (size_t)DT * NGP_BLK * NGP_BLK * sizeof(double);
+        const size_t slice_bytes = ((gram_bytes / nslice + 1023) / 1024) * 1024;
+        bool same_xcd = false, xcc_known = false;
+        __builtin_amdgcn_s_setprio(3);  // the loader's few scalar instructions go first on its SIMD: a late request costs the whole CU
+        if (nb > 0) dma_quads(0, 0, NQ, 0);
+        if (nb > 1) dma_quads(1, 0, H, NQ);
+        drain_vm();  // tile 0 has landed
+        wg_barrier();
+        for (int u = 0; u < nb + DT; ++u) {
+            NGP_FINE(0);
+            const int base1 = wrap(base + NQ), base2 = wrap(base1 + NQ);
+            // speed only: streamers on the sampler's XCD pull the Gram blocks of the next block into that XCD's L2 (the
+            // sampler is one latency-bound CU); requested first, so that the counted wait below covers them
+            // (the sampler's XCC id is read until it is known -- a scalar load that bypasses the scalar cache costs the
+            // loader about 1.5 us, during which it requests nothing: re-read every eighth block for the whole sweep, as the phase
+            // streamer does, it put 511 blocks of 6 us and more into a 50k x 600k sweep)
+            if (!xcc_known && (u & 7) == 0) {
+                const unsigned x = sld_u32(A.xcc_w);
+                xcc_known = (x != 0u);
+                same_xcd = (x == my_xcc);
+            }
+            if (same_xcd && u + 1 < nb && !no_dma) {
+                const char *gb = (const char *)(A.gramx + (size_t)(A.t0 + u + 1) * DT * NGP_BLK * NGP_BLK);
+                const size_t lo = (size_t)slice * slice_bytes, hi = min((size_t)(slice + 1) * slice_bytes, gram_bytes);
+                for (size_t off = lo; off + 1024 <= hi; off += 1024) dma16_s(scratch0, gb + off, voff);
+            }
+            if (u + 1 < nb) dma_quads(u + 1, H, NQ, base1);
+            int n2 = 0;
+            if (u + 2 < nb) n2 = dma_quads(u + 2, 0, H, base2);
+            NGP_FINE(1);
+            wait_vmcnt_le(n2);  // everything up to the last quad of tile u+1 has landed
+            NGP_FINE(2);
+            wg_barrier();
+            if (!*sflag) return;
+            base = base1;
+        }
+        drain_vm();
+    } else {
+        // ------------------------------ row-owning waves ------------------------------
+        const int c = lane & 7, ql = lane >> 3;
+        const int nqw = (NQ - wv + NGP_ROWS_NW - 1) / NGP_ROWS_NW;  // quads of this wave (wave-uniform)
+        const int qt = wv + NGP_ROWS_NW * ql;                       // the quad of this lane's update task
+        const bool has_task = qt < NQ;
+        const int qtc = has_task ? qt : wv;                         // idle lanes shadow a valid quad (nothing is stored)
+        float4 keep[DT][8];  // tile elements of the update task: rows 4 qt..4 qt+3 (x, y, z, w) of columns 8 c + jj
+#pragma unroll
+        for (int d = 0; d < DT; d++)
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) keep[d][jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned fl_pre = 0;  // poller: number of finished blocks as read just before the previous barrier
+        // publisher: the stored, not yet counted partial (ring slot), counted once VM_CNT of this wave reads zero
+        int sig_pending = -1;
+        auto try_signal = [&](bool force) {
+            if (wv != NGP_ROWS_PUBW || sig_pending < 0) return;
+            if (force) drain_vm();
+            else if ((__builtin_amdgcn_s_getreg((23 << 11) | 7) & 0xC0000Fu) != 0u) return;  // VM_CNT [3:0] and [23:22]
+            if (lane == 0) atomicAdd(&A.cnt_part[((size_t)sig_pending * A.NG + g) * 32], 1u);
+            sig_pending = -1;
+        };
+        wg_barrier();
+        for (int u0 = 0; u0 < nb + DT; u0 += DT) {
+#pragma unroll
+            for (int d = 0; d < DT; d++) {
+                const int u = u0 + d;
+                if (u >= nb + DT) break;
+                const int a = u - DT;  // block whose update is applied now (its tile waits in keep[d])
+                NGP_FINE(0);
+                // poller: dlt of the block applied in the NEXT iteration; the flag travels while this wave works
+                const int pa = u + 1 - DT;
+                const bool pollw = (wv == NGP_ROWS_POLLW) && (pa >= 0) && (u + 1 < nb + DT) && !(DBG && dbg_mode == 1);
+                // (every load of a streaming CU queues behind a microsecond of tile requests, so the two dependent loads -- flag,
+                // then the 64 values -- are taken off the end of the block: the flag was requested before the previous barrier,
+                // and if it already shows the block finished the values travel while this wave does its arithmetic)
+                unsigned fl = 0;
+                double dnext = 0.0;
+                bool have_dnext = false;
+                if (pollw) {
+                    if ((int)__shfl((int)fl_pre, 0) >= pa + 1) {
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        dnext = ld_f64(&A.dlt[(size_t)(pa % NGP_RING) * NGP_BLK + lane]);
+                        have_dnext = true;
+                    } else {
+                        fl = ld_u32(A.flag_dlt);
+                    }
+                }
+                // ---- ycorr -= X_a dlt_a for the rows of this wave ----
+                if (a >= 0 && !(DBG && dbg_mode == 1)) {
+                    const double *dq = dl + (u & 1) * NGP_BLK + 8 * c;
+                    double dqv[8];
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) dqv[jj] = dq[jj];
+                    double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) {
+                        p0 = __builtin_fma((double)keep[d][jj].x, dqv[jj], p0);
+                        p1 = __builtin_fma((double)keep[d][jj].y, dqv[jj], p1);
+                        p2 = __builtin_fma((double)keep[d][jj].z, dqv[jj], p2);
+                        p3 = __builtin_fma((double)keep[d][jj].w, dqv[jj], p3);
+                    }
+                    // ((p_0+p_1)+(p_2+p_3))+((p_4+p_5)+(p_6+p_7)) over the 8 chains = the 8 lanes of the group
+                    p0 = p0 + dpp_f64(p0, 0); p1 = p1 + dpp_f64(p1, 0); p2 = p2 + dpp_f64(p2, 0); p3 = p3 + dpp_f64(p3, 0);
+                    p0 = p0 + dpp_f64(p0, 1); p1 = p1 + dpp_f64(p1, 1); p2 = p2 + dpp_f64(p2, 1); p3 = p3 + dpp_f64(p3, 1);
+                    p0 = p0 + dpp_f64(p0, 2); p1 = p1 + dpp_f64(p1, 2); p2 = p2 + dpp_f64(p2, 2); p3 = p3 + dpp_f64(p3, 2);
+                    if (c == 0 && has_task) {
+                        double *yq = ys + 4 * qt;
+                        const double y0 = yq[0], y1 = yq[1], y2 = yq[2], y3 = yq[3];
+                        yq[0] = y0 - p0; yq[1] = y1 - p1; yq[2] = y2 - p2; yq[3] = y3 - p3;
+                    }
+                }
+                NGP_FINE(1);
+                try_signal(false);
+                if (u < nb) {
+                    // ---- GEMV chain of this wave: quads wv, wv+7, ... (lane = column); LDS serves a wave in order, so the
+                    //      rows written above are read back without a barrier ----
+                    double acc = 0.0;
+                    for (int k = 0; k < nqw; k++) {
+                        const int q = wv + NGP_ROWS_NW * k;
+                        const float4 x = *(const float4 *)(ring + (size_t)wrap(base + q) * NGP_QS + (size_t)lane * 16);
+                        const double *yq = ys + 4 * q;
+                        const double y0 = yq[0], y1 = yq[1], y2 = yq[2], y3 = yq[3];
+                        acc = __builtin_fma((double)x.x, y0, acc);
+                        acc = __builtin_fma((double)x.y, y1, acc);
+                        acc = __builtin_fma((double)x.z, y2, acc);
+                        acc = __builtin_fma((double)x.w, y3, acc);
+                    }
+                    red[((u & 1) * NGP_ROWS_NW + wv) * NGP_BLK + lane] = acc;
+                    NGP_FINE(2);
+                    try_signal(false);
+                    // ---- tile u into the delay line (task view of the same quads) ----
+                    const char *tq = ring + (size_t)wrap(base + qtc) * NGP_QS + c * 128;
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) keep[d][jj] = *(const float4 *)(tq + jj * 16);
+                }
+                NGP_FINE(3);
+                if (pollw) {
+                    int ok = 1;
+                    if (!have_dnext) {
+                        if (__shfl((int)fl, 0) < pa + 1 && !(DBG && (dbg_mode == 3 || dbg_mode == 4))) {
+                            if (lane == 0) {
+                                ok = wait_ge(A.flag_dlt, (unsigned)(pa + 1), A.abort_w, 1u) ? 1 : 0;
+                                if (!ok) *sflag = 0;
+                            }
+                            ok = __shfl(ok, 0);
+                        }
+                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                        if (ok) dnext = ld_f64(&A.dlt[(size_t)(pa % NGP_RING) * NGP_BLK + lane]);
+                    }
+                    if (ok) dl[((u + 1) & 1) * NGP_BLK + lane] = dnext;
+                }
+                if (wv == NGP_ROWS_POLLW && !(DBG && dbg_mode == 1)) fl_pre = ld_u32(A.flag_dlt);  // looked at after the barrier
+                NGP_FINE(4);
+                // Lag 3: dlt of block u-2, which the poller of this workgroup waits for before this barrier, needs the partial of
+                // block u-1 of EVERY streamer counted (the sampler fetches the group sums of the next block before it lets a
+                // block go) -- so the count must not slip behind the barrier.  From lag 4 on it may (needs: partials <= u-2).
+                try_signal(DT < 4);
+                wg_barrier();
+                if (!*sflag) return;
+                NGP_FINE(5);
+                if (wv == NGP_ROWS_PUBW && u < nb && !(DBG && dbg_mode == 1)) {
+                    const int slot = u % NGP_RING;
+                    const double *rp = red + (u & 1) * NGP_ROWS_NW * NGP_BLK + lane;
+                    const double p = ((rp[0] + rp[NGP_BLK]) + (rp[2 * NGP_BLK] + rp[3 * NGP_BLK])) + ((rp[4 * NGP_BLK] + rp[5 * NGP_BLK]) + rp[6 * NGP_BLK]);
+                    try_signal(true);  // the previous partial, if its store was still under way at every look
+                    st_f64(&A.part[((size_t)slot * S + s) * NGP_BLK + lane], p);
+                    sig_pending = slot;
+                    if (DBG && dbg && s == 0 && lane == 0) dbg[NGP_DBG_STREAM + 2 * (size_t)u] = wall_clock64();
+                }
+                base = wrap(base + NQ);
+                NGP_FINE(6);
+            }
+        }
+        try_signal(true);
+    }
+    if (fine_on && nb > 816) {
+        __syncthreads();
+        for (int i = tid; i < 1024; i += NGP_WG) dbg[NGP_DBG_ALL + 8192 + i] = fine[i];
+    }
+#undef NGP_FINE
+    __syncthreads();
+    for (int i = tid; i < R; i += NGP_WG) yg[i] = ys[i];
+}
+
 // ------------------------------------------------------------------------------------------
 // reducer g: every wave works on its own blocks (u = wave, wave+8, ...), no workgroup barrier
+template <bool DBG>
 __device__ inline void role_reducer(const SweepArgs &A, const int g) {
+    NGP_DBG_LOCALS
     const int S = A.S, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int s0 = g * NGP_GRP, s1 = min(s0 + NGP_GRP, S), gsize = s1 - s0;
     const int nb = A.t1 - A.t0;
@@ -457,7 +770,7 @@ __device__ inline void role_reducer(const SweepArgs &A, const int g) {
         if (lane == 0) ok = wait_ge(&A.cnt_part[((size_t)slot * A.NG + g) * 32], (unsigned)((round + 1) * gsize), A.abort_w, 2u) ? 1 : 0;
         ok = __shfl(ok, 0);
         if (!ok) return;
-        if (A.dbg && g == 0 && lane == 0) A.dbg[NGP_DBG_RED + 2 * (size_t)u] = wall_clock64();
+        if (dbg && g == 0 && lane == 0) dbg[NGP_DBG_RED + 2 * (size_t)u] = wall_clock64();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         const double *p = A.part + ((size_t)slot * S + s0) * NGP_BLK + lane;
         double vals[NGP_GRP];
@@ -475,7 +788,7 @@ __device__ inline void role_reducer(const SweepArgs &A, const int g) {
             double gr[NGP_BLK];
             load_rows_pair(A.gramx + ((size_t)(A.t0 + u) * A.D + d) * (NGP_BLK * NGP_BLK), lane, gr);
             int okd = 1;
-            if (lane == 0) okd = (A.dbg_mode == 3 || A.dbg_mode == 4 || A.dbg_mode == 6 || wait_ge(A.flag_dlt, (unsigned)(a + 1), A.abort_w, 4u)) ? 1 : 0;
+            if (lane == 0) okd = (dbg_mode == 3 || dbg_mode == 4 || dbg_mode == 6 || wait_ge(A.flag_dlt, (unsigned)(a + 1), A.abort_w, 4u)) ? 1 : 0;
             okd = __shfl(okd, 0);
             if (!okd) return;
             __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -494,7 +807,7 @@ __device__ inline void role_reducer(const SweepArgs &A, const int g) {
         drain_vm();
         if (lane == 0) {
             atomicAdd(&A.cnt_gs[(size_t)slot * 32], 1u);
-            if (A.dbg && g == 0) A.dbg[NGP_DBG_RED + 2 * (size_t)u + 1] = wall_clock64();
+            if (dbg && g == 0) dbg[NGP_DBG_RED + 2 * (size_t)u + 1] = wall_clock64();
         }
     }
 }
@@ -516,10 +829,12 @@ __device__ inline CoefRegs load_coef(const SweepArgs &A, long long k) {
 // workgroup barrier that drains LDS traffic only: global loads issued before it stay in flight
 
 // group sums of local block u -> per-lane total (lane 0 polls, whole wave loads); false on abort
+template <bool DBG>
 __device__ inline bool fetch_group_sums(const SweepArgs &A, int u, int j, double *tot_out) {
+    NGP_DBG_LOCALS
     const int NG = A.NG, slot = u % NGP_RING;
     int ok = 1;
-    if (j == 0) ok = (A.dbg_mode == 2 || wait_ge(&A.cnt_gs[(size_t)slot * 32], (unsigned)((u / NGP_RING + 1) * NG), A.abort_w, 3u)) ? 1 : 0;
+    if (j == 0) ok = (dbg_mode == 2 || wait_ge(&A.cnt_gs[(size_t)slot * 32], (unsigned)((u / NGP_RING + 1) * NG), A.abort_w, 3u)) ? 1 : 0;
     ok = __shfl(ok, 0);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (!ok) return false;
@@ -536,8 +851,10 @@ __device__ inline bool fetch_group_sums(const SweepArgs &A, int u, int j, double
 }
 
 // results of a finished block: dlt first (sc1 + drain + flag: the streamers are waiting), then beta / delta / varBeta
+template <bool DBG>
 __device__ inline void publish_block(const SweepArgs &A, int up, int j, const double *hist, const double *outb, const int *outi,
                                      const int *smeth, const double *ssdf) {
+    NGP_DBG_LOCALS
     const int pslot = up % NGP_RING, pbuf = up & 1;
     const long long k = (long long)(A.t0 + up) * NGP_BLK + j;
     // what the variance bookkeeping of BayesB needs is requested first, so that it travels while the store is acknowledged
@@ -549,7 +866,7 @@ __device__ inline void publish_block(const SweepArgs &A, int up, int j, const do
     drain_vm();
     if (j == 0) {
         st_u32(A.flag_dlt, (unsigned)(up + 1));
-        if (A.dbg) A.dbg[4 * (size_t)up + 2] = wall_clock64();
+        if (dbg) dbg[4 * (size_t)up + 2] = wall_clock64();
     }
     const double bn = outb[pbuf * NGP_BLK + j];
     const int isave = outi[pbuf * NGP_BLK + j];
@@ -579,7 +896,9 @@ __device__ inline void publish_block(const SweepArgs &A, int up, int j, const do
 //   wave 5   lag-1 correction (cross block in registers, loaded one block ahead), final total, LDS flag for wave 0
 //   wave 4, 6, 7   lag-2, lag-3 and (near = 4) lag-4 corrections, Gram rows loaded one block ahead into registers
 // LDS: Gd[3][4096] | hist[RING][64] | vacc[RING][64] | r0[4][64] | outb[2][64] | outi[2][64] | flags, per-set constants
+template <bool DBG>
 __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
+    NGP_DBG_LOCALS
     const int D = A.D, tid = threadIdx.x, wv = tid >> 6, j = tid & 63;
     double *Gd = (double *)smem;                // 3 x 4096: diagonal Gram blocks of local blocks u, u+1, u+2
     double *hist = Gd + 3 * 4096;               // RING x 64
@@ -601,7 +920,7 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
         *sabort = 0;
         *totflag = 0;
         st_u32(A.xcc_w, xcc_id() + 1u);
-        if (A.dbg) { A.dbg[NGP_DBG_ALL - 2] = xcc_id(); A.dbg[NGP_DBG_ALL - 1] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4); }
+        if (dbg) { dbg[NGP_DBG_ALL - 2] = xcc_id(); dbg[NGP_DBG_ALL - 1] = (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4); }
     }
     // prologue: diagonal Gram block of local block 0 (all waves) and its group sums (wave 2)
     {
@@ -615,14 +934,14 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
     __syncthreads();
     if (wv == 2) {
         double tot;
-        if (fetch_group_sums(A, 0, j, &tot)) r0[j] = tot;
+        if (fetch_group_sums<DBG>(A, 0, j, &tot)) r0[j] = tot;
         else if (j == 0) *sabort = 1;
     }
     __syncthreads();
     if (*sabort) return;
 #define NGP_END_OF_BLOCK()                                                                       \
     do {                                                                                         \
-        if (A.dbg && j == 0) A.dbg[NGP_DBG_WAVES + 8 * (size_t)u + wv] = wall_clock64();           \
+        if (dbg && j == 0) dbg[NGP_DBG_WAVES + 8 * (size_t)u + wv] = wall_clock64();           \
         wg_barrier();                                                                            \
         if (*sabort) return;                                                                     \
     } while (0)
@@ -633,15 +952,22 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
         for (int u = 0; u < nb; ++u) {
             const int t = A.t0 + u, buf = u & 1, slot = u % NGP_RING, rs = u & 3;
             if (u + 1 < nb) nxt = load_coef(A, (long long)(t + 1) * NGP_BLK + j);
-            if (A.dbg && j == 0) A.dbg[4 * (size_t)u] = wall_clock64();
+            if (dbg && j == 0) dbg[4 * (size_t)u] = wall_clock64();
             double tot;
             if (D == 1) {  // lag 1: nothing can be fetched or corrected ahead
                 tot = r0[rs * NGP_BLK + j];
                 bool okc = true;
-                if (u >= 1) okc = fetch_group_sums(A, u, j, &tot);
+                if (u >= 1) okc = fetch_group_sums<DBG>(A, u, j, &tot);
                 if (!okc && j == 0) *sabort = 1;
             } else {       // wave 5 applies the look-ahead corrections and leaves the final total in r0[buf]
-                while (__hip_atomic_load(totflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != u + 1) __builtin_amdgcn_s_sleep(0);
+                // bounded like every other spin: an abort raised by another wave of this workgroup ends the wait
+                for (unsigned sp = 0; __hip_atomic_load(totflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != u + 1; ++sp) {
+                    if ((sp & 255u) == 255u && (*(volatile int *)sabort != 0 || sp > (NGP_SPIN_LIMIT << 4))) {
+                        if (j == 0) *sabort = 1;
+                        break;
+                    }
+                    __builtin_amdgcn_s_sleep(0);
+                }
                 tot = r0[rs * NGP_BLK + j];
             }
             const double *gdb = Gd + (u % 3) * 4096 + j;
@@ -658,7 +984,7 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
             double e = __builtin_fma(r, cc, ww);
             double dsave;
             int isave = 1;
-            if (A.dbg_mode == 5 && __ballot(st >= 0.0) == 0ull) {
+            if (dbg_mode == 5 && __ballot(st >= 0.0) == 0ull) {
                 dsave = e;  // timing experiment: BayesPR blocks without the 64-step recursion
             } else if (__ballot(st >= 0.0) == 0ull) {
                 NGP_LOAD_G()
@@ -716,16 +1042,16 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
             hist[slot * NGP_BLK + j] = dsave;
             outb[buf * NGP_BLK + j] = bo + dsave;
             outi[buf * NGP_BLK + j] = isave;
-            if (A.dbg && j == 0) A.dbg[4 * (size_t)u + 1] = wall_clock64();
+            if (dbg && j == 0) dbg[4 * (size_t)u + 1] = wall_clock64();
             cur = nxt;
             NGP_END_OF_BLOCK();
         }
     } else if (wv == 1) {
         for (int u = 0; u < nb; ++u) {
-            if (u >= 1) publish_block(A, u - 1, j, hist, outb, outi, smeth, ssdf);
+            if (u >= 1) publish_block<DBG>(A, u - 1, j, hist, outb, outi, smeth, ssdf);
             NGP_END_OF_BLOCK();
         }
-        if (nb >= 1) publish_block(A, nb - 1, j, hist, outb, outi, smeth, ssdf);
+        if (nb >= 1) publish_block<DBG>(A, nb - 1, j, hist, outb, outi, smeth, ssdf);
     } else if (wv == 2) {
         // group sums -> r0 ring.  Lag >= 4: two blocks ahead -- the loads of block u+2 (and a probe of the counter of
         // block u+3) are issued during block u and consumed at the start of block u+1, so the memory round trip of this
@@ -749,7 +1075,7 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
                 for (int g = 1; g < 8; g++)
                     if (g < NG) tot = tot + gv[g];
                 r0[(ub & 3) * NGP_BLK + j] = tot;
-                if (A.dbg && j == 0) A.dbg[4 * (size_t)ub + 3] = wall_clock64();
+                if (dbg && j == 0) dbg[4 * (size_t)ub + 3] = wall_clock64();
             };
             int next_fetch = 1;   // first local block whose group sums have not been requested yet
             bool pend = false;    // loads of block next_fetch - 1 in flight
@@ -761,7 +1087,7 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
                 if (next_fetch < nb && next_fetch <= u + 2) {  // r0[(u+2) & 3] is free: block u-2 is done
                     const bool must = (next_fetch == u + 1);    // the next block needs these sums
                     int ok = 1;
-                    bool ready = (__shfl((int)probe, 0) >= (int)target_of(next_fetch)) || A.dbg_mode == 2;
+                    bool ready = (__shfl((int)probe, 0) >= (int)target_of(next_fetch)) || dbg_mode == 2;
                     if (!ready && must) {
                         if (j == 0) ok = wait_ge(&A.cnt_gs[(size_t)(next_fetch % NGP_RING) * 32], target_of(next_fetch), A.abort_w, 3u) ? 1 : 0;
                         ok = __shfl(ok, 0);
@@ -784,7 +1110,7 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
             for (int u = 0; u < nb; ++u) {
                 if (u + 1 < nb && D >= 2) {
                     double tot;
-                    if (fetch_group_sums(A, u + 1, j, &tot)) r0[((u + 1) & 3) * NGP_BLK + j] = tot;
+                    if (fetch_group_sums<DBG>(A, u + 1, j, &tot)) r0[((u + 1) & 3) * NGP_BLK + j] = tot;
                     else if (j == 0) *sabort = 1;
                 }
                 NGP_END_OF_BLOCK();
@@ -807,7 +1133,7 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
             } else {
                 drain_vm();
             }
-            if (A.dbg && j == 0) A.dbg[NGP_DBG_WAVES + 8 * (size_t)u + wv] = wall_clock64();
+            if (dbg && j == 0) dbg[NGP_DBG_WAVES + 8 * (size_t)u + wv] = wall_clock64();
             wg_barrier();
             if (sld_u32(A.abort_w) != 0u) return;
         }
@@ -892,31 +1218,42 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
 }
 
 // ------------------------------------------------------------------------------------------
+template <bool DBG>
 __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sweep(SweepArgs A) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
+    NGP_DBG_LOCALS
     const int b = blockIdx.x;
-    if (A.dbg_mode == 1 && b <= A.NG) return;
-    if ((A.dbg_mode == 2 && b != 0) || ((A.dbg_mode == 3 || A.dbg_mode == 4) && b == 0)) return;
+    if (dbg_mode == 1 && b <= A.NG) return;
+    if ((dbg_mode == 2 && b != 0) || ((dbg_mode == 3 || dbg_mode == 4) && b == 0)) return;
     if (b == 0)
-        role_sampler(A, smem);
+        role_sampler<DBG>(A, smem);
     else if (b <= A.NG)
-        role_reducer(A, b - 1);
+        role_reducer<DBG>(A, b - 1);
     else {
         const int s = b - 1 - A.NG;
+        if (A.variant == 2) {  // row-owning waves + loader wave (host: R <= NGP_ROWS_MAX_R, lag 3..6)
+            switch (A.D) {
+                case 3: role_streamer_rows<DBG, 3>(A, s, smem); break;
+                case 4: role_streamer_rows<DBG, 4>(A, s, smem); break;
+                case 5: role_streamer_rows<DBG, 5>(A, s, smem); break;
+                default: role_streamer_rows<DBG, 6>(A, s, smem); break;
+            }
+            return;
+        }
         const int tpt = (8 * A.R + NGP_WG - 1) / NGP_WG;  // 1..4
 #define NGP_DISPATCH_D(T)                                      \
     switch (A.D) {                                             \
-        case 1: role_streamer<1, T>(A, s, smem); break;        \
-        case 2: role_streamer<2, T>(A, s, smem); break;        \
-        case 3: role_streamer<3, T>(A, s, smem); break;        \
-        default: role_streamer<4, T>(A, s, smem); break;       \
+        case 1: role_streamer<DBG, 1, T>(A, s, smem); break;        \
+        case 2: role_streamer<DBG, 2, T>(A, s, smem); break;        \
+        case 3: role_streamer<DBG, 3, T>(A, s, smem); break;        \
+        default: role_streamer<DBG, 4, T>(A, s, smem); break;       \
     }
 #define NGP_DISPATCH_D8(T)                                     \
     switch (A.D) {                                             \
-        case 5: role_streamer<5, T>(A, s, smem); break;        \
-        case 6: role_streamer<6, T>(A, s, smem); break;        \
-        case 7: role_streamer<7, T>(A, s, smem); break;        \
-        case 8: role_streamer<8, T>(A, s, smem); break;        \
+        case 5: role_streamer<DBG, 5, T>(A, s, smem); break;        \
+        case 6: role_streamer<DBG, 6, T>(A, s, smem); break;        \
+        case 7: role_streamer<DBG, 7, T>(A, s, smem); break;        \
+        case 8: role_streamer<DBG, 8, T>(A, s, smem); break;        \
         default: NGP_DISPATCH_D(T)                             \
     }
         if (tpt == 1) {
@@ -925,7 +1262,7 @@ __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             NGP_DISPATCH_D8(2)
         } else {
             switch (A.D) {  // host clamps the lag to 5 for tall shards (register budget of the delay line: 32 VGPRs per lag)
-                case 5: role_streamer<5, 4>(A, s, smem); break;
+                case 5: role_streamer<DBG, 5, 4>(A, s, smem); break;
                 default: NGP_DISPATCH_D(4)
             }
         }

@@ -281,6 +281,7 @@ typedef struct {
     int64_t R, S, NBLK, Ppad; /* rows per shard, shards, blocks */
     int64_t D;                /* lag of the pipelined sweep (1 = no look-ahead) */
     int64_t near;             /* look-ahead lags 1..near corrected by the sampler, farther ones folded into the group sums */
+    int64_t nchain;           /* GEMV chains of a shard partial: 8 (phase streamer, per-block engine) or 7 (row-owning waves) */
     double *gramx;            /* [t][d][k][j], d = 1..D-1: x_{t-d,k}' x_{t,j} */
     float *tiles;             /* [s][t][j][i] */
     double *gram;             /* [t][64][64] */
@@ -317,13 +318,18 @@ int ora_create(int order, uint64_t seed, uint32_t chain, ora_t **out) {
     h->order = order; h->seed = seed; h->chain = chain;
     h->e_df = 4.0; h->e_scale = 0.0005; h->intercept = 1;
     h->chainLength = 0; h->burnIn = 0; h->thin = 1;
-    h->near = 3;
+    h->near = 3; h->nchain = 8;
     *out = h; return ORA_OK;
 }
 /* which look-ahead lags the sampler corrects itself (the library reports its choice: ngp_get_near_lags) */
 int ora_set_near(ora_t *h, int64_t near) {
     if (near < 1 || near > 8) { snprintf(h->err, 256, "near lags out of range"); return ORA_ERR; }
     h->near = near; return ORA_OK;
+}
+/* GEMV chains per shard partial (the library reports its choice: ngp_get_streamer) */
+int ora_set_nchain(ora_t *h, int64_t n) {
+    if (n != 7 && n != 8) { snprintf(h->err, 256, "GEMV chains must be 7 or 8"); return ORA_ERR; }
+    h->nchain = n; return ORA_OK;
 }
 static void free_sets(ora_t *h) {
     for (int s = 0; s < h->nsets; s++) { free(h->sets[s].reg_start); free(h->sets[s].reg_stop); }
@@ -796,13 +802,15 @@ static void iter_blocked(ora_t *h) {
             const double *ys = h->ycorr + s * R;
             for (int j = 0; j < BLK; j++) {
                 double a8[8];
-                for (int wv = 0; wv < 8; wv++) { /* chain wv: row quads wv, wv+8, ... */
+                const int64_t nch = h->nchain;
+                for (int wv = 0; wv < nch; wv++) { /* chain wv: row quads wv, wv+nch, ... */
                     double acc = 0.0;
-                    for (int64_t qd = wv; qd < R / 4; qd += 8)
+                    for (int64_t qd = wv; qd < R / 4; qd += nch)
                         for (int e = 0; e < 4; e++) { int64_t i = 4 * qd + e; acc = __builtin_fma((double)tl[j * R + i], ys[i], acc); }
                     a8[wv] = acc;
                 }
-                part[s * BLK + j] = ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]));
+                part[s * BLK + j] = (nch == 8) ? ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + (a8[6] + a8[7]))
+                                               : ((a8[0] + a8[1]) + (a8[2] + a8[3])) + ((a8[4] + a8[5]) + a8[6]);
             }
         }
         double rr[BLK], dlt[BLK]; int inc[BLK];

@@ -102,11 +102,12 @@ class Oracle:
         except Exception:
             pass
 
-    def set_panel_f32(self, X, R=0, S=0, D=1, near=3):
-        """Blocked order: the layout the library reports (ngp_get_layout, ngp_get_config, ngp_get_near_lags)."""
+    def set_panel_f32(self, X, R=0, S=0, D=1, near=3, nchain=8):
+        """Blocked order: the layout the library reports (ngp_get_layout, ngp_get_config, ngp_get_near_lags, ngp_get_streamer)."""
         X = np.asfortranarray(X, dtype=np.float32)
         self.N, self.P = X.shape
         self._chk(self.L.ora_set_near(self.h, C.c_int64(near)))
+        self._chk(self.L.ora_set_nchain(self.h, C.c_int64(nchain)))
         self._chk(self.L.ora_set_panel_f32(self.h, _p(X, C.c_float), C.c_int64(self.N), C.c_int64(self.P), C.c_int64(R),
                                            C.c_int64(S), C.c_int64(D)))
 

@@ -39,14 +39,16 @@ def test_draws_bit_exact(dev, O, what, p1, p2):
 
 
 # (mode, lag[, near lags]): per-block launches / persistent sweep; near = 4 is what tall shards (R > 128) run with
-ENGINES = [(0, 1), (1, 1), (1, 2), (1, 3), (1, 4), (1, 6), (1, 8), (1, 5, 4), (1, 8, 4)]
+# (mode, lag[, near lags[, streamer variant]]): per-block launches / persistent sweep; near = 4 is what tall shards (R > 128) run
+# with; streamer 2 = row-owning waves + loader wave (7 GEMV chains; the default for shards of 132..224 rows, forced here)
+ENGINES = [(0, 1), (1, 1), (1, 2), (1, 3), (1, 4), (1, 6), (1, 8), (1, 5, 4), (1, 8, 4), (1, 3, 3, 2), (1, 4, 3, 2), (1, 5, 4, 2), (1, 6, 4, 2)]
 ENGINE_IDS = ["blocklaunch", "persist_lag1", "persist_lag2", "persist_lag3", "persist_lag4", "persist_lag6", "persist_lag8",
-              "persist_lag5_near4", "persist_lag8_near4"]
+              "persist_lag5_near4", "persist_lag8_near4", "rows_lag3", "rows_lag4", "rows_lag5_near4", "rows_lag6_near4"]
 
 
 def _pair(ngp, O, X, seed=1001, chain=0, engine=(1, 6)):
-    """engine = (mode, lag) or (mode, lag, near lags)."""
-    s = ngp.Sampler(device=0, seed=seed, chain=chain, mode=engine[0], lag=engine[1])
+    """engine = (mode, lag), (mode, lag, near lags) or (mode, lag, near lags, streamer variant)."""
+    s = ngp.Sampler(device=0, seed=seed, chain=chain, mode=engine[0], lag=engine[1], streamer=engine[3] if len(engine) > 3 else 1)
     if len(engine) > 2:
         s.set_near(engine[2])
     s.set_panel(X)
@@ -54,8 +56,10 @@ def _pair(ngp, O, X, seed=1001, chain=0, engine=(1, 6)):
     mode, D = s.config()
     assert mode == engine[0] and D == (engine[1] if mode == 1 else 1)
     assert s.near() == (engine[2] if len(engine) > 2 else 3)   # short shards: 3 unless asked otherwise
+    variant, nchain = s.streamer()
+    assert (variant, nchain) == ((2, 7) if len(engine) > 3 and engine[3] == 2 else ((1, 8) if mode == 1 else (0, 8)))
     o = O.Oracle(order=1, seed=seed, chain=chain)
-    o.set_panel_f32(X, R=R, S=S, D=D, near=s.near())
+    o.set_panel_f32(X, R=R, S=S, D=D, near=s.near(), nchain=nchain)
     return s, o
 
 
@@ -229,7 +233,8 @@ def test_u8_panel_equals_f64_panel(ngp, O):
     assert np.allclose(s.mpm(), (G.astype(np.float64) ** 2).sum(axis=0))
 
 
-@pytest.mark.parametrize("N", [14700, 16000, 30400, 31700, 62000, 63232], ids=["R60", "R68", "R124", "R132", "R252", "R256"])
+@pytest.mark.parametrize("N", [14700, 16000, 30400, 31700, 54000, 55000, 62000, 63232],
+                         ids=["R60", "R68", "R124", "R132", "R220", "R228", "R252", "R256"])
 def test_shard_height_boundaries_bit_exact(ngp, O, N):
     """Rows per shard at the boundaries of the update-task mappings (1, 2, 4 rows per thread), of the lag / near-lag
     rules for tall shards and of the LDS budget: bit-exact against the blocked oracle with the layout the library reports."""
@@ -241,10 +246,12 @@ def test_shard_height_boundaries_bit_exact(ngp, O, N):
     s.set_panel(X)
     R, S, nblk = s.layout()
     mode, D = s.config()
-    assert mode == 1 and R == {14700: 60, 16000: 68, 30400: 124, 31700: 132, 62000: 252, 63232: 256}[N]
+    assert mode == 1 and R == {14700: 60, 16000: 68, 30400: 124, 31700: 132, 54000: 220, 55000: 228, 62000: 252, 63232: 256}[N]
     assert (D, s.near()) == ((8, 3) if R <= 128 else (5, 4))
+    variant, nchain = s.streamer()
+    assert (variant, nchain) == ((2, 7) if 128 < R <= 224 else (1, 8))   # row-owning waves where the phase streamer is barrier-bound
     o = O.Oracle(order=1, seed=21, chain=0)
-    o.set_panel_f32(X, R=R, S=S, D=D, near=s.near())
+    o.set_panel_f32(X, R=R, S=S, D=D, near=s.near(), nchain=nchain)
     v = 0.01
     for m in (s, o):
         add_sets(m, [(0, 300, "PR"), (300, P - 300, "B")], v)

@@ -7,7 +7,18 @@ ngp = load_pkg()
 N, P, lag = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
 iters = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 mode = int(sys.argv[5]) if len(sys.argv) > 5 else 1
-s = ngp.Sampler(device=0, seed=1001, chain=0, mode=mode, lag=lag)
+streamer = int(sys.argv[6]) if len(sys.argv) > 6 else None
+dbgmode = int(os.environ.get("NGP_TOOL_DEBUG_MODE", "0"))  # tools only: the library itself never reads the environment
+s = ngp.Sampler(device=0, seed=1001, chain=0, mode=mode, lag=lag, streamer=streamer)
+if dbgmode: s.debug_set_mode(dbgmode)
+if "NGP_TOOL_KNOB" in os.environ: s.debug_set_knob(int(os.environ["NGP_TOOL_KNOB"]))
+if "NGP_TOOL_NEAR" in os.environ: s.set_near(int(os.environ["NGP_TOOL_NEAR"]))
+_run = s.run
+def run_tolerant(n):
+    try: _run(n)
+    except ngp.NextGPHipError as e:
+        if "diagnostic" not in str(e): raise
+s.run = run_tolerant
 t = time.perf_counter(); s.generate_panel(N, P); setup = time.perf_counter() - t
 rng = np.random.default_rng(1); bt = np.zeros(P); idx = rng.choice(P, max(10, P // 100), replace=False); bt[idx] = rng.normal(size=len(idx))
 g = s.xbeta(bt); y = 10 + g + np.random.default_rng(2).normal(size=N) * np.sqrt(g.var())
@@ -17,6 +28,6 @@ s.run(2)
 t = time.perf_counter(); s.run(iters); dt = (time.perf_counter() - t) / iters
 R, S, nb = s.layout()
 gbs = 4.0 * N * P / dt / 1e9
-print(f"N={N} P={P} mode={mode} lag={lag} layout R={R} S={S} nblk={nb}: {dt*1e3:.3f} ms/iter, {dt/nb*1e6:.2f} us/block, {gbs:.0f} GB/s = {gbs/80:.1f}% of 8 TB/s, setup {setup:.2f}s")
+print(f"N={N} P={P} mode={mode} lag={s.config()[1]} streamer={s.streamer()} dbg={dbgmode} layout R={R} S={S} nblk={nb}: {dt*1e3:.3f} ms/iter, {dt/nb*1e6:.2f} us/block, {gbs:.0f} GB/s = {gbs/80:.1f}% of 8 TB/s, setup {setup:.2f}s")
 st = s.get_state(); resid = y - st["b"] - s.xbeta(st["beta"])
 print("   invariant |ycorr - (y - b - X beta)| max:", np.abs(st["ycorr"] - resid).max(), " varE", st["varE"])

@@ -6,7 +6,9 @@ ngp = load_pkg()
 lag = int(sys.argv[1]) if len(sys.argv)>1 else 6
 N = int(sys.argv[2]) if len(sys.argv)>2 else 10000
 P = int(sys.argv[3]) if len(sys.argv)>3 else 100000
-s = ngp.Sampler(device=0, seed=1001, chain=0, mode=1, lag=lag)
+s = ngp.Sampler(device=0, seed=1001, chain=0, mode=1, lag=lag, streamer=int(sys.argv[4]) if len(sys.argv) > 4 else None)
+if "NGP_TOOL_KNOB" in os.environ: s.debug_set_knob(int(os.environ["NGP_TOOL_KNOB"]))
+if "NGP_TOOL_NEAR" in os.environ: s.set_near(int(os.environ["NGP_TOOL_NEAR"]))
 s.generate_panel(N,P)
 rng=np.random.default_rng(1); bt=np.zeros(P); idx=rng.choice(P,P//100,replace=False); bt[idx]=rng.normal(size=P//100)
 g=s.xbeta(bt); y=10+g+np.random.default_rng(2).normal(size=N)*np.sqrt(g.var())
