@@ -1,14 +1,17 @@
 #!/usr/bin/env python3
-"""bench.py -- Gibbs iterations/s of the marker-effect sampler on a synthetic N x P SNP panel.
+"""bench.py -- Gibbs iterations/s (and effective samples/s) of the marker-effect sampler on a synthetic N x P SNP panel.
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W [--config C4|C2|C3]
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
 
-A "step" is one full Gibbs iteration (varE draw, intercept draw, sweep of all P SNPs with residual
-update, variance draws, posterior accumulation) of BASELINE.json configs[1]: BayesPR, single trait,
-10,000 individuals x 100,000 SNPs, fp32 panel resident in HBM.  With N > 1 every rank runs its own
-independent chain on its own GPU (seeds 1001+rank, weak scaling, no data-path collective); the
-posterior sums are all-reduced once over RCCL after the timed region.  Rank 0 prints ONE JSON line.
+A "step" is one full Gibbs iteration (varE draw, intercept draw, sweep of all P SNPs with residual update, variance
+draws, posterior accumulation).  Default workload = the configuration BASELINE.json's north-star target is stated on and
+the largest that fits one GPU: configs[3], N = 50,000 individuals x P = 600,000 SNPs as three BayesPR marker sets of
+200,000 columns (the reachable multi-breed random regression, SURVEY.md section 8 d), fp32 panel resident in HBM (120 GB,
+generated on the device).  --config C2 / C3 select configs[1] / configs[2] (10k x 100k BayesPR / BayesB).
+
+With N > 1 every rank runs its own independent chain on its own GPU (seeds 1001+rank, weak scaling, no data-path
+collective); the posterior sums are all-reduced once over RCCL after the timed region.  Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -16,113 +19,177 @@ import os
 import sys
 import time
 
-import numpy as np
+# before anything can initialise HIP / HSA (the host driver only supports dmabuf IPC; RCCL needs this for N > 1)
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+os.environ.setdefault("OMP_WAIT_POLICY", "ACTIVE")  # CPU baseline: threads spin at the per-SNP barrier instead of sleeping
+
+import numpy as np  # noqa: E402
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0  # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 
+CONFIGS = {
+    # name: (N, P, [(method, ncol), ...], BASELINE.json entry)
+    "C4": (50000, 600000, [("BayesPR", 200000)] * 3, "configs[3]: multi-breed random regression = three BayesPR marker sets of 200,000 SNPs"),
+    "C2": (10000, 100000, [("BayesPR", 100000)], "configs[1]: BayesPR single-trait"),
+    "C3": (10000, 100000, [("BayesB", 100000)], "configs[2]: BayesB (variable-selection indicators)"),
+}
+N_TRACE_LOCI = 128  # ESS of varE, of each varBeta / pi, and the minimum over a fixed set of 128 effects
 
-def build_chain(ngp, device, seed, N, P, method, panel_seed=20250509):
-    s = ngp.Sampler(device=device, seed=seed, chain=seed - 1001)
-    t0 = time.time()
-    s.generate_panel(N, P, 0.05, 0.5, panel_seed)
-    setup_s = time.time() - t0
-    # phenotype: y = 10 + X beta + e, 1 % causal SNPs ~ N(0,1), h2 = 0.5
+
+def split_sets(P, sets):
+    """Scale the set sizes of a named configuration to an overridden P (sizes keep their proportions, last set takes the rest)."""
+    tot = sum(n for _, n in sets)
+    out, c0 = [], 0
+    for i, (m, n) in enumerate(sets):
+        ncol = P - c0 if i == len(sets) - 1 else max(1, int(round(n * P / tot)))
+        out.append((m, c0, ncol))
+        c0 += ncol
+    return out
+
+
+def simulate_y(xbeta, N, P):
+    """y = 10 + X beta + e, 1 % causal SNPs ~ N(0,1), h2 = 0.5."""
     rng = np.random.default_rng(1)
     bt = np.zeros(P)
     idx = rng.choice(P, max(10, P // 100), replace=False)
     bt[idx] = rng.normal(size=len(idx))
-    g = s.xbeta(bt)
+    g = xbeta(bt)
     e = np.random.default_rng(2).normal(size=N) * np.sqrt(g.var())
-    y = 10.0 + g + e
-    sum2pq = s.mpm().sum() / N
-    v = 0.5 * y.var() / sum2pq
+    return 10.0 + g + e
+
+
+def build_chain(ngp, device, seed, N, P, sets, panel_seed=20250509):
+    s = ngp.Sampler(device=device, seed=seed, chain=seed - 1001)
+    t0 = time.time()
+    s.generate_panel(N, P, 0.05, 0.5, panel_seed)
+    setup_s = time.time() - t0
+    y = simulate_y(s.xbeta, N, P)
+    v = 0.5 * y.var() / (s.mpm().sum() / N)
     df = 4.0
-    if method == "BayesB":
-        s.add_marker_set(0, P, 1, df, v * (df - 2) / df, [(j, j + 1) for j in range(P)], np.full(P, v), pi0=0.01, estPi=True)
-    else:
-        s.add_marker_set(0, P, 0, df, v * (df - 2) / df, [(0, P)], [v])
+    for method, col0, ncol in sets:
+        if method == "BayesB":
+            s.add_marker_set(col0, ncol, 1, df, v * (df - 2) / df, [(j, j + 1) for j in range(ncol)], np.full(ncol, v), pi0=0.01, estPi=True)
+        else:
+            s.add_marker_set(col0, ncol, 0, df, v * (df - 2) / df, [(0, ncol)], [v])
     s.set_y(y)
-    ve = 0.5 * y.var()
-    s.set_residual_prior(4.0, ve * 2.0 / 4.0)
+    s.set_residual_prior(4.0, 0.5 * y.var() * 2.0 / 4.0)
     return s, setup_s
 
 
-def cpu_baseline(N, P, sample_cols, sample_iters):
-    """Reference-order CPU oracle (fp64, daxpy + ddot + daxpy per SNP, second copy of the panel) on a bounded sample."""
+def ess_geyer(x):
+    """Effective sample size by Geyer's initial positive sequence estimator (SURVEY.md section 8 d)."""
+    x = np.asarray(x, float)
+    x = x - x.mean()
+    n = len(x)
+    if n < 4 or not np.any(x):
+        return float(n)
+    f = np.fft.rfft(x, 2 * n)
+    acf = np.fft.irfft(f * np.conj(f))[:n] / (x @ x)
+    tau, k = -1.0, 0
+    while k + 1 < n:
+        pair = acf[k] + acf[k + 1]
+        if pair <= 0:
+            break
+        tau += 2.0 * pair
+        k += 2
+    return float(min(n, n / max(tau, 1e-12)))
+
+
+def cpu_model():
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def cpu_baseline(N, P, sets, sample_cols, budget_s):
+    """Reference-order CPU oracle (fp64; add-back daxpy, ddot over the Mp copy, update daxpy per SNP: 24 N bytes of DRAM traffic,
+    src/functions.jl:128-133) on a bounded sample: N rows x sample_cols columns of the same synthetic panel, it/s scaled by
+    sample_cols / P (the per-SNP cost does not depend on P).  Two settings, both reported: one thread, and all cores of this
+    box's share with ONE parallel region per sweep (oracle/ngp_oracle.c: ora_run_pr_threaded); the faster one is `value`."""
     from oracle import oracle as O
     X, mu = O.generate_panel(N, sample_cols)
-    rng = np.random.default_rng(1)
-    bt = np.zeros(sample_cols)
-    idx = rng.choice(sample_cols, max(10, sample_cols // 100), replace=False)
-    bt[idx] = rng.normal(size=len(idx))
-    g = X.astype(np.float64) @ bt
-    y = 10.0 + g + np.random.default_rng(2).normal(size=N) * np.sqrt(g.var())
+    y = simulate_y(lambda b: X.astype(np.float64) @ b, N, sample_cols)
     v = 0.5 * y.var() / float((mu * (1 - mu / 2)).sum())
-    def timed(threads, iters, budget_s, cols=None):
-        """it/s of the reference-order oracle on the first `cols` columns, in chunks so that a slow setting stops at the budget."""
-        cols = sample_cols if cols is None else cols
-        O.set_threads(threads)
+    threaded_ok = all(m == "BayesPR" for m, _, _ in sets)
+
+    def make():
         o = O.Oracle(order=0, seed=1001, chain=0)
-        o.set_panel_f32(X[:, :cols])
-        o.add_marker_set(0, cols, 0, 4.0, v * 0.5, [(0, cols)], [v])
+        o.set_panel_f32(X)
+        for m, c0, n in split_sets(sample_cols, [(m, n) for m, _, n in sets]):
+            if m == "BayesB":
+                o.add_marker_set(c0, n, 1, 4.0, v * 0.5, [(j, j + 1) for j in range(n)], np.full(n, v), pi0=0.01, estPi=True)
+            else:
+                o.add_marker_set(c0, n, 0, 4.0, v * 0.5, [(0, n)], [v])
         o.set_y(y)
         o.set_residual_prior(4.0, 0.25 * y.var())
-        o.run(1)  # warm-up
-        t0 = time.time()
-        done = 0
-        while done < iters and time.time() - t0 < budget_s:
-            k = min(max(1, iters // 20), iters - done)
-            o.run(k)
-            done += k
-        dt = time.time() - t0
-        O.set_threads(1)
-        return done / dt * cols / sample_cols, dt, done
+        return o
 
-    # SURVEY.md section 8(d): (i) one thread, (ii) the cores of the box (threaded daxpy / ddot, as OpenBLAS would run them).
-    # A GPU box shows far more CPUs than its share (16 per GPU): the thread count is capped, and the threaded setting is
-    # first tried on a few hundred columns -- with oversubscribed cores every one of its 3 P parallel regions per iteration
-    # costs milliseconds, and it is then left out.
+    def timed(run, budget):
+        run(1)  # warm-up (page-in, thread pool)
+        t0, done = time.time(), 0
+        while time.time() - t0 < budget or done < 2:
+            run(1)
+            done += 1
+        return done / (time.time() - t0), done
+
     avail = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-    ncores = max(1, min(avail, 16))
-    cal_cols = min(sample_cols, 400)
-    cal1, _, _ = timed(1, 2, 5.0, cal_cols)
-    caln = cal1 if ncores == 1 else timed(ncores, 2, 5.0, cal_cols)[0]
-    threads = ncores if caln > 1.15 * cal1 else 1
-    its, dt, done = timed(threads, sample_iters, 30.0)
+    ncores = max(1, min(avail, 16))  # a GPU box shows far more CPUs than its share: 16 per GPU
+    o1 = make()
+    its1, n1 = timed(o1.run, budget_s / 2)
+    itsn, nn = (None, 0)
+    if threaded_ok and ncores > 1:
+        on = make()
+        itsn, nn = timed(lambda k: on.run_pr_threaded(k, ncores), budget_s / 2)
+    scale = sample_cols / P
+    best, cores = (itsn, ncores) if (itsn is not None and itsn > its1) else (its1, 1)
     return {
-        "value": its * sample_cols / P,
+        "value": best * scale,
         "unit": "it/s",
-        "cores": threads,
+        "cores": cores,
         "kind": "port",
-        "sample": f"{done} iterations of N={N} x P={sample_cols} columns of the workload ({dt:.1f} s), it/s scaled by {sample_cols}/{P} "
-                  f"(per-SNP cost is independent of P); reference-order C restatement, 24*N bytes of DRAM traffic per SNP; "
-                  f"{threads} thread(s) chosen by a trial on {cal_cols} columns: 1 thread {cal1 * sample_cols / P:.3f} it/s, "
-                  f"{ncores} threads {caln * sample_cols / P:.3f} it/s",
+        "cpu_model": cpu_model(),
+        "cpus_available": avail,
+        "one_thread_it_per_s": its1 * scale,
+        "all_cores_it_per_s": None if itsn is None else itsn * scale,
+        "all_cores_threads": ncores if itsn is not None else None,
+        "sample": f"N={N} rows x {sample_cols} columns of the workload's panel, {n1} iterations on 1 thread and {nn} on {ncores} threads "
+                  f"(about {budget_s:.0f} s in all), it/s scaled by {sample_cols}/{P}: per-SNP cost is independent of P; reference-order C "
+                  f"restatement with the reference's second copy of the panel (24*N bytes of DRAM traffic per SNP); the threaded "
+                  f"setting keeps one parallel region per sweep, one barrier per SNP",
     }
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--N", type=int, default=10000)
-    ap.add_argument("--P", type=int, default=100000)
-    ap.add_argument("--method", default="BayesPR", choices=["BayesPR", "BayesB"])
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--config", default="C4", choices=sorted(CONFIGS))
+    ap.add_argument("--N", type=int, default=None, help="override the number of individuals (parity / contract tests)")
+    ap.add_argument("--P", type=int, default=None, help="override the number of SNPs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on one GPU)")
-    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0")
-    ap.add_argument("--cpu-cols", type=int, default=16000)
-    ap.add_argument("--cpu-iters", type=int, default=100)
+    ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0 (the persistent kernels then run one after the other)")
+    ap.add_argument("--cpu-cols", type=int, default=None, help="columns of the CPU baseline sample (default: about 1.6e8 / N)")
+    ap.add_argument("--cpu-seconds", type=float, default=20.0)
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
     from ngp_pkg import load_pkg
     ngp = load_pkg()
+
+    cN, cP, csets, cdesc = CONFIGS[args.config]
+    N, P = args.N or cN, args.P or cP
+    sets = split_sets(P, csets)
+    overridden = (N, P) != (cN, cP)
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -133,7 +200,6 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     if world > 1:
-        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
         if args.backend == "nccl":
             dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
         else:
@@ -145,8 +211,11 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    s, setup_s = build_chain(ngp, local_rank, 1001 + rank, args.N, args.P, args.method)
+    s, setup_s = build_chain(ngp, local_rank, 1001 + rank, N, P, sets)
     K, W = args.steps, args.warmup
+    loci = np.unique(np.linspace(0, P - 1, N_TRACE_LOCI).astype(np.int64))
+    ntvb = min(s.nvb, 8)
+    s.set_trace_loci(loci, ntvb)
     s.set_schedule(W + K, W, 1)
     s.run(W)
     s.get_timing()
@@ -160,17 +229,25 @@ def main():
         t = torch.tensor([dt], device="cuda", dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+    # effective sample sizes over the K timed iterations (rank 0's chain), Geyer's initial positive sequence
+    tr, trx = s.get_trace(K), s.get_trace_ext(K)
+    ess = {"varE": ess_geyer(tr["varE"]),
+           "varBeta": [ess_geyer(trx["varBeta"][:, i]) for i in range(ntvb)],
+           "beta_min_of_%d" % len(loci): min(ess_geyer(trx["beta"][:, i]) for i in range(len(loci)))}
+    if any(m == "BayesB" for m, _, _ in sets):
+        ess["pi"] = [ess_geyer(trx["pi"][:, i]) for i in range(s.nsets)]
+    ess_min = min([ess["varE"], ess["beta_min_of_%d" % len(loci)]] + ess["varBeta"] + ess.get("pi", []))
     # dominant-kernel launch duration, HIP events on the library's own stream (one extra iteration)
     prof = s.profile_iteration()
     achieved = prof["bytes_per_launch"] / (prof["avg_ms"] * 1e-3) / 1e9
-    bytes_iter = 4.0 * args.N * args.P
-    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the committed
-    # rocprofv3 summary of the same workload is quoted when the configuration matches (else null)
+    bytes_iter = 4.0 * N * P
+    # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the committed rocprofv3
+    # summary of the SAME workload (tools/profile_round.sh) is quoted when the configuration matches, else null
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", "r01_pmc_k_sweep.json")
-    if os.path.exists(pmc) and (args.N, args.P, args.method) == (10000, 100000, "BayesPR") and prof["launches"] == 1:
+    pmc = os.path.join(ROOT, "profiles", f"r02_pmc_k_sweep_{args.config}.json")
+    if os.path.exists(pmc) and not overridden and prof["launches"] == 1:
         pj = json.load(open(pmc))
-        traffic, traffic_src = pj["hbm_bytes_per_launch"], "profiles/r01_pmc_k_sweep.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+        traffic, traffic_src = pj["hbm_bytes_per_launch"], f"profiles/r02_pmc_k_sweep_{args.config}.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
     # posterior means across chains: ONE all-reduce of the packed sums over RCCL / xGMI
     allreduce_ms = None
     n = s.posterior_len()
@@ -182,12 +259,15 @@ def main():
         ngp.multichain.allreduce_posterior(buf)
         torch.cuda.synchronize()
         allreduce_ms = (time.perf_counter() - ta) * 1e3
-    pooled = ngp.multichain.unpack_means(buf.cpu().numpy(), args.P, s.nvb, s.nsets)
+    pooled = ngp.multichain.unpack_means(buf.cpu().numpy(), P, s.nvb, s.nsets)
     nkept, post_mean_varE = pooled["nKept"], pooled["varE"]
+    R, S, nblk = s.layout()
+    mode, lag = s.config()
+    variant, nchain = s.streamer()
 
-    out = None
     if rank == 0:
         its = world * K / dt
+        setdesc = " + ".join(f"{m}({ncol})" for m, _, ncol in sets)
         out = {
             "metric": "gibbs_iterations_per_sec",
             "value": its,
@@ -202,11 +282,14 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"{args.method} single-trait Gibbs sweep, N={args.N} individuals x P={args.P} SNPs, fp32 panel in HBM "
-                            "(BASELINE.json configs[1])",
-                "N": args.N, "P": args.P, "method": args.method, "chains": world,
+                "workload": f"single-trait Gibbs sweep, N={N} individuals x P={P} SNPs, marker sets {setdesc}, fp32 panel in HBM "
+                            + (f"(BASELINE.json {cdesc})" if not overridden else f"(shape overridden from {args.config})"),
+                "name": args.config if not overridden else f"{args.config}-override", "N": N, "P": P,
+                "sets": [{"method": m, "col0": c0, "ncol": n} for m, c0, n in sets], "chains": world,
                 "parallelism": "independent chains, one per GPU; one RCCL all-reduce of posterior sums at the end",
                 "panel_dtype": "f32", "accumulate_dtype": "f64",
+                "layout": {"rows_per_shard": R, "shards": S, "blocks": nblk, "engine": mode, "lag": lag, "near_lags": s.near(),
+                           "streamer": variant, "gemv_chains": nchain},
             },
             "roofline": {
                 "bound": "hbm",
@@ -223,6 +306,14 @@ def main():
                 "iteration_achieved": bytes_iter * (K / dt) / 1e9,
                 "iteration_frac": bytes_iter * (K / dt) / 1e9 / HBM_PEAK_GBS,
             },
+            "effective_samples": {
+                "estimator": "Geyer initial positive sequence over the timed iterations of rank 0's chain (every iteration kept)",
+                "ess": ess,
+                "ess_min": ess_min,
+                "ess_min_per_sec": ess_min / dt,
+                "ess_varE_per_sec": ess["varE"] / dt,
+                "note": "single-chain figures; with n_gpus chains the pooled rate is n_gpus times these",
+            },
             "device_iter_ms": tm["iter_ms"] / max(tm["iters"], 1),
             "setup_s": setup_s,
             "allreduce_ms": allreduce_ms,
@@ -230,7 +321,8 @@ def main():
             "pooled_kept_samples": nkept,
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args.N, args.P, min(args.cpu_cols, args.P), args.cpu_iters)
+            cols = args.cpu_cols or int(max(256, min(P, 1.6e8 // N)))
+            out["cpu_baseline"] = cpu_baseline(N, P, sets, min(cols, P), args.cpu_seconds)
             out["speedup_vs_cpu_baseline"] = its / out["cpu_baseline"]["value"]
         print(json.dumps(out), flush=True)
     if world > 1:

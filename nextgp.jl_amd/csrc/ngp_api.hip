@@ -57,6 +57,8 @@ struct ngp_handle {
     int NG = 1;        // reducer groups = ceil(S/32)
     int cu_count = 256;
     double *d_cpart = nullptr, *d_cgsum = nullptr, *d_cdlt = nullptr;
+    unsigned long long *d_cdltg = nullptr;  // dlt as tagged granules
+    unsigned launch_seq = 0;                // launch nonce of the granule tags
     unsigned *d_ccnt = nullptr, *d_abort = nullptr;
     unsigned long long *d_dbg = nullptr;
     size_t ccnt_words = 0;
@@ -101,7 +103,7 @@ struct ngp_handle {
     int64_t sweep_launches = 0;
     // diagnostics (ngp_debug_set_mode): != 0 makes every chain invalid, ngp_run / ngp_sweep_set then return NGP_ERR_DEBUG
     int dbg_mode = 0;
-    int knob = 2;  // helper issuers of the row-owning streamer (ngp_debug_set_knob)
+    int knob = 1;  // pacing of the loader wave of the row-owning streamer: s_sleep units after every four requests (ngp_debug_set_knob)
     bool poisoned = false;  // a sweep gave up half-way (abort word): the chain state is unusable until ngp_set_y / ngp_set_state
     // optional per-iteration traces of selected effects, variances and pi (ngp_set_trace_loci)
     int64_t *d_trace_loci = nullptr;
@@ -185,11 +187,11 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
     h->nchain = (h->streamer == 2) ? NGP_ROWS_NW : 8;
     if (h->streamer == 2) {
         if (h->D > 6) h->D = 6;  // register delay line: 32 VGPRs per lag
-        if (h->R > 128 && h->lag_auto && h->D > 5) h->D = 5;
     } else if (h->mode == 1 && h->R > 128 && h->D > 5) h->D = 5;  // tall shards: the register delay line holds 5 tiles at most
-    // a fourth near lag overloads the sampler CU at short shards (+17 % time at 10k x 100k); at tall shards, where with lag 5
-    // nothing is left for the reducers then, it saves 8 %
-    h->near = h->near_req ? h->near_req : ((h->mode == 1 && h->R > 128) ? 4 : 3);
+    // a fourth near lag overloads the sampler CU at short shards (+17 % time at 10k x 100k); the phase streamer of tall shards,
+    // where with lag 5 nothing is left for the reducers then, saves 8 % with it; with the row-owning streamer (lag 6) the sampler
+    // CU is again the busier end (its Gram traffic: 32 KB per near lag and block) and three near lags measure better
+    h->near = h->near_req ? h->near_req : ((h->mode == 1 && h->R > 128 && h->streamer != 2) ? 4 : 3);
     h->NBLK = (P + NGP_BLK - 1) / NGP_BLK;
     h->Ppad = h->NBLK * NGP_BLK;
     h->L = h->R * h->S;
@@ -256,6 +258,7 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
         if ((rc = dalloc(h, &h->d_cpart, (size_t)NGP_RING * h->S * NGP_BLK))) return rc;
         if ((rc = dalloc(h, &h->d_cgsum, (size_t)NGP_RING * h->NG * NGP_BLK))) return rc;
         if ((rc = dalloc(h, &h->d_cdlt, (size_t)NGP_RING * NGP_BLK))) return rc;
+        if ((rc = dalloc(h, &h->d_cdltg, (size_t)NGP_RING * NGP_BLK * 2))) return rc;
         h->ccnt_words = (size_t)NGP_RING * h->NG * 32 + (size_t)NGP_RING * 32 + 32;
         if ((rc = dalloc(h, &h->d_ccnt, h->ccnt_words))) return rc;
         if ((rc = dalloc(h, &h->d_abort, 32))) return rc;
@@ -359,7 +362,9 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
         A.D = h->D; A.R = R; A.S = S; A.NG = h->NG; A.near = h->near; A.fine_ok = 0; A.t0 = (int)tb0; A.t1 = (int)tb1;
         A.beta = h->d_beta; A.delta = h->d_delta; A.c = h->d_c; A.w = h->d_w; A.q = h->d_q; A.mpm = h->d_mpm; A.chi = h->d_chi;
         A.setof = h->d_setof; A.vbidx = h->d_vbidx; A.sets = h->d_sets; A.varBeta = h->d_varBeta;
-        A.part = h->d_cpart; A.gsum = h->d_cgsum; A.dlt = h->d_cdlt;
+        A.part = h->d_cpart; A.gsum = h->d_cgsum; A.dlt = h->d_cdlt; A.dltg = h->d_cdltg;
+        h->launch_seq = (h->launch_seq % 4095u) + 1u;  // 1..4095: never the zero the ring is born with
+        A.nonce = h->launch_seq;
         A.cnt_part = h->d_ccnt; A.cnt_gs = h->d_ccnt + (size_t)NGP_RING * h->NG * 32;
         A.flag_dlt = A.cnt_gs + (size_t)NGP_RING * 32; A.abort_w = h->d_abort; A.xcc_w = h->d_abort + 16;
         if (evs) (void)hipEventRecord(evs[0], h->stream);
@@ -484,7 +489,7 @@ int32_t ngp_destroy(ngp_handle *h) {
     if (!h) return NGP_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    dfree(h->d_tiles); dfree(h->d_gramx); dfree(h->d_cpart); dfree(h->d_cgsum); dfree(h->d_cdlt); dfree(h->d_ccnt); dfree(h->d_abort); dfree(h->d_dbg); dfree(h->d_mpm); dfree(h->d_lhs0); dfree(h->d_rhs0); dfree(h->d_beta);
+    dfree(h->d_tiles); dfree(h->d_gramx); dfree(h->d_cpart); dfree(h->d_cgsum); dfree(h->d_cdlt); dfree(h->d_cdltg); dfree(h->d_ccnt); dfree(h->d_abort); dfree(h->d_dbg); dfree(h->d_mpm); dfree(h->d_lhs0); dfree(h->d_rhs0); dfree(h->d_beta);
     dfree(h->d_c); dfree(h->d_w); dfree(h->d_q); dfree(h->d_T); dfree(h->d_chi); dfree(h->d_setof); dfree(h->d_loc);
     dfree(h->d_vbidx); dfree(h->d_delta); dfree(h->d_sum_beta); dfree(h->d_sum_beta2); dfree(h->d_sum_delta);
     dfree(h->d_ycorr); dfree(h->d_part); dfree(h->d_dlt); dfree(h->d_sets); dfree(h->d_scal); dfree(h->d_varBeta);

@@ -66,6 +66,8 @@ struct SweepArgs {
     double *part;        // [RING][S][64]
     double *gsum;        // [RING][NG][64]
     double *dlt;         // [RING][64]
+    unsigned long long *dltg;  // [RING][64][2] the same values as self-validating 8-byte granules {32 data bits, 32-bit tag}
+    unsigned nonce;      // 12-bit launch number inside every tag (the granule ring is not cleared between launches)
     unsigned *cnt_part;  // [RING][NG] counters, one 128-B line each
     unsigned *cnt_gs;    // [RING] counters, one 128-B line each
     unsigned *flag_dlt;  // number of blocks the sampler has finished
@@ -77,12 +79,25 @@ struct SweepArgs {
                               // 5 = whole pipeline, BayesPR blocks without the recursion, 6 = whole pipeline, reducers never wait for dlt
 };
 
-// The diagnostic build of the kernel (k_sweep<true>: time stamps, timing modes) is a separate instantiation; in the production
-// kernel (k_sweep<false>) every stamp and every mode test folds away at compile time.
-#define NGP_DBG_LOCALS                                                   \
+// Diagnostics (time stamps, timing modes) are run-time state of the launch (SweepArgs.dbg / dbg_mode, set per handle through
+// ngp_debug_* -- never from the environment): predicted-not-taken scalar branches in the production launch.  Compiling them
+// out (a k_sweep<false> instantiation with both folded to constants) was built and A/B-timed on one box: the phase streamer
+// became 20 % SLOWER (10k x 100k: 1.82 -> 2.24 us per block), reducers 3 %, sampler 4 % -- without the branches the compiler
+// places the waits of the look-ahead loads differently.  So the template parameter only selects folding for the row-owning
+// streamer, where it was measured to be neutral.
+#define NGP_DBG_FOLD                                                     \
     unsigned long long *const dbg = DBG ? A.dbg : nullptr;               \
     const int dbg_mode = DBG ? A.dbg_mode : 0;                           \
     (void)dbg; (void)dbg_mode;
+#define NGP_DBG_LOCALS                                                   \
+    unsigned long long *const dbg = A.dbg;                               \
+    const int dbg_mode = A.dbg_mode;                                     \
+    (void)dbg; (void)dbg_mode;
+#ifdef NGP_AB_ROWS_RUNTIME_DBG
+#define NGP_DBG_ROWS NGP_DBG_LOCALS
+#else
+#define NGP_DBG_ROWS NGP_DBG_FOLD
+#endif
 
 __device__ inline unsigned ld_u32(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline void st_u32(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -92,6 +107,45 @@ __device__ inline double ld_f64(const double *p) {
 }
 __device__ inline void st_f64(double *p, double v) {
     __hip_atomic_store((unsigned long long *)p, (unsigned long long)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ inline unsigned long long ld_u64(const unsigned long long *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void st_u64(unsigned long long *p, unsigned long long v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// dlt of a finished block as tagged granules (cdna_hip_programming.md Guideline 16, form R2): lane j owns two naturally aligned
+// 8-byte words {low half of dlt_j | tag << 32} and {high half | tag << 32}, each written by ONE 8-byte agent-scope store.  A
+// reader that finds the expected tag in a word has that word's data (single-copy atomicity of an aligned 8-byte access): no
+// flag, no store acknowledgement, no second load that depends on a first.  tag = launch nonce << 20 | (local block + 1).
+__device__ inline unsigned dlt_tag(const unsigned nonce, const int a) { return (nonce << 20) | (unsigned)(a + 1); }
+__device__ inline void publish_dlt_granules(unsigned long long *dltg, const unsigned nonce, const int a, const int j, const double v) {
+    const unsigned long long t = (unsigned long long)dlt_tag(nonce, a) << 32;
+    unsigned long long *g = dltg + ((size_t)(a % NGP_RING) * NGP_BLK + j) * 2;
+    st_u64(g, t | (unsigned)__double2loint(v));
+    st_u64(g + 1, t | (unsigned)__double2hiint(v));
+}
+__device__ inline bool dlt_granules_valid(const unsigned long long g0, const unsigned long long g1, const unsigned tag) {
+    return __ballot(((unsigned)(g0 >> 32) == tag) && ((unsigned)(g1 >> 32) == tag)) == ~0ull;
+}
+__device__ inline double dlt_granules_value(const unsigned long long g0, const unsigned long long g1) {
+    return __hiloint2double((int)(unsigned)g1, (int)(unsigned)g0);
+}
+// whole wave: spin (bounded) until the 64 x 2 granules of local block a carry its tag; false = give up.  Every lane re-reads
+// its own two granules: one round trip from "published" to "in registers".  (Used by the reducers and by the row-owning
+// streamers, which ask a block early and so rarely come here; the phase streamers, 228-246 of them polling from inside a
+// phase, keep the one-word flag: built with granules they ran 1.90 -> 3.43 us per block at 10k x 100k.)
+__device__ inline bool wait_dlt_granules_all(const unsigned long long *dltg, const unsigned nonce, const int a, const int j, unsigned *abort_w,
+                                             const unsigned code, unsigned long long &g0, unsigned long long &g1) {
+    const unsigned tag = dlt_tag(nonce, a);
+    const unsigned long long *g = dltg + ((size_t)(a % NGP_RING) * NGP_BLK + j) * 2;
+    for (unsigned spins = 0;; ++spins) {
+        if (dlt_granules_valid(g0, g1, tag)) return true;
+        if ((spins & 7u) == 7u && ld_u32(abort_w) != 0u) return false;
+        if (spins > (NGP_SPIN_LIMIT >> 3)) {  // every turn is a memory round trip
+            st_u32(abort_w, code);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
+        g0 = ld_u64(g);
+        g1 = ld_u64(g + 1);
+    }
 }
 // XCC (XCD) id of the executing wave: HW_REG_XCC_ID (id 20), bits 3:0
 __device__ inline unsigned xcc_id() { return (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xFu; }
@@ -122,6 +176,25 @@ __device__ inline void dma16_s(unsigned lds_addr_uniform, const void *gbase_unif
                  : "=&s"(keep_m0)
                  : "s"(lds_addr_uniform), "v"(voff), "s"(gbase_uniform)
                  : "memory");
+}
+
+// Four requests for four consecutive quads of global memory into four consecutive ring slots: ONE 64-bit scalar base, the
+// instruction's immediate offset walks the source (0, 1024, 2048, 3072).  The immediate is added to the LDS address too, so M0
+// carries slot address minus offset: M0 advances by NGP_QS - 1024 per request.  About six scalar instructions per request
+// instead of seventeen: the loader is then bound by memory, not by its own instruction stream (51 requests took 2.2 us).
+__device__ inline void dma16_s4(unsigned lds_addr_uniform, const void *gbase_uniform, unsigned voff) {
+    unsigned keep_m0;
+    const unsigned m1 = lds_addr_uniform + (NGP_QS - 1024), m2 = lds_addr_uniform + 2 * (NGP_QS - 1024), m3 = lds_addr_uniform + 3 * (NGP_QS - 1024);
+    asm volatile(
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %6\n\t"
+        "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %6 offset:1024\n\t"
+        "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %6 offset:2048\n\t"
+        "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %6 offset:3072\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep_m0)
+        : "s"(lds_addr_uniform), "s"(m1), "s"(m2), "s"(m3), "v"(voff), "s"(gbase_uniform)
+        : "memory");
 }
 
 // ONE lane polls ONE word; bounded; false = give up (abort word set by us or by somebody else)
@@ -415,7 +488,6 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
                         }
                         ok = __shfl(ok, 0);
                     }
-                    if (dbg && s == 0 && j == 0) dbg[NGP_DBG_STREAM + 2 * (size_t)(u + 1) + 1] = wall_clock64();
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     if (ok) {
                         dnext = ld_f64(&A.dlt[(size_t)(pa % NGP_RING) * NGP_BLK + j]);
@@ -494,7 +566,7 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
 // tree).  The blocked oracle takes the chain count as a layout parameter (ngp_get_streamer).
 #define NGP_ROWS_MAX_R 224
 #define NGP_ROWS_NW 7       // row-owning waves
-#define NGP_ROWS_HMAX 24    // quads of tile u+2 requested during block u (the counted wait keeps them in flight)
+#define NGP_ROWS_HMAX 32    // quads of tile u+2 requested during block u (the counted wait keeps them in flight)
 #define NGP_ROWS_PUBW 2
 #define NGP_ROWS_POLLW 6
 
@@ -519,7 +591,7 @@ __device__ inline void wait_vmcnt_le(int n) {
     switch (n) {
         NGP_VMC(1) NGP_VMC(2) NGP_VMC(3) NGP_VMC(4) NGP_VMC(5) NGP_VMC(6) NGP_VMC(7) NGP_VMC(8) NGP_VMC(9) NGP_VMC(10) NGP_VMC(11)
         NGP_VMC(12) NGP_VMC(13) NGP_VMC(14) NGP_VMC(15) NGP_VMC(16) NGP_VMC(17) NGP_VMC(18) NGP_VMC(19) NGP_VMC(20) NGP_VMC(21)
-        NGP_VMC(22) NGP_VMC(23) NGP_VMC(24)
+        NGP_VMC(22) NGP_VMC(23) NGP_VMC(24) NGP_VMC(25) NGP_VMC(26) NGP_VMC(27) NGP_VMC(28) NGP_VMC(29) NGP_VMC(30) NGP_VMC(31) NGP_VMC(32) NGP_VMC(36) NGP_VMC(40) NGP_VMC(44) NGP_VMC(48) NGP_VMC(56)
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
 #undef NGP_VMC
@@ -527,7 +599,7 @@ __device__ inline void wait_vmcnt_le(int n) {
 
 template <bool DBG, int DT>
 __device__ inline void role_streamer_rows(const SweepArgs &A, const int s, char *smem) {
-    NGP_DBG_LOCALS
+    NGP_DBG_ROWS
     const int R = A.R, S = A.S, tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int NQ = R >> 2;                                   // quads per tile
@@ -559,12 +631,38 @@ __device__ inline void role_streamer_rows(const SweepArgs &A, const int s, char 
         const unsigned scratch0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)scratch;
         const unsigned voff = (unsigned)lane * 16u;
         const bool no_dma = DBG && dbg_mode == 4;  // timing experiment: the arithmetic without the stream
+        // Pacing: a short sleep after every four requests spreads them over the block.  Requested back to back (1.4 us per tile)
+        // they stream faster in isolation (2.14 against 2.47 us per block) but every other memory access of this CU -- the partial
+        // sums going out, dlt coming in -- then queues behind a full tile of requests, and the sweep is bound by that hand-off
+        // loop, not by the stream.  Capping the outstanding requests with counted vmcnt waits instead was far worse (4.9 us).
+        const int pace = A.knob;
         // quads [q0, q1) of local tile `tile` into ring slots tbase + q (everything wave-uniform: scalar registers only)
         auto dma_quads = [&](int tile, int q0, int q1, int tbase) {
             if (no_dma || q0 >= q1) return 0;
             const char *g = (const char *)(A.tiles + ((size_t)(A.t0 + tile) * S + s) * tile_elems) + (size_t)q0 * 1024;
             int p = wrap(tbase + q0);
-            for (int q = q0; q < q1; ++q) {
+            int q = q0;
+            for (; q + 4 <= q1; q += 4) {
+                if (p + 4 <= RQ) {
+                    dma16_s4(ring0 + (unsigned)p * NGP_QS, g, voff);
+                    p += 4;
+                    if (p == RQ) p = 0;
+                    switch (pace) {  // s_sleep takes an immediate (units of 64 clocks)
+                        case 1: __builtin_amdgcn_s_sleep(1); break;
+                        case 2: __builtin_amdgcn_s_sleep(2); break;
+                        case 3: __builtin_amdgcn_s_sleep(3); break;
+                        case 4: __builtin_amdgcn_s_sleep(4); break;
+                        default: break;
+                    }
+                } else {
+                    for (int k = 0; k < 4; k++) {
+                        dma16_s(ring0 + (unsigned)p * NGP_QS, g + k * 1024, voff);
+                        if (++p == RQ) p = 0;
+                    }
+                }
+                g += 4096;
+            }
+            for (; q < q1; ++q) {
                 dma16_s(ring0 + (unsigned)p * NGP_QS, g, voff);
                 g += 1024;
                 if (++p == RQ) p = 0;
@@ -574,7 +672,8 @@ __device__ inline void role_streamer_rows(const SweepArgs &A, const int s, char 
         const unsigned my_xcc = xcc_id() + 1u;
         const int nslice = max(1, S / 8);
         const int slice = (s / 8) % nslice;
-        const size_t gram_bytes = (size_t)DT * NGP_BLK * NGP_BLK * sizeof(double);
+        // (only the planes the sampler itself reads: the diagonal block and the near lags; the far ones go to the reducers' CUs)
+        const size_t gram_bytes = (size_t)min(DT, A.near + 1) * NGP_BLK * NGP_BLK * sizeof(double);
         const size_t slice_bytes = ((gram_bytes / nslice + 1023) / 1024) * 1024;
         bool same_xcd = false, xcc_known = false;
         __builtin_amdgcn_s_setprio(3);  // the loader's few scalar instructions go first on its SIMD: a late request costs the whole CU
@@ -623,7 +722,7 @@ __device__ inline void role_streamer_rows(const SweepArgs &A, const int s, char 
         for (int d = 0; d < DT; d++)
 #pragma unroll
             for (int jj = 0; jj < 8; jj++) keep[d][jj] = make_float4(0.f, 0.f, 0.f, 0.f);
-        unsigned fl_pre = 0;  // poller: number of finished blocks as read just before the previous barrier
+        unsigned long long pg0 = 0, pg1 = 0;  // poller: granules of the next dlt as read just before the previous barrier
         // publisher: the stored, not yet counted partial (ring slot), counted once VM_CNT of this wave reads zero
         int sig_pending = -1;
         auto try_signal = [&](bool force) {
@@ -644,19 +743,16 @@ __device__ inline void role_streamer_rows(const SweepArgs &A, const int s, char 
                 // poller: dlt of the block applied in the NEXT iteration; the flag travels while this wave works
                 const int pa = u + 1 - DT;
                 const bool pollw = (wv == NGP_ROWS_POLLW) && (pa >= 0) && (u + 1 < nb + DT) && !(DBG && dbg_mode == 1);
-                // (every load of a streaming CU queues behind a microsecond of tile requests, so the two dependent loads -- flag,
-                // then the 64 values -- are taken off the end of the block: the flag was requested before the previous barrier,
-                // and if it already shows the block finished the values travel while this wave does its arithmetic)
-                unsigned fl = 0;
-                double dnext = 0.0;
+                // (every load of a streaming CU queues behind a microsecond of tile requests: dlt comes as self-validating granules,
+                // ONE load, requested before the previous barrier; only if that was too early is it requested again here)
                 bool have_dnext = false;
                 if (pollw) {
-                    if ((int)__shfl((int)fl_pre, 0) >= pa + 1) {
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        dnext = ld_f64(&A.dlt[(size_t)(pa % NGP_RING) * NGP_BLK + lane]);
+                    if (dlt_granules_valid(pg0, pg1, dlt_tag(A.nonce, pa))) {
                         have_dnext = true;
-                    } else {
-                        fl = ld_u32(A.flag_dlt);
+                    } else {  // asked for too early: ask again, the answer travels while this wave does its arithmetic
+                        const unsigned long long *gp = A.dltg + ((size_t)(pa % NGP_RING) * NGP_BLK + lane) * 2;
+                        pg0 = ld_u64(gp);
+                        pg1 = ld_u64(gp + 1);
                     }
                 }
                 // ---- ycorr -= X_a dlt_a for the rows of this wave ----
@@ -710,20 +806,18 @@ __device__ inline void role_streamer_rows(const SweepArgs &A, const int s, char 
                 NGP_FINE(3);
                 if (pollw) {
                     int ok = 1;
-                    if (!have_dnext) {
-                        if (__shfl((int)fl, 0) < pa + 1 && !(DBG && (dbg_mode == 3 || dbg_mode == 4))) {
-                            if (lane == 0) {
-                                ok = wait_ge(A.flag_dlt, (unsigned)(pa + 1), A.abort_w, 1u) ? 1 : 0;
-                                if (!ok) *sflag = 0;
-                            }
-                            ok = __shfl(ok, 0);
-                        }
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        if (ok) dnext = ld_f64(&A.dlt[(size_t)(pa % NGP_RING) * NGP_BLK + lane]);
+                    if (!have_dnext && !(DBG && (dbg_mode == 3 || dbg_mode == 4))) {
+                        ok = wait_dlt_granules_all(A.dltg, A.nonce, pa, lane, A.abort_w, 1u, pg0, pg1) ? 1 : 0;
+                        if (!ok && lane == 0) *sflag = 0;
                     }
-                    if (ok) dl[((u + 1) & 1) * NGP_BLK + lane] = dnext;
+                    if (ok) dl[((u + 1) & 1) * NGP_BLK + lane] = dlt_granules_value(pg0, pg1);
                 }
-                if (wv == NGP_ROWS_POLLW && !(DBG && dbg_mode == 1)) fl_pre = ld_u32(A.flag_dlt);  // looked at after the barrier
+                if (wv == NGP_ROWS_POLLW && pa + 1 >= 0 && u + 2 < nb + DT && !(DBG && dbg_mode == 1)) {
+                    // dlt of the block after that: looked at behind the barrier (if the sampler is that far, the next block pays nothing)
+                    const unsigned long long *gp = A.dltg + ((size_t)((pa + 1) % NGP_RING) * NGP_BLK + lane) * 2;
+                    pg0 = ld_u64(gp);
+                    pg1 = ld_u64(gp + 1);
+                }
                 NGP_FINE(4);
                 // Lag 3: dlt of block u-2, which the poller of this workgroup waits for before this barrier, needs the partial of
                 // block u-1 of EVERY streamer counted (the sampler fetches the group sums of the next block before it lets a
@@ -787,12 +881,14 @@ __device__ inline void role_reducer(const SweepArgs &A, const int g) {
             if (a < 0) continue;
             double gr[NGP_BLK];
             load_rows_pair(A.gramx + ((size_t)(A.t0 + u) * A.D + d) * (NGP_BLK * NGP_BLK), lane, gr);
-            int okd = 1;
-            if (lane == 0) okd = (dbg_mode == 3 || dbg_mode == 4 || dbg_mode == 6 || wait_ge(A.flag_dlt, (unsigned)(a + 1), A.abort_w, 4u)) ? 1 : 0;
-            okd = __shfl(okd, 0);
-            if (!okd) return;
-            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-            const double dreg = ld_f64(&A.dlt[(size_t)(a % NGP_RING) * NGP_BLK + lane]);  // lane k holds dlt_k
+            unsigned long long q0, q1;
+            {
+                const unsigned long long *gp = A.dltg + ((size_t)(a % NGP_RING) * NGP_BLK + lane) * 2;
+                q0 = ld_u64(gp);
+                q1 = ld_u64(gp + 1);
+            }
+            if (!(dbg_mode == 3 || dbg_mode == 4 || dbg_mode == 6) && !wait_dlt_granules_all(A.dltg, A.nonce, a, lane, A.abort_w, 4u, q0, q1)) return;
+            const double dreg = dlt_granules_value(q0, q1);  // lane k holds dlt_k
             double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
             for (int kk = 0; kk < NGP_BLK; kk += 4) {
@@ -850,24 +946,25 @@ __device__ inline bool fetch_group_sums(const SweepArgs &A, int u, int j, double
     return true;
 }
 
-// results of a finished block: dlt first (sc1 + drain + flag: the streamers are waiting), then beta / delta / varBeta
+// results of a finished block: beta / delta / varBeta (dlt itself left as granules when the chain ended, see role_sampler)
 template <bool DBG>
 __device__ inline void publish_block(const SweepArgs &A, int up, int j, const double *hist, const double *outb, const int *outi,
                                      const int *smeth, const double *ssdf) {
     NGP_DBG_LOCALS
-    const int pslot = up % NGP_RING, pbuf = up & 1;
+    const int pbuf = up & 1;
+    (void)hist;
     const long long k = (long long)(A.t0 + up) * NGP_BLK + j;
     // what the variance bookkeeping of BayesB needs is requested first, so that it travels while the store is acknowledged
     // (three dependent round trips here made the publisher the slowest wave of BayesB sweeps)
     const int si = A.setof[k];
     const double chik = A.chi[k];
     const int vbi = A.vbidx[k];
-    st_f64(&A.dlt[(size_t)pslot * NGP_BLK + j], hist[pslot * NGP_BLK + j]);
+    // plain copy + flag for the phase streamers (they poll ONE word and then read 512 bytes; polling the granules from their
+    // phase C was built and measured: 10k x 100k 1.90 -> 3.43 us per block)
+    st_f64(&A.dlt[(size_t)(up % NGP_RING) * NGP_BLK + j], hist[(up % NGP_RING) * NGP_BLK + j]);
     drain_vm();
-    if (j == 0) {
-        st_u32(A.flag_dlt, (unsigned)(up + 1));
-        if (dbg) dbg[4 * (size_t)up + 2] = wall_clock64();
-    }
+    if (j == 0) st_u32(A.flag_dlt, (unsigned)(up + 1));
+    if (dbg && j == 0) dbg[4 * (size_t)up + 2] = wall_clock64();
     const double bn = outb[pbuf * NGP_BLK + j];
     const int isave = outi[pbuf * NGP_BLK + j];
     A.beta[k] = bn;
@@ -960,6 +1057,9 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
                 if (u >= 1) okc = fetch_group_sums<DBG>(A, u, j, &tot);
                 if (!okc && j == 0) *sabort = 1;
             } else {       // wave 5 applies the look-ahead corrections and leaves the final total in r0[buf]
+#ifdef NGP_AB_OLD_TOTFLAG
+                while (__hip_atomic_load(totflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != u + 1) __builtin_amdgcn_s_sleep(0);
+#else
                 // bounded like every other spin: an abort raised by another wave of this workgroup ends the wait
                 for (unsigned sp = 0; __hip_atomic_load(totflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != u + 1; ++sp) {
                     if ((sp & 255u) == 255u && (*(volatile int *)sabort != 0 || sp > (NGP_SPIN_LIMIT << 4))) {
@@ -968,6 +1068,7 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
                     }
                     __builtin_amdgcn_s_sleep(0);
                 }
+#endif
                 tot = r0[rs * NGP_BLK + j];
             }
             const double *gdb = Gd + (u % 3) * 4096 + j;
@@ -1040,6 +1141,11 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
             }
 #undef NGP_LOAD_G
             hist[slot * NGP_BLK + j] = dsave;
+            // dlt leaves the chain wave at once as tagged granules (two fire-and-forget stores): streamers and reducers poll those.
+            // (Handing this and the coefficient prefetch to wave 1 through an LDS flag was built and measured: wave 1's memory
+            // operations queue behind the Gram blocks of five waves and it became the slowest wave -- 10k x 100k 1.71 -> 3.42 us
+            // per block.)
+            publish_dlt_granules(A.dltg, A.nonce, u, j, dsave);
             outb[buf * NGP_BLK + j] = bo + dsave;
             outi[buf * NGP_BLK + j] = isave;
             if (dbg && j == 0) dbg[4 * (size_t)u + 1] = wall_clock64();
@@ -1231,6 +1337,7 @@ __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         role_reducer<DBG>(A, b - 1);
     else {
         const int s = b - 1 - A.NG;
+#ifndef NGP_AB_NO_ROWS
         if (A.variant == 2) {  // row-owning waves + loader wave (host: R <= NGP_ROWS_MAX_R, lag 3..6)
             switch (A.D) {
                 case 3: role_streamer_rows<DBG, 3>(A, s, smem); break;
@@ -1240,6 +1347,7 @@ __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             }
             return;
         }
+#endif
         const int tpt = (8 * A.R + NGP_WG - 1) / NGP_WG;  // 1..4
 #define NGP_DISPATCH_D(T)                                      \
     switch (A.D) {                                             \

@@ -933,6 +933,94 @@ static void iter_blocked(ora_t *h) {
     h->iter = it;
 }
 
+/* ------------------------------------------------------------------ */
+/* order 0, all cores: ONE parallel region per sweep                    */
+/* ------------------------------------------------------------------ */
+/* bench.py's all-core CPU baseline (never used by a test).  The reference runs OpenBLAS, whose level-1 calls thread over
+   the rows of a long vector; a fork/join per ddot / daxpy (what ora_set_threads gives) costs more than it saves on a busy
+   box, so this path keeps the same arithmetic per SNP (add-back daxpy over M.data, ddot over the Mp copy, draw, update
+   daxpy: 24 N bytes of DRAM traffic, src/functions.jl:128-133) but gives every thread a fixed chunk of rows for the whole
+   sweep: per SNP each thread adds the old effect back into its rows and forms its part of the dot product, ONE barrier,
+   then every thread adds the T parts in the same order, draws the same beta_j (the keyed draw layer makes that free of
+   communication) and updates its rows.  Partial dot products are double-buffered by SNP parity, so one barrier per SNP
+   suffices.  Summation order differs from the 1-thread path (chunked dot): a timing path, not a parity path.
+   BayesPR sets only (the configuration the headline is quoted on); returns ORA_ERR otherwise. */
+int ora_run_pr_threaded(ora_t *h, int64_t niter, int T) {
+    if (h->order != 0 || !h->ycorr) { snprintf(h->err, 256, "threaded baseline: reference order only"); return ORA_ERR; }
+    for (int si = 0; si < h->nsets; si++)
+        if (h->sets[si].method != METHOD_PR) { snprintf(h->err, 256, "threaded baseline: BayesPR sets only"); return ORA_ERR; }
+    if (T < 1) T = 1;
+    if (T > 64) T = 64;
+    const int64_t N = h->N;
+    double (*part)[64][8] = (double (*)[64][8])calloc(2, sizeof(*part)); /* [parity][thread][pad to a cache line] */
+    if (!part) return ORA_ERR;
+    for (int64_t n = 0; n < niter; n++) {
+        const int64_t it = h->iter + 1;
+        rng_t r;
+        rng_seed(&r, h->seed, h->chain, it, KIND_VARE_CHI2, 0);
+        double varE = (h->e_df * h->e_scale + dot8_1(h->ycorr, h->ycorr, N)) / rng_chisq(&r, h->e_df + (double)N);
+        h->varE = varE;
+        const double iVarE = 1.0 / varE;
+        if (h->intercept) {
+            double s = 0.0;
+            for (int64_t i = 0; i < N; i++) { h->ycorr[i] += h->b; s += h->ycorr[i]; }
+            double lhs = (double)N * iVarE;
+            rng_seed(&r, h->seed, h->chain, it, KIND_FIXED_NORMAL, 0);
+            h->b = (s * iVarE) / lhs + sqrt(1.0 / lhs) * rng_normal(&r);
+            for (int64_t k = 0; k < N; k++) h->ycorr[k] -= h->b;
+        }
+#pragma omp parallel num_threads(T)
+        {
+            int tid = 0, nt = 1;
+#ifdef _OPENMP
+            extern int omp_get_thread_num(void); extern int omp_get_num_threads(void);
+            tid = omp_get_thread_num(); nt = omp_get_num_threads();
+#endif
+            const int64_t chunk = (((N + nt - 1) / nt) + 7) & ~(int64_t)7;
+            const int64_t lo = tid * chunk < N ? tid * chunk : N, hi = lo + chunk < N ? lo + chunk : N;
+            rng_t rr;
+            int64_t snp = 0;
+            for (int si = 0; si < h->nsets; si++) {
+                oset_t *S = &h->sets[si];
+                double *vb = h->varBeta + S->vb_off;
+                for (int64_t rg = 0; rg < S->nreg; rg++) {
+                    const double iVarBeta = 1.0 / vb[rg];
+                    double ssq = 0.0;
+                    for (int64_t l = S->reg_start[rg]; l < S->reg_stop[rg]; l++, snp++) {
+                        const int64_t j = S->col0 + l;
+                        const double *col = h->data + j * N, *mp = h->Mp + j * N;
+                        const double bold = h->beta[j];
+                        double *y = h->ycorr;
+                        for (int64_t i = lo; i < hi; i++) y[i] = __builtin_fma(bold, col[i], y[i]);          /* :128 */
+                        part[snp & 1][tid][0] = dot8_1(mp + lo, y + lo, hi - lo);                            /* :129, this chunk */
+#pragma omp barrier
+                        double d = 0.0;
+                        for (int t = 0; t < nt; t++) d += part[snp & 1][t][0];
+                        const double rhs = d * iVarE + h->rhs0[j];
+                        const double lhs = h->mpm[j] * iVarE + h->lhs0[j] + iVarBeta;                         /* :130 */
+                        rng_seed(&rr, h->seed, h->chain, it, KIND_BETA_NORMAL, ((uint64_t)si << 40) | (uint64_t)l);
+                        const double bn = rhs / lhs + sqrt(1.0 / lhs) * rng_normal(&rr);                      /* :131-132 */
+                        for (int64_t i = lo; i < hi; i++) y[i] = __builtin_fma(-bn, col[i], y[i]);           /* :133 */
+                        ssq = __builtin_fma(bn, bn, ssq);
+                        /* beta[j] is read again only in the next iteration; one writer keeps the store race-free, and the
+                           barrier of the next SNP orders it before anybody's next read */
+                        if (tid == 0) h->beta[j] = bn;
+                    }
+                    rng_seed(&rr, h->seed, h->chain, it, KIND_REGION_CHI2, ((uint64_t)si << 40) | (uint64_t)rg);
+                    const double vnew = (S->scale * S->df + ssq) / rng_chisq(&rr, S->df + (double)(S->reg_stop[rg] - S->reg_start[rg]));
+#pragma omp barrier
+                    if (tid == 0) vb[rg] = vnew;                                                              /* :135 */
+#pragma omp barrier
+                }
+            }
+        }
+        h->iter = it;
+        if (is_kept(h, h->iter)) accumulate(h);
+    }
+    free(part);
+    return ORA_OK;
+}
+
 /* advance the chain by niter iterations (samplers.jl:29-105) */
 int ora_run(ora_t *h, int64_t niter) {
     if (!h->ycorr || !h->beta) { snprintf(h->err, 256, "panel / y not set"); return ORA_ERR; }

@@ -142,6 +142,10 @@ class Oracle:
     def run(self, niter):
         self._chk(self.L.ora_run(self.h, C.c_int64(niter)))
 
+    def run_pr_threaded(self, niter, threads):
+        """bench.py's all-core baseline: one parallel region per sweep, BayesPR sets, reference order (timing only)."""
+        self._chk(self.L.ora_run_pr_threaded(self.h, C.c_int64(niter), C.c_int(int(threads))))
+
     def get_state(self):
         nvb = self.L.ora_nvb(self.h)
         yc = np.empty(self.N); beta = np.empty(self.P); delta = np.empty(self.P, dtype=np.int64)

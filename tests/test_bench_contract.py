@@ -11,8 +11,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_line_has_the_contract_fields():
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--N", "2000", "--P", "6400", "--steps", "3", "--warmup", "1",
-                          "--cpu-cols", "640", "--cpu-iters", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C4", "--N", "2000", "--P", "6400", "--steps", "8", "--warmup", "1",
+                          "--cpu-cols", "640", "--cpu-seconds", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -20,12 +20,15 @@ def test_bench_line_has_the_contract_fields():
     for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline", "dtype",
               "data", "config", "roofline", "cpu_baseline"):
         assert k in d, k
-    assert d["metric"] == "gibbs_iterations_per_sec" and d["unit"] == "it/s" and d["n_gpus"] == 1 and d["steps"] == 3 and d["warmup"] == 1
+    assert d["metric"] == "gibbs_iterations_per_sec" and d["unit"] == "it/s" and d["n_gpus"] == 1 and d["steps"] == 8 and d["warmup"] == 1
     assert d["higher_is_better"] is True and d["scaling"] == "weak" and d["vs_baseline"] is None and d["data"] == "synthetic"
     assert "workload" in d["config"] and "model" not in d["config"]
     r = d["roofline"]
     assert r["bound"] == "hbm" and r["unit"] == "GB/s" and r["peak"] == 8000.0 and abs(r["frac"] - r["achieved"] / r["peak"]) < 1e-12
     assert "traffic" in r
     c = d["cpu_baseline"]
-    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c
+    assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["cpu_model"] and c["one_thread_it_per_s"] > 0
+    assert len(d["config"]["sets"]) == 3 and sum(x["ncol"] for x in d["config"]["sets"]) == 6400      # three BayesPR sets, like configs[3]
+    e = d["effective_samples"]
+    assert 0 < e["ess_min"] <= 8 and e["ess_min_per_sec"] > 0 and len(e["ess"]["varBeta"]) == 3 and "beta_min_of_128" in e["ess"]
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
