@@ -344,6 +344,7 @@ void ora_destroy(ora_t *h) {
 }
 const char *ora_last_error(ora_t *h) { return h->err; }
 
+static inline double dot8_1(const double *a, const double *b, int64_t n);
 /* hierarchical sequential sum of n shard partials in groups of GRP */
 static double group_sum(const double *p, int64_t n, int64_t stride) {
     double tot = 0.0;
@@ -432,6 +433,33 @@ int ora_set_panel_f32(ora_t *h, const float *X, int64_t N, int64_t P, int64_t R,
     h->rhs0 = (double *)calloc(h->Ppad, sizeof(double));
     h->beta = (double *)calloc(h->Ppad, sizeof(double));               /* mme.jl:443 */
     h->delta = (int64_t *)malloc(sizeof(int64_t) * h->Ppad);          /* mme.jl:444 */
+    for (int64_t k = 0; k < h->Ppad; k++) h->delta[k] = 1;
+    h->sum_beta = (double *)calloc(h->Ppad, sizeof(double));
+    h->sum_beta2 = (double *)calloc(h->Ppad, sizeof(double));
+    h->sum_delta = (double *)calloc(h->Ppad, sizeof(double));
+    h->c = (double *)calloc(h->Ppad, sizeof(double)); h->w = (double *)calloc(h->Ppad, sizeof(double));
+    h->q = (double *)calloc(h->Ppad, sizeof(double)); h->T = (double *)calloc(h->Ppad, sizeof(double));
+    h->chi = (double *)calloc(h->Ppad, sizeof(double));
+    return ORA_OK;
+}
+
+/* Reference order only: the panel as the REFERENCE holds it -- Float64, centred in Float64 (prepMatVec.jl:129) -- so that the
+   effect of the product's fp32 tiles can be measured against it (tests/test_oracle.py::test_fp32_panel_deviation). */
+int ora_set_panel_f64(ora_t *h, const double *X, int64_t N, int64_t P) {
+    if (h->order != 0) { snprintf(h->err, 256, "Float64 panel: reference order only"); return ORA_ERR; }
+    h->N = N; h->P = P;
+    h->data = (double *)malloc(sizeof(double) * N * P);
+    h->Mp = (double *)malloc(sizeof(double) * N * P);
+    h->mpm = (double *)calloc(P, sizeof(double));
+    if (!h->data || !h->Mp || !h->mpm) { snprintf(h->err, 256, "out of memory"); return ORA_ERR; }
+    memcpy(h->data, X, sizeof(double) * N * P);
+    memcpy(h->Mp, X, sizeof(double) * N * P);
+    for (int64_t j = 0; j < P; j++) h->mpm[j] = dot8_1(h->data + j * N, h->data + j * N, N); /* mme.jl:305-307 */
+    h->Ppad = P;
+    h->lhs0 = (double *)calloc(h->Ppad, sizeof(double));
+    h->rhs0 = (double *)calloc(h->Ppad, sizeof(double));
+    h->beta = (double *)calloc(h->Ppad, sizeof(double));
+    h->delta = (int64_t *)malloc(sizeof(int64_t) * h->Ppad);
     for (int64_t k = 0; k < h->Ppad; k++) h->delta[k] = 1;
     h->sum_beta = (double *)calloc(h->Ppad, sizeof(double));
     h->sum_beta2 = (double *)calloc(h->Ppad, sizeof(double));

@@ -111,6 +111,12 @@ class Oracle:
         self._chk(self.L.ora_set_panel_f32(self.h, _p(X, C.c_float), C.c_int64(self.N), C.c_int64(self.P), C.c_int64(R),
                                            C.c_int64(S), C.c_int64(D)))
 
+    def set_panel_f64(self, X):
+        """Reference order only: the Float64 panel of the reference (already centred in Float64)."""
+        X = np.asfortranarray(X, dtype=np.float64)
+        self.N, self.P = X.shape
+        self._chk(self.L.ora_set_panel_f64(self.h, _p(X, C.c_double), C.c_int64(self.N), C.c_int64(self.P)))
+
     def add_marker_set(self, col0, ncol, method, df, scale, regions, varBeta0, pi0=0.0, estPi=False, lhs0=None, rhs0=None):
         rs = np.ascontiguousarray([r[0] for r in regions], dtype=np.int64)
         re = np.ascontiguousarray([r[1] for r in regions], dtype=np.int64)

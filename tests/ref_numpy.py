@@ -1,0 +1,167 @@
+"""Independent numpy restatement of the reference's marker-effect Gibbs iteration (TEST INFRASTRUCTURE).
+
+Written from the Julia source, not from oracle/ngp_oracle.c, so that a transcription error in the C oracle does not
+pass unnoticed ("parity" item 1): data structures keep the reference's shape -- M[set] holds
+data / Mp / mpm / lhs / rhs / regionArray / scale / df / logPi / piHat / estPi, beta and delta are per-set row vectors,
+varBeta[set] a vector -- and every statement cites the line it restates:
+
+    /root/reference/src/samplers.jl:29-53      iteration order (varE, fixed effects, marker sets)
+    /root/reference/src/functions.jl:39-47     sampleX!, single column (the intercept)
+    /root/reference/src/functions.jl:118-137   sampleBayesPR!(::Symbol)
+    /root/reference/src/functions.jl:157-195   sampleBayesB!
+    /root/reference/src/functions.jl:197-235   sampleBayesC!
+    /root/reference/src/functions.jl:493-495, 509-511, 523-525, 531-533   sampleBeta, sampleVarBetaPR, sampleVarE, samplePi
+
+The only thing shared with the oracle is the draw layer (the reference's own draws come from Distributions.jl / Random,
+absent from /root/reference): `draw(kind, index, what, p1, p2)` returns the first draw of the keyed stream, exactly the
+number the oracle and the device use at that site.  Dots are numpy's (pairwise summation), so results agree with the C
+oracle to rounding, not bit for bit.
+"""
+import math
+
+import numpy as np
+
+KIND = dict(VARE_CHI2=1, FIXED_NORMAL=2, BETA_NORMAL=3, REGION_CHI2=4, B_UNIFORM=5, B_LOCUS_CHI2=6, PI_BETA=7, R_UNIFORM=8, R_DIRICHLET=9)
+
+
+class RefChain:
+    def __init__(self, O, X, y, seed, chain, intercept=True):
+        self.O, self.seed, self.chain = O, seed, chain
+        self.N = len(y)
+        self.X = np.asarray(X, dtype=np.float64)            # M[set].data is a Float64 matrix (prepMatVec.jl:116-129)
+        self.ycorr = np.array(y, dtype=np.float64)          # mme.jl:57
+        self.intercept = intercept
+        self.ones = np.ones(self.N)                         # prepMatVec.jl:163-165
+        self.b = np.zeros(1)
+        self.M, self.beta, self.delta, self.varBeta = [], [], [], []
+        self.E_df, self.E_scale = 4.0, 0.0005               # mme.jl:87-93
+        self.iter = 0
+        self.varE = float("nan")
+
+    def draw(self, kind, index, what, p1=0.0, p2=0.0):
+        return float(self.O.draws(self.seed, self.chain, self.iter, KIND[kind], index, what, 1, p1, p2, indexed=True)[0])
+
+    def add_set(self, col0, ncol, method, df, scale, regions, varBeta0, pi0=0.0, estPi=False, lhs=None, rhs=None):
+        data = self.X[:, col0:col0 + ncol]
+        m = dict(method=method, data=data, Mp=[data[:, j].copy() for j in range(ncol)],          # mme.jl:308: a second copy
+                 mpm=[float(np.dot(data[:, j], data[:, j])) for j in range(ncol)],               # mme.jl:305-307
+                 lhs=np.zeros(ncol) if lhs is None else np.array(lhs, float),                     # mme.jl:314-322
+                 rhs=np.zeros(ncol) if rhs is None else np.array(rhs, float),
+                 regionArray=[range(a, b) for a, b in regions], scale=scale, df=df, estPi=estPi, dims=(self.N, ncol),
+                 piHat=np.array([1.0 - pi0, pi0]), logPi=np.array([math.log(1.0 - pi0), math.log(pi0)]) if pi0 > 0 else np.zeros(2))
+        self.M.append(m)
+        self.beta.append(np.zeros(ncol))                     # mme.jl:443
+        self.delta.append(np.ones(ncol, dtype=np.int64))     # mme.jl:444
+        self.varBeta.append(np.array(varBeta0, dtype=np.float64))  # mme.jl:516
+
+    # ---- functions.jl ----
+    def sampleVarE(self):                                    # :523-525
+        return (self.E_df * self.E_scale + np.dot(self.ycorr, self.ycorr)) / self.draw("VARE_CHI2", 0, 2, self.E_df + self.N)
+
+    def sampleX(self, varE):                                 # :39-47, length(b) == 1
+        iVarE = 1.0 / varE
+        self.ycorr += self.ones * self.b[0]
+        rhs = np.dot(self.ones, self.ycorr) * iVarE + 0.0
+        lhs = float(self.N) * iVarE + 0.0                    # xpx = N (mme.jl:138)
+        meanMu = rhs / lhs
+        self.b[0] = meanMu + math.sqrt(1.0 / lhs) * self.draw("FIXED_NORMAL", 0, 1)
+        self.ycorr -= self.ones * self.b[0]
+
+    def sampleBeta(self, si, locus, meanBeta, lhs):          # :493-495
+        return meanBeta + math.sqrt(1.0 / lhs) * self.draw("BETA_NORMAL", (si << 40) | locus, 1)
+
+    def sampleBayesPR(self, si, varE):                       # :118-137
+        M, beta, vb = self.M[si], self.beta[si], self.varBeta[si]
+        iVarE = 1.0 / varE
+        for r, theseLoci in enumerate(M["regionArray"]):
+            regionSize = len(theseLoci)
+            iVarBeta = 1.0 / vb[r]
+            for locus in theseLoci:
+                self.ycorr += beta[locus] * M["data"][:, locus]                                   # :128
+                rhs = np.dot(M["Mp"][locus], self.ycorr) * iVarE + M["rhs"][locus]                # :129
+                lhs = M["mpm"][locus] * iVarE + M["lhs"][locus] + iVarBeta                        # :130
+                meanBeta = rhs / lhs                                                              # :131
+                beta[locus] = self.sampleBeta(si, locus, meanBeta, lhs)                           # :132
+                self.ycorr += -1.0 * beta[locus] * M["data"][:, locus]                            # :133
+            sub = beta[theseLoci.start:theseLoci.stop]
+            vb[r] = (M["scale"] * M["df"] + np.dot(sub, sub)) / self.draw("REGION_CHI2", (si << 40) | r, 2, M["df"] + regionSize)  # :135
+
+    def _inclusion(self, si, locus, rrr, varE, vbeta):       # :169-174 / :210-217
+        M = self.M[si]
+        with np.errstate(divide="ignore", invalid="ignore", over="ignore"):
+            v0 = np.float64(M["mpm"][locus]) * varE
+            v1 = (np.float64(M["mpm"][locus]) ** 2) * vbeta + v0
+            logDelta0 = -0.5 * (np.log(v0) + (rrr ** 2) / v0) + M["logPi"][0]
+            logDelta1 = -0.5 * (np.log(v1) + (rrr ** 2) / v1) + M["logPi"][1]
+            probDelta1 = 1.0 / (1.0 + np.exp(logDelta0 - logDelta1))
+        return self.draw("B_UNIFORM", (si << 40) | locus, 0) < probDelta1                         # NaN compares false
+
+    def samplePi(self, si, nLoci):                           # :531-533, then :190-194
+        M = self.M[si]
+        piIn = self.draw("PI_BETA", si, 3, nLoci + 1.0, M["dims"][1] - nLoci + 1.0)
+        M["piHat"][:] = [1.0 - piIn, piIn]
+        M["logPi"][:] = np.log(M["piHat"])
+
+    def sampleBayesB(self, si, varE):                        # :157-195
+        M, beta, delta, vb = self.M[si], self.beta[si], self.delta[si], self.varBeta[si]
+        nLoci = 0
+        for r, theseLoci in enumerate(M["regionArray"]):     # one region per locus: r == locus
+            iVarE = 1.0 / varE
+            with np.errstate(divide="ignore"):
+                iVarBeta = np.float64(1.0) / vb[r]            # :165, Inf after an exclusion
+            for locus in theseLoci:
+                self.ycorr += beta[locus] * M["data"][:, locus]                                   # :167
+                rrr = np.dot(M["data"][:, locus], self.ycorr)                                     # :168
+                if self._inclusion(si, locus, rrr, varE, vb[r]):                                  # :174
+                    delta[locus] = 1
+                    nLoci += 1
+                    rhs = np.dot(M["Mp"][locus], self.ycorr) * iVarE + M["rhs"][locus]            # :177
+                    lhs = M["mpm"][locus] * iVarE + M["lhs"][locus] + iVarBeta                    # :178
+                    meanBeta = rhs / lhs
+                    beta[locus] = self.sampleBeta(si, locus, meanBeta, lhs)                       # :180
+                    self.ycorr += -1.0 * beta[locus] * M["data"][:, locus]                        # :181
+                    vb[r] = (M["scale"] * M["df"] + beta[locus] * beta[locus]) / self.draw("B_LOCUS_CHI2", (si << 40) | locus, 2, M["df"] + 1.0)  # :182
+                else:
+                    beta[locus] = 0.0                                                             # :184
+                    delta[locus] = 0
+                    vb[r] = 0.0                                                                   # :186
+        if M["estPi"]:
+            self.samplePi(si, nLoci)
+
+    def sampleBayesC(self, si, varE):                        # :197-235
+        M, beta, delta, vb = self.M[si], self.beta[si], self.delta[si], self.varBeta[si]
+        nLoci = 0
+        iVarE = 1.0 / varE
+        iVarBeta = 1.0 / vb[0]                                                                    # :205
+        for locus in range(M["dims"][1]):
+            self.ycorr += beta[locus] * M["data"][:, locus]                                       # :208
+            rrr = np.dot(M["data"][:, locus], self.ycorr)                                         # :209
+            if self._inclusion(si, locus, rrr, varE, vb[0]):                                      # :217
+                delta[locus] = 1
+                nLoci += 1
+                rhs = np.dot(M["Mp"][locus], self.ycorr) * iVarE                                  # :220 (M.rhs commented out)
+                lhs = M["mpm"][locus] * iVarE + M["lhs"][locus] + iVarBeta                        # :221
+                meanBeta = rhs / lhs
+                beta[locus] = self.sampleBeta(si, locus, meanBeta, lhs)
+                self.ycorr += -1.0 * beta[locus] * M["data"][:, locus]                            # :224
+            else:
+                beta[locus] = 0.0
+                delta[locus] = 0
+        vb[0] = (M["scale"] * M["df"] + np.dot(beta, beta)) / self.draw("REGION_CHI2", (si << 40), 2, M["df"] + nLoci)  # :231
+        if M["estPi"]:
+            self.samplePi(si, nLoci)
+
+    # ---- samplers.jl:29-53 ----
+    def run(self, niter):
+        for _ in range(niter):
+            self.iter += 1
+            varE = self.sampleVarE()                         # :32-35
+            self.varE = varE
+            if self.intercept:
+                self.sampleX(varE)                           # :39-41
+            for si, M in enumerate(self.M):                  # :50-53
+                {0: self.sampleBayesPR, 1: self.sampleBayesB, 2: self.sampleBayesC}[M["method"]](si, varE)
+
+    def state(self):
+        return dict(ycorr=self.ycorr.copy(), beta=np.concatenate(self.beta), delta=np.concatenate(self.delta),
+                    varBeta=np.concatenate(self.varBeta), piHat=np.concatenate([m["piHat"] for m in self.M]), varE=self.varE, b=float(self.b[0]))

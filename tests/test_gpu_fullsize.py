@@ -104,3 +104,57 @@ def test_tallest_shards_and_fallback(ngp, N_, P_, mode_):
     s.set_y(y); s.set_residual_prior(4.0, 0.25 * y.var()); s.run(6)
     st = s.get_state()
     assert np.abs(st["ycorr"] - (y - st["b"] - s.xbeta(st["beta"]))).max() < 1e-9
+
+
+def test_north_star_shape_50k_x_600k(ngp):
+    """BASELINE.json configs[3] at full size (N = 50,000, P = 600,000 as three BayesPR sets; 120 GB of tiles, 64-bit tile
+    offsets, 204-row shards, lag 6, the row-owning streamer): the oracle cannot run this, so the size-independent properties
+    carry parity -- ycorr == y - 1 b - X beta recomputed from scratch, bitwise reproducibility of two chains with the same
+    seed, sensitivity to the seed, and agreement (1e-9) of the row-owning streamer with the phase streamer, a different
+    summation order of the same chain."""
+    N_, P_ = 50000, 600000
+    out = []
+    for seed, streamer in ((1001, None), (1001, None), (1002, None), (1001, 1)):
+        s = ngp.Sampler(device=0, seed=seed, chain=0, streamer=streamer)
+        s.generate_panel(N_, P_)
+        if not out:
+            R, S, nblk = s.layout()
+            assert (R, S, nblk) == (204, 246, 9375) and s.config() == (1, 6) and s.near() == 3 and s.streamer() == (2, 7)
+            rng = np.random.default_rng(1)
+            bt = np.zeros(P_); idx = rng.choice(P_, P_ // 100, replace=False); bt[idx] = rng.normal(size=len(idx))
+            g = s.xbeta(bt)
+            y = 10.0 + g + np.random.default_rng(2).normal(size=N_) * np.sqrt(g.var())
+            v = 0.5 * y.var() / (s.mpm().sum() / N_)
+        for c in range(3):
+            s.add_marker_set(c * 200000, 200000, 0, 4.0, v * 0.5, [(0, 200000)], [v])
+        s.set_y(y); s.set_residual_prior(4.0, 0.25 * y.var()); s.set_schedule(6, 0, 1)
+        s.run(6)
+        st = s.get_state()
+        if len(out) == 0:
+            resid = y - st["b"] - s.xbeta(st["beta"])
+            assert np.abs(st["ycorr"] - resid).max() <= 1e-9 * np.abs(y).max()
+            assert np.isfinite(st["beta"]).all() and st["varE"] > 0 and st["iter"] == 6 and st["delta"].min() == 1 and np.all(st["varBeta"] > 0)
+            assert s.get_posterior_sums()["nKept"] == 6
+        out.append(st)
+        s.close()
+    a, b, c, d = out
+    for k in ("ycorr", "beta", "varBeta"):
+        assert np.array_equal(a[k], b[k]), k
+        assert np.abs(a[k] - d[k]).max() <= 1e-9 * np.abs(a[k]).max(), k
+    assert a["varE"] == b["varE"] and not np.array_equal(a["beta"], c["beta"]) and abs(a["varE"] - d["varE"]) <= 1e-9 * a["varE"]
+
+
+@pytest.mark.parametrize("lag", [8], ids=["lag8_default"])
+def test_default_engine_at_full_size(ngp, lag):
+    """The default production engine of short shards (lag 8, lazily counted partials) at 10k x 100k: residual invariant and
+    equality with the per-block engine (round 1 ran these checks at lag 6 only)."""
+    P_ = 20032
+    a, y = _chain(ngp, "multi", 8, engine=(0, 1), P_=P_)
+    b, _ = _chain(ngp, "multi", 8, engine=(1, lag), P_=P_)
+    sa, sb = a.get_state(), b.get_state()
+    assert b.config() == (1, 8)
+    assert np.array_equal(sa["delta"], sb["delta"])
+    assert np.abs(sa["beta"] - sb["beta"]).max() <= 1e-9 * max(1e-3, np.abs(sa["beta"]).max())
+    c, y2 = _chain(ngp, "PR", 12, engine=(1, lag))
+    st = c.get_state()
+    assert np.abs(st["ycorr"] - (y2 - st["b"] - c.xbeta(st["beta"]))).max() <= 1e-9 * np.abs(y2).max()

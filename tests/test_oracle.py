@@ -216,3 +216,121 @@ def test_golden_vectors(O, name):
             assert np.abs(s["beta"] - g[f"beta_{it}"]).max() <= tol * max(1.0, np.abs(g[f"beta_{it}"]).max())
             assert abs(s["varE"] - float(g[f"varE_{it}"])) <= tol * float(g[f"varE_{it}"])
             assert np.abs(s["varBeta"] - g[f"varBeta_{it}"]).max() <= tol * max(1e-9, np.abs(g[f"varBeta_{it}"]).max())
+
+
+# ----------------------------------------------------------------------------------------------
+# independent numpy restatement of the reference (tests/ref_numpy.py) against the C oracle
+# ----------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("spec,intercept", [
+    ([(0, 45, "PR")], True), ([(0, 45, ("PRw", 7))], True), ([(0, 45, "PR1")], False), ([(0, 45, "B")], True), ([(0, 45, "Bfix")], True),
+    ([(0, 45, "C")], True), ([(0, 15, "PR"), (15, 18, "B"), (33, 12, "Cfix")], True)],
+    ids=["pr", "pr_regions", "pr_r1_no_intercept", "b", "b_fixpi", "c", "multi"])
+def test_numpy_restatement_of_the_reference_agrees(O, spec, intercept):
+    """The C oracle's reference-order path and a separate numpy transcription of functions.jl:118-235 + samplers.jl:29-53
+    consume the same draws and must produce the same chain (indicators identical, floats to rounding: numpy's dots are
+    summed pairwise, the oracle's in eight interleaved chains)."""
+    from ref_numpy import RefChain
+    N, P = 60, 45
+    X, y, bt, v = make_problem(O, N, P, seed=3)
+    rng = np.random.default_rng(8)
+    o = O.Oracle(0, seed=21, chain=2); o.set_panel_f32(X)
+    ref = RefChain(O, X.astype(np.float64), y, seed=21, chain=2, intercept=intercept)
+    df = 4.0
+    for col0, ncol, kind in spec:
+        lhs0 = np.abs(rng.normal(size=ncol)) * 0.2
+        rhs0 = rng.normal(size=ncol) * 0.1
+        if kind == "PR": args = (0, [(0, ncol)], [v], 0.0, False)
+        elif kind == "PR1": args = (0, [(j, j + 1) for j in range(ncol)], [v] * ncol, 0.0, False)
+        elif isinstance(kind, tuple): args = (0, [(a, min(a + kind[1], ncol)) for a in range(0, ncol, kind[1])], None, 0.0, False)
+        elif kind == "B": args = (1, [(j, j + 1) for j in range(ncol)], [v] * ncol, 0.05, True)
+        elif kind == "Bfix": args = (1, [(j, j + 1) for j in range(ncol)], [v] * ncol, 0.3, False)
+        elif kind == "C": args = (2, [(0, ncol)], [v], 0.1, True)
+        else: args = (2, [(0, ncol)], [v], 0.4, False)
+        method, regs, vb0, pi0, estPi = args
+        vb0 = [v] * len(regs) if vb0 is None else vb0
+        o.add_marker_set(col0, ncol, method, df, v * (df - 2) / df, regs, vb0, pi0=pi0, estPi=estPi, lhs0=lhs0, rhs0=rhs0)
+        ref.add_set(col0, ncol, method, df, v * (df - 2) / df, regs, vb0, pi0=pi0, estPi=estPi, lhs=lhs0, rhs=rhs0)
+    o.set_y(y); o.set_intercept(intercept); o.set_residual_prior(4.0, 0.3 * y.var())
+    ref.E_df, ref.E_scale = 4.0, 0.3 * y.var()
+    for it in range(8):
+        o.run(1); ref.run(1)
+        a, b = o.get_state(), ref.state()
+        assert np.array_equal(a["delta"], b["delta"]), it
+        for k in ("beta", "ycorr", "varBeta", "piHat"):
+            assert np.abs(a[k] - b[k]).max() <= 1e-10 * max(1e-6, np.abs(b[k]).max()), (it, k)
+        assert abs(a["varE"] - b["varE"]) <= 1e-12 * b["varE"] and abs(a["b"] - b["b"]) <= 1e-10 * max(1.0, abs(b["b"]))
+
+
+def test_hand_derived_one_snp_chain(O):
+    """A chain small enough to write out by hand from functions.jl:128-135 and :523-525 with the draws fixed: one SNP, no
+    intercept.  Every number below is computed here with plain Python floats from the formulas, not by the oracle."""
+    N = 6
+    x = np.array([1.0, -1.0, 0.5, -0.5, 2.0, -2.0], dtype=np.float32)
+    y = np.array([0.3, -0.2, 0.1, 0.4, 1.1, -0.9])
+    o = O.Oracle(0, seed=4, chain=0); o.set_panel_f32(x.reshape(N, 1))
+    df, scale, vb0, e_df, e_scale = 4.0, 0.02, 0.05, 4.0, 0.1
+    o.add_marker_set(0, 1, 0, df, scale, [(0, 1)], [vb0]); o.set_y(y); o.set_intercept(False); o.set_residual_prior(e_df, e_scale)
+    o.run(2)
+    ycorr, beta, vb = [float(t) for t in y], 0.0, vb0
+    xs = [float(t) for t in x]
+    for it in (1, 2):
+        chi_e = float(O.draws(4, 0, it, 1, 0, 2, 1, e_df + N, indexed=True)[0])
+        z = float(O.draws(4, 0, it, 3, 0, 1, 1, indexed=True)[0])
+        chi_b = float(O.draws(4, 0, it, 4, 0, 2, 1, df + 1, indexed=True)[0])
+        varE = (e_df * e_scale + sum(t * t for t in ycorr)) / chi_e                  # :523-525
+        ycorr = [t + beta * xi for t, xi in zip(ycorr, xs)]                           # :128
+        rhs = sum(xi * t for xi, t in zip(xs, ycorr)) / varE                          # :129
+        lhs = sum(xi * xi for xi in xs) / varE + 1.0 / vb                             # :130
+        beta = rhs / lhs + math.sqrt(1.0 / lhs) * z                                   # :131-132, :493-495
+        ycorr = [t - beta * xi for t, xi in zip(ycorr, xs)]                           # :133
+        vb = (scale * df + beta * beta) / chi_b                                       # :135, :509-511
+    st = o.get_state()
+    assert abs(st["beta"][0] - beta) <= 1e-14 * abs(beta) and abs(st["varBeta"][0] - vb) <= 1e-14 * vb and abs(st["varE"] - varE) <= 1e-14 * varE
+    assert np.abs(st["ycorr"] - np.array(ycorr)).max() <= 1e-14
+
+
+@pytest.mark.parametrize("kind", ["PR", "B"])
+def test_fp32_panel_deviation(O, kind):
+    """How far does the product's fp32 panel (centred value rounded to fp32) move the chain away from the reference's Float64
+    panel (prepMatVec.jl:129)?  BASELINE.json configs[0] size: 500 x 5,000, 1,000 iterations, same draws.  BayesPR is a smooth
+    function of the data: the chains stay together to 1e-6 of the effect scale over the whole run.  BayesB compares a
+    uniform draw with an inclusion probability: a locus whose draw falls within the rounding difference flips, and from
+    there the two chains are different realisations of the same posterior -- reported as the first flip and the Monte-Carlo
+    size difference of the posterior means ("fp32 panel")."""
+    N, P, niter = 500, 5000, 1000
+    X32, mu = O.generate_panel(N, P)
+    G = np.rint(X32.astype(np.float64) + mu)                    # the 0/1/2 genotypes
+    X64 = G - G.mean(axis=0)                                     # centred in Float64, as the reference does
+    assert np.abs(X64 - X32).max() < 1e-6
+    y = 10.0 + X64[:, ::97] @ np.random.default_rng(1).normal(size=len(range(0, P, 97))) + np.random.default_rng(2).normal(size=N) * 3.0
+    v = 0.5 * y.var() / float((mu * (1 - mu / 2)).sum())
+    chains = []
+    for panel in ("f32", "f64"):
+        o = O.Oracle(0, seed=1001, chain=0)
+        if panel == "f32": o.set_panel_f32(X32)
+        else: o.set_panel_f64(X64)
+        add_sets(o, [(0, P, kind)], v); o.set_y(y); o.set_residual_prior(4.0, 0.25 * y.var()); o.set_schedule(niter, 200, 1)
+        first_flip, deltas = None, []
+        if kind == "B":
+            for it in range(niter // 50):
+                o.run(50); deltas.append(o.get_state()["delta"].copy())
+        else:
+            o.run(niter)
+        chains.append((o.get_state(), o.get_posterior_sums(), deltas))
+    (sa, pa, da), (sb, pb, db) = chains
+    scale = np.abs(pb["sum_beta"] / pb["nKept"]).max()
+    dmean = np.abs(pa["sum_beta"] / pa["nKept"] - pb["sum_beta"] / pb["nKept"]).max()
+    if kind == "PR":
+        print(f"fp32 vs Float64 panel, BayesPR 500 x 5000 x 1000 it: max |d posterior mean| = {dmean:.3e} (scale {scale:.3e}), "
+              f"max |d beta| at the end = {np.abs(sa['beta'] - sb['beta']).max():.3e}, d varE = {abs(sa['varE'] - sb['varE']) / sb['varE']:.3e}")
+        assert dmean <= 1e-6 * scale and np.abs(sa["beta"] - sb["beta"]).max() <= 1e-5 * scale
+    else:
+        same = [np.array_equal(x, z) for x, z in zip(da, db)]
+        first = (same.index(False) + 1) * 50 if False in same else None
+        flips = int((da[-1] != db[-1]).sum())
+        sd = np.sqrt(np.maximum(pb["sum_beta2"] / pb["nKept"] - (pb["sum_beta"] / pb["nKept"]) ** 2, 0)).max()
+        print(f"fp32 vs Float64 panel, BayesB 500 x 5000 x 1000 it: indicators identical through iteration "
+              f"{'1000 (no flip)' if first is None else first - 50}, differing indicators at the end {flips} of {P}, "
+              f"max |d posterior mean| = {dmean:.3e} (largest posterior sd {sd:.3e})")
+        assert same[0]                                            # the first 50 iterations agree locus by locus
+        assert dmean <= 1.0 * sd + 1e-12                          # afterwards: two realisations of one posterior
