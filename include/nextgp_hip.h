@@ -37,6 +37,7 @@ extern "C" {
 #define NGP_METHOD_BAYESPR 0 /* src/runTime.jl:30-45 */
 #define NGP_METHOD_BAYESB 1  /* src/runTime.jl:48-61 */
 #define NGP_METHOD_BAYESC 2  /* src/runTime.jl:64-77, sampler src/functions.jl:197-235 */
+#define NGP_METHOD_BAYESR 3  /* src/runTime.jl:78-93, sampler src/functions.jl:238-289; added with ngp_add_marker_set_r */
 
 typedef struct ngp_handle ngp_handle;
 
@@ -97,6 +98,19 @@ int32_t ngp_add_marker_set(ngp_handle *h, int64_t col0, int64_t ncol, int32_t me
                            const int64_t *reg_start, const int64_t *reg_stop, int64_t nreg, const double *varBeta0,
                            double pi0, int32_t estPi, const double *lhs0, const double *rhs0, int32_t *set_id);
 
+/* BayesR marker set (set-up src/mme.jl:374-383): ONE variance for the set (varBeta0, nVarCov = 1), K = 2..4 variance classes with
+ * multipliers vClass[v] of that variance (multiplier 0: the effect is exactly 0) and class probabilities pi[v] (sum 1);
+ * estPi: pi ~ Dirichlet(nLoci + 1) after every sweep (src/functions.jl:284-288).  delta then holds the CLASS of a locus,
+ * counted from 1 as the reference writes it (src/functions.jl:262).  The reference's class search compares cumulative
+ * probabilities with a FRESH uniform per comparison (src/functions.jl:261); that is reproduced, one keyed uniform per (locus,
+ * comparison).  ngp_get_state / ngp_get_posterior_sums report [0.5, 0.5]-style placeholders in piHat / sum_pi for such a set;
+ * its K probabilities are read and restored with ngp_get_class_state / ngp_set_class_state, and travel in the packed
+ * posterior (ngp_posterior_len) and in snapshots. */
+int32_t ngp_add_marker_set_r(ngp_handle *h, int64_t col0, int64_t ncol, double df, double scale, double varBeta0, const double *vClass,
+                             const double *pi, int32_t K, int32_t estPi, const double *lhs0, const double *rhs0, int32_t *set_id);
+int32_t ngp_get_class_state(ngp_handle *h, int32_t set_id, double *piHat, double *sum_pi, int64_t *K);
+int32_t ngp_set_class_state(ngp_handle *h, int32_t set_id, const double *piHat, const double *sum_pi, int64_t K);
+
 /* Phenotypes; resets the chain: ycorr = y (src/mme.jl:57), b = 0, beta = 0, delta = 1, iter = 0, every variance and pi back to
  * the values given to ngp_add_marker_set (src/mme.jl:351-360, 516), all posterior sums and nKept zero. */
 int32_t ngp_set_y(ngp_handle *h, const double *y, int64_t N);
@@ -125,8 +139,8 @@ int32_t ngp_get_trace(ngp_handle *h, double *varE, double *b, int64_t n);
 int32_t ngp_get_posterior_sums(ngp_handle *h, double *sum_beta, double *sum_beta2, double *sum_delta, double *sum_varBeta,
                                double *sum_pi, double *sum_varE, double *sum_b, int64_t *nKept);
 /* Same sums packed into a DEVICE buffer [sum_beta P | sum_beta2 P | sum_delta P | sum_varBeta nvb |
- * sum_pi 2*nsets | sum_varE | sum_b | nKept] so the host can all-reduce them over RCCL without a
- * PCIe round trip.  len = 3P + nvb + 2 nsets + 3 doubles. */
+ * sum_pi 2*nsets | class-probability sums of the BayesR sets, K each | sum_varE | sum_b | nKept] so the host can
+ * all-reduce them over RCCL without a PCIe round trip.  len = 3P + nvb + 2 nsets + sum K + 3 doubles. */
 int32_t ngp_posterior_len(ngp_handle *h, int64_t *len);
 int32_t ngp_export_posterior_device(ngp_handle *h, void *device_ptr, int64_t len);
 

@@ -12,7 +12,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NGP_HIP_LIB") or os.path.join(_HERE, "libnextgp_hip.so")  # override: a library built elsewhere
 
-METHOD_BAYESPR, METHOD_BAYESB, METHOD_BAYESC = 0, 1, 2
+METHOD_BAYESPR, METHOD_BAYESB, METHOD_BAYESC, METHOD_BAYESR = 0, 1, 2, 3
 
 # every symbol include/nextgp_hip.h declares
 SYMBOLS = [
@@ -22,7 +22,7 @@ SYMBOLS = [
     "ngp_get_trace", "ngp_get_posterior_sums", "ngp_posterior_len", "ngp_export_posterior_device", "ngp_sweep_set",
     "ngp_get_timing", "ngp_profile_iteration", "ngp_draws_indexed", "ngp_eval_math", "ngp_configure", "ngp_get_config", "ngp_debug_stamps", "ngp_set_near_lags", "ngp_get_near_lags",
     "ngp_set_streamer", "ngp_get_streamer", "ngp_debug_set_mode", "ngp_debug_set_knob", "ngp_set_posterior_sums", "ngp_save_snapshot", "ngp_load_snapshot",
-    "ngp_set_trace_loci", "ngp_get_trace_ext", "ngp_allreduce_posterior",
+    "ngp_set_trace_loci", "ngp_get_trace_ext", "ngp_allreduce_posterior", "ngp_add_marker_set_r", "ngp_get_class_state", "ngp_set_class_state",
 ]
 
 _lib = None
@@ -178,6 +178,33 @@ class Sampler:
         self.nsets += 1
         self.set_shapes.append((ncol, len(rs)))
         return sid.value
+
+    def add_marker_set_r(self, col0, ncol, df, scale, varBeta0, vClass, pi, estPi=False, lhs0=None, rhs0=None):
+        """BayesR set: class multipliers vClass of the set's single variance, class probabilities pi (src/mme.jl:374-383)."""
+        vc = np.ascontiguousarray(vClass, dtype=np.float64); pp = np.ascontiguousarray(pi, dtype=np.float64)
+        if len(vc) != len(pp):
+            raise ValueError("vClass and pi need one entry per class")
+        l0 = None if lhs0 is None else np.ascontiguousarray(lhs0, dtype=np.float64)
+        r0 = None if rhs0 is None else np.ascontiguousarray(rhs0, dtype=np.float64)
+        sid = C.c_int32()
+        self._chk(self.L.ngp_add_marker_set_r(self.h, C.c_int64(col0), C.c_int64(ncol), C.c_double(df), C.c_double(scale), C.c_double(varBeta0),
+                                              _p(vc, C.c_double), _p(pp, C.c_double), C.c_int32(len(vc)), C.c_int32(int(estPi)), _p(l0, C.c_double),
+                                              _p(r0, C.c_double), C.byref(sid)))
+        self.nsets += 1
+        self.set_shapes.append((ncol, 1))
+        self.nclasses = getattr(self, "nclasses", 0) + len(vc)
+        return sid.value
+
+    def get_class_state(self, set_id):
+        pi = np.empty(8); sp = np.empty(8); K = C.c_int64()
+        self._chk(self.L.ngp_get_class_state(self.h, C.c_int32(set_id), _p(pi, C.c_double), _p(sp, C.c_double), C.byref(K)))
+        return dict(piHat=pi[:K.value].copy(), sum_pi=sp[:K.value].copy())
+
+    def set_class_state(self, set_id, piHat=None, sum_pi=None):
+        a = None if piHat is None else np.ascontiguousarray(piHat, dtype=np.float64)
+        b = None if sum_pi is None else np.ascontiguousarray(sum_pi, dtype=np.float64)
+        K = len(a) if a is not None else len(b)
+        self._chk(self.L.ngp_set_class_state(self.h, C.c_int32(set_id), _p(a, C.c_double), _p(b, C.c_double), C.c_int64(K)))
 
     def set_y(self, y):
         y = np.ascontiguousarray(y, dtype=np.float64)

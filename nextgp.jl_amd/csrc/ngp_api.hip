@@ -32,6 +32,8 @@ struct HSet {
     uint64_t fine_calls;
     double pi0;               // prior inclusion probability (src/mme.jl:351,360): what ngp_set_y goes back to
     std::vector<double> vb0;  // initial variances (src/mme.jl:516)
+    int K = 0;                // BayesR: classes, their multipliers and prior probabilities (src/mme.jl:374-383)
+    std::vector<double> vcls, rpi;
 };
 
 std::string g_create_err;
@@ -74,6 +76,10 @@ struct ngp_handle {
     DScal *d_scal = nullptr;
     double *d_varBeta = nullptr, *d_sum_varBeta = nullptr;
     int64_t vb_cap = 0;
+    double *d_rcls = nullptr;        // BayesR per-locus class coefficients [4][NGP_RMAX][Ppad] (allocated with the first BayesR set)
+    int32_t *d_seg_set = nullptr;    // set of every variance segment
+    std::vector<int32_t> h_seg_set;
+    int64_t nclass_total = 0;        // sum of K over the BayesR sets (entries of the packed posterior)
     // PR region tables
     DReg *d_regs = nullptr;
     long long *d_seg_k0 = nullptr;
@@ -104,6 +110,7 @@ struct ngp_handle {
     // diagnostics (ngp_debug_set_mode): != 0 makes every chain invalid, ngp_run / ngp_sweep_set then return NGP_ERR_DEBUG
     int dbg_mode = 0;
     int knob = 1;  // pacing of the loader wave of the row-owning streamer: s_sleep units after every four requests (ngp_debug_set_knob)
+    bool adding_r = false;  // ngp_add_marker_set is being called by ngp_add_marker_set_r
     bool poisoned = false;  // a sweep gave up half-way (abort word): the chain state is unusable until ngp_set_y / ngp_set_state
     // optional per-iteration traces of selected effects, variances and pi (ngp_set_trace_loci)
     int64_t *d_trace_loci = nullptr;
@@ -227,12 +234,13 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
     h->h_setof.assign(pp, -1);
     h->h_loc.assign(pp, 0);
     h->h_vbidx.assign(pp, 0);
-    h->sets.clear(); h->nvb = 0; h->h_regs.clear(); h->h_seg_k0.clear(); h->h_seg_len.clear();
+    h->sets.clear(); h->nvb = 0; h->h_regs.clear(); h->h_seg_k0.clear(); h->h_seg_len.clear(); h->h_seg_set.clear(); h->nclass_total = 0;
+    dfree(h->d_rcls);
     dfree(h->d_varBeta); dfree(h->d_sum_varBeta); h->vb_cap = 0;
     h->have_y = false; h->iter = 0;
     HCHK(hipFuncSetAttribute((const void *)k_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_step));
     if (h->mode == 1) {
-        const size_t lds_sampler = (size_t)(3 * 4096 + 2 * NGP_RING * NGP_BLK + 6 * NGP_BLK) * sizeof(double) + 2 * NGP_BLK * sizeof(int) + 256;
+        const size_t lds_sampler = (size_t)(3 * 4096 + 2 * NGP_RING * NGP_BLK + 6 * NGP_BLK) * sizeof(double) + 2 * NGP_BLK * sizeof(int) + 320;
         const size_t lds_max = 160 * 1024;
         const size_t misc = (size_t)h->R * 16 + 4096 + 2 * 512 + 128 + 3072 + (size_t)h->R * 64;
         const size_t TB = (size_t)(h->R / 4) * NGP_QS;  // LDS footprint of one tile (quads NGP_QS bytes apart)
@@ -337,11 +345,13 @@ int sync_tables(ngp_handle *h) {
     if ((rc = dalloc(h, &h->d_seg_k0, h->h_seg_k0.size()))) return rc;
     if ((rc = dalloc(h, &h->d_seg_len, h->h_seg_len.size()))) return rc;
     if ((rc = dalloc(h, &h->d_segpart, h->h_seg_k0.size()))) return rc;
+    if ((rc = dalloc(h, &h->d_seg_set, h->h_seg_set.size()))) return rc;
     if ((rc = dalloc(h, &h->d_regchi, h->h_regs.size()))) return rc;
     if (!h->h_regs.empty()) {
         HCHK(hipMemcpy(h->d_regs, h->h_regs.data(), h->h_regs.size() * sizeof(DReg), hipMemcpyHostToDevice));
         HCHK(hipMemcpy(h->d_seg_k0, h->h_seg_k0.data(), h->h_seg_k0.size() * sizeof(long long), hipMemcpyHostToDevice));
         HCHK(hipMemcpy(h->d_seg_len, h->h_seg_len.data(), h->h_seg_len.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HCHK(hipMemcpy(h->d_seg_set, h->h_seg_set.data(), h->h_seg_set.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
     h->tables_dirty = false;
     return NGP_OK;
@@ -362,6 +372,7 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
         A.D = h->D; A.R = R; A.S = S; A.NG = h->NG; A.near = h->near; A.fine_ok = 0; A.t0 = (int)tb0; A.t1 = (int)tb1;
         A.beta = h->d_beta; A.delta = h->d_delta; A.c = h->d_c; A.w = h->d_w; A.q = h->d_q; A.mpm = h->d_mpm; A.chi = h->d_chi;
         A.setof = h->d_setof; A.vbidx = h->d_vbidx; A.sets = h->d_sets; A.varBeta = h->d_varBeta;
+        A.rcls = h->d_rcls; A.rhs0 = h->d_rhs0; A.scal = h->d_scal; A.Ppad = h->Ppad;
         A.part = h->d_cpart; A.gsum = h->d_cgsum; A.dlt = h->d_cdlt; A.dltg = h->d_cdltg;
         h->launch_seq = (h->launch_seq % 4095u) + 1u;  // 1..4095: never the zero the ring is born with
         A.nonce = h->launch_seq;
@@ -390,7 +401,8 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
         if (evs && do_gemv) (void)hipEventRecord(evs[e++], h->stream);
         if (do_gemv)
             hipLaunchKernelGGL(k_recur, dim3(1), dim3(256), 0, h->stream, h->d_part, h->d_gramx, h->D, S, (int)t, h->d_beta, h->d_delta,
-                               h->d_c, h->d_w, h->d_q, h->d_mpm, h->d_chi, h->d_setof, h->d_vbidx, h->d_sets, h->d_varBeta, h->d_dlt);
+                               h->d_c, h->d_w, h->d_q, h->d_mpm, h->d_chi, h->d_setof, h->d_vbidx, h->d_sets, h->d_varBeta, h->d_dlt, h->d_rcls,
+                               (long long)h->Ppad, h->d_rhs0, h->d_scal);
     }
     h->sweep_launches += 2 * (tb1 - tb0) + 1;
 }
@@ -414,6 +426,9 @@ void launch_variance(ngp_handle *h, int active_set, uint64_t it) {
     if (nseg > 0) {
         hipLaunchKernelGGL(k_regssq, dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, h->stream, nseg, h->d_seg_k0, h->d_seg_len,
                            h->d_beta, h->d_segpart);
+        if (h->nclass_total > 0)
+            hipLaunchKernelGGL(k_rssq, dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, h->stream, nseg, h->d_seg_k0, h->d_seg_len, h->d_seg_set,
+                               h->d_sets, h->d_beta, h->d_delta, h->d_segpart);
         hipLaunchKernelGGL(k_regdraw, dim3((unsigned)((nreg + 63) / 64)), dim3(64), 0, h->stream, nreg, h->d_regs, h->d_segpart,
                            h->d_sets, h->d_varBeta, active_set, h->d_regchi, h->seed, (uint64_t)h->chain, it);
     }
@@ -427,7 +442,7 @@ int one_iteration(ngp_handle *h, int64_t trace_idx, hipEvent_t *evs) {
                        h->e_scale, h->intercept, 1, h->seed, (uint64_t)h->chain, it, h->d_tr_varE, h->d_tr_b, (long long)trace_idx);
     hipLaunchKernelGGL(k_prep, dim3((unsigned)(h->Ppad / 256 + 1)), dim3(256), 0, h->stream, (long long)h->Ppad, h->d_setof, h->d_loc,
                        h->d_vbidx, h->d_sets, h->d_scal, h->d_varBeta, h->d_mpm, h->d_lhs0, h->d_rhs0, h->d_beta, h->d_c, h->d_w,
-                       h->d_q, h->d_T, h->d_chi, -1, h->seed, (uint64_t)h->chain, it, (long long)h->h_regs.size(), h->d_regs, h->d_regchi);
+                       h->d_q, h->d_T, h->d_chi, -1, h->seed, (uint64_t)h->chain, it, (long long)h->h_regs.size(), h->d_regs, h->d_regchi, h->d_rcls);
     launch_sweep(h, 0, h->NBLK, evs);
     launch_variance(h, -1, it);
     h->iter += 1;
@@ -442,6 +457,21 @@ int one_iteration(ngp_handle *h, int64_t trace_idx, hipEvent_t *evs) {
                            (int)h->sets.size(), h->d_beta, h->d_delta, h->d_varBeta, h->d_sum_beta, h->d_sum_beta2, h->d_sum_delta,
                            h->d_sum_varBeta, h->d_sets, h->d_scal);
     }
+    return NGP_OK;
+}
+
+// class probabilities / their posterior sums of a BayesR set (either may be null); also clears the class counters
+int set_class_state_dev(ngp_handle *h, int si, const double *pi, const double *sum_pi) {
+    const int K = h->sets[(size_t)si].K;
+    double *d = nullptr;
+    int rc;
+    if ((rc = dalloc(h, &d, (size_t)2 * NGP_RMAX))) return rc;
+    if (pi) HCHK(hipMemcpyAsync(d, pi, (size_t)K * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    if (sum_pi) HCHK(hipMemcpyAsync(d + NGP_RMAX, sum_pi, (size_t)K * sizeof(double), hipMemcpyHostToDevice, h->stream));
+    hipLaunchKernelGGL(k_set_class_state, dim3(1), dim3(1), 0, h->stream, h->d_sets, si, K, pi ? d : nullptr, sum_pi ? d + NGP_RMAX : nullptr);
+    hipError_t e = hipStreamSynchronize(h->stream);
+    dfree(d);
+    if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("class state: ") + hipGetErrorString(e));
     return NGP_OK;
 }
 
@@ -489,7 +519,7 @@ int32_t ngp_destroy(ngp_handle *h) {
     if (!h) return NGP_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    dfree(h->d_tiles); dfree(h->d_gramx); dfree(h->d_cpart); dfree(h->d_cgsum); dfree(h->d_cdlt); dfree(h->d_cdltg); dfree(h->d_ccnt); dfree(h->d_abort); dfree(h->d_dbg); dfree(h->d_mpm); dfree(h->d_lhs0); dfree(h->d_rhs0); dfree(h->d_beta);
+    dfree(h->d_tiles); dfree(h->d_gramx); dfree(h->d_cpart); dfree(h->d_cgsum); dfree(h->d_cdlt); dfree(h->d_cdltg); dfree(h->d_rcls); dfree(h->d_seg_set); dfree(h->d_ccnt); dfree(h->d_abort); dfree(h->d_dbg); dfree(h->d_mpm); dfree(h->d_lhs0); dfree(h->d_rhs0); dfree(h->d_beta);
     dfree(h->d_c); dfree(h->d_w); dfree(h->d_q); dfree(h->d_T); dfree(h->d_chi); dfree(h->d_setof); dfree(h->d_loc);
     dfree(h->d_vbidx); dfree(h->d_delta); dfree(h->d_sum_beta); dfree(h->d_sum_beta2); dfree(h->d_sum_delta);
     dfree(h->d_ycorr); dfree(h->d_part); dfree(h->d_dlt); dfree(h->d_sets); dfree(h->d_scal); dfree(h->d_varBeta);
@@ -623,7 +653,9 @@ int32_t ngp_add_marker_set(ngp_handle *h, int64_t col0, int64_t ncol, int32_t me
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
     REQUIRE(h->sets.size() < 16, NGP_ERR_ARG, "at most 16 marker sets");
     REQUIRE(col0 >= 0 && ncol > 0 && col0 + ncol <= h->P, NGP_ERR_ARG, "marker set outside the panel");
-    REQUIRE(method == NGP_METHOD_BAYESPR || method == NGP_METHOD_BAYESB || method == NGP_METHOD_BAYESC, NGP_ERR_ARG, "unknown method");
+    REQUIRE(method == NGP_METHOD_BAYESPR || method == NGP_METHOD_BAYESB || method == NGP_METHOD_BAYESC || method == NGP_METHOD_BAYESR, NGP_ERR_ARG,
+            "unknown method");
+    if (method == NGP_METHOD_BAYESR) REQUIRE(h->adding_r, NGP_ERR_ARG, "BayesR sets are added with ngp_add_marker_set_r (classes and their probabilities)");
     REQUIRE(reg_start && reg_stop && varBeta0 && nreg > 0, NGP_ERR_ARG, "regions / varBeta0 missing");
     REQUIRE(std::isfinite(df) && std::isfinite(scale) && df > 0, NGP_ERR_ARG, "df/scale must be finite, df > 0");
     for (int64_t k = col0; k < col0 + ncol; k++) REQUIRE(h->h_setof[k] < 0, NGP_ERR_ARG, "marker sets overlap");
@@ -669,7 +701,7 @@ int32_t ngp_add_marker_set(ngp_handle *h, int64_t col0, int64_t ncol, int32_t me
             h->h_loc[k] = (int32_t)l;
             h->h_vbidx[k] = (int32_t)(h->nvb + (method == NGP_METHOD_BAYESB ? l : r));
         }
-    if (method == NGP_METHOD_BAYESPR || method == NGP_METHOD_BAYESC) {  // sets whose variance comes from a sum of squares
+    if (method == NGP_METHOD_BAYESPR || method == NGP_METHOD_BAYESC || method == NGP_METHOD_BAYESR) {  // sets whose variance comes from a sum of squares
         for (int64_t r = 0; r < nreg; r++) {
             DReg dr;
             dr.seg0 = (long long)h->h_seg_k0.size();
@@ -678,6 +710,7 @@ int32_t ngp_add_marker_set(ngp_handle *h, int64_t col0, int64_t ncol, int32_t me
             for (int64_t l0 = reg_start[r]; l0 < reg_stop[r]; l0 += NGP_SEG) {
                 h->h_seg_k0.push_back(col0 + l0);
                 h->h_seg_len.push_back((int32_t)std::min<int64_t>(NGP_SEG, reg_stop[r] - l0));
+                h->h_seg_set.push_back((int32_t)si);
                 ns++;
             }
             dr.nseg = ns;
@@ -722,6 +755,10 @@ int32_t ngp_set_y(ngp_handle *h, const double *y, int64_t N) {
         HCHK(hipMemcpyAsync(h->d_varBeta + hs.vb_off, hs.vb0.data(), hs.vb0.size() * sizeof(double), hipMemcpyHostToDevice, h->stream));
         hipLaunchKernelGGL(k_set_pi, dim3(1), dim3(1), 0, h->stream, h->d_sets, (int)si, 1.0 - hs.pi0, hs.pi0);
         hipLaunchKernelGGL(k_set_sum_pi, dim3(1), dim3(1), 0, h->stream, h->d_sets, (int)si, 0.0, 0.0);
+        if (hs.K > 0) {
+            int rc2 = set_class_state_dev(h, (int)si, hs.rpi.data(), std::vector<double>((size_t)hs.K, 0.0).data());
+            if (rc2) return rc2;
+        }
     }
     HCHK(hipStreamSynchronize(h->stream));
     h->iter = 0; h->have_y = true; h->poisoned = false; h->ntrace = 0;
@@ -880,7 +917,7 @@ int32_t ngp_posterior_len(ngp_handle *h, int64_t *len) {
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(len != nullptr, NGP_ERR_ARG, "null len");
-    *len = 3 * h->P + h->nvb + 2 * (int64_t)h->sets.size() + 3;
+    *len = 3 * h->P + h->nvb + 2 * (int64_t)h->sets.size() + h->nclass_total + 3;
     return NGP_OK;
 }
 
@@ -888,7 +925,7 @@ int32_t ngp_export_posterior_device(ngp_handle *h, void *device_ptr, int64_t len
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
-    const int64_t need = 3 * h->P + h->nvb + 2 * (int64_t)h->sets.size() + 3;
+    const int64_t need = 3 * h->P + h->nvb + 2 * (int64_t)h->sets.size() + h->nclass_total + 3;
     REQUIRE(device_ptr && len == need, NGP_ERR_ARG, "export buffer length mismatch (see ngp_posterior_len)");
     double *o = (double *)device_ptr;
     const size_t pb = (size_t)h->P * sizeof(double);
@@ -903,6 +940,7 @@ int32_t ngp_export_posterior_device(ngp_handle *h, void *device_ptr, int64_t len
     HCHK(hipMemcpy(&sc, h->d_scal, sizeof(DScal), hipMemcpyDeviceToHost));
     std::vector<double> tail;
     for (auto &s : ds) { tail.push_back(s.sum_pi0); tail.push_back(s.sum_pi1); }
+    for (auto &s : ds) for (int v = 0; v < s.K; v++) tail.push_back(s.sum_pic[v]);  // BayesR class probabilities, set by set
     tail.push_back(sc.sum_varE); tail.push_back(sc.sum_b); tail.push_back((double)sc.nKept);
     HCHK(hipMemcpy(o + 3 * h->P + h->nvb, tail.data(), tail.size() * sizeof(double), hipMemcpyHostToDevice));
     return NGP_OK;
@@ -930,7 +968,7 @@ int32_t ngp_sweep_set(ngp_handle *h, int32_t set_id, double varE, double *ycorr,
     hipLaunchKernelGGL(k_set_varE, dim3(1), dim3(1), 0, h->stream, h->d_scal, varE);
     hipLaunchKernelGGL(k_prep, dim3((unsigned)(h->Ppad / 256 + 1)), dim3(256), 0, h->stream, (long long)h->Ppad, h->d_setof, h->d_loc,
                        h->d_vbidx, h->d_sets, h->d_scal, h->d_varBeta, h->d_mpm, h->d_lhs0, h->d_rhs0, h->d_beta, h->d_c, h->d_w,
-                       h->d_q, h->d_T, h->d_chi, (int)set_id, h->seed, (uint64_t)h->chain, it, (long long)h->h_regs.size(), h->d_regs, h->d_regchi);
+                       h->d_q, h->d_T, h->d_chi, (int)set_id, h->seed, (uint64_t)h->chain, it, (long long)h->h_regs.size(), h->d_regs, h->d_regchi, h->d_rcls);
     const int64_t tb0 = hs.col0 / NGP_BLK, tb1 = (hs.col0 + hs.ncol - 1) / NGP_BLK + 1;
     launch_sweep(h, tb0, tb1, nullptr);
     launch_variance(h, (int)set_id, it);
@@ -1135,7 +1173,8 @@ int32_t ngp_set_posterior_sums(ngp_handle *h, const double *sum_beta, const doub
 /* Snapshot file: the chain state and the posterior sums, little-endian, no padding:
  *   char[8] "NGPSNAP1" | int64 N, P, nvb, nsets, iter, nKept | uint64 seed | uint64 chain |
  *   double varE, b, sum_varE, sum_b | ycorr[N] | beta[P] | delta[P] (uint8) | varBeta[nvb] | piHat[2 nsets] |
- *   sum_beta[P] | sum_beta2[P] | sum_delta[P] | sum_varBeta[nvb] | sum_pi[2 nsets] | fine_calls[nsets] (uint64)
+ *   sum_beta[P] | sum_beta2[P] | sum_delta[P] | sum_varBeta[nvb] | sum_pi[2 nsets] | fine_calls[nsets] (uint64) |
+ *   per BayesR set: piHat[K] | sum_pi[K]
  * It plays the role of the reference's append-only *Out files for a resumed run (src/outFiles.jl:17-21): what was kept
  * before the interruption is not lost. */
 int32_t ngp_save_snapshot(ngp_handle *h, const char *path) {
@@ -1166,6 +1205,13 @@ int32_t ngp_save_snapshot(ngp_handle *h, const char *path) {
     W(yc.data(), N * 8); W(be.data(), P * 8); W(d8.data(), P); W(vb.data(), nvb * 8); W(pi.data(), 2 * ns * 8);
     W(sb.data(), P * 8); W(sb2.data(), P * 8); W(sd.data(), P * 8); W(sv.data(), nvb * 8); W(sp.data(), 2 * ns * 8);
     for (auto &hs : h->sets) W(&hs.fine_calls, 8);
+    for (size_t si = 0; si < ns; si++)  // BayesR sets: class probabilities and their posterior sums (K each)
+        if (h->sets[si].K > 0) {
+            double cp[NGP_RMAX], cs[NGP_RMAX];
+            int64_t K = 0;
+            if ((rc = ngp_get_class_state(h, (int32_t)si, cp, cs, &K))) { fclose(f); remove(tmp.c_str()); return rc; }
+            W(cp, (size_t)K * 8); W(cs, (size_t)K * 8);
+        }
     if (fclose(f) != 0) ok = false;
     if (!ok || rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); return fail(h, NGP_ERR_ARG, std::string("writing the snapshot failed: ") + path); }
     return NGP_OK;
@@ -1194,6 +1240,8 @@ int32_t ngp_load_snapshot(ngp_handle *h, const char *path) {
     std::vector<uint64_t> fc(std::max<size_t>(ns, 1));
     Rd(yc.data(), N * 8); Rd(be.data(), P * 8); Rd(d8.data(), P); Rd(vb.data(), nvb * 8); Rd(pi.data(), 2 * ns * 8);
     Rd(sb.data(), P * 8); Rd(sb2.data(), P * 8); Rd(sd.data(), P * 8); Rd(sv.data(), nvb * 8); Rd(sp.data(), 2 * ns * 8); Rd(fc.data(), ns * 8);
+    std::vector<double> cls((size_t)2 * std::max<int64_t>(h->nclass_total, 1));
+    Rd(cls.data(), (size_t)2 * h->nclass_total * 8);
     char extra;
     const bool at_end = fread(&extra, 1, 1, f) == 0;
     fclose(f);
@@ -1203,6 +1251,15 @@ int32_t ngp_load_snapshot(ngp_handle *h, const char *path) {
     if ((rc = ngp_set_state(h, yc.data(), be.data(), de.data(), vb.data(), pi.data(), scal[0], scal[1], hdr[4]))) return rc;
     if ((rc = ngp_set_posterior_sums(h, sb.data(), sb2.data(), sd.data(), sv.data(), sp.data(), scal[2], scal[3], hdr[5]))) return rc;
     for (size_t si = 0; si < ns; si++) h->sets[si].fine_calls = fc[si];
+    {
+        size_t off = 0;
+        for (size_t si = 0; si < ns; si++)
+            if (h->sets[si].K > 0) {
+                const size_t K = (size_t)h->sets[si].K;
+                if ((rc = set_class_state_dev(h, (int)si, cls.data() + off, cls.data() + off + K))) return rc;
+                off += 2 * K;
+            }
+    }
     h->seed = ids[0]; h->chain = (uint32_t)ids[1];  // the draws continue the interrupted chain's streams
     return NGP_OK;
 }
@@ -1275,14 +1332,23 @@ int import_posterior_device(ngp_handle *h, const double *o) {  // inverse of ngp
     HCHK(hipMemcpyAsync(h->d_sum_beta2, o + h->P, pb, hipMemcpyDeviceToDevice, h->stream));
     HCHK(hipMemcpyAsync(h->d_sum_delta, o + 2 * h->P, pb, hipMemcpyDeviceToDevice, h->stream));
     if (h->nvb) HCHK(hipMemcpyAsync(h->d_sum_varBeta, o + 3 * h->P, (size_t)h->nvb * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    std::vector<double> tail(2 * h->sets.size() + 3);
+    std::vector<double> tail(2 * h->sets.size() + (size_t)h->nclass_total + 3);
     HCHK(hipMemcpyAsync(tail.data(), o + 3 * h->P + h->nvb, tail.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HCHK(hipStreamSynchronize(h->stream));
     for (size_t si = 0; si < h->sets.size(); si++)
         hipLaunchKernelGGL(k_set_sum_pi, dim3(1), dim3(1), 0, h->stream, h->d_sets, (int)si, tail[2 * si], tail[2 * si + 1]);
+    {
+        size_t off = 2 * h->sets.size();
+        for (size_t si = 0; si < h->sets.size(); si++)
+            if (h->sets[si].K > 0) {
+                int rc2 = set_class_state_dev(h, (int)si, nullptr, tail.data() + off);
+                if (rc2) return rc2;
+                off += (size_t)h->sets[si].K;
+            }
+    }
     DScal sc;
     HCHK(hipMemcpy(&sc, h->d_scal, sizeof(DScal), hipMemcpyDeviceToHost));
-    const size_t t0 = 2 * h->sets.size();
+    const size_t t0 = 2 * h->sets.size() + (size_t)h->nclass_total;
     sc.sum_varE = tail[t0]; sc.sum_b = tail[t0 + 1]; sc.nKept = (long long)std::llround(tail[t0 + 2]);
     HCHK(hipMemcpy(h->d_scal, &sc, sizeof(DScal), hipMemcpyHostToDevice));
     HCHK(hipStreamSynchronize(h->stream));
@@ -1355,6 +1421,71 @@ int32_t ngp_allreduce_posterior(ngp_handle **hs, int32_t n) {
     }
     cleanup();
     return NGP_OK;
+}
+
+
+/* BayesR marker set (src/runTime.jl:78-93, set-up src/mme.jl:374-383, sampler src/functions.jl:238-289): ONE variance for the set
+ * (varBeta0), K <= 4 variance classes with multipliers vClass[v] of that variance (a class with multiplier 0 = effect exactly
+ * 0) and class probabilities pi[v]; estPi: pi ~ Dirichlet(nLoci + 1) after every sweep.  delta holds the class of a locus,
+ * counted from 1 as the reference writes it. */
+int32_t ngp_add_marker_set_r(ngp_handle *h, int64_t col0, int64_t ncol, double df, double scale, double varBeta0, const double *vClass,
+                             const double *pi, int32_t K, int32_t estPi, const double *lhs0, const double *rhs0, int32_t *set_id) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
+    REQUIRE(vClass && pi && K >= 2 && K <= NGP_RMAX, NGP_ERR_ARG, "BayesR needs 2..4 variance classes with their probabilities");
+    double ps = 0.0;
+    for (int v = 0; v < K; v++) {
+        REQUIRE(std::isfinite(vClass[v]) && vClass[v] >= 0.0 && std::isfinite(pi[v]) && pi[v] > 0.0, NGP_ERR_ARG,
+                "BayesR: class multipliers must be >= 0 and class probabilities > 0");
+        ps += pi[v];
+    }
+    REQUIRE(std::fabs(ps - 1.0) < 1e-8, NGP_ERR_ARG, "BayesR: class probabilities must sum to 1");
+    REQUIRE(std::isfinite(varBeta0) && varBeta0 > 0.0, NGP_ERR_ARG, "BayesR varBeta0 must be positive");
+    if (!h->d_rcls) {
+        if ((rc = dalloc(h, &h->d_rcls, (size_t)4 * NGP_RMAX * (size_t)h->Ppad))) return rc;
+    }
+    const int64_t rs = 0, re = ncol;
+    int32_t sid = -1;
+    h->adding_r = true;
+    rc = ngp_add_marker_set(h, col0, ncol, NGP_METHOD_BAYESR, df, scale, &rs, &re, 1, &varBeta0, 0.5, estPi, lhs0, rhs0, &sid);
+    h->adding_r = false;
+    if (rc) return rc;
+    HSet &hs = h->sets[(size_t)sid];
+    hs.K = K; hs.vcls.assign(vClass, vClass + K); hs.rpi.assign(pi, pi + K);
+    DSet ds;
+    HCHK(hipMemcpy(&ds, h->d_sets + sid, sizeof(DSet), hipMemcpyDeviceToHost));
+    ds.K = K;
+    for (int v = 0; v < NGP_RMAX; v++) { ds.vcls[v] = v < K ? vClass[v] : 0.0; ds.pic[v] = 0.0; ds.logpic[v] = 0.0; ds.sum_pic[v] = 0.0; ds.ncls[v] = 0; }
+    HCHK(hipMemcpy(h->d_sets + sid, &ds, sizeof(DSet), hipMemcpyHostToDevice));
+    if ((rc = set_class_state_dev(h, sid, pi, std::vector<double>((size_t)K, 0.0).data()))) return rc;
+    h->nclass_total += K;
+    if (set_id) *set_id = sid;
+    return NGP_OK;
+}
+
+int32_t ngp_get_class_state(ngp_handle *h, int32_t set_id, double *piHat, double *sum_pi, int64_t *K) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(set_id >= 0 && set_id < (int)h->sets.size(), NGP_ERR_ARG, "unknown set id");
+    HCHK(hipStreamSynchronize(h->stream));
+    DSet ds;
+    HCHK(hipMemcpy(&ds, h->d_sets + set_id, sizeof(DSet), hipMemcpyDeviceToHost));
+    if (K) *K = h->sets[(size_t)set_id].K;
+    for (int v = 0; v < h->sets[(size_t)set_id].K; v++) {
+        if (piHat) piHat[v] = ds.pic[v];
+        if (sum_pi) sum_pi[v] = ds.sum_pic[v];
+    }
+    return NGP_OK;
+}
+
+int32_t ngp_set_class_state(ngp_handle *h, int32_t set_id, const double *piHat, const double *sum_pi, int64_t K) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(set_id >= 0 && set_id < (int)h->sets.size(), NGP_ERR_ARG, "unknown set id");
+    REQUIRE(h->sets[(size_t)set_id].K > 0 && K == h->sets[(size_t)set_id].K, NGP_ERR_ARG, "not a BayesR set, or another number of classes");
+    if (piHat) for (int64_t v = 0; v < K; v++) REQUIRE(std::isfinite(piHat[v]) && piHat[v] > 0.0, NGP_ERR_ARG, "class probabilities must be > 0");
+    return set_class_state_dev(h, set_id, piHat, sum_pi);
 }
 
 }  // extern "C"

@@ -19,6 +19,7 @@
 #define NGP_BLK 64
 #define NGP_SEG 256
 #define NGP_GRP 32
+#define NGP_RMAX 4  // variance classes of a BayesR set (the chain keeps their coefficients in registers)
 
 namespace ngp {
 
@@ -30,6 +31,10 @@ struct DSet {  // one marker set (src/mme.jl:324-361, 492-520)
     int nloci;  // included loci of the running BayesB sweep
     int pad_;
     double sum_pi0, sum_pi1;
+    // BayesR (src/functions.jl:238-289, set-up src/mme.jl:374-383): K classes, multipliers of the set's single variance
+    int K, pad2_;
+    double vcls[NGP_RMAX], pic[NGP_RMAX], logpic[NGP_RMAX], sum_pic[NGP_RMAX];
+    int ncls[NGP_RMAX];  // loci per class of the running sweep
 };
 
 struct DReg {  // one BayesPR variance region
@@ -49,6 +54,83 @@ __device__ inline double readlane_d(double v, int lane) {
     lo = __builtin_amdgcn_readlane(lo, lane);
     hi = __builtin_amdgcn_readlane(hi, lane);
     return __hiloint2double(hi, lo);
+}
+
+// ------------------------------------------------------------------------------------------
+// "r-form" of the block chain (blocks that hold a BayesR locus; DESIGN.md section 2, step 5'): every lane forms its candidate
+// dlt from the current r = x'(ycorr + x beta); the first lane at or behind the cursor with a non-zero candidate takes its
+// step, the candidates behind it are formed again.  One lane's rule:
+//   BayesR   class search of src/functions.jl:250-261 in a stable form (L_v - max L through det_exp; the v-th comparison
+//            cum_v >= u_v * sum with its own uniform u_v), then dlt = rhs / lhs_c + sd_c z - beta, or -beta in a zero class
+//   others   in = |r c| > thr, dlt = in ? r c + w : -beta   (BayesPR: always in)
+// ------------------------------------------------------------------------------------------
+struct RLane {  // class coefficients of one BayesR locus (k_prep): 1/lhs_v, log-weight a_v, sd_v z, uniform u_v; M.rhs
+    double q[NGP_RMAX], a[NGP_RMAX], t[NGP_RMAX], u[NGP_RMAX];
+    double rhs0;
+    int K;
+};
+__device__ inline RLane load_rlane(const double *__restrict__ rcls, long long Ppad, long long k, int K, const double *__restrict__ rhs0) {
+    RLane L;
+    L.K = K;
+    L.rhs0 = rhs0[k];
+#pragma unroll
+    for (int v = 0; v < NGP_RMAX; v++) {
+        const bool on = v < K;
+        const size_t o = (size_t)(on ? v : 0) * (size_t)Ppad + (size_t)k;
+        L.q[v] = on ? rcls[o] : 0.0;
+        L.a[v] = on ? rcls[(size_t)NGP_RMAX * Ppad + o] : 0.0;
+        L.t[v] = on ? rcls[(size_t)2 * NGP_RMAX * Ppad + o] : 0.0;
+        L.u[v] = on ? rcls[(size_t)3 * NGP_RMAX * Ppad + o] : 0.0;
+    }
+    return L;
+}
+__device__ inline void eval_rform(const int meth, const double r, const double bo, const double cc, const double ww, const double st,
+                                  const RLane &L, const double iVarE, double &cand, int &cls) {
+    if (meth == 3) {
+        const double t = r * iVarE;
+        const double rhs = t + L.rhs0;
+        const double s2 = rhs * rhs;
+        const double hs = 0.5 * s2;
+        double Lv[NGP_RMAX], e[NGP_RMAX];
+#pragma unroll
+        for (int v = 0; v < NGP_RMAX; v++) Lv[v] = (L.q[v] == 0.0) ? L.a[v] : __builtin_fma(hs, L.q[v], L.a[v]);
+        double m = Lv[0];
+#pragma unroll
+        for (int v = 1; v < NGP_RMAX; v++)
+            if (v < L.K && Lv[v] > m) m = Lv[v];
+        double S = 0.0;
+#pragma unroll
+        for (int v = 0; v < NGP_RMAX; v++)
+            if (v < L.K) {
+                e[v] = det_exp(Lv[v] - m);
+                S = S + e[v];
+            } else e[v] = 0.0;
+        int c = L.K - 1;
+        double cum = 0.0;
+        bool found = false;
+#pragma unroll
+        for (int v = 0; v < NGP_RMAX; v++)
+            if (v < L.K && !found) {
+                cum = cum + e[v];
+                const double thr = L.u[v] * S;
+                if (cum >= thr) { c = v; found = true; }
+            }
+        double qc = L.q[0], tc = L.t[0];
+#pragma unroll
+        for (int v = 1; v < NGP_RMAX; v++)
+            if (c == v) { qc = L.q[v]; tc = L.t[v]; }
+        if (qc != 0.0) {
+            const double d = __builtin_fma(rhs, qc, tc);
+            cand = d - bo;
+        } else cand = -bo;
+        cls = c + 1;
+    } else {
+        const double f = r * cc;
+        const int in = __builtin_fabs(f) > st;
+        const double e1 = __builtin_fma(r, cc, ww);
+        cand = in ? e1 : -bo;
+        cls = in;
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -138,7 +220,7 @@ __global__ __launch_bounds__(256) void k_prep(long long Ppad, const int8_t *__re
                                               double *__restrict__ c, double *__restrict__ w, double *__restrict__ q,
                                               double *__restrict__ T, double *__restrict__ chi, int active_set, uint64_t seed,
                                               uint64_t chain, uint64_t it, long long nreg, const DReg *__restrict__ regs,
-                                              double *__restrict__ regchi) {
+                                              double *__restrict__ regchi, double *__restrict__ rcls) {
     long long k = (long long)blockIdx.x * 256 + threadIdx.x;
     if (k < nreg) {  // data-independent draws of the region variances (functions.jl:509-511): off the post-sweep path
         const DReg Rg = regs[k];
@@ -161,6 +243,41 @@ __global__ __launch_bounds__(256) void k_prep(long long Ppad, const int8_t *__re
     const double varE = sc->varE, iVarE = sc->iVarE;
     const uint64_t l = (uint64_t)loc[k];
     const uint64_t key = ((uint64_t)si << 40) | l;
+    if (S.method == 3) {  // BayesR: per-class coefficients (src/functions.jl:254-255); the class is chosen inside the block chain
+        double *rq = rcls, *ra = rcls + (size_t)NGP_RMAX * Ppad, *rt = rcls + (size_t)2 * NGP_RMAX * Ppad, *ru = rcls + (size_t)3 * NGP_RMAX * Ppad;
+        const double varB = varBeta[vbidx[k]];
+        const double t1r = mpm[k] * iVarE;
+        const double t2r = t1r + lhs0[k];
+        Rng rz = rng_seed(seed, chain, it, NGP_KIND_BETA_NORMAL, key);
+        const double zr = rng_normal(rz);
+        for (int v = 0; v < S.K; v++) {
+            const double varc = varB * S.vcls[v];
+            Rng ruu = rng_seed(seed, chain, it, NGP_KIND_R_UNIFORM, ((uint64_t)si << 40) | (l << 3) | (uint64_t)v);
+            ru[(size_t)v * Ppad + k] = rng_uniform(ruu);
+            if (varc == 0.0) {
+                rq[(size_t)v * Ppad + k] = 0.0;
+                ra[(size_t)v * Ppad + k] = S.logpic[v];
+                rt[(size_t)v * Ppad + k] = 0.0;
+            } else {
+                const double iv = 1.0 / varc;
+                const double lhsv = t2r + iv;
+                const double ilhs = 1.0 / lhsv;
+                const double prod = varc * lhsv;
+                const double lg = det_log(prod);
+                const double hl = 0.5 * lg;
+                const double sd = det_sqrt(ilhs);
+                rq[(size_t)v * Ppad + k] = ilhs;
+                ra[(size_t)v * Ppad + k] = S.logpic[v] - hl;
+                rt[(size_t)v * Ppad + k] = sd * zr;
+            }
+        }
+        c[k] = 0.0;
+        w[k] = 0.0;
+        q[k] = -1.0;
+        T[k] = 1.0;
+        chi[k] = 1.0;
+        return;
+    }
     double vbk = varBeta[vbidx[k]];
     double m = mpm[k];
     double t1 = m * iVarE;
@@ -297,7 +414,8 @@ __global__ __launch_bounds__(256) void k_recur(const double *__restrict__ part, 
                                                const double *__restrict__ q, const double *__restrict__ mpm,
                                                const double *__restrict__ chi, const int8_t *__restrict__ setof,
                                                const int32_t *__restrict__ vbidx, DSet *__restrict__ sets,
-                                               double *__restrict__ varBeta, double *__restrict__ dlt) {
+                                               double *__restrict__ varBeta, double *__restrict__ dlt, const double *__restrict__ rcls,
+                                               long long Ppad, const double *__restrict__ rhs0, const DScal *__restrict__ sc) {
     __shared__ double gs[32 * NGP_BLK];
     const int tid = threadIdx.x, j = tid & 63, g4 = tid >> 6;
     const int ngroups = (S + NGP_GRP - 1) / NGP_GRP;
@@ -313,12 +431,58 @@ __global__ __launch_bounds__(256) void k_recur(const double *__restrict__ part, 
     for (int g = 1; g < ngroups; g++) tot = tot + gs[g * NGP_BLK + j];
     const long long k = (long long)t * NGP_BLK + j;
     const double *G = gramx + (size_t)t * D * NGP_BLK * NGP_BLK;
-    double Gr[NGP_BLK];
-#pragma unroll
-    for (int kk = 0; kk < NGP_BLK; kk++) Gr[kk] = G[kk * NGP_BLK + j];
     const double gd = mpm[k];
     const double bo = beta[k], cc = c[k], ww = w[k], st = q[k];
     const double r = __builtin_fma(gd, bo, tot);
+    const int si0 = setof[k];
+    const int meth0 = (si0 >= 0) ? sets[si0].method : -1;
+    if (__ballot(meth0 == 3) != 0ull) {  // a BayesR locus in the block: r-form chain (eval_rform)
+        RLane RL;
+        RL.K = 2; RL.rhs0 = 0.0;
+#pragma unroll
+        for (int v = 0; v < NGP_RMAX; v++) { RL.q[v] = 0.0; RL.a[v] = 0.0; RL.t[v] = 0.0; RL.u[v] = 0.0; }
+        if (meth0 == 3) RL = load_rlane(rcls, Ppad, k, sets[si0].K, rhs0);
+        const double iVarE = sc->iVarE;
+        double rcur = r, dfin = 0.0;
+        int cfin = 1, kstart = 0;
+        for (int guard = 0; guard < NGP_BLK + 1; ++guard) {
+            double cand;
+            int cls;
+            eval_rform(meth0, rcur, bo, cc, ww, st, RL, iVarE, cand, cls);
+            if (j >= kstart) { dfin = cand; cfin = cls; }
+            const unsigned long long todo = __ballot(cand != 0.0) & (~0ull << kstart);
+            if (!todo) break;
+            const int kk = __builtin_ctzll(todo);
+            const double dk = readlane_d(cand, kk);
+            const double Hk = -(G[(size_t)kk * NGP_BLK + j]);
+            rcur = __builtin_fma(Hk, dk, rcur);
+            kstart = kk + 1;
+            if (kstart >= NGP_BLK) break;
+        }
+        const double bn = bo + dfin;
+        beta[k] = bn;
+        delta[k] = (uint8_t)cfin;
+        dlt[j] = dfin;
+        if (meth0 == 1) {
+            double vb = 0.0;
+            if (cfin) {
+                double tt = sets[si0].sdf;
+                double b2 = bn * bn;
+                tt = tt + b2;
+                vb = tt / chi[k];
+                atomicAdd(&sets[si0].nloci, 1);
+            }
+            varBeta[vbidx[k]] = vb;
+        } else if (meth0 == 2) {
+            if (cfin) atomicAdd(&sets[si0].nloci, 1);
+        } else if (meth0 == 3) {
+            atomicAdd(&sets[si0].ncls[cfin - 1], 1);
+        }
+        return;
+    }
+    double Gr[NGP_BLK];
+#pragma unroll
+    for (int kk = 0; kk < NGP_BLK; kk++) Gr[kk] = G[kk * NGP_BLK + j];
     // scaled recursion: e = c r + w (candidate draw), f = c r (inclusion test |f| > thr), H_k = -(c G[.][k])
     double e = __builtin_fma(r, cc, ww), f = r * cc;
 #pragma unroll
@@ -378,6 +542,39 @@ __global__ __launch_bounds__(256) void k_regssq(long long nseg, const long long 
 }
 
 
+// BayesR: sum of beta^2 / vClass[class] over the loci of non-zero classes (sumS, src/functions.jl:272-273), same segment
+// pattern; overwrites the plain sums of the segments that belong to a BayesR set
+__global__ __launch_bounds__(256) void k_rssq(long long nseg, const long long *__restrict__ seg_k0, const int32_t *__restrict__ seg_len,
+                                              const int32_t *__restrict__ seg_set, const DSet *__restrict__ sets,
+                                              const double *__restrict__ beta, const uint8_t *__restrict__ delta,
+                                              double *__restrict__ segpart) {
+    const long long sg = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (sg >= nseg) return;
+    const int si = seg_set[sg];
+    if (sets[si].method != 3) return;
+    const int lane = threadIdx.x & 63;
+    const long long k0 = seg_k0[sg];
+    const int n = seg_len[sg];
+    double a = 0.0;
+#pragma unroll
+    for (int m = 0; m < 4; m++) {
+        const int i = lane + 64 * m;
+        if (i < n) {
+            const double bv = beta[k0 + i];
+            const int cl = (int)delta[k0 + i] - 1;
+            const double vc = sets[si].vcls[cl < 0 ? 0 : cl];
+            if (vc != 0.0) {
+                const double b2 = bv * bv;
+                const double term = b2 / vc;
+                a = a + term;
+            }
+        }
+    }
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) a = a + __shfl_xor(a, off);
+    if (lane == 0) segpart[sg] = a;
+}
+
 __global__ __launch_bounds__(64) void k_regdraw(long long nreg, const DReg *__restrict__ regs, const double *__restrict__ segpart,
                                                 const DSet *__restrict__ sets, double *__restrict__ varBeta, int active_set,
                                                 const double *__restrict__ regchi, uint64_t seed, uint64_t chain, uint64_t it) {
@@ -393,6 +590,13 @@ __global__ __launch_bounds__(64) void k_regdraw(long long nreg, const DReg *__re
         Rng rr = rng_seed(seed, chain, it, NGP_KIND_REGION_CHI2, ((uint64_t)R.set << 40) | (uint64_t)R.rg);
         ch = rng_chisq(rr, S.df + (double)S.nloci);
     }
+    if (S.method == 3) {     // BayesR (src/functions.jl:281, :518-520): df + loci in non-zero classes; tot is sumS (k_rssq)
+        long long nnz = 0;
+        for (int v = 0; v < S.K; v++)
+            if (S.vcls[v] != 0.0) nnz += S.ncls[v];
+        Rng rr = rng_seed(seed, chain, it, NGP_KIND_REGION_CHI2, ((uint64_t)R.set << 40));
+        ch = rng_chisq(rr, S.df + (double)nnz);
+    }
     double tt = S.scale * S.df;
     tt = tt + tot;
     varBeta[R.vb] = tt / ch;
@@ -404,6 +608,23 @@ __global__ void k_pidraw(int nsets, DSet *__restrict__ sets, int active_set, uin
     if (si >= nsets) return;
     if (active_set >= 0 && si != active_set) return;
     DSet *S = &sets[si];
+    if (S->method == 3) {  // BayesR: Dirichlet(nLoci + 1) as normalised gammas (src/functions.jl:284-288, :536-538)
+        if (S->estPi) {
+            double g[NGP_RMAX], gsum = 0.0;
+            for (int v = 0; v < S->K; v++) {
+                Rng rg = rng_seed(seed, chain, it, NGP_KIND_R_DIRICHLET, ((uint64_t)si << 40) | (uint64_t)v);
+                g[v] = rng_gamma(rg, (double)S->ncls[v] + 1.0);
+                gsum = gsum + g[v];
+            }
+            for (int v = 0; v < S->K; v++) {
+                S->pic[v] = g[v] / gsum;
+                S->logpic[v] = det_log(S->pic[v]);
+            }
+        }
+        for (int v = 0; v < NGP_RMAX; v++) S->ncls[v] = 0;
+        S->nloci = 0;
+        return;
+    }
     if (S->method >= 1 && S->estPi) {
         int nLoci = S->nloci;
         Rng r = rng_seed(seed, chain, it, NGP_KIND_PI_BETA, (uint64_t)si);
@@ -422,6 +643,13 @@ __global__ void k_set_pi(DSet *__restrict__ sets, int si, double p0, double p1) 
     sets[si].logPi0 = det_log(p0);
     sets[si].logPi1 = det_log(p1);
     sets[si].nloci = 0;
+}
+__global__ void k_set_class_state(DSet *__restrict__ sets, int si, int K, const double *__restrict__ pi, const double *__restrict__ sum_pi) {
+    for (int v = 0; v < K; v++) {
+        if (pi) { sets[si].pic[v] = pi[v]; sets[si].logpic[v] = det_log(pi[v]); }
+        if (sum_pi) sets[si].sum_pic[v] = sum_pi[v];
+    }
+    for (int v = 0; v < NGP_RMAX; v++) sets[si].ncls[v] = 0;
 }
 __global__ void k_set_sum_pi(DSet *__restrict__ sets, int si, double s0, double s1) {
     sets[si].sum_pi0 = s0;
@@ -464,6 +692,7 @@ __global__ __launch_bounds__(256) void k_accum(long long P, long long nvb, int n
     if (k < nsets) {
         sets[k].sum_pi0 += sets[k].piHat0;
         sets[k].sum_pi1 += sets[k].piHat1;
+        for (int v = 0; v < sets[k].K; v++) sets[k].sum_pic[v] += sets[k].pic[v];
     }
     if (k == 0) {
         sc->sum_varE += sc->varE;

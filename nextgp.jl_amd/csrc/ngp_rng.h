@@ -19,6 +19,8 @@
 #define NGP_KIND_B_UNIFORM 5
 #define NGP_KIND_B_LOCUS_CHI2 6
 #define NGP_KIND_PI_BETA 7
+#define NGP_KIND_R_UNIFORM 8    // BayesR: the fresh uniform of every comparison of the class search (src/functions.jl:261)
+#define NGP_KIND_R_DIRICHLET 9  // BayesR: gamma draws of the Dirichlet (src/functions.jl:536-538)
 
 #define NGP_GOLD 0x9E3779B97F4A7C15ULL
 
@@ -101,6 +103,26 @@ __device__ inline double det_log(double x) {
     double R = t2 + t1;
     double hfsq = 0.5 * f * f;
     return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
+}
+
+// det_exp for x <= 0: fixed IEEE sequence (fdlibm's argument reduction and degree-5 rational), bit for bit the oracle's; results
+// below 2^-1021 come back as 0.  Only the blocked BayesR class search uses it (on L - max L <= 0).
+__device__ inline double det_exp(double x) {
+    const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00;
+    const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    if (x != x) return x;
+    if (x < -708.0) return 0.0;
+    if (x > 0.0) x = 0.0;
+    const int k = (int)(invln2 * x - 0.5);
+    const double t = (double)k;
+    const double hi = x - t * ln2HI, lo = t * ln2LO;
+    const double xr = hi - lo;
+    const double tt = xr * xr;
+    const double c = xr - tt * (P1 + tt * (P2 + tt * (P3 + tt * (P4 + tt * P5))));
+    const double y = 1.0 - ((lo - (xr * c) / (2.0 - c)) - hi);
+    const double sc = __longlong_as_double((long long)((uint64_t)(k + 1023) << 52));
+    return y * sc;
 }
 
 // IEEE correctly rounded square root (sqrt() lowers to the ocml routine, which is)

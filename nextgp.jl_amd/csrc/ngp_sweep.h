@@ -62,6 +62,11 @@ struct SweepArgs {
     const int32_t *vbidx;
     DSet *sets;
     double *varBeta;
+    // BayesR (null / unused when the model has no BayesR set): per-class coefficients of k_prep, M.rhs, chain scalars
+    const double *rcls;
+    const double *rhs0;
+    const DScal *scal;
+    long long Ppad;
     // communication (zeroed before every launch)
     double *part;        // [RING][S][64]
     double *gsum;        // [RING][NG][64]
@@ -982,6 +987,8 @@ __device__ inline void publish_block(const SweepArgs &A, int up, int j, const do
         A.varBeta[vbi] = vb;
     } else if (meth == 2) {
         if (isave) atomicAdd(&A.sets[si].nloci, 1);  // BayesC: one variance per set, drawn after the sweep
+    } else if (meth == 3) {
+        atomicAdd(&A.sets[si].ncls[isave - 1], 1);   // BayesR: loci per class (nLoci, src/functions.jl:263); isave = class, from 1
     }
 }
 
@@ -1009,9 +1016,11 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
     double *ssdf = (double *)(sabort + 20);      // scale * df of each set
     const int nb = A.t1 - A.t0;
     const size_t bsz = NGP_BLK * NGP_BLK;
+    int *sK = sabort + 52;  // classes of each set (BayesR), behind ssdf
     if (tid < 16) {
         smeth[tid] = A.sets[tid].method;
         ssdf[tid] = A.sets[tid].sdf;
+        sK[tid] = A.sets[tid].K;
     }
     if (tid == 0) {
         *sabort = 0;
@@ -1085,7 +1094,40 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
             double e = __builtin_fma(r, cc, ww);
             double dsave;
             int isave = 1;
-            if (dbg_mode == 5 && __ballot(st >= 0.0) == 0ull) {
+            // BayesR: the lane's set and method (one byte per lane, read only when the model has a BayesR set at all)
+            int meth0 = -1, si0 = -1;
+            if (A.rcls) {
+                si0 = A.setof[(long long)t * NGP_BLK + j];
+                meth0 = (si0 >= 0) ? smeth[si0] : -1;
+            }
+            if (A.rcls && __ballot(meth0 == 3) != 0ull) {
+                // r-form chain (eval_rform, ngp_kernels.h): candidates of all lanes from the current r, the first non-zero one at
+                // or behind the cursor takes its step.  With most loci in the zero class that is a few steps per block.
+                RLane RL;
+                RL.K = 2; RL.rhs0 = 0.0;
+#pragma unroll
+                for (int v = 0; v < NGP_RMAX; v++) { RL.q[v] = 0.0; RL.a[v] = 0.0; RL.t[v] = 0.0; RL.u[v] = 0.0; }
+                if (meth0 == 3) RL = load_rlane(A.rcls, A.Ppad, (long long)t * NGP_BLK + j, sK[si0], A.rhs0);
+                const double iVarE = A.scal->iVarE;
+                double rcur = r, dfin = 0.0;
+                int cfin = 1, kstart = 0;
+                for (int guard = 0; guard < NGP_BLK + 1; ++guard) {
+                    double cand;
+                    int cls;
+                    eval_rform(meth0, rcur, bo, cc, ww, st, RL, iVarE, cand, cls);
+                    if (j >= kstart) { dfin = cand; cfin = cls; }
+                    const unsigned long long todo = __ballot(cand != 0.0) & (~0ull << kstart);
+                    if (!todo) break;
+                    const int kk = __builtin_ctzll(todo);
+                    const double dk = readlane_d(cand, kk);
+                    const double Hk = -(gdb[kk * NGP_BLK]);  // row kk of the one-sided block: 0 for lanes <= kk
+                    rcur = __builtin_fma(Hk, dk, rcur);
+                    kstart = kk + 1;
+                    if (kstart >= NGP_BLK) break;
+                }
+                dsave = dfin;
+                isave = cfin;
+            } else if (dbg_mode == 5 && __ballot(st >= 0.0) == 0ull) {
                 dsave = e;  // timing experiment: BayesPR blocks without the 64-step recursion
             } else if (__ballot(st >= 0.0) == 0ull) {
                 NGP_LOAD_G()

@@ -55,10 +55,14 @@
 #define KIND_B_UNIFORM 5
 #define KIND_B_LOCUS_CHI2 6
 #define KIND_PI_BETA 7
+#define KIND_R_UNIFORM 8   /* BayesR: the fresh uniform of every comparison of the class search (functions.jl:261) */
+#define KIND_R_DIRICHLET 9 /* BayesR: gamma draws of the Dirichlet (functions.jl:536-538) */
 
 #define METHOD_PR 0
 #define METHOD_B 1
 #define METHOD_C 2 /* BayesC: src/functions.jl:197-235 */
+#define METHOD_R 3 /* BayesR: src/functions.jl:238-289 */
+#define RMAX 4     /* variance classes of a BayesR set (the device keeps them in registers) */
 
 #define BLK 64
 #define SEG 256
@@ -138,6 +142,28 @@ static inline double det_log(double x) {
     double hfsq = 0.5 * f * f;
     return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
 }
+
+/* det_exp for x <= 0: fixed IEEE sequence (fdlibm's argument reduction and degree-5 rational), so that CPU and GPU agree
+   bitwise.  Results below 2^-1021 are returned as 0; the blocked BayesR path only ever calls it on L - max(L) <= 0. */
+static inline double det_exp(double x) {
+    const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00;
+    const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
+                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
+    if (x != x) return x;
+    if (x < -708.0) return 0.0;
+    if (x > 0.0) x = 0.0;
+    const int k = (int)(invln2 * x - 0.5);
+    const double t = (double)k;
+    const double hi = x - t * ln2HI, lo = t * ln2LO;
+    const double xr = hi - lo;
+    const double tt = xr * xr;
+    const double c = xr - tt * (P1 + tt * (P2 + tt * (P3 + tt * (P4 + tt * P5))));
+    const double y = 1.0 - ((lo - (xr * c) / (2.0 - c)) - hi);
+    uint64_t sb = (uint64_t)(k + 1023) << 52; /* 2^k, k >= -1021 */
+    double sc; memcpy(&sc, &sb, 8);
+    return y * sc;
+}
+double ora_det_exp(double x) { return det_exp(x); }
 
 /* ------------------------------------------------------------------ */
 /* Normal quantile, Wichura (1988) AS241 PPND16                         */
@@ -269,6 +295,8 @@ typedef struct {
     double piHat[2], logPi[2];
     int estPi;
     double sum_pi[2];
+    /* BayesR (functions.jl:238-289): K variance classes with multipliers vcls of the set's single variance */
+    int K; double vcls[RMAX], pic[RMAX], logpic[RMAX], sum_pic[RMAX];
 } oset_t;
 
 typedef struct {
@@ -309,6 +337,7 @@ typedef struct {
     int64_t ntrace; double *tr_varE, *tr_b;
     /* scratch for blocked */
     double *c, *w, *q, *T, *chi;
+    double *rcls; /* BayesR per-locus class coefficients of the blocked order: [4][RMAX][Ppad] = 1/lhs, a, sd z, u */
     char err[256];
 } ora_t;
 
@@ -339,7 +368,7 @@ void ora_destroy(ora_t *h) {
     free(h->data); free(h->Mp); free(h->tiles); free(h->gram); free(h->gramx); free(h->mpm); free(h->lhs0); free(h->rhs0);
     free_sets(h); free(h->varBeta); free(h->sum_varBeta); free(h->y); free(h->ycorr); free(h->beta); free(h->delta);
     free(h->sum_beta); free(h->sum_beta2); free(h->sum_delta); free(h->tr_varE); free(h->tr_b);
-    free(h->c); free(h->w); free(h->q); free(h->T); free(h->chi);
+    free(h->c); free(h->w); free(h->q); free(h->T); free(h->chi); free(h->rcls);
     free(h);
 }
 const char *ora_last_error(ora_t *h) { return h->err; }
@@ -499,6 +528,30 @@ int ora_add_marker_set(ora_t *h, int64_t col0, int64_t ncol, int method, double 
     return ORA_OK;
 }
 
+/* BayesR set (mme.jl:374-383): one variance (nVarCov = 1), class multipliers vClass and class probabilities pi (K each) */
+int ora_add_marker_set_r(ora_t *h, int64_t col0, int64_t ncol, double df, double scale, double varBeta0, const double *vClass,
+                         const double *pi, int K, int estPi, const double *lhs0, const double *rhs0, int *set_id) {
+    if (K < 2 || K > RMAX) { snprintf(h->err, 256, "BayesR: 2..%d variance classes", RMAX); return ORA_ERR; }
+    const int64_t rs = 0, re = ncol;
+    int rc = ora_add_marker_set(h, col0, ncol, METHOD_R, df, scale, &rs, &re, 1, &varBeta0, 0.5, estPi, lhs0, rhs0, set_id);
+    if (rc) return rc;
+    oset_t *s = &h->sets[h->nsets - 1];
+    if (h->order == 1 && !h->rcls) h->rcls = (double *)calloc((size_t)4 * RMAX * h->Ppad, sizeof(double));
+    s->K = K;
+    for (int v = 0; v < K; v++) {
+        s->vcls[v] = vClass[v]; s->pic[v] = pi[v]; s->sum_pic[v] = 0.0;
+        s->logpic[v] = (h->order == 0) ? log(pi[v]) : det_log(pi[v]);   /* mme.jl:375 */
+    }
+    return ORA_OK;
+}
+int ora_get_class_state(ora_t *h, int si, double *piHat, double *sum_pi, int64_t *K) {
+    if (si < 0 || si >= h->nsets) return ORA_ERR;
+    oset_t *s = &h->sets[si];
+    if (K) *K = s->K;
+    for (int v = 0; v < s->K; v++) { if (piHat) piHat[v] = s->pic[v]; if (sum_pi) sum_pi[v] = s->sum_pic[v]; }
+    return ORA_OK;
+}
+
 int ora_set_y(ora_t *h, const double *y, int64_t N) {
     if (N != h->N) { snprintf(h->err, 256, "y length mismatch"); return ORA_ERR; }
     int64_t L = (h->order == 0) ? N : h->R * h->S;
@@ -529,6 +582,7 @@ static void accumulate(ora_t *h) {
     }
     for (int64_t r = 0; r < h->nvb; r++) h->sum_varBeta[r] += h->varBeta[r];
     for (int s = 0; s < h->nsets; s++) { h->sets[s].sum_pi[0] += h->sets[s].piHat[0]; h->sets[s].sum_pi[1] += h->sets[s].piHat[1]; }
+    for (int s = 0; s < h->nsets; s++) for (int v = 0; v < h->sets[s].K; v++) h->sets[s].sum_pic[v] += h->sets[s].pic[v];
     h->sum_varE += h->varE; h->sum_b += h->b; h->nKept++;
 }
 
@@ -663,6 +717,58 @@ static void iter_ref(ora_t *h) {
                 S->piHat[0] = 1.0 - piIn; S->piHat[1] = piIn;
                 S->logPi[0] = log(1.0 - piIn); S->logPi[1] = log(piIn);
             }
+        } else if (S->method == METHOD_R) {
+            /* functions.jl:238-289.  The class search `findfirst(x->x>=rand(), cumProbs)` (:261) draws a FRESH uniform for every
+               comparison -- a biased categorical draw for more than two classes; reproduced, with one keyed uniform per
+               (locus, comparison).  If no comparison succeeds (cumProbs[end] rounded below a uniform, or NaN probabilities
+               after an overflow of exp) the reference fails with an indexing error; here the last class is taken. */
+            const int K = S->K;
+            int64_t nLoci[RMAX] = {0, 0, 0, 0};
+            int64_t nNonZero = 0;
+            double varc[RMAX];
+            for (int v = 0; v < K; v++) varc[v] = vb[0] * S->vcls[v];                             /* :244 */
+            double sumS = 0.0;
+            for (int64_t l = 0; l < S->ncol; l++) {
+                int64_t j = S->col0 + l;
+                const double *col = h->data + j * N, *mp = h->Mp + j * N;
+                axpy(h->beta[j], col, h->ycorr, N);                                               /* :249 */
+                double rhs = dot8(mp, h->ycorr, N) * iVarE + h->rhs0[j];                          /* :250 */
+                double lhs[RMAX], ExpLogL[RMAX], sum = 0.0;
+                for (int v = 0; v < K; v++) {
+                    lhs[v] = (varc[v] == 0.0) ? 0.0 : h->mpm[j] * iVarE + h->lhs0[j] + 1.0 / varc[v];                        /* :254 */
+                    double logLc = (varc[v] == 0.0) ? S->logpic[v] : -0.5 * (log(varc[v] * lhs[v]) - ((rhs * rhs) / lhs[v])) + S->logpic[v]; /* :255 */
+                    ExpLogL[v] = exp(logLc);                                                      /* :256 */
+                    sum += ExpLogL[v];
+                }
+                int cls = K - 1;
+                double cum = 0.0;
+                for (int v = 0; v < K; v++) {
+                    cum += ExpLogL[v] / sum;                                                      /* :259-260 */
+                    rng_seed(&r, h->seed, h->chain, it, KIND_R_UNIFORM, ((uint64_t)si << 40) | ((uint64_t)l << 3) | (uint64_t)v);
+                    if (cum >= rng_uniform(&r)) { cls = v; break; }                               /* :261 */
+                }
+                h->delta[j] = cls + 1;                                                            /* :262, classes count from 1 */
+                nLoci[cls]++;
+                if (varc[cls] != 0.0) {                                                           /* :265 */
+                    nNonZero++;
+                    double mean = rhs / lhs[cls];
+                    rng_seed(&r, h->seed, h->chain, it, KIND_BETA_NORMAL, ((uint64_t)si << 40) | (uint64_t)l);
+                    h->beta[j] = mean + sqrt(1.0 / lhs[cls]) * rng_normal(&r);                    /* :268 */
+                    axpy(-1.0 * h->beta[j], col, h->ycorr, N);                                    /* :270 */
+                    sumS += (h->beta[j] * h->beta[j]) / S->vcls[cls];                             /* :272-273 */
+                } else h->beta[j] = 0.0;                                                          /* :275 */
+            }
+            rng_seed(&r, h->seed, h->chain, it, KIND_REGION_CHI2, ((uint64_t)si << 40));
+            vb[0] = (S->scale * S->df + sumS) / rng_chisq(&r, S->df + (double)nNonZero);          /* :281, :518-520 */
+            if (S->estPi) {                                                                       /* :284-288, :536-538 */
+                double g[RMAX], gs = 0.0;
+                for (int v = 0; v < K; v++) {
+                    rng_seed(&r, h->seed, h->chain, it, KIND_R_DIRICHLET, ((uint64_t)si << 40) | (uint64_t)v);
+                    g[v] = rng_gamma(&r, (double)nLoci[v] + 1.0);
+                    gs += g[v];
+                }
+                for (int v = 0; v < K; v++) { S->pic[v] = g[v] / gs; S->logpic[v] = log(S->pic[v]); }
+            }
         } else {
             /* functions.jl:157-195; one region per locus (mme.jl:356-358) */
             int64_t nLoci = 0;
@@ -759,6 +865,26 @@ static void iter_blocked(ora_t *h) {
         for (int64_t rg = 0; rg < Sx->nreg; rg++)
             for (int64_t l = Sx->reg_start[rg]; l < Sx->reg_stop[rg]; l++) {
                 int64_t k = Sx->col0 + l;
+                if (Sx->method == METHOD_R) { /* per-class coefficients; the class is chosen inside the block chain */
+                    const size_t PP = (size_t)h->Ppad;
+                    double *rq = h->rcls, *ra = h->rcls + RMAX * PP, *rt = h->rcls + 2 * RMAX * PP, *ru = h->rcls + 3 * RMAX * PP;
+                    double t1r = h->mpm[k] * iVarE; double t2r = t1r + h->lhs0[k];
+                    rng_seed(&r, h->seed, h->chain, it, KIND_BETA_NORMAL, ((uint64_t)si << 40) | (uint64_t)l);
+                    double zr = rng_normal(&r);
+                    for (int v = 0; v < Sx->K; v++) {
+                        double varc = vb[0] * Sx->vcls[v];
+                        rng_seed(&r, h->seed, h->chain, it, KIND_R_UNIFORM, ((uint64_t)si << 40) | ((uint64_t)l << 3) | (uint64_t)v);
+                        ru[v * PP + k] = rng_uniform(&r);
+                        if (varc == 0.0) { rq[v * PP + k] = 0.0; ra[v * PP + k] = Sx->logpic[v]; rt[v * PP + k] = 0.0; }
+                        else {
+                            double iv = 1.0 / varc; double lhsv = t2r + iv; double ilhs = 1.0 / lhsv;
+                            double prod = varc * lhsv; double lg = det_log(prod); double hl = 0.5 * lg;
+                            double sd = sqrt(ilhs);
+                            rq[v * PP + k] = ilhs; ra[v * PP + k] = Sx->logpic[v] - hl; rt[v * PP + k] = sd * zr;
+                        }
+                    }
+                    continue; /* c = w = 0, q = -1 stay (unused by the r-form chain for this lane) */
+                }
                 double vbk = (Sx->method == METHOD_B) ? vb[l] : vb[rg];
                 double mpm = h->mpm[k];
                 double t1 = mpm * iVarE; double t2 = t1 + h->lhs0[k];
@@ -878,6 +1004,64 @@ static void iter_blocked(ora_t *h) {
             }
             rr[j] = __builtin_fma(G[j * BLK + j], h->beta[k0 + j], tot);
         }
+        /* Blocks that hold a BayesR locus: the chain runs on r itself ("r-form").  All lanes form their candidate dlt from the
+           current r; the first lane at or behind the cursor whose candidate is not zero takes its step (r_j -= G_jk dlt_k for
+           the later lanes) and the candidates behind it are formed again; lanes whose candidate is zero change nothing and
+           are passed over.  Lanes of other methods in such a block follow their own rule, written in r. */
+        int has_r = 0;
+        int lane_set[BLK];
+        for (int j = 0; j < BLK; j++) {
+            lane_set[j] = -1;
+            for (int si = 0; si < h->nsets; si++)
+                if (k0 + j >= h->sets[si].col0 && k0 + j < h->sets[si].col0 + h->sets[si].ncol) lane_set[j] = si;
+            if (lane_set[j] >= 0 && h->sets[lane_set[j]].method == METHOD_R) has_r = 1;
+        }
+        if (has_r) {
+            const size_t PP = (size_t)h->Ppad;
+            const double *rq = h->rcls, *ra = h->rcls + RMAX * PP, *rt = h->rcls + 2 * RMAX * PP, *ru = h->rcls + 3 * RMAX * PP;
+            double cand[BLK]; int cls[BLK];
+            int kstart = 0;
+            for (;;) {
+                for (int j = kstart; j < BLK; j++) {
+                    const int64_t k = k0 + j;
+                    const double bo = h->beta[k];
+                    const int si = lane_set[j];
+                    if (si >= 0 && h->sets[si].method == METHOD_R) {
+                        const oset_t *Sx = &h->sets[si];
+                        double t = rr[j] * iVarE; double rhs = t + h->rhs0[k]; double s2 = rhs * rhs; double hs = 0.5 * s2;
+                        double L[RMAX], e[RMAX];
+                        for (int v = 0; v < Sx->K; v++) L[v] = (rq[v * PP + k] == 0.0) ? ra[v * PP + k] : __builtin_fma(hs, rq[v * PP + k], ra[v * PP + k]);
+                        double m = L[0];
+                        for (int v = 1; v < Sx->K; v++) if (L[v] > m) m = L[v];
+                        double Ssum = 0.0;
+                        for (int v = 0; v < Sx->K; v++) { e[v] = det_exp(L[v] - m); Ssum = Ssum + e[v]; }
+                        int c = Sx->K - 1; double cum = 0.0;
+                        for (int v = 0; v < Sx->K; v++) { cum = cum + e[v]; double thr = ru[v * PP + k] * Ssum; if (cum >= thr) { c = v; break; } }
+                        if (rq[c * PP + k] != 0.0) { double d = __builtin_fma(rhs, rq[c * PP + k], rt[c * PP + k]); cand[j] = d - bo; }
+                        else cand[j] = -bo;
+                        cls[j] = c + 1;
+                    } else {
+                        double f = rr[j] * h->c[k];
+                        int in = fabs(f) > h->q[k];
+                        double e1 = __builtin_fma(rr[j], h->c[k], h->w[k]);
+                        cand[j] = in ? e1 : -bo;
+                        cls[j] = in;
+                    }
+                }
+                int kk = -1;
+                for (int j = kstart; j < BLK; j++) if (cand[j] != 0.0) { kk = j; break; }
+                if (kk < 0) break;
+                for (int j = kk + 1; j < BLK; j++) rr[j] = __builtin_fma(-G[j * BLK + kk], cand[kk], rr[j]);
+                kstart = kk + 1;
+                if (kstart >= BLK) break;
+            }
+            for (int k = 0; k < BLK; k++) {
+                hist[tb * BLK + k] = cand[k];
+                h->beta[k0 + k] = h->beta[k0 + k] + cand[k];
+                h->delta[k0 + k] = cls[k];
+            }
+            continue;
+        }
         /* recursion in the scaled variables e_j = c_j r_j + w_j (the candidate draw) and f_j = c_j r_j (for the
            inclusion test |f_j| > thr_j = st_j c_j): one fma per step on the serial path, H_jk = -(c_j G_jk) */
         double ee[BLK], ff[BLK];
@@ -906,6 +1090,43 @@ static void iter_blocked(ora_t *h) {
     for (int si = 0; si < h->nsets; si++) {
         oset_t *Sx = &h->sets[si];
         double *vb = h->varBeta + Sx->vb_off;
+        if (Sx->method == METHOD_R) {
+            int64_t nL[RMAX] = {0, 0, 0, 0}, nNonZero = 0;
+            for (int64_t l = 0; l < Sx->ncol; l++) nL[h->delta[Sx->col0 + l] - 1]++;
+            for (int v = 0; v < Sx->K; v++) if (Sx->vcls[v] != 0.0) nNonZero += nL[v];
+            double tot = 0.0; int first = 1;
+            for (int64_t l0 = 0; l0 < Sx->ncol; l0 += SEG) {
+                int64_t l1 = l0 + SEG < Sx->ncol ? l0 + SEG : Sx->ncol;
+                double lane[64];
+                for (int l = 0; l < 64; l++) {
+                    double a = 0.0;
+                    for (int m = 0; m < 4; m++) {
+                        int64_t ll = l0 + l + 64 * m;
+                        if (ll < l1) {
+                            double bv = h->beta[Sx->col0 + ll]; double vc = Sx->vcls[h->delta[Sx->col0 + ll] - 1];
+                            if (vc != 0.0) { double b2 = bv * bv; double term = b2 / vc; a = a + term; }
+                        }
+                    }
+                    lane[l] = a;
+                }
+                double p = wave_butterfly(lane);
+                tot = first ? p : tot + p; first = 0;
+            }
+            rng_seed(&r, h->seed, h->chain, it, KIND_REGION_CHI2, ((uint64_t)si << 40));
+            double ch = rng_chisq(&r, Sx->df + (double)nNonZero);
+            double tt = Sx->scale * Sx->df; tt = tt + tot;
+            vb[0] = tt / ch;
+            if (Sx->estPi) {
+                double g[RMAX], gs = 0.0;
+                for (int v = 0; v < Sx->K; v++) {
+                    rng_seed(&r, h->seed, h->chain, it, KIND_R_DIRICHLET, ((uint64_t)si << 40) | (uint64_t)v);
+                    g[v] = rng_gamma(&r, (double)nL[v] + 1.0);
+                    gs = gs + g[v];
+                }
+                for (int v = 0; v < Sx->K; v++) { Sx->pic[v] = g[v] / gs; Sx->logpic[v] = det_log(Sx->pic[v]); }
+            }
+            continue;
+        }
         if (Sx->method == METHOD_PR || Sx->method == METHOD_C) {
             int64_t nLoci = 0;
             if (Sx->method == METHOD_C)

@@ -36,6 +36,8 @@ def lib():
         L.ora_det_log.argtypes = [C.c_double]
         L.ora_ppnd16.restype = C.c_double
         L.ora_ppnd16.argtypes = [C.c_double]
+        L.ora_det_exp.restype = C.c_double
+        L.ora_det_exp.argtypes = [C.c_double]
         L.ora_last_error.restype = C.c_char_p
         L.ora_nvb.restype = C.c_int64
         _lib = L
@@ -57,6 +59,10 @@ def det_log(x):
 
 def ppnd16(p):
     return lib().ora_ppnd16(float(p))
+
+
+def det_exp(x):
+    return lib().ora_det_exp(float(x))
 
 
 def draws(seed, chain, it, kind, index, what, n, p1=0.0, p2=0.0, indexed=False):
@@ -131,6 +137,24 @@ class Oracle:
                                             _p(r0, C.c_double), C.byref(sid)))
         self.nsets += 1
         return sid.value
+
+    def add_marker_set_r(self, col0, ncol, df, scale, varBeta0, vClass, pi, estPi=False, lhs0=None, rhs0=None):
+        """BayesR set (mme.jl:374-383): class multipliers vClass and class probabilities pi."""
+        vc = np.ascontiguousarray(vClass, dtype=np.float64); pp = np.ascontiguousarray(pi, dtype=np.float64)
+        assert len(vc) == len(pp)
+        l0 = None if lhs0 is None else np.ascontiguousarray(lhs0, dtype=np.float64)
+        r0 = None if rhs0 is None else np.ascontiguousarray(rhs0, dtype=np.float64)
+        sid = C.c_int()
+        self._chk(self.L.ora_add_marker_set_r(self.h, C.c_int64(col0), C.c_int64(ncol), C.c_double(df), C.c_double(scale), C.c_double(varBeta0),
+                                              _p(vc, C.c_double), _p(pp, C.c_double), C.c_int(len(vc)), C.c_int(int(estPi)), _p(l0, C.c_double),
+                                              _p(r0, C.c_double), C.byref(sid)))
+        self.nsets += 1
+        return sid.value
+
+    def get_class_state(self, set_id):
+        pi = np.empty(8); sp = np.empty(8); K = C.c_int64()
+        self._chk(self.L.ora_get_class_state(self.h, C.c_int(set_id), _p(pi, C.c_double), _p(sp, C.c_double), C.byref(K)))
+        return dict(piHat=pi[:K.value].copy(), sum_pi=sp[:K.value].copy())
 
     def set_y(self, y):
         y = np.ascontiguousarray(y, dtype=np.float64)

@@ -22,6 +22,11 @@ def O():
 
 @pytest.fixture(scope="session")
 def ngp():
+    try:  # torch's HIP initialisation first (tests that hand torch device buffers to the library found it failing when it came second)
+        import torch
+        torch.cuda.is_available()
+    except Exception:
+        pass
     from ngp_pkg import load_pkg
     return load_pkg()
 
@@ -43,7 +48,7 @@ def make_problem(O, N, P, seed=1, ncausal=10, h2=0.5, panel_seed=20250509):
 
 
 def add_sets(m, spec, v):
-    """spec: list of (col0, ncol, 'PR'|'B'|'Bfix'|'C'|'Cfix'|'PR1'|('PRw', width)); same calls on oracle and product."""
+    """spec: list of (col0, ncol, 'PR'|'B'|'Bfix'|'C'|'Cfix'|'PR1'|('PRw', width)|'R'|'Rfix'|'R2'); same calls on oracle and product."""
     df = 4.0
     for col0, ncol, kind in spec:
         if kind == "PR":
@@ -64,5 +69,11 @@ def add_sets(m, spec, v):
             m.add_marker_set(col0, ncol, 2, df, v * (df - 2) / df, [(0, ncol)], [v], pi0=0.05, estPi=True)
         elif kind == "Cfix":
             m.add_marker_set(col0, ncol, 2, df, v * (df - 2) / df, [(0, ncol)], [v], pi0=0.3, estPi=False)
+        elif kind == "R":      # BayesR: zero class + three non-zero classes, pi estimated (src/mme.jl:374-383)
+            m.add_marker_set_r(col0, ncol, df, v * (df - 2) / df, v, [0.0, 0.01, 0.1, 1.0], [0.85, 0.10, 0.04, 0.01], estPi=True)
+        elif kind == "Rfix":   # three classes, none of them zero, pi fixed
+            m.add_marker_set_r(col0, ncol, df, v * (df - 2) / df, v, [0.001, 0.1, 1.0], [0.6, 0.3, 0.1], estPi=False)
+        elif kind == "R2":     # two classes: the zero class first is not required by the reference
+            m.add_marker_set_r(col0, ncol, df, v * (df - 2) / df, v, [1.0, 0.0], [0.3, 0.7], estPi=True)
         else:
             raise ValueError(kind)

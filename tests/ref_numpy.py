@@ -10,6 +10,7 @@ varBeta[set] a vector -- and every statement cites the line it restates:
     /root/reference/src/functions.jl:118-137   sampleBayesPR!(::Symbol)
     /root/reference/src/functions.jl:157-195   sampleBayesB!
     /root/reference/src/functions.jl:197-235   sampleBayesC!
+    /root/reference/src/functions.jl:238-289   sampleBayesR!
     /root/reference/src/functions.jl:493-495, 509-511, 523-525, 531-533   sampleBeta, sampleVarBetaPR, sampleVarE, samplePi
 
 The only thing shared with the oracle is the draw layer (the reference's own draws come from Distributions.jl / Random,
@@ -151,6 +152,53 @@ class RefChain:
         if M["estPi"]:
             self.samplePi(si, nLoci)
 
+    def add_set_r(self, col0, ncol, df, scale, varBeta0, vClass, pi, estPi=False, lhs=None, rhs=None):   # mme.jl:374-383
+        self.add_set(col0, ncol, 3, df, scale, [(j, j + 1) for j in range(ncol)], [varBeta0], pi0=0.5, estPi=estPi, lhs=lhs, rhs=rhs)
+        M = self.M[-1]
+        M["vClass"] = np.array(vClass, float); M["piHat"] = np.array(pi, float); M["logPi"] = np.log(M["piHat"])
+
+    def sampleBayesR(self, si, varE):                        # :238-289
+        M, beta, delta, vb = self.M[si], self.beta[si], self.delta[si], self.varBeta[si]
+        nVarClass = len(M["vClass"])
+        nLoci = np.zeros(nVarClass, dtype=np.int64)
+        nNonZero = 0
+        varc = vb[0] * M["vClass"]                                                                # :244
+        sumS = 0.0
+        iVarE = 1.0 / varE
+        for r, theseLoci in enumerate(M["regionArray"]):
+            for locus in theseLoci:
+                self.ycorr += beta[locus] * M["data"][:, locus]                                   # :249
+                rhs = np.dot(M["Mp"][locus], self.ycorr) * iVarE + M["rhs"][locus]                # :250
+                lhs = np.zeros(nVarClass); ExpLogL = np.zeros(nVarClass)
+                for v in range(nVarClass):
+                    lhs[v] = 0.0 if varc[v] == 0.0 else M["mpm"][locus] * iVarE + M["lhs"][locus] + 1.0 / varc[v]                 # :254
+                    logLc = M["logPi"][v] if varc[v] == 0.0 else -0.5 * (math.log(varc[v] * lhs[v]) - ((rhs ** 2) / lhs[v])) + M["logPi"][v]  # :255
+                    ExpLogL[v] = math.exp(logLc)
+                probs = ExpLogL / ExpLogL.sum()                                                   # :259
+                cumProbs = np.cumsum(probs)
+                classSNP = nVarClass - 1
+                for v in range(nVarClass):                    # findfirst(x -> x >= rand(), cumProbs): a fresh uniform per comparison
+                    if cumProbs[v] >= self.draw("R_UNIFORM", (si << 40) | (locus << 3) | v, 0):
+                        classSNP = v
+                        break
+                delta[locus] = classSNP + 1                                                       # :262
+                nLoci[classSNP] += 1
+                if varc[classSNP] != 0.0:                                                         # :265
+                    nNonZero += 1
+                    meanBeta = rhs / lhs[classSNP]
+                    betaSample = self.sampleBeta(si, locus, meanBeta, lhs[classSNP])
+                    beta[locus] = betaSample
+                    self.ycorr += -1.0 * beta[locus] * M["data"][:, locus]                        # :270
+                    sumS += betaSample ** 2 / M["vClass"][classSNP]                               # :272-273
+                else:
+                    beta[locus] = 0.0
+        vb[0] = (M["scale"] * M["df"] + sumS) / self.draw("REGION_CHI2", (si << 40), 2, M["df"] + nNonZero)   # :281, :518-520
+        if M["estPi"]:                                                                            # :284-288, :536-538
+            g = np.array([self.O.draws(self.seed, self.chain, self.iter, KIND["R_DIRICHLET"], (si << 40) | v, 4, 1, nLoci[v] + 1.0, indexed=True)[0]
+                          for v in range(nVarClass)])
+            M["piHat"][:] = g / g.sum()
+            M["logPi"][:] = np.log(M["piHat"])
+
     # ---- samplers.jl:29-53 ----
     def run(self, niter):
         for _ in range(niter):
@@ -160,8 +208,10 @@ class RefChain:
             if self.intercept:
                 self.sampleX(varE)                           # :39-41
             for si, M in enumerate(self.M):                  # :50-53
-                {0: self.sampleBayesPR, 1: self.sampleBayesB, 2: self.sampleBayesC}[M["method"]](si, varE)
+                {0: self.sampleBayesPR, 1: self.sampleBayesB, 2: self.sampleBayesC, 3: self.sampleBayesR}[M["method"]](si, varE)
 
     def state(self):
         return dict(ycorr=self.ycorr.copy(), beta=np.concatenate(self.beta), delta=np.concatenate(self.delta),
-                    varBeta=np.concatenate(self.varBeta), piHat=np.concatenate([m["piHat"] for m in self.M]), varE=self.varE, b=float(self.b[0]))
+                    varBeta=np.concatenate(self.varBeta),
+                    piHat=np.concatenate([m["piHat"] if m["method"] != 3 else np.array([0.5, 0.5]) for m in self.M]),
+                    class_pi=[m["piHat"].copy() if m["method"] == 3 else None for m in self.M], varE=self.varE, b=float(self.b[0]))

@@ -96,6 +96,8 @@ CASES = [
     ("c_single", 400, 520, [(0, 520, "C")]),
     ("c_fixpi_multi", 300, 330, [(0, 100, "Cfix"), (100, 90, "B"), (190, 140, "C")]),
     ("tiny", 7, 3, [(0, 3, "PR")]),
+    ("r_single", 400, 520, [(0, 520, "R")]),                                     # BayesR (src/functions.jl:238-289)
+    ("r_multi", 300, 330, [(0, 100, "Rfix"), (100, 90, "B"), (190, 100, "R2"), (290, 40, "PR")]),   # BayesR lanes beside others in one block
 ]
 
 
@@ -123,13 +125,19 @@ def test_chain_bit_exact_vs_blocked_oracle(ngp, O, name, N, P, spec, engine):
     for k in ("sum_beta", "sum_beta2", "sum_delta", "sum_varBeta", "sum_pi"):
         assert np.array_equal(pa[k], pb[k]), k
     assert pa["sum_varE"] == pb["sum_varE"] and pa["sum_b"] == pb["sum_b"]
+    for si, (_, _, kind) in enumerate(spec):
+        if isinstance(kind, str) and kind.startswith("R"):          # BayesR: class probabilities and their posterior sums
+            ca, cb = s.get_class_state(si), o.get_class_state(si)
+            assert np.array_equal(ca["piHat"], cb["piHat"]) and np.array_equal(ca["sum_pi"], cb["sum_pi"]) and abs(ca["piHat"].sum() - 1.0) < 1e-14
+            cls = a["delta"][spec[si][0]:spec[si][0] + spec[si][1]]
+            assert cls.min() >= 1 and cls.max() <= len(ca["piHat"])
     # self-consistency: ycorr == y - 1 b - X beta recomputed from scratch
     resid = y - a["b"] - s.xbeta(a["beta"])
     assert np.abs(a["ycorr"] - resid).max() <= 1e-10 * max(1.0, np.abs(y).max())
 
 
 @pytest.mark.parametrize("engine", [(0, 1), (1, 6)], ids=["blocklaunch", "persist_lag6"])
-@pytest.mark.parametrize("kind", ["PR", "B", "C"])
+@pytest.mark.parametrize("kind", ["PR", "B", "C", "R"])
 def test_chain_vs_reference_order_oracle(ngp, O, kind, engine):
     """Same Markov chain, reference summation order: indicators identical, floats within 1e-9 relative."""
     N, P = 500, 1000

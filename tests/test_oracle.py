@@ -334,3 +334,41 @@ def test_fp32_panel_deviation(O, kind):
               f"max |d posterior mean| = {dmean:.3e} (largest posterior sd {sd:.3e})")
         assert same[0]                                            # the first 50 iterations agree locus by locus
         assert dmean <= 1.0 * sd + 1e-12                          # afterwards: two realisations of one posterior
+
+
+def test_numpy_restatement_bayesr(O):
+    """BayesR (functions.jl:238-289) in the numpy restatement against both orders of the C oracle: classes identical, floats to
+    rounding; the fresh-uniform-per-comparison class search (:261) is part of what is compared."""
+    from ref_numpy import RefChain
+    N, P = 80, 70
+    X, y, bt, v = make_problem(O, N, P, seed=6)
+    vcl, pi0 = [0.0, 0.01, 0.1, 1.0], [0.8, 0.12, 0.06, 0.02]
+    o0 = O.Oracle(0, seed=9, chain=1); o0.set_panel_f32(X)
+    o1 = O.Oracle(1, seed=9, chain=1); o1.set_panel_f32(X, R=4, S=20, D=3, near=3)
+    ref = RefChain(O, X.astype(np.float64), y, seed=9, chain=1)
+    for m in (o0, o1):
+        m.add_marker_set(0, 20, 0, 4.0, v * 0.5, [(0, 20)], [v])
+        m.add_marker_set_r(20, 50, 4.0, v * 0.5, v, vcl, pi0, estPi=True)
+        m.set_y(y); m.set_residual_prior(4.0, 0.3 * y.var())
+    ref.add_set(0, 20, 0, 4.0, v * 0.5, [(0, 20)], [v]); ref.add_set_r(20, 50, 4.0, v * 0.5, v, vcl, pi0, estPi=True)
+    ref.E_df, ref.E_scale = 4.0, 0.3 * y.var()
+    for it in range(10):
+        o0.run(1); o1.run(1); ref.run(1)
+        a, b, c = o0.get_state(), o1.get_state(), ref.state()
+        assert np.array_equal(a["delta"], c["delta"]) and np.array_equal(a["delta"], b["delta"]), it
+        for k in ("beta", "ycorr", "varBeta"):
+            assert np.abs(a[k] - c[k]).max() <= 1e-10 * max(1e-6, np.abs(c[k]).max()), (it, k)
+            assert np.abs(a[k] - b[k]).max() <= 1e-10 * max(1e-6, np.abs(a[k]).max()), (it, k)
+        assert np.abs(o0.get_class_state(1)["piHat"] - c["class_pi"][1]).max() <= 1e-12
+        assert np.abs(o1.get_class_state(1)["piHat"] - c["class_pi"][1]).max() <= 1e-12
+    cls = a["delta"][20:]
+    assert set(np.unique(cls)) <= {1, 2, 3, 4}
+    assert np.all(a["beta"][20:][cls == 1] == 0.0)                                # :275
+
+
+def test_det_exp_within_one_ulp(O):
+    xs = -np.concatenate([10.0 ** np.random.default_rng(0).uniform(-12, 2.8, 20000), [0.0, 1e-30, 0.3465, 0.3466, 0.35, 707.9]])
+    for x in xs:
+        ref = math.exp(x)
+        assert abs(O.det_exp(x) - ref) <= 1.01 * np.spacing(ref)
+    assert O.det_exp(0.0) == 1.0 and O.det_exp(-800.0) == 0.0 and math.isnan(O.det_exp(float("nan")))
