@@ -11,7 +11,7 @@ Same names, argument meaning and output files as the reference, so a model scrip
     summaryMCMC("betaM"; outFolder)                     summaryMCMC("betaM", outFolder=...)                    src/misc.jl:241-244
 
 Only what the hot path needs is interpreted here: the response, the intercept `1` and `SNP(...)` terms.
-Fixed covariates, `PED(...)`, `(1|g)` terms, GBLUP priors, BayesC/R/RC/LV are outside the accelerated
+Fixed covariates, `PED(...)`, `(1|g)` terms, GBLUP priors, BayesRC/LV are outside the accelerated
 path and raise NotImplementedError naming the reference code that handles them.
 All arithmetic happens in libnextgp_hip.so; this file only parses, reshapes and writes files.
 """
@@ -24,7 +24,7 @@ import numpy as np
 
 from ._lib import METHOD_BAYESB, METHOD_BAYESC, METHOD_BAYESPR, Sampler
 
-__all__ = ["BayesPR", "BayesB", "BayesC", "Random", "SNP", "runLMEM", "summaryMCMC", "read_genotypes", "prep2RegionData", "parse_formula"]
+__all__ = ["BayesPR", "BayesB", "BayesC", "BayesR", "Random", "SNP", "runLMEM", "summaryMCMC", "read_genotypes", "prep2RegionData", "parse_formula"]
 
 
 # ----------------------------------------------------------------------------------------------
@@ -54,6 +54,15 @@ class BayesCType:  # src/runTime.jl:64-77
 
 
 @dataclass
+class BayesRType:  # src/runTime.jl:78-93
+    pi: object      # class probabilities (one per class)
+    class_: object  # variance-class multipliers (the reference's field is `class`, a Python keyword)
+    v: float
+    name: str = "BayesR"
+    estimatePi: bool = False
+
+
+@dataclass
 class RandomEffectType:  # src/runTime.jl:135-146
     str: object
     v: float
@@ -77,6 +86,11 @@ def BayesB(pi, v, name="BayesB", estimatePi=False):
 
 def BayesC(pi, v, name="BayesC", estimatePi=False):
     return BayesCType(float(pi), float(v), name, bool(estimatePi))
+
+
+def BayesR(pi, class_, v, name="BayesR", estimatePi=False):
+    """BayesR(pi, class, v; estimatePi) of src/runTime.jl:87-93: `class_` = variance-class multipliers, `pi` their probabilities."""
+    return BayesRType([float(x) for x in pi], [float(x) for x in class_], float(v), name, bool(estimatePi))
 
 
 def Random(str, v, type=1):
@@ -196,7 +210,7 @@ def _regions_for(prior, P, map_path, out_folder, set_name):
     """M[set][:regionArray] (src/mme.jl:324-358)."""
     if isinstance(prior, BayesBType):
         return [(j, j + 1) for j in range(P)]
-    if isinstance(prior, BayesCType):  # one variance for the set (nVarCov = 1, src/mme.jl:370)
+    if isinstance(prior, (BayesCType, BayesRType)):  # one variance for the set (nVarCov = 1, src/mme.jl:370, :381)
         return [(0, P)]
     if not map_path:
         if prior.r == 1:
@@ -278,8 +292,8 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
         prior = VCV.get(t.name)
         if prior is None:  # src/mme.jl:324-329, 504, 518
             prior = BayesPR(9999, 0.05)
-        if not isinstance(prior, (BayesPRType, BayesBType, BayesCType)):
-            raise NotImplementedError(f"prior {type(prior).__name__} for {t.name}: only BayesPR, BayesB and BayesC are on the accelerated path")
+        if not isinstance(prior, (BayesPRType, BayesBType, BayesCType, BayesRType)):
+            raise NotImplementedError(f"prior {type(prior).__name__} for {t.name}: only BayesPR, BayesB, BayesC and BayesR are on the accelerated path")
         df = 4.0                                  # 3 + size(v,1), src/mme.jl:493
         scale = prior.v * (df - 2.0) / df         # src/mme.jl:501
         regions = _regions_for(prior, P, t.map, outFolder, t.name)
@@ -294,6 +308,8 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
         elif isinstance(prior, BayesCType):
             sid = smp.add_marker_set(col0, P, METHOD_BAYESC, df, scale, regions, [prior.v], pi0=prior.pi, estPi=prior.estimatePi,
                                      lhs0=lhs0, rhs0=rhs0)
+        elif isinstance(prior, BayesRType):  # src/mme.jl:374-383
+            sid = smp.add_marker_set_r(col0, P, df, scale, prior.v, prior.class_, prior.pi, estPi=prior.estimatePi, lhs0=lhs0, rhs0=rhs0)
         else:
             sid = smp.add_marker_set(col0, P, METHOD_BAYESPR, df, scale, regions, [prior.v] * len(regions), lhs0=lhs0, rhs0=rhs0)
         sets.append(dict(id=sid, name=t.name, col0=col0, P=P, prior=prior, nreg=len(regions)))
@@ -310,6 +326,8 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
             _out(outFolder, f"delta{s['name']}", names)
             if isinstance(s["prior"], (BayesBType, BayesCType)):  # src/samplers.jl:80-82
                 _out(outFolder, f"pi{s['name']}", ["pi1", "pi2"])
+            if isinstance(s["prior"], BayesRType):               # one column per class (src/mme.jl:589-591)
+                _out(outFolder, f"pi{s['name']}", [f"pi{v + 1}" for v in range(len(s["prior"].pi))])
             _out(outFolder, f"var{s['name']}", [f"reg_{r + 1}" for r in range(s["nreg"])])
     # the chain (src/samplers.jl:29-105): kept iterations = burnIn+thin : thin : chainLength
     done = 0
@@ -327,6 +345,8 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
                 _out(outFolder, f"delta{s['name']}", [str(int(v)) for v in st["delta"][sl]])
                 if isinstance(s["prior"], (BayesBType, BayesCType)):
                     _out(outFolder, f"pi{s['name']}", _fmt(st["piHat"][2 * k:2 * k + 2]))
+                if isinstance(s["prior"], BayesRType):
+                    _out(outFolder, f"pi{s['name']}", _fmt(smp.get_class_state(s["id"])["piHat"]))
                 _out(outFolder, f"var{s['name']}", _fmt(st["varBeta"][vb_off:vb_off + s["nreg"]]))
                 vb_off += s["nreg"]
     smp.run(nChain - done)
@@ -338,6 +358,8 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
         sl = slice(s["col0"], s["col0"] + s["P"])
         res["sets"][s["name"]] = dict(beta=ps["sum_beta"][sl] / n, delta=ps["sum_delta"][sl] / n,
                                       var=ps["sum_varBeta"][vb_off:vb_off + s["nreg"]] / n, pi=ps["sum_pi"][2 * k:2 * k + 2] / n)
+        if isinstance(s["prior"], BayesRType):
+            res["sets"][s["name"]]["pi"] = smp.get_class_state(s["id"])["sum_pi"] / n
         vb_off += s["nreg"]
     res["sampler"] = smp
     return res

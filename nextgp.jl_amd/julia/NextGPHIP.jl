@@ -1,7 +1,8 @@
 # NextGPHIP.jl -- reference-side binding of libnextgp_hip.so (include/nextgp_hip.h) for NextGP.jl.
 #
-# NOT runnable in the build container (no Julia toolchain there, SURVEY.md section 8c); it is the
-# stub a NextGP.jl maintainer adds next to src/samplers.jl.  Two seams, both defined by the reference:
+# NEVER EXECUTED: the build container has no Julia toolchain (SURVEY.md section 8c), so this file has not been run once.  It is
+# the stub a NextGP.jl maintainer adds next to src/samplers.jl; every ccall signature below is checked by hand against
+# include/nextgp_hip.h, and the same entry points are exercised through Python ctypes (nextgp.jl_amd/_lib.py).  Two seams, both defined by the reference:
 #
 #   coarse:  replace `samplers.runSampler!(...)` (src/samplers.jl:23, called at src/MCMC.jl:39)
 #            by `NextGPHIP.runSampler!(...)`: the whole chain runs on the GPU, the same *Out files
@@ -61,6 +62,32 @@ function add_marker_set!(h::Handle, col0::Integer, ncol::Integer, method::Intege
     return id[]
 end
 
+# BayesR set (src/mme.jl:374-383): ONE variance, M[s].vClass multipliers, M[s].piHat class probabilities
+function add_marker_set_r!(h::Handle, col0::Integer, ncol::Integer, df::Float64, scale::Float64, varBeta0::Float64,
+                           vClass::Vector{Float64}, pi::Vector{Float64}; estPi::Bool=false, lhs0=C_NULL, rhs0=C_NULL)
+    id = Ref{Int32}(0)
+    check(h, ccall((:ngp_add_marker_set_r, LIB), Int32,
+                   (Ptr{Cvoid}, Int64, Int64, Float64, Float64, Float64, Ptr{Float64}, Ptr{Float64}, Int32, Int32, Ptr{Float64}, Ptr{Float64}, Ref{Int32}),
+                   h.ptr, col0, ncol, df, scale, varBeta0, vClass, pi, length(vClass), estPi, lhs0, rhs0, id))
+    return id[]
+end
+
+function class_state(h::Handle, set_id::Integer)
+    pi = zeros(8); sp = zeros(8); K = Ref{Int64}(0)
+    check(h, ccall((:ngp_get_class_state, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Ref{Int64}), h.ptr, set_id, pi, sp, K))
+    return pi[1:K[]], sp[1:K[]]
+end
+
+# resume: chain state + posterior sums + stream identity in one file (the role of the append-only *Out files, src/outFiles.jl:17-21)
+save_snapshot(h::Handle, path::AbstractString) = check(h, ccall((:ngp_save_snapshot, LIB), Int32, (Ptr{Cvoid}, Cstring), h.ptr, path))
+load_snapshot!(h::Handle, path::AbstractString) = check(h, ccall((:ngp_load_snapshot, LIB), Int32, (Ptr{Cvoid}, Cstring), h.ptr, path))
+
+# pooled posterior sums of several chains (one Handle per chain / device): ONE RCCL all-reduce inside the library
+function allreduce_posterior!(hs::Vector{Handle})
+    ptrs = Ptr{Cvoid}[x.ptr for x in hs]
+    check(hs[1], ccall((:ngp_allreduce_posterior, LIB), Int32, (Ptr{Ptr{Cvoid}}, Int32), ptrs, length(ptrs)))
+end
+
 set_y!(h::Handle, y::Vector{Float64}) = check(h, ccall((:ngp_set_y, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64), h.ptr, y, length(y)))
 set_residual_prior!(h::Handle, df, scale) = check(h, ccall((:ngp_set_residual_prior, LIB), Int32, (Ptr{Cvoid}, Float64, Float64), h.ptr, df, scale))
 set_schedule!(h::Handle, n, burn, thin) = check(h, ccall((:ngp_set_schedule, LIB), Int32, (Ptr{Cvoid}, Int64, Int64, Int64), h.ptr, n, burn, thin))
@@ -93,7 +120,7 @@ end
     runSampler!(ycorr, nData, E, X, b, Z, u, varU, M, beta, varBeta, delta, chainLength, burnIn, outputFreq, outPut; seed=1)
 
 Coarse seam: drop-in for `samplers.runSampler!` (src/samplers.jl:23) for models made of an intercept and
-Symbol marker sets with BayesPR / BayesB / BayesC priors.  Anything else falls back to the reference sampler.
+Symbol marker sets with BayesPR / BayesB / BayesC / BayesR priors.  Anything else falls back to the reference sampler.
 """
 function runSampler!(ycorr, nData, E, X, b, Z, u, varU, M, beta, varBeta, delta, chainLength, burnIn, outputFreq, outPut;
                      seed::Integer=1, device::Integer=0)
@@ -108,12 +135,17 @@ function runSampler!(ycorr, nData, E, X, b, Z, u, varU, M, beta, varBeta, delta,
     ids = Dict{Any,Int32}()
     for s in sets
         P = M[s].dims[2]
-        method = M[s].method == "BayesB" ? 1 : (M[s].method == "BayesC" ? 2 : 0)
-        # BayesC loops over one-locus ranges but has ONE variance (nVarCov = 1, src/mme.jl:370): a single region for the library
-        regions = method == 2 ? [1:P] : M[s].regionArray
-        ids[s] = add_marker_set!(h, col0, P, method, Float64(M[s].df), Float64(M[s].scale), regions,
-                                 Float64.(varBeta[s]); pi0 = method >= 1 ? M[s].piHat[2] : 0.0,
-                                 estPi = method >= 1 ? M[s].estPi : false, lhs0 = Float64.(M[s].lhs), rhs0 = Float64.(M[s].rhs))
+        method = M[s].method == "BayesB" ? 1 : (M[s].method == "BayesC" ? 2 : (M[s].method == "BayesR" ? 3 : 0))
+        if method == 3   # ONE variance, class multipliers and class probabilities (src/mme.jl:374-383)
+            ids[s] = add_marker_set_r!(h, col0, P, Float64(M[s].df), Float64(M[s].scale), Float64(varBeta[s][1]), Float64.(vec(M[s].vClass)),
+                                       Float64.(vec(M[s].piHat)); estPi = M[s].estPi, lhs0 = Float64.(M[s].lhs), rhs0 = Float64.(M[s].rhs))
+        else
+            # BayesC loops over one-locus ranges but has ONE variance (nVarCov = 1, src/mme.jl:370): a single region for the library
+            regions = method == 2 ? [1:P] : M[s].regionArray
+            ids[s] = add_marker_set!(h, col0, P, method, Float64(M[s].df), Float64(M[s].scale), regions,
+                                     Float64.(varBeta[s]); pi0 = method >= 1 ? M[s].piHat[2] : 0.0,
+                                     estPi = method >= 1 ? M[s].estPi : false, lhs0 = Float64.(M[s].lhs), rhs0 = Float64.(M[s].rhs))
+        end
         col0 += P
     end
     set_y!(h, Vector{Float64}(ycorr))            # ycorr == y at this point (src/mme.jl:57)
@@ -138,6 +170,7 @@ function runSampler!(ycorr, nData, E, X, b, Z, u, varU, M, beta, varBeta, delta,
             open(io -> writedlm(io, bet[c0+1:c0+P]'), outPut * "/beta$(s)Out", "a")    # :80
             open(io -> writedlm(io, del[c0+1:c0+P]'), outPut * "/delta$(s)Out", "a")   # :81
             M[s].method in ("BayesB", "BayesC") && open(io -> writedlm(io, pih[2k-1:2k]'), outPut * "/pi$(s)Out", "a")   # :80-82
+            M[s].method == "BayesR" && open(io -> writedlm(io, class_state(h, ids[s])[1]'), outPut * "/pi$(s)Out", "a")  # one column per class
             nr = length(varBeta[s])
             open(io -> writedlm(io, vb[v0+1:v0+nr]'), outPut * "/var$(s)Out", "a")     # :101-103
             c0 += P; v0 += nr

@@ -113,3 +113,35 @@ def test_runLMEM_bayesc_matches_oracle(ngp, O, tmp_path):
     for name, ncol in (("betaM", P), ("deltaM", P), ("piM", 2), ("varM", 1)):
         lines = (out / f"{name}Out").read_text().splitlines()
         assert len(lines) == 5 and len(lines[0].split("\t")) == ncol, name
+
+
+@pytest.mark.gpu
+def test_runLMEM_bayesr_matches_oracle(ngp, O, tmp_path):
+    """BayesR through the reference's interface (src/runTime.jl:78-93, src/mme.jl:374-383): class file per kept iteration with one
+    column per class (header pi1..piK, src/mme.jl:569-570), delta = class of a locus, posterior means against the oracle."""
+    N, P = 100, 150
+    X, y, bt, v = make_problem(O, N, P, seed=4)
+    X1 = O.generate_panel(N, P, seed=6)[0]
+    G = np.rint(X1.astype(np.float64) - X1.astype(np.float64).min(axis=0))
+    g = tmp_path / "g.txt"
+    np.savetxt(g, G, fmt="%d", delimiter=" ")
+    out = tmp_path / "outR"
+    cls, pi0 = [0.0, 0.001, 0.01, 0.1], [0.7, 0.2, 0.07, 0.03]
+    VCV = {"M": ngp.BayesR(pi0, cls, v, estimatePi=True), "e": ngp.Random("I", 0.5 * y.var())}
+    res = ngp.runLMEM(f'y ~ 1 + SNP(M,"{g}")', {"y": y}, 16, 4, 3, outFolder=str(out), VCV=VCV, seed=5, engine=(1, 4))
+    assert res["nKept"] == 4
+    Gc = (G - G.mean(axis=0)).astype(np.float32)
+    o = O.Oracle(0, seed=5, chain=0)
+    o.set_panel_f32(Gc)
+    o.add_marker_set_r(0, P, 4.0, v * 0.5, v, cls, pi0, estPi=True)
+    o.set_y(y); o.set_residual_prior(4.0, 0.5 * y.var() * 0.5); o.set_schedule(16, 4, 3); o.run(16)
+    ps = o.get_posterior_sums()
+    assert np.array_equal(res["sets"]["M"]["delta"], ps["sum_delta"] / 4)
+    assert np.abs(res["sets"]["M"]["beta"] - ps["sum_beta"] / 4).max() < 1e-9
+    assert abs(res["sets"]["M"]["var"][0] - ps["sum_varBeta"][0] / 4) < 1e-9 * res["sets"]["M"]["var"][0]
+    assert np.abs(res["sets"]["M"]["pi"] - o.get_class_state(0)["sum_pi"] / 4).max() < 1e-12 and abs(res["sets"]["M"]["pi"].sum() - 1.0) < 1e-12
+    for name, ncol in (("betaM", P), ("deltaM", P), ("piM", 4), ("varM", 1)):
+        lines = (out / f"{name}Out").read_text().splitlines()
+        assert len(lines) == 5 and len(lines[0].split("\t")) == ncol, name
+    assert (out / "piMOut").read_text().splitlines()[0].split("\t") == ["pi1", "pi2", "pi3", "pi4"]
+    assert set(np.loadtxt(out / "deltaMOut", skiprows=1).ravel()) <= {1.0, 2.0, 3.0, 4.0}
