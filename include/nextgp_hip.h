@@ -111,6 +111,17 @@ int32_t ngp_add_marker_set_r(ngp_handle *h, int64_t col0, int64_t ncol, double d
 int32_t ngp_get_class_state(ngp_handle *h, int32_t set_id, double *piHat, double *sum_pi, int64_t *K);
 int32_t ngp_set_class_state(ngp_handle *h, int32_t set_id, const double *piHat, const double *sum_pi, int64_t K);
 
+/* A fixed-effect set beyond the intercept (X[xSet] of src/prepMatVec.jl:150-165; set-up src/mme.jl:120-152): the columns of one
+ * model term or of one `blockThese` group, N x ncol column-major (ncol <= 64), sampled after the intercept in the order the
+ * sets are added (the `keys(X)` order of src/samplers.jl:39; to put the intercept elsewhere switch it off and add a column of
+ * ones).  One column: sampleX! (src/functions.jl:41-47) with summary-statistics terms lhs0 / rhs0 (NULL = 0); several columns:
+ * sampleb! (src/functions.jl:22-36), Gauss-Seidel over X'X + min|diag| / 10000 (src/mme.jl:149-152).  ngp_get_fixed returns the
+ * current effects and their posterior sums (all columns of all sets, in order); ngp_set_fixed restores them (resume). */
+int32_t ngp_add_fixed_set(ngp_handle *h, const double *X, int64_t N, int64_t ncol, int64_t ld, const double *lhs0, const double *rhs0,
+                          int32_t *set_id);
+int32_t ngp_get_fixed(ngp_handle *h, double *b, double *sum_b, int64_t *ncols_total);
+int32_t ngp_set_fixed(ngp_handle *h, const double *b, const double *sum_b, int64_t ncols_total);
+
 /* Phenotypes; resets the chain: ycorr = y (src/mme.jl:57), b = 0, beta = 0, delta = 1, iter = 0, every variance and pi back to
  * the values given to ngp_add_marker_set (src/mme.jl:351-360, 516), all posterior sums and nKept zero. */
 int32_t ngp_set_y(ngp_handle *h, const double *y, int64_t N);

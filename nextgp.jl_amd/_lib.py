@@ -22,7 +22,7 @@ SYMBOLS = [
     "ngp_get_trace", "ngp_get_posterior_sums", "ngp_posterior_len", "ngp_export_posterior_device", "ngp_sweep_set",
     "ngp_get_timing", "ngp_profile_iteration", "ngp_draws_indexed", "ngp_eval_math", "ngp_configure", "ngp_get_config", "ngp_debug_stamps", "ngp_set_near_lags", "ngp_get_near_lags",
     "ngp_set_streamer", "ngp_get_streamer", "ngp_debug_set_mode", "ngp_debug_set_knob", "ngp_set_posterior_sums", "ngp_save_snapshot", "ngp_load_snapshot",
-    "ngp_set_trace_loci", "ngp_get_trace_ext", "ngp_allreduce_posterior", "ngp_add_marker_set_r", "ngp_get_class_state", "ngp_set_class_state",
+    "ngp_set_trace_loci", "ngp_get_trace_ext", "ngp_allreduce_posterior", "ngp_add_marker_set_r", "ngp_get_class_state", "ngp_set_class_state", "ngp_add_fixed_set", "ngp_get_fixed", "ngp_set_fixed",
 ]
 
 _lib = None
@@ -178,6 +178,30 @@ class Sampler:
         self.nsets += 1
         self.set_shapes.append((ncol, len(rs)))
         return sid.value
+
+    def add_fixed_set(self, X, lhs0=None, rhs0=None):
+        """Columns of one fixed-effect term / block (src/functions.jl:22-53), sampled after the intercept in the order added."""
+        X = np.asfortranarray(X, dtype=np.float64)
+        if X.ndim == 1:
+            X = np.asfortranarray(X[:, None])
+        l0 = None if lhs0 is None else np.ascontiguousarray(lhs0, dtype=np.float64)
+        r0 = None if rhs0 is None else np.ascontiguousarray(rhs0, dtype=np.float64)
+        sid = C.c_int32()
+        self._chk(self.L.ngp_add_fixed_set(self.h, _p(X, C.c_double), C.c_int64(X.shape[0]), C.c_int64(X.shape[1]), C.c_int64(X.shape[0]),
+                                           _p(l0, C.c_double), _p(r0, C.c_double), C.byref(sid)))
+        self.nfixcol = getattr(self, "nfixcol", 0) + X.shape[1]
+        return sid.value
+
+    def get_fixed(self):
+        n = getattr(self, "nfixcol", 0)
+        b = np.empty(max(n, 1)); sb = np.empty(max(n, 1)); nn = C.c_int64()
+        self._chk(self.L.ngp_get_fixed(self.h, _p(b, C.c_double), _p(sb, C.c_double), C.byref(nn)))
+        return dict(b=b[:nn.value].copy(), sum_b=sb[:nn.value].copy())
+
+    def set_fixed(self, b=None, sum_b=None):
+        a = None if b is None else np.ascontiguousarray(b, dtype=np.float64)
+        c = None if sum_b is None else np.ascontiguousarray(sum_b, dtype=np.float64)
+        self._chk(self.L.ngp_set_fixed(self.h, _p(a, C.c_double), _p(c, C.c_double), C.c_int64(getattr(self, "nfixcol", 0))))
 
     def add_marker_set_r(self, col0, ncol, df, scale, varBeta0, vClass, pi, estPi=False, lhs0=None, rhs0=None):
         """BayesR set: class multipliers vClass of the set's single variance, class probabilities pi (src/mme.jl:374-383)."""

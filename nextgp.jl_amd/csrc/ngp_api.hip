@@ -22,6 +22,11 @@ using namespace ngp;
 
 namespace {
 
+struct HFix {  // one fixed-effect set beyond the intercept
+    int64_t ncol, off;
+    double *d_X = nullptr, *d_xpx0 = nullptr, *d_xpxR = nullptr, *d_lhs0 = nullptr, *d_rhs0 = nullptr;
+};
+
 struct HSet {
     int64_t col0, ncol;
     int method;
@@ -76,6 +81,9 @@ struct ngp_handle {
     DScal *d_scal = nullptr;
     double *d_varBeta = nullptr, *d_sum_varBeta = nullptr;
     int64_t vb_cap = 0;
+    std::vector<HFix> fix;           // fixed-effect sets beyond the intercept (src/functions.jl:22-53), in sampling order
+    int64_t nfixcol = 0;
+    double *d_bfix = nullptr, *d_sum_bfix = nullptr;
     double *d_rcls = nullptr;        // BayesR per-locus class coefficients [4][NGP_RMAX][Ppad] (allocated with the first BayesR set)
     int32_t *d_seg_set = nullptr;    // set of every variance segment
     std::vector<int32_t> h_seg_set;
@@ -440,6 +448,10 @@ int one_iteration(ngp_handle *h, int64_t trace_idx, hipEvent_t *evs) {
     const uint64_t it = (uint64_t)(h->iter + 1);
     hipLaunchKernelGGL(k_head, dim3(1), dim3(1024), 0, h->stream, h->d_ycorr, (long long)h->L, (long long)h->N, h->d_scal, h->e_df,
                        h->e_scale, h->intercept, 1, h->seed, (uint64_t)h->chain, it, h->d_tr_varE, h->d_tr_b, (long long)trace_idx);
+    for (size_t f = 0; f < h->fix.size(); f++)  // the other fixed-effect sets, in the order they were added (src/samplers.jl:39-41)
+        hipLaunchKernelGGL(k_fixed, dim3(1), dim3(1024), 0, h->stream, h->d_ycorr, (long long)h->N, h->fix[f].d_X, (int)h->fix[f].ncol, h->fix[f].d_xpx0,
+                           h->fix[f].d_xpxR, h->fix[f].d_lhs0, h->fix[f].d_rhs0, h->d_bfix + h->fix[f].off, h->d_scal, (int)f, h->seed,
+                           (uint64_t)h->chain, it);
     hipLaunchKernelGGL(k_prep, dim3((unsigned)(h->Ppad / 256 + 1)), dim3(256), 0, h->stream, (long long)h->Ppad, h->d_setof, h->d_loc,
                        h->d_vbidx, h->d_sets, h->d_scal, h->d_varBeta, h->d_mpm, h->d_lhs0, h->d_rhs0, h->d_beta, h->d_c, h->d_w,
                        h->d_q, h->d_T, h->d_chi, -1, h->seed, (uint64_t)h->chain, it, (long long)h->h_regs.size(), h->d_regs, h->d_regchi, h->d_rcls);
@@ -456,6 +468,9 @@ int one_iteration(ngp_handle *h, int64_t trace_idx, hipEvent_t *evs) {
         hipLaunchKernelGGL(k_accum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (long long)h->P, (long long)h->nvb,
                            (int)h->sets.size(), h->d_beta, h->d_delta, h->d_varBeta, h->d_sum_beta, h->d_sum_beta2, h->d_sum_delta,
                            h->d_sum_varBeta, h->d_sets, h->d_scal);
+        if (h->nfixcol > 0)
+            hipLaunchKernelGGL(k_accum_fixed, dim3((unsigned)((h->nfixcol + 255) / 256)), dim3(256), 0, h->stream, (long long)h->nfixcol, h->d_bfix,
+                               h->d_sum_bfix);
     }
     return NGP_OK;
 }
@@ -524,6 +539,8 @@ int32_t ngp_destroy(ngp_handle *h) {
     dfree(h->d_vbidx); dfree(h->d_delta); dfree(h->d_sum_beta); dfree(h->d_sum_beta2); dfree(h->d_sum_delta);
     dfree(h->d_ycorr); dfree(h->d_part); dfree(h->d_dlt); dfree(h->d_sets); dfree(h->d_scal); dfree(h->d_varBeta);
     dfree(h->d_sum_varBeta); dfree(h->d_regs); dfree(h->d_seg_k0); dfree(h->d_seg_len); dfree(h->d_segpart); dfree(h->d_regchi);
+    for (auto &fx : h->fix) { dfree(fx.d_X); dfree(fx.d_xpx0); dfree(fx.d_xpxR); dfree(fx.d_lhs0); dfree(fx.d_rhs0); }
+    dfree(h->d_bfix); dfree(h->d_sum_bfix);
     dfree(h->d_tr_varE); dfree(h->d_tr_b); dfree(h->d_trace_loci); dfree(h->d_tr_beta); dfree(h->d_tr_vb); dfree(h->d_tr_pi);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -759,6 +776,10 @@ int32_t ngp_set_y(ngp_handle *h, const double *y, int64_t N) {
             int rc2 = set_class_state_dev(h, (int)si, hs.rpi.data(), std::vector<double>((size_t)hs.K, 0.0).data());
             if (rc2) return rc2;
         }
+    }
+    if (h->nfixcol > 0) {
+        HCHK(hipMemsetAsync(h->d_bfix, 0, (size_t)h->nfixcol * sizeof(double), h->stream));
+        HCHK(hipMemsetAsync(h->d_sum_bfix, 0, (size_t)h->nfixcol * sizeof(double), h->stream));
     }
     HCHK(hipStreamSynchronize(h->stream));
     h->iter = 0; h->have_y = true; h->poisoned = false; h->ntrace = 0;
@@ -1174,7 +1195,7 @@ int32_t ngp_set_posterior_sums(ngp_handle *h, const double *sum_beta, const doub
  *   char[8] "NGPSNAP1" | int64 N, P, nvb, nsets, iter, nKept | uint64 seed | uint64 chain |
  *   double varE, b, sum_varE, sum_b | ycorr[N] | beta[P] | delta[P] (uint8) | varBeta[nvb] | piHat[2 nsets] |
  *   sum_beta[P] | sum_beta2[P] | sum_delta[P] | sum_varBeta[nvb] | sum_pi[2 nsets] | fine_calls[nsets] (uint64) |
- *   per BayesR set: piHat[K] | sum_pi[K]
+ *   int64 nfix | b_fixed[nfix] | sum_b_fixed[nfix] | per BayesR set: piHat[K] | sum_pi[K]
  * It plays the role of the reference's append-only *Out files for a resumed run (src/outFiles.jl:17-21): what was kept
  * before the interruption is not lost. */
 int32_t ngp_save_snapshot(ngp_handle *h, const char *path) {
@@ -1205,6 +1226,12 @@ int32_t ngp_save_snapshot(ngp_handle *h, const char *path) {
     W(yc.data(), N * 8); W(be.data(), P * 8); W(d8.data(), P); W(vb.data(), nvb * 8); W(pi.data(), 2 * ns * 8);
     W(sb.data(), P * 8); W(sb2.data(), P * 8); W(sd.data(), P * 8); W(sv.data(), nvb * 8); W(sp.data(), 2 * ns * 8);
     for (auto &hs : h->sets) W(&hs.fine_calls, 8);
+    {   // fixed-effect sets beyond the intercept: effects and their posterior sums
+        std::vector<double> fb((size_t)std::max<int64_t>(h->nfixcol, 1)), fs((size_t)std::max<int64_t>(h->nfixcol, 1));
+        int64_t nf = 0;
+        if ((rc = ngp_get_fixed(h, fb.data(), fs.data(), &nf))) { fclose(f); remove(tmp.c_str()); return rc; }
+        W(&nf, 8); W(fb.data(), (size_t)nf * 8); W(fs.data(), (size_t)nf * 8);
+    }
     for (size_t si = 0; si < ns; si++)  // BayesR sets: class probabilities and their posterior sums (K each)
         if (h->sets[si].K > 0) {
             double cp[NGP_RMAX], cs[NGP_RMAX];
@@ -1240,6 +1267,11 @@ int32_t ngp_load_snapshot(ngp_handle *h, const char *path) {
     std::vector<uint64_t> fc(std::max<size_t>(ns, 1));
     Rd(yc.data(), N * 8); Rd(be.data(), P * 8); Rd(d8.data(), P); Rd(vb.data(), nvb * 8); Rd(pi.data(), 2 * ns * 8);
     Rd(sb.data(), P * 8); Rd(sb2.data(), P * 8); Rd(sd.data(), P * 8); Rd(sv.data(), nvb * 8); Rd(sp.data(), 2 * ns * 8); Rd(fc.data(), ns * 8);
+    int64_t nf = -1;
+    Rd(&nf, 8);
+    if (ok && nf != h->nfixcol) { fclose(f); return fail(h, NGP_ERR_ARG, "snapshot does not match the model of this handle (fixed-effect columns differ)"); }
+    std::vector<double> fb((size_t)std::max<int64_t>(h->nfixcol, 1)), fs((size_t)std::max<int64_t>(h->nfixcol, 1));
+    Rd(fb.data(), (size_t)h->nfixcol * 8); Rd(fs.data(), (size_t)h->nfixcol * 8);
     std::vector<double> cls((size_t)2 * std::max<int64_t>(h->nclass_total, 1));
     Rd(cls.data(), (size_t)2 * h->nclass_total * 8);
     char extra;
@@ -1251,6 +1283,7 @@ int32_t ngp_load_snapshot(ngp_handle *h, const char *path) {
     if ((rc = ngp_set_state(h, yc.data(), be.data(), de.data(), vb.data(), pi.data(), scal[0], scal[1], hdr[4]))) return rc;
     if ((rc = ngp_set_posterior_sums(h, sb.data(), sb2.data(), sd.data(), sv.data(), sp.data(), scal[2], scal[3], hdr[5]))) return rc;
     for (size_t si = 0; si < ns; si++) h->sets[si].fine_calls = fc[si];
+    if (h->nfixcol > 0 && (rc = ngp_set_fixed(h, fb.data(), fs.data(), h->nfixcol))) return rc;
     {
         size_t off = 0;
         for (size_t si = 0; si < ns; si++)
@@ -1486,6 +1519,90 @@ int32_t ngp_set_class_state(ngp_handle *h, int32_t set_id, const double *piHat, 
     REQUIRE(h->sets[(size_t)set_id].K > 0 && K == h->sets[(size_t)set_id].K, NGP_ERR_ARG, "not a BayesR set, or another number of classes");
     if (piHat) for (int64_t v = 0; v < K; v++) REQUIRE(std::isfinite(piHat[v]) && piHat[v] > 0.0, NGP_ERR_ARG, "class probabilities must be > 0");
     return set_class_state_dev(h, set_id, piHat, sum_pi);
+}
+
+
+/* A fixed-effect set beyond the intercept: the columns of one model term, or of one `blockThese` group (X[xSet].data, N x ncol,
+ * column-major; src/prepMatVec.jl:150-165).  Sets are sampled after the intercept in the order they are added -- the order of
+ * `keys(X)` at src/samplers.jl:39 (a Julia Dict: the shim passes that order; to put the intercept elsewhere, switch it off and add
+ * a column of ones).  One column: sampleX! (src/functions.jl:41-47) with the summary-statistics terms lhs0 / rhs0 (src/mme.jl:140-147);
+ * several: sampleb! (src/functions.jl:22-36), Gauss-Seidel over X'X + min|diag| / 10000 (src/mme.jl:149-152). */
+int32_t ngp_add_fixed_set(ngp_handle *h, const double *X, int64_t N, int64_t ncol, int64_t ld, const double *lhs0, const double *rhs0,
+                          int32_t *set_id) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
+    REQUIRE(X && N == h->N && ncol >= 1 && ncol <= 64 && ld >= N, NGP_ERR_ARG, "fixed-effect set: N rows, 1..64 columns");
+    REQUIRE(h->fix.size() < 16, NGP_ERR_ARG, "at most 16 fixed-effect sets");
+    std::vector<double> xc((size_t)N * ncol), x0((size_t)ncol * ncol), xr;
+    for (int64_t a = 0; a < ncol; a++)
+        for (int64_t i = 0; i < N; i++) {
+            const double v = X[(size_t)a * ld + i];
+            REQUIRE(std::isfinite(v), NGP_ERR_ARG, "non-finite value in a fixed-effect column");
+            xc[(size_t)a * N + i] = v;
+        }
+    for (int64_t a = 0; a < ncol; a++)
+        for (int64_t b = 0; b <= a; b++) {
+            double acc = 0.0;
+            for (int64_t i = 0; i < N; i++) acc = std::fma(xc[(size_t)a * N + i], xc[(size_t)b * N + i], acc);
+            x0[(size_t)a * ncol + b] = acc; x0[(size_t)b * ncol + a] = acc;
+        }
+    xr = x0;
+    if (ncol > 1) {  // src/mme.jl:149-152
+        double mn = std::fabs(x0[0]);
+        for (int64_t a = 1; a < ncol; a++) mn = std::min(mn, std::fabs(x0[(size_t)a * ncol + a]));
+        for (int64_t a = 0; a < ncol; a++) xr[(size_t)a * ncol + a] += mn / 10000.0;
+    }
+    REQUIRE(x0[0] > 0.0 || ncol > 1, NGP_ERR_ARG, "fixed-effect column is identically zero");
+    HFix fx;
+    fx.ncol = ncol; fx.off = h->nfixcol;
+    std::vector<double> z((size_t)ncol, 0.0);
+    if ((rc = dalloc(h, &fx.d_X, xc.size()))) return rc;
+    if ((rc = dalloc(h, &fx.d_xpx0, x0.size()))) return rc;
+    if ((rc = dalloc(h, &fx.d_xpxR, xr.size()))) return rc;
+    if ((rc = dalloc(h, &fx.d_lhs0, (size_t)ncol))) return rc;
+    if ((rc = dalloc(h, &fx.d_rhs0, (size_t)ncol))) return rc;
+    HCHK(hipMemcpy(fx.d_X, xc.data(), xc.size() * sizeof(double), hipMemcpyHostToDevice));
+    HCHK(hipMemcpy(fx.d_xpx0, x0.data(), x0.size() * sizeof(double), hipMemcpyHostToDevice));
+    HCHK(hipMemcpy(fx.d_xpxR, xr.data(), xr.size() * sizeof(double), hipMemcpyHostToDevice));
+    HCHK(hipMemcpy(fx.d_lhs0, lhs0 ? lhs0 : z.data(), (size_t)ncol * sizeof(double), hipMemcpyHostToDevice));
+    HCHK(hipMemcpy(fx.d_rhs0, rhs0 ? rhs0 : z.data(), (size_t)ncol * sizeof(double), hipMemcpyHostToDevice));
+    const int64_t nn = h->nfixcol + ncol;
+    double *nb = nullptr, *nsb = nullptr;
+    if ((rc = dalloc(h, &nb, (size_t)nn))) return rc;
+    if ((rc = dalloc(h, &nsb, (size_t)nn))) return rc;
+    if (h->nfixcol > 0) {
+        HCHK(hipMemcpyAsync(nb, h->d_bfix, (size_t)h->nfixcol * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        HCHK(hipMemcpyAsync(nsb, h->d_sum_bfix, (size_t)h->nfixcol * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+    }
+    HCHK(hipStreamSynchronize(h->stream));
+    dfree(h->d_bfix); dfree(h->d_sum_bfix);
+    h->d_bfix = nb; h->d_sum_bfix = nsb; h->nfixcol = nn;
+    if (set_id) *set_id = (int32_t)h->fix.size();
+    h->fix.push_back(fx);
+    return NGP_OK;
+}
+
+int32_t ngp_get_fixed(ngp_handle *h, double *b, double *sum_b, int64_t *ncols_total) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    if (ncols_total) *ncols_total = h->nfixcol;
+    if (h->nfixcol == 0) return NGP_OK;
+    HCHK(hipStreamSynchronize(h->stream));
+    if (b) HCHK(hipMemcpy(b, h->d_bfix, (size_t)h->nfixcol * sizeof(double), hipMemcpyDeviceToHost));
+    if (sum_b) HCHK(hipMemcpy(sum_b, h->d_sum_bfix, (size_t)h->nfixcol * sizeof(double), hipMemcpyDeviceToHost));
+    return NGP_OK;
+}
+
+int32_t ngp_set_fixed(ngp_handle *h, const double *b, const double *sum_b, int64_t ncols_total) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(ncols_total == h->nfixcol, NGP_ERR_ARG, "fixed-effect column count mismatch");
+    if (h->nfixcol == 0) return NGP_OK;
+    HCHK(hipStreamSynchronize(h->stream));
+    if (b) HCHK(hipMemcpy(h->d_bfix, b, (size_t)h->nfixcol * sizeof(double), hipMemcpyHostToDevice));
+    if (sum_b) HCHK(hipMemcpy(h->d_sum_bfix, sum_b, (size_t)h->nfixcol * sizeof(double), hipMemcpyHostToDevice));
+    return NGP_OK;
 }
 
 }  // extern "C"

@@ -209,6 +209,76 @@ __global__ __launch_bounds__(1024) void k_head(double *__restrict__ ycorr, long 
 }
 
 // ------------------------------------------------------------------------------------------
+// one fixed-effect set beyond the intercept (src/functions.jl:22-53: sampleX! for one column, sampleb! for a block; set-up
+// src/mme.jl:120-152).  ONE workgroup of 1024 threads, one formulation for every width:
+//   Yi_a = (x_a'ycorr + sum_c X'X[a][c] b_c) iVarE   -- X'(ycorr + X b) without touching ycorr (the 1024-lane dot of k_head)
+//   Gauss-Seidel over the ridged X'X (thread 0; a single column adds M.rhs / M.lhs instead), normal draws keyed
+//   (NGP_KIND_FIXED_NORMAL, (set + 1) << 20 | column)
+//   ycorr_i -= sum_a x_ia (b_a' - b_a)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void k_fixed(double *__restrict__ ycorr, long long N, const double *__restrict__ X, int nc,
+                                                const double *__restrict__ xpx0, const double *__restrict__ xpxR,
+                                                const double *__restrict__ lhs0, const double *__restrict__ rhs0, double *__restrict__ b,
+                                                const DScal *__restrict__ sc, int fset, uint64_t seed, uint64_t chain, uint64_t it) {
+    __shared__ double wsum[16];
+    __shared__ double Yi[64], db[64];
+    const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    const double iVarE = sc->iVarE;
+    for (int a = 0; a < nc; a++) {
+        const double *xa = X + (size_t)a * N;
+        double acc = 0.0;
+        for (long long i = tid; i < N; i += 1024) acc = __builtin_fma(xa[i], ycorr[i], acc);
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off);
+        if (lane == 0) wsum[wv] = acc;
+        __syncthreads();
+        if (tid == 0) {
+            double d = wsum[0];
+            for (int k = 1; k < 16; k++) d = d + wsum[k];
+            double xb = 0.0;
+            for (int c = 0; c < nc; c++) xb = __builtin_fma(xpx0[a * nc + c], b[c], xb);
+            const double tot = d + xb;
+            Yi[a] = tot * iVarE;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        double bVec[64];
+        for (int a = 0; a < nc; a++) bVec[a] = b[a];
+        for (int a = 0; a < nc; a++) {
+            bVec[a] = 0.0;
+            double d = 0.0;
+            for (int c = 0; c < nc; c++) d = __builtin_fma(xpxR[a * nc + c], bVec[c], d);
+            const double t1 = d * iVarE;
+            const double rhsb = (nc == 1) ? (Yi[a] + rhs0[0]) : (Yi[a] - t1);
+            double lhsb = xpxR[a * nc + a] * iVarE;
+            if (nc == 1) lhsb = lhsb + lhs0[0];
+            const double inv = 1.0 / lhsb;
+            const double meanb = inv * rhsb;
+            Rng r = rng_seed(seed, chain, it, NGP_KIND_FIXED_NORMAL, ((uint64_t)(fset + 1) << 20) | (uint64_t)a);
+            const double z = rng_normal(r);
+            const double sd = det_sqrt(inv);
+            const double tz = sd * z;
+            bVec[a] = meanb + tz;
+        }
+        for (int a = 0; a < nc; a++) {
+            db[a] = bVec[a] - b[a];
+            b[a] = bVec[a];
+        }
+    }
+    __syncthreads();
+    for (long long i = tid; i < N; i += 1024) {
+        double t = 0.0;
+        for (int a = 0; a < nc; a++) t = __builtin_fma(X[(size_t)a * N + i], db[a], t);
+        ycorr[i] = ycorr[i] - t;
+    }
+}
+__global__ void k_accum_fixed(long long n, const double *__restrict__ b, double *__restrict__ sum_b) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) sum_b[k] += b[k];
+}
+
+// ------------------------------------------------------------------------------------------
 // per-locus coefficients of the block recursion (everything the serial chain does NOT need to
 // compute): c, w, q, T and the pre-drawn chi-square of BayesB.  active_set < 0: all sets.
 // ------------------------------------------------------------------------------------------

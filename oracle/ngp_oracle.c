@@ -56,7 +56,8 @@
 #define KIND_B_LOCUS_CHI2 6
 #define KIND_PI_BETA 7
 #define KIND_R_UNIFORM 8   /* BayesR: the fresh uniform of every comparison of the class search (functions.jl:261) */
-#define KIND_R_DIRICHLET 9 /* BayesR: gamma draws of the Dirichlet (functions.jl:536-538) */
+#define KIND_R_DIRICHLET 9
+/* fixed-effect columns beyond the intercept draw from KIND_FIXED_NORMAL with index ((set + 1) << 20) | column */ /* BayesR: gamma draws of the Dirichlet (functions.jl:536-538) */
 
 #define METHOD_PR 0
 #define METHOD_B 1
@@ -337,6 +338,9 @@ typedef struct {
     int64_t ntrace; double *tr_varE, *tr_b;
     /* scratch for blocked */
     double *c, *w, *q, *T, *chi;
+    /* fixed-effect sets beyond the intercept (functions.jl:22-53; set-up mme.jl:120-152): columns, X'X, X'X + ridge */
+    int nfix; struct { int64_t ncol, off; double *X, *xpx0, *xpxR, *lhs0, *rhs0; } fix[16];
+    int64_t nfixcol; double *bfix, *sum_bfix;
     double *rcls; /* BayesR per-locus class coefficients of the blocked order: [4][RMAX][Ppad] = 1/lhs, a, sd z, u */
     char err[256];
 } ora_t;
@@ -374,6 +378,7 @@ void ora_destroy(ora_t *h) {
 const char *ora_last_error(ora_t *h) { return h->err; }
 
 static inline double dot8_1(const double *a, const double *b, int64_t n);
+static double wave_butterfly(double *v);
 /* hierarchical sequential sum of n shard partials in groups of GRP */
 static double group_sum(const double *p, int64_t n, int64_t stride) {
     double tot = 0.0;
@@ -528,6 +533,133 @@ int ora_add_marker_set(ora_t *h, int64_t col0, int64_t ncol, int method, double 
     return ORA_OK;
 }
 
+/* A fixed-effect set = the columns of one model term (or of one `blockThese` group): N x ncol, column-major.  X'X as the
+   reference forms it (mme.jl:137), plus, for ncol > 1, the ridge min|diag| / 10000 on the diagonal (mme.jl:149-152). */
+int ora_add_fixed_set(ora_t *h, const double *X, int64_t N, int64_t ncol, const double *lhs0, const double *rhs0, int *set_id) {
+    if (h->nfix >= 16 || N != h->N || ncol < 1 || ncol > 64) { snprintf(h->err, 256, "bad fixed-effect set"); return ORA_ERR; }
+    int f = h->nfix;
+    h->fix[f].ncol = ncol; h->fix[f].off = h->nfixcol;
+    h->fix[f].X = (double *)malloc(sizeof(double) * N * ncol); memcpy(h->fix[f].X, X, sizeof(double) * N * ncol);
+    h->fix[f].xpx0 = (double *)calloc(ncol * ncol, sizeof(double)); h->fix[f].xpxR = (double *)calloc(ncol * ncol, sizeof(double));
+    h->fix[f].lhs0 = (double *)calloc(ncol, sizeof(double)); h->fix[f].rhs0 = (double *)calloc(ncol, sizeof(double));
+    for (int64_t a = 0; a < ncol; a++) {
+        for (int64_t b = 0; b <= a; b++) {
+            double acc = 0.0;
+            for (int64_t i = 0; i < N; i++) acc = __builtin_fma(X[a * N + i], X[b * N + i], acc);
+            h->fix[f].xpx0[a * ncol + b] = acc; h->fix[f].xpx0[b * ncol + a] = acc;
+        }
+        if (lhs0) h->fix[f].lhs0[a] = lhs0[a];
+        if (rhs0) h->fix[f].rhs0[a] = rhs0[a];
+    }
+    memcpy(h->fix[f].xpxR, h->fix[f].xpx0, sizeof(double) * ncol * ncol);
+    if (ncol > 1) {
+        double mn = fabs(h->fix[f].xpx0[0]);
+        for (int64_t a = 1; a < ncol; a++) { double d = fabs(h->fix[f].xpx0[a * ncol + a]); if (d < mn) mn = d; }
+        for (int64_t a = 0; a < ncol; a++) h->fix[f].xpxR[a * ncol + a] += mn / 10000.0;
+    }
+    h->nfixcol += ncol;
+    h->bfix = (double *)realloc(h->bfix, sizeof(double) * h->nfixcol); h->sum_bfix = (double *)realloc(h->sum_bfix, sizeof(double) * h->nfixcol);
+    for (int64_t a = h->fix[f].off; a < h->nfixcol; a++) { h->bfix[a] = 0.0; h->sum_bfix[a] = 0.0; }
+    if (set_id) *set_id = f;
+    h->nfix++;
+    return ORA_OK;
+}
+int ora_get_fixed(ora_t *h, double *b, double *sum_b, int64_t *n) {
+    if (n) *n = h->nfixcol;
+    for (int64_t a = 0; a < h->nfixcol; a++) { if (b) b[a] = h->bfix[a]; if (sum_b) sum_b[a] = h->sum_bfix[a]; }
+    return ORA_OK;
+}
+
+/* reference order: sampleX! / sampleb! (functions.jl:22-53) for every fixed set, in the order the sets were added */
+static void fixed_ref(ora_t *h, int64_t it, double iVarE) {
+    const int64_t N = h->N;
+    rng_t r;
+    for (int f = 0; f < h->nfix; f++) {
+        const int64_t nc = h->fix[f].ncol;
+        const double *X = h->fix[f].X;
+        double *b = h->bfix + h->fix[f].off;
+        if (nc == 1) {                                                                     /* :41-47 */
+            for (int64_t i = 0; i < N; i++) h->ycorr[i] += X[i] * b[0];
+            double rhs = dot8_1(X, h->ycorr, N) * iVarE + h->fix[f].rhs0[0];
+            double lhs = h->fix[f].xpx0[0] * iVarE + h->fix[f].lhs0[0];
+            double mean = rhs / lhs;
+            rng_seed(&r, h->seed, h->chain, it, KIND_FIXED_NORMAL, ((uint64_t)(f + 1) << 20));
+            b[0] = mean + sqrt(1.0 / lhs) * rng_normal(&r);
+            for (int64_t i = 0; i < N; i++) h->ycorr[i] -= X[i] * b[0];
+        } else {                                                                           /* :48-52, :22-36 */
+            double Yi[64], bVec[64];
+            for (int64_t i = 0; i < N; i++) { double t = 0.0; for (int64_t a = 0; a < nc; a++) t += X[a * N + i] * b[a]; h->ycorr[i] += t; }   /* :49 */
+            for (int64_t a = 0; a < nc; a++) { Yi[a] = dot8_1(X + a * N, h->ycorr, N) * iVarE; bVec[a] = b[a]; }                           /* :25 */
+            for (int64_t a = 0; a < nc; a++) {
+                bVec[a] = 0.0;                                                             /* :28 */
+                double d = 0.0;
+                for (int64_t c = 0; c < nc; c++) d += h->fix[f].xpxR[a * nc + c] * bVec[c];
+                double rhsb = Yi[a] - d * iVarE;                                           /* :29 */
+                double lhsb = h->fix[f].xpxR[a * nc + a] * iVarE;                          /* :30 */
+                double inv = 1.0 / lhsb;
+                double meanb = inv * rhsb;
+                rng_seed(&r, h->seed, h->chain, it, KIND_FIXED_NORMAL, ((uint64_t)(f + 1) << 20) | (uint64_t)a);
+                bVec[a] = meanb + sqrt(inv) * rng_normal(&r);                              /* :33 */
+            }
+            for (int64_t a = 0; a < nc; a++) b[a] = bVec[a];
+            for (int64_t i = 0; i < N; i++) { double t = 0.0; for (int64_t a = 0; a < nc; a++) t += X[a * N + i] * b[a]; h->ycorr[i] -= t; }   /* :51 */
+        }
+    }
+}
+
+/* blocked order: one formulation for every width (mirrors k_fixed): Yi_a = (x_a'ycorr + sum_c X'X[a][c] b_c) iVarE with the
+   1024-lane dot of the iteration head, Gauss-Seidel on the ridged matrix, ycorr -= X (b_new - b_old) */
+static void fixed_blocked(ora_t *h, int64_t it, double iVarE) {
+    const int64_t N = h->N;
+    rng_t r;
+    for (int f = 0; f < h->nfix; f++) {
+        const int64_t nc = h->fix[f].ncol;
+        const double *X = h->fix[f].X;
+        double *b = h->bfix + h->fix[f].off;
+        double Yi[64], bVec[64], db[64];
+        for (int64_t a = 0; a < nc; a++) {
+            double w16[16];
+            for (int wv = 0; wv < 16; wv++) {
+                double lane[64];
+                for (int l = 0; l < 64; l++) {
+                    double acc = 0.0;
+                    for (int64_t i = wv * 64 + l; i < N; i += 1024) acc = __builtin_fma(X[a * N + i], h->ycorr[i], acc);
+                    lane[l] = acc;
+                }
+                w16[wv] = wave_butterfly(lane);
+            }
+            double d = w16[0];
+            for (int wv = 1; wv < 16; wv++) d = d + w16[wv];
+            double xb = 0.0;
+            for (int64_t c = 0; c < nc; c++) xb = __builtin_fma(h->fix[f].xpx0[a * nc + c], b[c], xb);
+            double tot = d + xb;
+            Yi[a] = tot * iVarE;
+            bVec[a] = b[a];
+        }
+        for (int64_t a = 0; a < nc; a++) {
+            bVec[a] = 0.0;
+            double d = 0.0;
+            for (int64_t c = 0; c < nc; c++) d = __builtin_fma(h->fix[f].xpxR[a * nc + c], bVec[c], d);
+            double t1 = d * iVarE;
+            double rhsb = (nc == 1) ? (Yi[a] + h->fix[f].rhs0[0]) : (Yi[a] - t1);
+            double lhsb = h->fix[f].xpxR[a * nc + a] * iVarE;
+            if (nc == 1) lhsb = lhsb + h->fix[f].lhs0[0];
+            double inv = 1.0 / lhsb;
+            double meanb = inv * rhsb;
+            rng_seed(&r, h->seed, h->chain, it, KIND_FIXED_NORMAL, ((uint64_t)(f + 1) << 20) | (uint64_t)a);
+            double z = rng_normal(&r);
+            double sd = sqrt(inv); double tz = sd * z;
+            bVec[a] = meanb + tz;
+        }
+        for (int64_t a = 0; a < nc; a++) { db[a] = bVec[a] - b[a]; b[a] = bVec[a]; }
+        for (int64_t i = 0; i < N; i++) {
+            double t = 0.0;
+            for (int64_t a = 0; a < nc; a++) t = __builtin_fma(X[a * N + i], db[a], t);
+            h->ycorr[i] = h->ycorr[i] - t;
+        }
+    }
+}
+
 /* BayesR set (mme.jl:374-383): one variance (nVarCov = 1), class multipliers vClass and class probabilities pi (K each) */
 int ora_add_marker_set_r(ora_t *h, int64_t col0, int64_t ncol, double df, double scale, double varBeta0, const double *vClass,
                          const double *pi, int K, int estPi, const double *lhs0, const double *rhs0, int *set_id) {
@@ -561,6 +693,7 @@ int ora_set_y(ora_t *h, const double *y, int64_t N) {
     memcpy(h->y, y, sizeof(double) * N);
     memcpy(h->ycorr, y, sizeof(double) * N); /* mme.jl:57 */
     h->b = 0.0; h->iter = 0;
+    for (int64_t a = 0; a < h->nfixcol; a++) { h->bfix[a] = 0.0; h->sum_bfix[a] = 0.0; }
     return ORA_OK;
 }
 int ora_set_residual_prior(ora_t *h, double df, double scale) { h->e_df = df; h->e_scale = scale; return ORA_OK; }
@@ -583,6 +716,7 @@ static void accumulate(ora_t *h) {
     for (int64_t r = 0; r < h->nvb; r++) h->sum_varBeta[r] += h->varBeta[r];
     for (int s = 0; s < h->nsets; s++) { h->sets[s].sum_pi[0] += h->sets[s].piHat[0]; h->sets[s].sum_pi[1] += h->sets[s].piHat[1]; }
     for (int s = 0; s < h->nsets; s++) for (int v = 0; v < h->sets[s].K; v++) h->sets[s].sum_pic[v] += h->sets[s].pic[v];
+    for (int64_t a = 0; a < h->nfixcol; a++) h->sum_bfix[a] += h->bfix[a];
     h->sum_varE += h->varE; h->sum_b += h->b; h->nKept++;
 }
 
@@ -652,6 +786,7 @@ static void iter_ref(ora_t *h) {
         h->b = mean + sqrt(1.0 / lhs) * rng_normal(&r);
         for (int64_t k = 0; k < N; k++) h->ycorr[k] -= h->b;
     }
+    fixed_ref(h, it, iVarE);   /* the other fixed-effect sets (samplers.jl:39-41) */
     /* samplers.jl:50-53 */
     for (int si = 0; si < h->nsets; si++) {
         oset_t *S = &h->sets[si];
@@ -857,6 +992,7 @@ static void iter_blocked(ora_t *h) {
         h->b = bn;
         for (int64_t i = 0; i < N; i++) h->ycorr[i] = h->ycorr[i] - db;
     }
+    fixed_blocked(h, it, iVarE);
     /* ---- set_prep: per-locus coefficients */
     for (int64_t k = 0; k < h->Ppad; k++) { h->c[k] = 0.0; h->w[k] = 0.0; h->q[k] = -1.0; h->T[k] = 1.0; h->chi[k] = 1.0; }
     for (int si = 0; si < h->nsets; si++) {

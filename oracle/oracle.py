@@ -138,6 +138,23 @@ class Oracle:
         self.nsets += 1
         return sid.value
 
+    def add_fixed_set(self, X, lhs0=None, rhs0=None):
+        """Columns of one fixed-effect term / block (functions.jl:22-53), sampled after the intercept in the order added."""
+        X = np.asfortranarray(X, dtype=np.float64)
+        if X.ndim == 1:
+            X = X[:, None]
+        l0 = None if lhs0 is None else np.ascontiguousarray(lhs0, dtype=np.float64)
+        r0 = None if rhs0 is None else np.ascontiguousarray(rhs0, dtype=np.float64)
+        sid = C.c_int()
+        self._chk(self.L.ora_add_fixed_set(self.h, _p(X, C.c_double), C.c_int64(X.shape[0]), C.c_int64(X.shape[1]), _p(l0, C.c_double),
+                                           _p(r0, C.c_double), C.byref(sid)))
+        return sid.value
+
+    def get_fixed(self):
+        b = np.empty(1024); sb = np.empty(1024); n = C.c_int64()
+        self._chk(self.L.ora_get_fixed(self.h, _p(b, C.c_double), _p(sb, C.c_double), C.byref(n)))
+        return dict(b=b[:n.value].copy(), sum_b=sb[:n.value].copy())
+
     def add_marker_set_r(self, col0, ncol, df, scale, varBeta0, vClass, pi, estPi=False, lhs0=None, rhs0=None):
         """BayesR set (mme.jl:374-383): class multipliers vClass and class probabilities pi."""
         vc = np.ascontiguousarray(vClass, dtype=np.float64); pp = np.ascontiguousarray(pi, dtype=np.float64)

@@ -68,6 +68,40 @@ class RefChain:
         self.b[0] = meanMu + math.sqrt(1.0 / lhs) * self.draw("FIXED_NORMAL", 0, 1)
         self.ycorr -= self.ones * self.b[0]
 
+    def add_fixed(self, X, lhs=None, rhs=None):              # mme.jl:120-152
+        X = np.asarray(X, float)
+        X = X[:, None] if X.ndim == 1 else X
+        nCol = X.shape[1]
+        xpx = X.T @ X                                                                             # :137
+        if nCol > 1:
+            xpx = xpx + np.eye(nCol) * (np.abs(np.diag(xpx)) / 10000).min()                       # :149-152
+        self.Xfix = getattr(self, "Xfix", [])
+        self.Xfix.append(dict(data=X, Xp=X.T.copy(), xpx=xpx, nCol=nCol, b=np.zeros(nCol),
+                              lhs=np.zeros(nCol) if lhs is None else np.array(lhs, float), rhs=np.zeros(nCol) if rhs is None else np.array(rhs, float)))
+
+    def sampleXset(self, f, varE):                           # :39-53
+        Xs = self.Xfix[f]
+        iVarE = 1.0 / varE
+        b = Xs["b"]
+        if Xs["nCol"] == 1:
+            self.ycorr += Xs["data"][:, 0] * b[0]
+            rhs = float(Xs["Xp"][0] @ self.ycorr) * iVarE + Xs["rhs"][0]
+            lhs = float(Xs["xpx"][0, 0]) * iVarE + Xs["lhs"][0]
+            b[0] = rhs / lhs + math.sqrt(1.0 / lhs) * self.draw("FIXED_NORMAL", (f + 1) << 20, 1)
+            self.ycorr -= Xs["data"][:, 0] * b[0]
+        else:
+            self.ycorr += Xs["data"] @ b                                                          # :49
+            bVec = b.copy()                                                                       # :22-36
+            Yi = Xs["Xp"] @ self.ycorr * iVarE
+            for i in range(Xs["nCol"]):
+                bVec[i] = 0.0
+                rhsb = Yi[i] - np.dot(Xs["xpx"][i, :], bVec) * iVarE
+                lhsb = Xs["xpx"][i, i] * iVarE
+                invLhsb = 1.0 / lhsb
+                bVec[i] = invLhsb * rhsb + math.sqrt(invLhsb) * self.draw("FIXED_NORMAL", ((f + 1) << 20) | i, 1)
+            b[:] = bVec
+            self.ycorr -= Xs["data"] @ b                                                          # :51
+
     def sampleBeta(self, si, locus, meanBeta, lhs):          # :493-495
         return meanBeta + math.sqrt(1.0 / lhs) * self.draw("BETA_NORMAL", (si << 40) | locus, 1)
 
@@ -207,6 +241,8 @@ class RefChain:
             self.varE = varE
             if self.intercept:
                 self.sampleX(varE)                           # :39-41
+            for f in range(len(getattr(self, "Xfix", []))):
+                self.sampleXset(f, varE)
             for si, M in enumerate(self.M):                  # :50-53
                 {0: self.sampleBayesPR, 1: self.sampleBayesB, 2: self.sampleBayesC, 3: self.sampleBayesR}[M["method"]](si, varE)
 

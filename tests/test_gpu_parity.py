@@ -521,3 +521,47 @@ def test_diagnostic_mode_is_explicit_and_flagged(ngp, O):
     c.set_y(y)                                               # a fresh, valid chain again
     c.run(2)
     assert np.array_equal(c.get_state()["beta"], _small_model(ngp, O)[0].get_state()["beta"]) is False or True
+
+
+@pytest.mark.parametrize("engine", [(0, 1), (1, 6), (1, 4, 3, 2)], ids=["blocklaunch", "persist_lag6", "rows_lag4"])
+def test_fixed_effect_sets_beyond_the_intercept(ngp, O, engine, tmp_path):
+    """Covariates and a blocked group of fixed effects on the device (sampleX! for one column, sampleb! with its ridge for a
+    block; src/functions.jl:22-53, src/mme.jl:120-152): bit-exact against the blocked oracle, 1e-9 against the reference-order
+    oracle, the true effects recovered, and a snapshot carries them."""
+    N, P = 300, 200
+    X, y, bt, v = make_problem(O, N, P, seed=5)
+    rng = np.random.default_rng(3)
+    F1 = rng.normal(size=(N, 1))
+    F3 = np.column_stack([rng.integers(0, 2, N).astype(float), rng.normal(size=N), rng.normal(size=N) * 3])
+    y = y + 2.0 * F1[:, 0] - 1.5 * F3[:, 1]
+    s, o = _pair(ngp, O, X, seed=7, chain=0, engine=engine)
+    ro = O.Oracle(order=0, seed=7, chain=0); ro.set_panel_f32(X)
+    for m in (s, o, ro):
+        m.add_fixed_set(F1, lhs0=[0.3], rhs0=[0.1]); m.add_fixed_set(F3)
+        add_sets(m, [(0, 120, "PR"), (120, 80, "B")], v)
+        m.set_y(y); m.set_residual_prior(4.0, 0.25 * y.var()); m.set_schedule(40, 10, 1); m.run(40)
+    a, b, c = s.get_state(), o.get_state(), ro.get_state()
+    fa, fb, fc = s.get_fixed(), o.get_fixed(), ro.get_fixed()
+    assert np.array_equal(fa["b"], fb["b"]) and np.array_equal(fa["sum_b"], fb["sum_b"])
+    assert np.abs(fa["b"] - fc["b"]).max() <= 1e-9 * np.abs(fc["b"]).max() and np.abs(fa["sum_b"] - fc["sum_b"]).max() <= 1e-9 * np.abs(fc["sum_b"]).max()
+    assert np.array_equal(a["delta"], b["delta"]) and np.array_equal(a["delta"], c["delta"])
+    for k in ("beta", "ycorr", "varBeta"):
+        assert np.array_equal(a[k], b[k]), k
+        assert np.abs(a[k] - c[k]).max() <= 1e-9 * max(1e-6, np.abs(c[k]).max()), k
+    post = fa["sum_b"] / 30
+    assert abs(post[0] - 2.0) < 0.4 and abs(post[2] + 1.5) < 0.4 and abs(post[1]) < 0.6 and abs(post[3]) < 0.2
+    resid = y - a["b"] - np.column_stack([F1, F3]) @ fa["b"] - s.xbeta(a["beta"])
+    assert np.abs(a["ycorr"] - resid).max() <= 1e-9 * np.abs(y).max()
+    # resume through a snapshot
+    path = str(tmp_path / "fx.ngpsnap")
+    s.save_snapshot(path)
+    s2 = ngp.Sampler(device=0, seed=1, chain=9, mode=engine[0], lag=engine[1], streamer=engine[3] if len(engine) > 3 else 1)
+    if len(engine) > 2:
+        s2.set_near(engine[2])
+    s2.set_panel(X); s2.add_fixed_set(F1, lhs0=[0.3], rhs0=[0.1]); s2.add_fixed_set(F3)
+    add_sets(s2, [(0, 120, "PR"), (120, 80, "B")], v); s2.set_y(y); s2.set_residual_prior(4.0, 0.25 * y.var()); s2.set_schedule(40, 10, 1)
+    s2.load_snapshot(path)
+    s.set_schedule(50, 10, 1); s2.set_schedule(50, 10, 1)
+    s.run(10); s2.run(10)
+    assert np.array_equal(s.get_fixed()["b"], s2.get_fixed()["b"]) and np.array_equal(s.get_fixed()["sum_b"], s2.get_fixed()["sum_b"])
+    assert np.array_equal(s.get_state()["beta"], s2.get_state()["beta"])

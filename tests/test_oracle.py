@@ -372,3 +372,28 @@ def test_det_exp_within_one_ulp(O):
         ref = math.exp(x)
         assert abs(O.det_exp(x) - ref) <= 1.01 * np.spacing(ref)
     assert O.det_exp(0.0) == 1.0 and O.det_exp(-800.0) == 0.0 and math.isnan(O.det_exp(float("nan")))
+
+
+def test_numpy_restatement_fixed_effect_sets(O):
+    """sampleX! (one column) and sampleb! (a block, with the ridge of mme.jl:149-152) in the numpy restatement against both orders
+    of the C oracle."""
+    from ref_numpy import RefChain
+    N, P = 70, 40
+    X, y, bt, v = make_problem(O, N, P, seed=2)
+    rng = np.random.default_rng(5)
+    F1 = rng.normal(size=N); F3 = rng.normal(size=(N, 3)); F3[:, 0] = (rng.uniform(size=N) < 0.4)
+    y = y + 1.5 * F1 - 0.7 * F3[:, 2]
+    o0 = O.Oracle(0, seed=3, chain=0); o0.set_panel_f32(X)
+    o1 = O.Oracle(1, seed=3, chain=0); o1.set_panel_f32(X, R=4, S=18, D=1)
+    ref = RefChain(O, X.astype(np.float64), y, seed=3, chain=0)
+    for m in (o0, o1):
+        m.add_fixed_set(F1, lhs0=[0.2], rhs0=[0.05]); m.add_fixed_set(F3)
+        m.add_marker_set(0, P, 0, 4.0, v * 0.5, [(0, P)], [v]); m.set_y(y); m.set_residual_prior(4.0, 0.3 * y.var())
+    ref.add_fixed(F1, lhs=[0.2], rhs=[0.05]); ref.add_fixed(F3)
+    ref.add_set(0, P, 0, 4.0, v * 0.5, [(0, P)], [v]); ref.E_df, ref.E_scale = 4.0, 0.3 * y.var()
+    for it in range(8):
+        o0.run(1); o1.run(1); ref.run(1)
+        bref = np.concatenate([x["b"] for x in ref.Xfix])
+        for o in (o0, o1):
+            assert np.abs(o.get_fixed()["b"] - bref).max() <= 1e-10 * max(1.0, np.abs(bref).max()), it
+            assert np.abs(o.get_state()["beta"] - ref.state()["beta"]).max() <= 1e-10, it
