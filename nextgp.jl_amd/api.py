@@ -10,8 +10,8 @@ Same names, argument meaning and output files as the reference, so a model scrip
     SNP(M, "geno.txt"[, "map.txt"]) in the formula      the same text inside the formula string                src/runTime.jl:13-28
     summaryMCMC("betaM"; outFolder)                     summaryMCMC("betaM", outFolder=...)                    src/misc.jl:241-244
 
-Only what the hot path needs is interpreted here: the response, the intercept `1` and `SNP(...)` terms.
-Fixed covariates, `PED(...)`, `(1|g)` terms, GBLUP priors, BayesRC/LV are outside the accelerated
+Interpreted here: the response, the intercept `1`, covariate / factor columns (optionally grouped by `blockThese`) and `SNP(...)`
+terms.  Interactions, `PED(...)`, `(1|g)` terms, GBLUP priors, BayesRC/LV are outside the accelerated
 path and raise NotImplementedError naming the reference code that handles them.
 All arithmetic happens in libnextgp_hip.so; this file only parses, reshapes and writes files.
 """
@@ -24,7 +24,7 @@ import numpy as np
 
 from ._lib import METHOD_BAYESB, METHOD_BAYESC, METHOD_BAYESPR, Sampler
 
-__all__ = ["BayesPR", "BayesB", "BayesC", "BayesR", "Random", "SNP", "runLMEM", "summaryMCMC", "read_genotypes", "prep2RegionData", "parse_formula"]
+__all__ = ["BayesPR", "BayesB", "BayesC", "BayesR", "Random", "SNP", "runLMEM", "summaryMCMC", "read_genotypes", "prep2RegionData", "parse_formula", "design_columns"]
 
 
 # ----------------------------------------------------------------------------------------------
@@ -122,7 +122,7 @@ def parse_formula(formula):
             cur += ch
     if cur.strip():
         terms.append(cur.strip())
-    intercept, snps = False, []
+    intercept, snps, covs = False, [], []
     for t in terms:
         if t == "1":
             intercept = True
@@ -137,10 +137,27 @@ def parse_formula(formula):
         elif t.startswith("PED(") or "|" in t:
             raise NotImplementedError(f"term '{t}': pedigree / (1|g) random effects stay on the reference's Julia path "
                                       "(src/functions.jl:57-110, src/mme.jl:165-272); they are outside the accelerated sweep")
+        elif re.fullmatch(r"[A-Za-z_][A-Za-z_0-9]*", t):
+            covs.append(t)  # a column of the data: covariate or factor (src/prepMatVec.jl:150-165)
         else:
-            raise NotImplementedError(f"term '{t}': fixed covariates other than the intercept stay on the reference's Julia path "
-                                      "(src/functions.jl:22-53); use the fine seam (ngp_sweep_set) to combine them with the GPU sweep")
+            raise NotImplementedError(f"term '{t}': interactions / function terms stay on the reference's Julia path (StatsModels, "
+                                      "src/prepMatVec.jl:150-165); use the fine seam (ngp_sweep_set) to combine them with the GPU sweep")
+    parse_formula.last_covariates = covs
     return lhs, intercept, snps
+
+
+def design_columns(name, col):
+    """One model term -> (N x k design, level names): Float columns are centred, Int / String columns dummy coded with the first
+    level as the base (the reference's rules, src/prepMatVec.jl docstring :33-37 and :46-60, through StatsModels)."""
+    col = np.asarray(col)
+    if col.dtype.kind == "f":
+        x = col.astype(np.float64)
+        return (x - x.mean())[:, None], [name]
+    levels = sorted(set(col.tolist()))
+    if len(levels) < 2:
+        raise ValueError(f"factor {name} has a single level")
+    X = np.column_stack([(col == lv).astype(np.float64) for lv in levels[1:]])
+    return X, [f"{name}: {lv}" for lv in levels[1:]]
 
 
 # ----------------------------------------------------------------------------------------------
@@ -250,8 +267,6 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
     seeds); (2) an existing non-empty outFolder is refused unless overwrite=True (the reference deletes it,
     src/misc.jl:221-227); (3) samples="none" skips the per-iteration text rows and only returns posterior means.
     Returns a dict of posterior means taken from the on-device sums."""
-    if blockThese:
-        raise NotImplementedError("blockThese: blocked fixed effects stay on the Julia path (src/functions.jl:22-36)")
     if userPedData is not None and len(userPedData):
         raise NotImplementedError("userPedData: pedigree effects stay on the Julia path (src/mme.jl:26-46)")
     VCV = dict(VCV or {})
@@ -285,6 +300,31 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
     e_scale = 0.0005 if e_prior.v == 0.0 else e_prior.v * (e_df - 2.0) / e_df
     smp.set_residual_prior(e_df, e_scale)
     smp.set_intercept(intercept)
+    # fixed effects beyond the intercept (src/prepMatVec.jl:150-165, blocks src/mme.jl:96-108): every term its own set, the terms of a
+    # blockThese group one multi-column set (sampleb!, src/functions.jl:22-36); blocks first, in the user's order, then the rest in
+    # model order (the reference walks a Julia Dict, whose order is not defined: documented difference)
+    covs = list(getattr(parse_formula, "last_covariates", []))
+    fixed_names = ["(Intercept)"] if intercept else []
+    designs = {c: design_columns(c, userData[c]) for c in covs}
+    used = set()
+    for blk in (blockThese or []):
+        blk = [c for c in covs if c in set(blk)]          # columns inside a block keep the model's order
+        if not blk:
+            continue
+        smp.add_fixed_set(np.column_stack([designs[c][0] for c in blk]))
+        for c in blk:
+            fixed_names += designs[c][1]
+            used.add(c)
+    for c in covs:
+        if c in used:
+            continue
+        Xc, names = designs[c]
+        if c in summaryStat and Xc.shape[1] == 1:         # src/mme.jl:140-147
+            m, vv = float(np.atleast_1d(summaryStat[c][0])[0]), float(np.atleast_1d(summaryStat[c][1])[0])
+            smp.add_fixed_set(Xc, lhs0=[1.0 / vv], rhs0=[m / vv])
+        else:
+            smp.add_fixed_set(Xc)
+        fixed_names += names
     # marker sets (src/mme.jl:287-347, 492-520)
     sets, col0 = [], 0
     for t, M in zip(snps, mats):
@@ -318,7 +358,7 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
     smp.set_schedule(nChain, nBurn, nThin)
     # header rows (src/mme.jl:543-595)
     if samples == "text":
-        _out(outFolder, "b", ["(Intercept)"] if intercept else [])
+        _out(outFolder, "b", fixed_names)
         _out(outFolder, "varE", ["e"])
         for s in sets:
             names = [f"M{i + 1}" for i in range(s["P"])]  # src/prepMatVec.jl:131
@@ -336,7 +376,7 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
             smp.run(it - done)
             done = it
             st = smp.get_state()
-            _out(outFolder, "b", _fmt(st["b"]) if intercept else [])
+            _out(outFolder, "b", (_fmt(st["b"]) if intercept else []) + (_fmt(smp.get_fixed()["b"]) if len(fixed_names) > int(intercept) else []))
             _out(outFolder, "varE", _fmt(st["varE"]))
             vb_off = 0
             for k, s in enumerate(sets):
@@ -352,7 +392,8 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
     smp.run(nChain - done)
     ps = smp.get_posterior_sums()
     n = max(ps["nKept"], 1)
-    res = dict(nKept=ps["nKept"], b=ps["sum_b"] / n, varE=ps["sum_varE"] / n, sets={})
+    res = dict(nKept=ps["nKept"], b=ps["sum_b"] / n, varE=ps["sum_varE"] / n, sets={}, fixed_names=fixed_names,
+               fixed=smp.get_fixed()["sum_b"] / n if len(fixed_names) > int(intercept) else np.zeros(0))
     vb_off = 0
     for k, s in enumerate(sets):
         sl = slice(s["col0"], s["col0"] + s["P"])

@@ -119,13 +119,12 @@ end
 """
     runSampler!(ycorr, nData, E, X, b, Z, u, varU, M, beta, varBeta, delta, chainLength, burnIn, outputFreq, outPut; seed=1)
 
-Coarse seam: drop-in for `samplers.runSampler!` (src/samplers.jl:23) for models made of an intercept and
-Symbol marker sets with BayesPR / BayesB / BayesC / BayesR priors.  Anything else falls back to the reference sampler.
+Coarse seam: drop-in for `samplers.runSampler!` (src/samplers.jl:23) for models made of fixed effects (intercept, covariates,
+factors, blocked groups) and Symbol marker sets with BayesPR / BayesB / BayesC / BayesR priors.  Anything else falls back to the reference sampler.
 """
 function runSampler!(ycorr, nData, E, X, b, Z, u, varU, M, beta, varBeta, delta, chainLength, burnIn, outputFreq, outPut;
                      seed::Integer=1, device::Integer=0)
     isempty(Z) || error("random effects present: use the fine seam (NextGPHIP.sweep!) instead")
-    (length(X) <= 1 && all(x -> X[x].nCol == 1, keys(X))) || error("only the intercept is supported on the coarse seam")
     E.str == "I" || error("weighted residuals: use the reference sampler")
     h = Handle(device=device, seed=seed)
     sets = collect(keys(M))                       # Dict order, as src/samplers.jl:50
@@ -148,9 +147,19 @@ function runSampler!(ycorr, nData, E, X, b, Z, u, varU, M, beta, varBeta, delta,
         end
         col0 += P
     end
+    # fixed effects: EVERY set of X (the intercept's column of ones included) becomes a fixed-effect set of the library, in the
+    # order of keys(X) -- exactly the order src/samplers.jl:39-41 samples them in; the library's own intercept is switched off
+    xsets = collect(keys(X))
+    for x in xsets
+        Xd = Matrix{Float64}(reshape(X[x].data, :, X[x].nCol))
+        check(h, ccall((:ngp_add_fixed_set, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Ptr{Float64}, Ptr{Float64}, Ref{Int32}),
+                       h.ptr, Xd, size(Xd, 1), size(Xd, 2), size(Xd, 1), Float64.(X[x].lhs), Float64.(X[x].rhs), Ref{Int32}(0)))
+    end
+    nfix = isempty(xsets) ? 0 : sum(X[x].nCol for x in xsets)
+    bfix = Vector{Float64}(undef, max(nfix, 1)); sbfix = similar(bfix); nfx = Ref{Int64}(0)
     set_y!(h, Vector{Float64}(ycorr))            # ycorr == y at this point (src/mme.jl:57)
     set_residual_prior!(h, E.df, E.scale)
-    check(h, ccall((:ngp_set_intercept, LIB), Int32, (Ptr{Cvoid}, Int32), h.ptr, isempty(X) ? 0 : 1))
+    check(h, ccall((:ngp_set_intercept, LIB), Int32, (Ptr{Cvoid}, Int32), h.ptr, 0))
     set_schedule!(h, chainLength, burnIn, outputFreq)
     Ptot = col0
     bet = Vector{Float64}(undef, Ptot); del = Vector{Int64}(undef, Ptot)
@@ -162,7 +171,9 @@ function runSampler!(ycorr, nData, E, X, b, Z, u, varU, M, beta, varBeta, delta,
         check(h, ccall((:ngp_get_state, LIB), Int32,
                        (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}, Ref{Float64}, Ref{Int64}),
                        h.ptr, ycorr, bet, del, vb, pih, ve, bb, it))
-        open(io -> writedlm(io, [bb[]]'), outPut * "/bOut", "a")          # src/samplers.jl:57
+        check(h, ccall((:ngp_get_fixed, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ref{Int64}), h.ptr, bfix, sbfix, nfx))
+        b[1:nfix] .= bfix[1:nfix]                                          # positions follow keys(X), like X[xSet].pos (src/mme.jl:112-117)
+        open(io -> writedlm(io, bfix[1:nfix]'), outPut * "/bOut", "a")     # src/samplers.jl:57
         open(io -> writedlm(io, ve[]), outPut * "/varEOut", "a")          # src/samplers.jl:58
         c0 = 0; v0 = 0
         for (k, s) in enumerate(sets)

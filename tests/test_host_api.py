@@ -13,9 +13,15 @@ def test_parse_formula(ngp):
     assert (lhs, ic) == ("y", True) and snps[0].name == "M" and snps[0].path == "geno.txt" and snps[0].map == ""
     lhs, ic, snps = ngp.parse_formula('pheno ~ 0 + SNP(M1,"a b.txt","map.csv") + SNP(M2, "g2.txt")')
     assert (lhs, ic) == ("pheno", False) and [s.name for s in snps] == ["M1", "M2"] and snps[0].map == "map.csv"
-    for bad in ("y ~ 1 + x1 + SNP(M,\"g\")", "y ~ 1 + PED(ID) + SNP(M,\"g\")", "y ~ 1 + (1|herd) + SNP(M,\"g\")"):
+    for bad in ("y ~ 1 + x1&x2 + SNP(M,\"g\")", "y ~ 1 + PED(ID) + SNP(M,\"g\")", "y ~ 1 + (1|herd) + SNP(M,\"g\")"):
         with pytest.raises(NotImplementedError, match="Julia path"):
             ngp.parse_formula(bad)
+    ngp.parse_formula('y ~ 1 + age + herd + SNP(M,"g")')
+    assert ngp.parse_formula.last_covariates == ["age", "herd"]      # covariates / factors: fixed-effect sets on the device
+    Xd, names = ngp.design_columns("herd", np.array(["a", "c", "b", "a"]))
+    assert names == ["herd: b", "herd: c"] and np.array_equal(Xd, [[0, 0], [0, 1], [1, 0], [0, 0]])
+    Xc, _ = ngp.design_columns("age", np.array([1.0, 2.0, 6.0]))
+    assert np.allclose(Xc[:, 0], [-2.0, -1.0, 3.0])                   # Float columns are centred
 
 
 def test_priors_have_reference_fields(ngp):
@@ -145,3 +151,33 @@ def test_runLMEM_bayesr_matches_oracle(ngp, O, tmp_path):
         assert len(lines) == 5 and len(lines[0].split("\t")) == ncol, name
     assert (out / "piMOut").read_text().splitlines()[0].split("\t") == ["pi1", "pi2", "pi3", "pi4"]
     assert set(np.loadtxt(out / "deltaMOut", skiprows=1).ravel()) <= {1.0, 2.0, 3.0, 4.0}
+
+
+@pytest.mark.gpu
+def test_runLMEM_covariates_and_blocks(ngp, O, tmp_path):
+    """Fixed effects through the reference's interface: a Float covariate (centred), a factor (dummy coded), two terms blocked with
+    blockThese (sampleb!, src/functions.jl:22-36): bOut carries every level, posterior means against the oracle."""
+    N, P = 120, 100
+    X, y, bt, v = make_problem(O, N, P, seed=4)
+    X1 = O.generate_panel(N, P, seed=6)[0]
+    G = np.rint(X1.astype(np.float64) - X1.astype(np.float64).min(axis=0))
+    rng = np.random.default_rng(2)
+    age = rng.normal(40, 5, N); w = rng.normal(size=N); herd = rng.choice(["a", "b", "c"], N)
+    y = y + 0.3 * (age - 40) + 1.2 * (herd == "c")
+    g = tmp_path / "g.txt"
+    np.savetxt(g, G, fmt="%d", delimiter=" ")
+    out = tmp_path / "outF"
+    VCV = {"M": ngp.BayesPR(9999, v), "e": ngp.Random("I", 0.5 * y.var())}
+    res = ngp.runLMEM(f'y ~ 1 + age + herd + w + SNP(M,"{g}")', {"y": y, "age": age, "herd": herd, "w": w}, 30, 10, 2, outFolder=str(out), VCV=VCV,
+                      seed=5, blockThese=[("age", "w")])
+    assert res["fixed_names"] == ["(Intercept)", "age", "w", "herd: b", "herd: c"] and res["nKept"] == 10
+    Gc = (G - G.mean(axis=0)).astype(np.float32)
+    o = O.Oracle(0, seed=5, chain=0); o.set_panel_f32(Gc)
+    o.add_fixed_set(np.column_stack([age - age.mean(), w - w.mean()]))
+    o.add_fixed_set(np.column_stack([(herd == "b").astype(float), (herd == "c").astype(float)]))
+    o.add_marker_set(0, P, 0, 4.0, v * 0.5, [(0, P)], [v])
+    o.set_y(y); o.set_residual_prior(4.0, 0.5 * y.var() * 0.5); o.set_schedule(30, 10, 2); o.run(30)
+    assert np.abs(res["fixed"] - o.get_fixed()["sum_b"] / 10).max() < 1e-9
+    assert abs(res["fixed"][0] - 0.3) < 0.15 and abs(res["fixed"][3] - 1.2) < 0.9
+    lines = (out / "bOut").read_text().splitlines()
+    assert len(lines) == 11 and lines[0].split("\t") == res["fixed_names"] and len(lines[1].split("\t")) == 5
