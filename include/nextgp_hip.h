@@ -57,8 +57,8 @@ const char *ngp_last_error(ngp_handle *h);
 int32_t ngp_configure(ngp_handle *h, int32_t mode, int32_t lag);
 int32_t ngp_get_config(ngp_handle *h, int32_t *mode, int32_t *lag);
 /* Persistent sweep only: look-ahead lags 1..near are corrected inside the sampler workgroup, lags near+1..lag-1 by the
- * reducer workgroups (another summation order, which the blocked oracle needs to know).  0 = automatic (3; 4 for the phase
- * streamer on shards taller than 128 rows); to be chosen before the panel is set.  ngp_get_near_lags reports the value in force. */
+ * reducer workgroups (another summation order, which the blocked oracle needs to know).  1..4, 0 = automatic (3; on shards
+ * taller than 128 rows 2 for the row-owning streamer and 4 for the phase streamer); to be chosen before the panel is set.  ngp_get_near_lags reports the value in force. */
 int32_t ngp_set_near_lags(ngp_handle *h, int32_t near);
 int32_t ngp_get_near_lags(ngp_handle *h, int32_t *near);
 /* Diagnostic only: enable != 0 makes the persistent kernel write 100 MHz time stamps (sampler: 4 words per
@@ -188,7 +188,7 @@ int32_t ngp_get_streamer(ngp_handle *h, int32_t *variant, int32_t *gemv_chains);
  * their launches and then return NGP_ERR_DEBUG: the chain they leave behind is invalid.  0 = off. */
 int32_t ngp_debug_set_mode(ngp_handle *h, int32_t mode);
 /* Tuning knob of the row-owning streamer: pacing of its loader wave, 0..4 = s_sleep units (64 clocks) after every four tile
- * requests (default 1).  Changes timing only, never results. */
+ * requests (default 0), + 16 = count every partial before the block's barrier.  Changes timing only, never results. */
 int32_t ngp_debug_set_knob(ngp_handle *h, int32_t knob);
 
 /* Resume support, second half: overwrite the posterior sums (same shapes as ngp_get_posterior_sums).  With ngp_set_state a

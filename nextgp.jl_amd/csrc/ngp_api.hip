@@ -117,7 +117,7 @@ struct ngp_handle {
     int64_t sweep_launches = 0;
     // diagnostics (ngp_debug_set_mode): != 0 makes every chain invalid, ngp_run / ngp_sweep_set then return NGP_ERR_DEBUG
     int dbg_mode = 0;
-    int knob = 1;  // pacing of the loader wave of the row-owning streamer: s_sleep units after every four requests (ngp_debug_set_knob)
+    int knob = 0;  // pacing of the loader wave of the row-owning streamer: s_sleep units after every four requests (ngp_debug_set_knob)
     bool adding_r = false;  // ngp_add_marker_set is being called by ngp_add_marker_set_r
     bool poisoned = false;  // a sweep gave up half-way (abort word): the chain state is unusable until ngp_set_y / ngp_set_state
     // optional per-iteration traces of selected effects, variances and pi (ngp_set_trace_loci)
@@ -206,7 +206,8 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
     // a fourth near lag overloads the sampler CU at short shards (+17 % time at 10k x 100k); the phase streamer of tall shards,
     // where with lag 5 nothing is left for the reducers then, saves 8 % with it; with the row-owning streamer (lag 6) the sampler
     // CU is again the busier end (its Gram traffic: 32 KB per near lag and block) and three near lags measure better
-    h->near = h->near_req ? h->near_req : ((h->mode == 1 && h->R > 128 && h->streamer != 2) ? 4 : 3);
+    // (row-owning streamer on tall shards: two near lags measured 1.5 % better still -- the far path is one hop since dlt travels as granules)
+    h->near = h->near_req ? h->near_req : ((h->mode == 1 && h->R > 128) ? (h->streamer == 2 ? 2 : 4) : 3);
     h->NBLK = (P + NGP_BLK - 1) / NGP_BLK;
     h->Ppad = h->NBLK * NGP_BLK;
     h->L = h->R * h->S;
@@ -1078,7 +1079,7 @@ int32_t ngp_set_near_lags(ngp_handle *h, int32_t near) {
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles == nullptr, NGP_ERR_STATE, "ngp_set_near_lags must precede the panel upload");
-    REQUIRE(near == 0 || near == 3 || near == 4, NGP_ERR_ARG, "near lags: 0 (automatic), 3 or 4");
+    REQUIRE(near >= 0 && near <= 4, NGP_ERR_ARG, "near lags: 0 (automatic) or 1..4");
     h->near_req = near;
     return NGP_OK;
 }

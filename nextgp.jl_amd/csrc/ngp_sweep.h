@@ -571,7 +571,10 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
 // tree).  The blocked oracle takes the chain count as a layout parameter (ngp_get_streamer).
 #define NGP_ROWS_MAX_R 224
 #define NGP_ROWS_NW 7       // row-owning waves
-#define NGP_ROWS_HMAX 32    // quads of tile u+2 requested during block u (the counted wait keeps them in flight)
+#ifndef NGP_ROWS_HMAX
+#define NGP_ROWS_HMAX 32
+#endif
+//   // quads of tile u+2 requested during block u (the counted wait keeps them in flight)
 #define NGP_ROWS_PUBW 2
 #define NGP_ROWS_POLLW 6
 
@@ -640,7 +643,7 @@ __device__ inline void role_streamer_rows(const SweepArgs &A, const int s, char 
         // they stream faster in isolation (2.14 against 2.47 us per block) but every other memory access of this CU -- the partial
         // sums going out, dlt coming in -- then queues behind a full tile of requests, and the sweep is bound by that hand-off
         // loop, not by the stream.  Capping the outstanding requests with counted vmcnt waits instead was far worse (4.9 us).
-        const int pace = A.knob;
+        const int pace = A.knob & 7;
         // quads [q0, q1) of local tile `tile` into ring slots tbase + q (everything wave-uniform: scalar registers only)
         auto dma_quads = [&](int tile, int q0, int q1, int tbase) {
             if (no_dma || q0 >= q1) return 0;
@@ -827,7 +830,7 @@ __device__ inline void role_streamer_rows(const SweepArgs &A, const int s, char 
                 // Lag 3: dlt of block u-2, which the poller of this workgroup waits for before this barrier, needs the partial of
                 // block u-1 of EVERY streamer counted (the sampler fetches the group sums of the next block before it lets a
                 // block go) -- so the count must not slip behind the barrier.  From lag 4 on it may (needs: partials <= u-2).
-                try_signal(DT < 4);
+                try_signal(DT < 4 || (A.knob & 16));
                 wg_barrier();
                 if (!*sflag) return;
                 NGP_FINE(5);
@@ -1295,7 +1298,7 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
             if (D >= 2) {
                 const int slot = u % NGP_RING, rs = u & 3;
                 double tot = r0[rs * NGP_BLK + j];
-                const bool have_far = (D >= 3) && (u >= 2);
+                const bool have_far = (D >= 3) && (u >= 2) && (A.near >= 2);
                 const bool have_one = (u >= 1);
                 double cor = have_far ? vacc[slot * NGP_BLK + j] : 0.0;
                 if (have_one) {
@@ -1337,7 +1340,7 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
         // waves 4, 6 and 7: the lag-2, lag-3 and lag-4 corrections (farther lags are folded into the group sums by the
         // reducers -- a loop sampler -> reducer -> sampler of about 7 us that must fit into `near` block periods);
         // their Gram rows are loaded one block ahead.
-        const int fx = (wv == 4) ? 2 : (wv == 6 ? 3 : (wv == 7 && A.near >= 4 ? 4 : 99));
+        const int fx = (wv == 4 && A.near >= 2) ? 2 : ((wv == 6 && A.near >= 3) ? 3 : (wv == 7 && A.near >= 4 ? 4 : 99));
         const int top = min(A.near, D - 1);  // highest lag corrected here: its term opens the sum of a target
         double gr[NGP_BLK];
 #pragma unroll
@@ -1385,7 +1388,7 @@ __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
                 case 3: role_streamer_rows<DBG, 3>(A, s, smem); break;
                 case 4: role_streamer_rows<DBG, 4>(A, s, smem); break;
                 case 5: role_streamer_rows<DBG, 5>(A, s, smem); break;
-                default: role_streamer_rows<DBG, 6>(A, s, smem); break;
+                default: role_streamer_rows<DBG, 6>(A, s, smem); break;  // (lag 7 was built: 58 VGPRs of the delay line spill, 2.58 -> 3.08 us per block)
             }
             return;
         }

@@ -119,7 +119,7 @@ def test_north_star_shape_50k_x_600k(ngp):
         s.generate_panel(N_, P_)
         if not out:
             R, S, nblk = s.layout()
-            assert (R, S, nblk) == (204, 246, 9375) and s.config() == (1, 6) and s.near() == 3 and s.streamer() == (2, 7)
+            assert (R, S, nblk) == (204, 246, 9375) and s.config() == (1, 6) and s.near() == 2 and s.streamer() == (2, 7)
             rng = np.random.default_rng(1)
             bt = np.zeros(P_); idx = rng.choice(P_, P_ // 100, replace=False); bt[idx] = rng.normal(size=len(idx))
             g = s.xbeta(bt)

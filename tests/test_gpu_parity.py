@@ -41,9 +41,11 @@ def test_draws_bit_exact(dev, O, what, p1, p2):
 # (mode, lag[, near lags]): per-block launches / persistent sweep; near = 4 is what tall shards (R > 128) run with
 # (mode, lag[, near lags[, streamer variant]]): per-block launches / persistent sweep; near = 4 is what tall shards (R > 128) run
 # with; streamer 2 = row-owning waves + loader wave (7 GEMV chains; the default for shards of 132..224 rows, forced here)
-ENGINES = [(0, 1), (1, 1), (1, 2), (1, 3), (1, 4), (1, 6), (1, 8), (1, 5, 4), (1, 8, 4), (1, 3, 3, 2), (1, 4, 3, 2), (1, 5, 4, 2), (1, 6, 4, 2)]
+ENGINES = [(0, 1), (1, 1), (1, 2), (1, 3), (1, 4), (1, 6), (1, 8), (1, 5, 4), (1, 8, 4), (1, 3, 3, 2), (1, 4, 3, 2), (1, 5, 4, 2), (1, 6, 4, 2),
+           (1, 8, 2), (1, 6, 2, 2), (1, 6, 1, 2), (1, 8, 1)]
 ENGINE_IDS = ["blocklaunch", "persist_lag1", "persist_lag2", "persist_lag3", "persist_lag4", "persist_lag6", "persist_lag8",
-              "persist_lag5_near4", "persist_lag8_near4", "rows_lag3", "rows_lag4", "rows_lag5_near4", "rows_lag6_near4"]
+              "persist_lag5_near4", "persist_lag8_near4", "rows_lag3", "rows_lag4", "rows_lag5_near4", "rows_lag6_near4",
+              "persist_lag8_near2", "rows_lag6_near2", "rows_lag6_near1", "persist_lag8_near1"]
 
 
 def _pair(ngp, O, X, seed=1001, chain=0, engine=(1, 6)):
@@ -257,7 +259,7 @@ def test_shard_height_boundaries_bit_exact(ngp, O, N):
     assert mode == 1 and R == {14700: 60, 16000: 68, 30400: 124, 31700: 132, 54000: 220, 55000: 228, 62000: 252, 63232: 256}[N]
     variant, nchain = s.streamer()
     assert (variant, nchain) == ((2, 7) if 128 < R <= 224 else (1, 8))   # row-owning waves where the phase streamer is barrier-bound
-    assert (D, s.near()) == ((8, 3) if R <= 128 else ((6, 3) if variant == 2 else (5, 4)))
+    assert (D, s.near()) == ((8, 3) if R <= 128 else ((6, 2) if variant == 2 else (5, 4)))
     o = O.Oracle(order=1, seed=21, chain=0)
     o.set_panel_f32(X, R=R, S=S, D=D, near=s.near(), nchain=nchain)
     v = 0.01
