@@ -183,6 +183,27 @@ int32_t ngp_eval_math(ngp_handle *h, int32_t which, const double *in, int64_t n,
 int32_t ngp_set_streamer(ngp_handle *h, int32_t variant);
 int32_t ngp_get_streamer(ngp_handle *h, int32_t *variant, int32_t *gemv_chains);
 
+/* ---- panel storage (before the panel is set) ----
+ * NGP_STORAGE_F32 (default): the centred panel as fp32 tiles (4 bytes per genotype).
+ * NGP_STORAGE_U8 ("compact"): the genotype codes stay one byte each and the centring of src/prepMatVec.jl:129 is applied
+ * analytically with the Float64 column means m_j = (sum_i g_ij) / N: x_j'ycorr = sum_i g_ij ycorr_i - m_j sum_i ycorr_i,
+ * ycorr -= x_j dlt = ycorr_i - (g_ij dlt - m_j dlt), x_k'x_j = (exact integer dot product) - N m_k m_j.  A quarter of the
+ * memory and of the bytes streamed per iteration, and no fp32 rounding of the panel: the chain agrees with the reference's
+ * Float64 arithmetic to rounding error of the sums (the fp32 tiles deviate by ~1e-7 relative).  Persistent sweep only; shards
+ * are multiples of 16 rows (up to 896 rows, N up to ~196k on one MI355X); look-ahead lags 3, 4, 6, 8, 12 (4 or 8 for shards
+ * taller than 224 rows, 4 above 448 rows; a request is rounded down to the next of these); ngp_get_streamer reports variant 3, 7 GEMV chains.  Input: ngp_set_panel_u8,
+ * ngp_load_panel_file, ngp_generate_panel (ngp_set_panel_f64 / _f32 are refused: they carry centred values, not codes).
+ * ngp_get_storage: the storage in force and, optionally (compact storage), the P column means. */
+/* ngp_set_max_shards: the persistent sweep normally splits the rows over every CU but the sampler's and the reducers' (one
+ * streamer workgroup per CU, all co-resident).  A smaller number makes the shards taller and leaves CUs free -- for a second
+ * chain on the same device (each chain's whole grid must be resident at once), or to exercise tall-shard layouts on small
+ * panels.  0 = automatic.  Before the panel is set. */
+int32_t ngp_set_max_shards(ngp_handle *h, int32_t max_shards);
+#define NGP_STORAGE_F32 0
+#define NGP_STORAGE_U8 1
+int32_t ngp_set_storage(ngp_handle *h, int32_t storage);
+int32_t ngp_get_storage(ngp_handle *h, int32_t *storage, double *means, int64_t P);
+
 /* Diagnostic timing modes of the persistent kernel (1..6: parts of the pipeline switched off, ngp_sweep.h).  They are an
  * explicit, per-handle setting -- never read from the environment -- and while one is active ngp_run / ngp_sweep_set do
  * their launches and then return NGP_ERR_DEBUG: the chain they leave behind is invalid.  0 = off. */

@@ -21,7 +21,7 @@ SYMBOLS = [
     "ngp_set_residual_prior", "ngp_set_intercept", "ngp_set_schedule", "ngp_run", "ngp_get_state", "ngp_set_state",
     "ngp_get_trace", "ngp_get_posterior_sums", "ngp_posterior_len", "ngp_export_posterior_device", "ngp_sweep_set",
     "ngp_get_timing", "ngp_profile_iteration", "ngp_draws_indexed", "ngp_eval_math", "ngp_configure", "ngp_get_config", "ngp_debug_stamps", "ngp_set_near_lags", "ngp_get_near_lags",
-    "ngp_set_streamer", "ngp_get_streamer", "ngp_debug_set_mode", "ngp_debug_set_knob", "ngp_set_posterior_sums", "ngp_save_snapshot", "ngp_load_snapshot",
+    "ngp_set_streamer", "ngp_get_streamer", "ngp_set_storage", "ngp_get_storage", "ngp_set_max_shards", "ngp_debug_set_mode", "ngp_debug_set_knob", "ngp_set_posterior_sums", "ngp_save_snapshot", "ngp_load_snapshot",
     "ngp_set_trace_loci", "ngp_get_trace_ext", "ngp_allreduce_posterior", "ngp_add_marker_set_r", "ngp_get_class_state", "ngp_set_class_state", "ngp_add_fixed_set", "ngp_get_fixed", "ngp_set_fixed",
 ]
 
@@ -54,7 +54,7 @@ def _p(a, t):
 class Sampler:
     """One chain on one device == one `ngp_handle` (reference: one Julia task running runSampler!)."""
 
-    def __init__(self, device=0, seed=1, chain=0, mode=None, lag=None, streamer=None):
+    def __init__(self, device=0, seed=1, chain=0, mode=None, lag=None, streamer=None, storage=None):
         self.L = load()
         self.h = C.c_void_p()
         rc = self.L.ngp_create(C.c_int32(device), C.c_uint64(seed), C.c_uint32(chain), C.byref(self.h))
@@ -68,6 +68,8 @@ class Sampler:
             self.configure(1 if mode is None else mode, 8 if lag is None else lag)
         if streamer is not None:
             self.set_streamer(streamer)
+        if storage is not None:
+            self.set_storage(storage)
 
     def configure(self, mode, lag):
         self._chk(self.L.ngp_configure(self.h, C.c_int32(mode), C.c_int32(lag)))
@@ -82,6 +84,26 @@ class Sampler:
 
     def set_streamer(self, variant):
         self._chk(self.L.ngp_set_streamer(self.h, C.c_int32(variant)))
+
+    def set_max_shards(self, n):
+        self._chk(self.L.ngp_set_max_shards(self.h, C.c_int32(int(n))))
+
+    def set_storage(self, storage):
+        """0 / "f32": centred fp32 tiles; 1 / "u8": compact storage (bytes + Float64 column means, analytic centring)."""
+        code = {"f32": 0, "u8": 1}.get(storage, storage)
+        self._chk(self.L.ngp_set_storage(self.h, C.c_int32(int(code))))
+
+    def storage(self):
+        v = C.c_int32()
+        self._chk(self.L.ngp_get_storage(self.h, C.byref(v), None, C.c_int64(0)))
+        return v.value
+
+    def means(self):
+        """Compact storage: the P column means the centring uses."""
+        out = np.zeros(self.P)
+        v = C.c_int32()
+        self._chk(self.L.ngp_get_storage(self.h, C.byref(v), _p(out, C.c_double), C.c_int64(self.P)))
+        return out
 
     def streamer(self):
         """(variant in force, GEMV chains per shard partial)"""

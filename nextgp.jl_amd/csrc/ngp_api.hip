@@ -57,6 +57,9 @@ struct ngp_handle {
     bool lag_auto = true;  // lag not chosen by the caller (ngp_configure): tall shards then take the measured best
     int near_req = 0;  // near lags requested (0 = automatic)
     int near = 3;      // look-ahead lags 1..near corrected by the sampler itself, farther ones by the reducers
+    int max_shards_req = 0;  // streamer workgroups the persistent sweep may use (0 = all CUs but the sampler's and the reducers')
+    int storage = 0;       // 0: centred fp32 tiles; 1: compact -- byte tiles + Float64 column means (ngp_set_storage)
+    double *d_mean = nullptr;  // compact storage: column means, Ppad
     int streamer_req = 0;  // streamer variant requested: 0 automatic, 1 phase streamer, 2 row-owning waves + loader wave
     int streamer = 1;      // variant in force (persistent sweep only)
     int nchain = 8;        // GEMV chains per shard partial: 8 (phase streamer, per-block engine) or 7 (row-owning waves)
@@ -187,14 +190,37 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
     h->N = N; h->P = P;
     // persistent mode: sampler + reducers + S streamers must all be resident, one workgroup per CU
     int64_t max_shards = 256;
+    if (h->storage == 1) {
+        // compact storage: byte tiles, units of 16 rows, the row-owning roles only (persistent sweep)
+        REQUIRE(h->mode == 1, NGP_ERR_ARG, "compact storage runs in the persistent sweep (ngp_configure mode 1) only");
+        max_shards = h->cu_count - 1 - (h->cu_count + NGP_GRP - 1) / NGP_GRP;
+        if (h->max_shards_req > 0) max_shards = std::min<int64_t>(max_shards, h->max_shards_req);
+        const int64_t r0 = (N + max_shards - 1) / max_shards;
+        h->R = 16 * std::max<int64_t>(1, (r0 + 15) / 16);
+        REQUIRE(h->R <= NGP_U8_MAX_R, NGP_ERR_ARG, "N too large for one resident wave of streamers in compact storage");
+        h->S = (N + h->R - 1) / h->R;
+        h->NG = (int)((h->S + NGP_GRP - 1) / NGP_GRP);
+        h->streamer = 3;
+        h->nchain = NGP_ROWS_NW;
+        // delay line: 8 VGPRs per lag and update task of a lane (1, 2 or 4 tasks: ngp_u8_tasks)
+        const int nt = ngp_u8_tasks((int)h->R);
+        const int want = h->lag_auto ? 8 : h->lag;
+        int D;  // the instantiated lags (ngp_sweep.h, variant 3): the largest one not above the request
+        if (nt == 1) D = want >= 12 ? 12 : (want >= 8 ? 8 : (want >= 6 ? 6 : (want >= 4 ? 4 : 3)));
+        else if (nt == 2) D = want >= 8 ? 8 : 4;
+        else D = 4;
+        h->D = D;
+        h->near = h->near_req ? h->near_req : ((h->R > 128) ? 2 : 3);
+    } else {
     if (h->mode == 1) {
         max_shards = h->cu_count - 1 - (h->cu_count + NGP_GRP - 1) / NGP_GRP;
+        if (h->max_shards_req > 0) max_shards = std::min<int64_t>(max_shards, h->max_shards_req);
         if (N > max_shards * 256) h->mode = 0;  // too many rows for one resident wave of streamers (2 LDS tile slots + partials)
         else choose_layout(N, max_shards, 256, &h->R, &h->S);  // 8 R / 4 update tasks <= 512 threads, two 1040 R / 4 byte LDS slots
     }
     if (h->mode == 0) choose_layout(N, 256, 508, &h->R, &h->S);  // LDS bound of k_step: R*264 + 4096 <= 160 KiB
     h->NG = (int)((h->S + NGP_GRP - 1) / NGP_GRP);
-    h->D = (h->mode == 1) ? h->lag : 1;
+    h->D = (h->mode == 1) ? std::min(h->lag, 8) : 1;
     // streamer variant (ngp_sweep.h): the row-owning waves serve shards of up to NGP_ROWS_MAX_R rows at lags 3..6 and are the
     // default where the phase streamer is bound by its barriers (shards taller than 128 rows)
     h->streamer = 1;
@@ -208,13 +234,18 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
     // CU is again the busier end (its Gram traffic: 32 KB per near lag and block) and three near lags measure better
     // (row-owning streamer on tall shards: two near lags measured 1.5 % better still -- the far path is one hop since dlt travels as granules)
     h->near = h->near_req ? h->near_req : ((h->mode == 1 && h->R > 128) ? (h->streamer == 2 ? 2 : 4) : 3);
+    }
     h->NBLK = (P + NGP_BLK - 1) / NGP_BLK;
     h->Ppad = h->NBLK * NGP_BLK;
     h->L = h->R * h->S;
     h->lds_step = (size_t)h->R * 264 + 4096;
     int rc;
     size_t tile_elems = (size_t)h->R * NGP_BLK;
-    if ((rc = dalloc(h, &h->d_tiles, (size_t)h->NBLK * h->S * tile_elems))) return rc;
+    if (h->storage == 1) {  // one byte per element (R is a multiple of 16), held behind the same pointer
+        if ((rc = dalloc(h, &h->d_tiles, (size_t)h->NBLK * h->S * tile_elems / 4))) return rc;
+        if ((rc = dalloc(h, &h->d_mean, (size_t)h->Ppad))) return rc;
+        HCHK(hipMemsetAsync(h->d_mean, 0, (size_t)h->Ppad * sizeof(double), h->stream));
+    } else if ((rc = dalloc(h, &h->d_tiles, (size_t)h->NBLK * h->S * tile_elems))) return rc;
     if ((rc = dalloc(h, &h->d_gramx, (size_t)h->NBLK * h->D * NGP_BLK * NGP_BLK))) return rc;
     const size_t pp = (size_t)h->Ppad;
     if ((rc = dalloc(h, &h->d_mpm, pp))) return rc;
@@ -255,9 +286,9 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
         const size_t TB = (size_t)(h->R / 4) * NGP_QS;  // LDS footprint of one tile (quads NGP_QS bytes apart)
         h->lds_sweep = std::max(2 * TB + misc, lds_sampler);
         if (2 * TB + misc + 8192 <= lds_max) h->lds_sweep = std::max(h->lds_sweep, 2 * TB + misc + 8192);  // room for the diagnostic timeline
-        if (h->streamer == 2) {  // ring of 2 NQ + H quads | shard | 2 x 7 x 64 chain partials | 2 x 64 dlt | flags | 1 KiB sink
-            const size_t nq = (size_t)h->R / 4, hq = std::min<size_t>(NGP_ROWS_HMAX, (nq + 1) / 2);
-            const size_t need = (2 * nq + hq) * NGP_QS + (size_t)((h->R + 7) & ~7) * 8 + 2 * NGP_ROWS_NW * NGP_BLK * 8 + 2 * NGP_BLK * 8 + 64 + 1024;
+        if (h->streamer >= 2) {  // ring of 2 NQ + H slots | shard | 2 x 7 x 64 chain partials | 2 x 72 dlt | 2 x 8 row sums | flags | 1 KiB sink
+            const size_t nq = (h->streamer == 3) ? (size_t)h->R / 16 : (size_t)h->R / 4, hq = std::min<size_t>(NGP_ROWS_HMAX, (nq + 1) / 2);
+            const size_t need = (2 * nq + hq) * NGP_QS + (size_t)((h->R + 7) & ~7) * 8 + 2 * NGP_ROWS_NW * NGP_BLK * 8 + 2 * NGP_DLS * 8 + 16 * 8 + 64 + 1024;
             h->lds_rows = need;
             h->lds_sweep = std::max(need, lds_sampler);
             if (need + 8192 <= lds_max) h->lds_sweep = std::max(h->lds_sweep, need + 8192);
@@ -284,7 +315,32 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
     return NGP_OK;
 }
 
+int build_gram8(ngp_handle *h) {  // compact storage: exact integer dot products, then G = dot - N (m_k m_j)
+    const size_t per_block = (size_t)h->S * NGP_BLK * NGP_BLK * sizeof(uint32_t);
+    int nb_max = (int)std::max<size_t>(1, std::min<size_t>((size_t)h->NBLK, ((size_t)1 << 30) / per_block));
+    nb_max = std::min(nb_max, 32768);
+    uint32_t *d_gpart = nullptr;
+    int rc;
+    if ((rc = dalloc(h, &d_gpart, (size_t)nb_max * h->S * NGP_BLK * NGP_BLK))) return rc;
+    for (int d = 0; d < h->D; d++)
+        for (int64_t t0 = 0; t0 < h->NBLK; t0 += nb_max) {
+            int nb = (int)std::min<int64_t>(nb_max, h->NBLK - t0);
+            hipLaunchKernelGGL(k_gram8_part, dim3((unsigned)h->S, (unsigned)nb), dim3(256), 0, h->stream, (const uint8_t *)h->d_tiles, d_gpart,
+                               (int)h->R, (int)h->S, (int)t0, d);
+            long long ne = (long long)nb * NGP_BLK * NGP_BLK;
+            hipLaunchKernelGGL(k_gram8_reduce, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, h->stream, d_gpart, h->d_gramx, h->d_mpm,
+                               h->d_mean, (long long)h->N, (int)h->S, (int)t0, nb, d, h->D);
+        }
+    hipError_t e = hipStreamSynchronize(h->stream);
+    dfree(d_gpart);
+    if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("gram: ") + hipGetErrorString(e));
+    e = hipGetLastError();
+    if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("gram launch: ") + hipGetErrorString(e));
+    return NGP_OK;
+}
+
 int build_gram(ngp_handle *h) {
+    if (h->storage == 1) return build_gram8(h);
     // batches of blocks so the shard-partial scratch stays <= ~1 GiB
     const size_t per_block = (size_t)h->S * NGP_BLK * NGP_BLK * sizeof(double);
     int nb_max = (int)std::max<size_t>(1, std::min<size_t>((size_t)h->NBLK, ((size_t)1 << 30) / per_block));
@@ -315,6 +371,7 @@ int set_panel_host(ngp_handle *h, const TIn *M, int64_t N, int64_t P, int64_t ld
     if ((rc = enter(h))) return rc;
     REQUIRE(M != nullptr, NGP_ERR_ARG, "null panel pointer");
     REQUIRE(ld >= N, NGP_ERR_ARG, "leading dimension smaller than N");
+    REQUIRE(h->storage == 0, NGP_ERR_ARG, "compact storage takes genotype codes: ngp_set_panel_u8, ngp_load_panel_file or ngp_generate_panel");
     if ((rc = alloc_panel(h, N, P))) return rc;
     const int64_t R = h->R, S = h->S;
     const size_t blk_elems = (size_t)S * R * NGP_BLK;
@@ -391,7 +448,8 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
         A.dbg = h->d_dbg;
         A.fine_ok = ((size_t)2 * (R / 4) * NGP_QS + (size_t)R * 80 + 8320 + 8192 <= h->lds_sweep) ? 1 : 0;  // diagnostic timeline fits in LDS
         A.variant = h->streamer; A.knob = h->knob;
-        if (h->streamer == 2) A.fine_ok = (h->lds_rows + 8192 <= h->lds_sweep) ? 1 : 0;
+        if (h->streamer >= 2) A.fine_ok = (h->lds_rows + 8192 <= h->lds_sweep) ? 1 : 0;
+        A.mean = h->d_mean; A.N = h->N;
         A.dbg_mode = h->dbg_mode;
         if (h->d_dbg || h->dbg_mode)  // diagnostic instantiation: stamps and timing modes exist only there
             hipLaunchKernelGGL(k_sweep<true>, dim3((unsigned)(1 + h->NG + S)), dim3(NGP_WG), h->lds_sweep, h->stream, A);
@@ -535,7 +593,7 @@ int32_t ngp_destroy(ngp_handle *h) {
     if (!h) return NGP_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    dfree(h->d_tiles); dfree(h->d_gramx); dfree(h->d_cpart); dfree(h->d_cgsum); dfree(h->d_cdlt); dfree(h->d_cdltg); dfree(h->d_rcls); dfree(h->d_seg_set); dfree(h->d_ccnt); dfree(h->d_abort); dfree(h->d_dbg); dfree(h->d_mpm); dfree(h->d_lhs0); dfree(h->d_rhs0); dfree(h->d_beta);
+    dfree(h->d_tiles); dfree(h->d_mean); dfree(h->d_gramx); dfree(h->d_cpart); dfree(h->d_cgsum); dfree(h->d_cdlt); dfree(h->d_cdltg); dfree(h->d_rcls); dfree(h->d_seg_set); dfree(h->d_ccnt); dfree(h->d_abort); dfree(h->d_dbg); dfree(h->d_mpm); dfree(h->d_lhs0); dfree(h->d_rhs0); dfree(h->d_beta);
     dfree(h->d_c); dfree(h->d_w); dfree(h->d_q); dfree(h->d_T); dfree(h->d_chi); dfree(h->d_setof); dfree(h->d_loc);
     dfree(h->d_vbidx); dfree(h->d_delta); dfree(h->d_sum_beta); dfree(h->d_sum_beta2); dfree(h->d_sum_delta);
     dfree(h->d_ycorr); dfree(h->d_part); dfree(h->d_dlt); dfree(h->d_sets); dfree(h->d_scal); dfree(h->d_varBeta);
@@ -580,9 +638,16 @@ int32_t ngp_set_panel_u8(ngp_handle *h, const uint8_t *G, int64_t N, int64_t P, 
         const size_t bytes = (size_t)(ncols - 1) * ld + (size_t)N;
         e = hipMemcpyAsync(d_g, G + (size_t)c0 * ld, bytes, hipMemcpyHostToDevice, h->stream);
         if (e != hipSuccess) break;
+        if (h->storage == 1) {  // the bytes stay bytes; the means go to the handle
+            hipLaunchKernelGGL(k_u8_colmean, dim3((unsigned)ncols), dim3(256), 0, h->stream, d_g, (long long)N, (long long)ld, (int)centre,
+                               h->d_mean + c0);
+            hipLaunchKernelGGL(k_u8_fill8, dim3((unsigned)h->S, (unsigned)nb), dim3(256), 0, h->stream, (uint8_t *)h->d_tiles, d_g, (long long)N,
+                               (long long)ld, (long long)ncols, (int)h->R, (int)h->S, (long long)t0);
+        } else {
         hipLaunchKernelGGL(k_u8_colmean, dim3((unsigned)ncols), dim3(256), 0, h->stream, d_g, (long long)N, (long long)ld, (int)centre, d_mu);
         hipLaunchKernelGGL(k_u8_fill, dim3((unsigned)h->S, (unsigned)nb), dim3(256), 0, h->stream, h->d_tiles, d_g, (long long)N,
                            (long long)ld, (long long)ncols, (int)h->R, (int)h->S, (long long)t0, d_mu);
+        }
         e = hipStreamSynchronize(h->stream);  // the staging buffer is reused by the next chunk
     }
     (void)hipFree(d_g);
@@ -602,6 +667,11 @@ int32_t ngp_generate_panel(ngp_handle *h, int64_t N, int64_t P, double maf_lo, d
     if ((rc = dalloc(h, &d_thr, (size_t)P))) { dfree(d_mu); return rc; }
     hipLaunchKernelGGL(k_gen_colmean, dim3((unsigned)P), dim3(256), 0, h->stream, (long long)N, (long long)P, maf_lo, maf_hi, panel_seed,
                        d_mu, d_thr);
+    if (h->storage == 1) {
+        (void)hipMemcpyAsync(h->d_mean, d_mu, (size_t)P * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
+        hipLaunchKernelGGL(k_gen_fill8, dim3((unsigned)h->S, (unsigned)h->NBLK), dim3(256), 0, h->stream, (uint8_t *)h->d_tiles, (long long)N,
+                           (long long)P, (int)h->R, (int)h->S, panel_seed, d_thr);
+    } else
     hipLaunchKernelGGL(k_gen_fill, dim3((unsigned)h->S, (unsigned)h->NBLK), dim3(256), 0, h->stream, h->d_tiles, (long long)N,
                        (long long)P, (int)h->R, (int)h->S, panel_seed, d_mu, d_thr);
     hipError_t e = hipStreamSynchronize(h->stream);
@@ -654,6 +724,11 @@ int32_t ngp_xbeta(ngp_handle *h, const double *beta, int64_t P, double *out, int
     if ((rc = dalloc(h, &d_b, (size_t)h->Ppad))) return rc;
     if ((rc = dalloc(h, &d_o, (size_t)h->L))) { dfree(d_b); return rc; }
     hipError_t e = hipMemcpyAsync(d_b, beta, (size_t)P * sizeof(double), hipMemcpyHostToDevice, h->stream);
+    if (e == hipSuccess && (size_t)h->Ppad > (size_t)P) e = hipMemsetAsync(d_b + P, 0, ((size_t)h->Ppad - (size_t)P) * sizeof(double), h->stream);
+    if (h->storage == 1)
+        hipLaunchKernelGGL(k_xbeta8, dim3((unsigned)h->S), dim3(256), 0, h->stream, (const uint8_t *)h->d_tiles, h->d_mean, d_b, d_o, (int)h->R,
+                           (int)h->S, (long long)h->NBLK, (long long)h->N);
+    else
     hipLaunchKernelGGL(k_xbeta, dim3((unsigned)h->S), dim3(256), 0, h->stream, h->d_tiles, d_b, d_o, (int)h->R, (int)h->S,
                        (long long)h->NBLK);
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_o, (size_t)N * sizeof(double), hipMemcpyDeviceToHost, h->stream);
@@ -1070,7 +1145,7 @@ int32_t ngp_configure(ngp_handle *h, int32_t mode, int32_t lag) {
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles == nullptr, NGP_ERR_STATE, "ngp_configure must precede the panel upload");
     REQUIRE(mode == 0 || mode == 1, NGP_ERR_ARG, "mode must be 0 (per-block launches) or 1 (persistent sweep)");
-    REQUIRE(lag >= 1 && lag <= NGP_MAX_LAG, NGP_ERR_ARG, "lag must be in 1..8");
+    REQUIRE(lag >= 1 && lag <= NGP_MAX_LAG, NGP_ERR_ARG, "lag must be in 1..12 (above 8: compact storage)");
     h->mode = mode; h->lag = lag; h->lag_auto = false;
     return NGP_OK;
 }
@@ -1157,6 +1232,37 @@ int32_t ngp_set_streamer(ngp_handle *h, int32_t variant) {
     REQUIRE(h->d_tiles == nullptr, NGP_ERR_STATE, "ngp_set_streamer must precede the panel upload");
     REQUIRE(variant >= 0 && variant <= 2, NGP_ERR_ARG, "streamer variant: 0 (automatic), 1 (phase streamer) or 2 (row-owning waves)");
     h->streamer_req = variant;
+    return NGP_OK;
+}
+
+int32_t ngp_set_max_shards(ngp_handle *h, int32_t max_shards) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(h->d_tiles == nullptr, NGP_ERR_STATE, "ngp_set_max_shards must precede the panel upload");
+    REQUIRE(max_shards >= 0, NGP_ERR_ARG, "max_shards: 0 (automatic) or a positive number of streamer workgroups");
+    h->max_shards_req = max_shards;
+    return NGP_OK;
+}
+
+int32_t ngp_set_storage(ngp_handle *h, int32_t storage) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(h->d_tiles == nullptr, NGP_ERR_STATE, "ngp_set_storage must precede the panel upload");
+    REQUIRE(storage == NGP_STORAGE_F32 || storage == NGP_STORAGE_U8, NGP_ERR_ARG, "storage: 0 (fp32 tiles) or 1 (compact: bytes + column means)");
+    h->storage = storage;
+    return NGP_OK;
+}
+
+int32_t ngp_get_storage(ngp_handle *h, int32_t *storage, double *means, int64_t P) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    if (storage) *storage = h->storage;
+    if (means) {
+        REQUIRE(h->storage == 1 && h->d_tiles != nullptr, NGP_ERR_STATE, "column means exist in compact storage only, after the panel is set");
+        REQUIRE(P == h->P, NGP_ERR_ARG, "means buffer must hold P entries");
+        HCHK(hipStreamSynchronize(h->stream));
+        HCHK(hipMemcpy(means, h->d_mean, (size_t)P * sizeof(double), hipMemcpyDeviceToHost));
+    }
     return NGP_OK;
 }
 

@@ -920,6 +920,119 @@ __global__ __launch_bounds__(256) void k_u8_fill(float *__restrict__ tiles, cons
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// compact storage: byte tiles (genotype codes) + Float64 column means, centred analytically (ngp_sweep.h, variant 3)
+// ------------------------------------------------------------------------------------------
+// byte offset of element (row i, column j) inside a tile: units of 16 rows, a column's 16 bytes contiguous (one lane, one 16-byte read)
+__host__ __device__ inline size_t tile8_off(int i, int j) { return ((size_t)(i >> 4) << 10) + (size_t)(j << 4) + (size_t)(i & 15); }
+
+__global__ __launch_bounds__(256) void k_u8_fill8(uint8_t *__restrict__ tiles8, const uint8_t *__restrict__ G, long long N, long long ld,
+                                                  long long ncols, int R, int S, long long t0) {
+    const int s = blockIdx.x;
+    const long long tb = blockIdx.y;  // block of the chunk
+    uint8_t *tp = tiles8 + ((size_t)(t0 + tb) * S + s) * ((size_t)R * NGP_BLK);
+    for (int idx = threadIdx.x; idx < R * NGP_BLK; idx += 256) {
+        const int ii = ((idx >> 10) << 4) + (idx & 15), jj = (idx >> 4) & (NGP_BLK - 1);  // idx is the unit-major offset
+        const long long i = (long long)s * R + ii, jc = tb * NGP_BLK + jj;
+        tp[idx] = (i < N && jc < ncols) ? G[(size_t)jc * ld + i] : (uint8_t)0;
+    }
+}
+__global__ __launch_bounds__(256) void k_gen_fill8(uint8_t *__restrict__ tiles8, long long N, long long P, int R, int S, uint64_t pseed,
+                                                   const uint32_t *__restrict__ thr) {
+    const int s = blockIdx.x;
+    const long long t = blockIdx.y;
+    uint8_t *tp = tiles8 + ((size_t)t * S + s) * ((size_t)R * NGP_BLK);
+    for (int idx = threadIdx.x; idx < R * NGP_BLK; idx += 256) {
+        const int ii = ((idx >> 10) << 4) + (idx & 15), jj = (idx >> 4) & (NGP_BLK - 1);
+        const long long i = (long long)s * R + ii, j = t * NGP_BLK + jj;
+        tp[idx] = (i < N && j < P) ? (uint8_t)panel_gij(panel_colkey(pseed, j), i, thr[j]) : (uint8_t)0;
+    }
+}
+
+// shard partial of the integer dot products g_{t-d,k}' g_{t,j} (exact): thread (tk, tj) owns a 4x4 sub-block, 4 rows per v_dot4
+#define NGP_GRAM8_RC 208
+#define NGP_GRAM8_LD (NGP_GRAM8_RC + 4)
+__global__ __launch_bounds__(256) void k_gram8_part(const uint8_t *__restrict__ tiles8, uint32_t *__restrict__ gpart, int R, int S, int t0, int d) {
+    __shared__ __attribute__((aligned(16))) uint8_t ta[NGP_BLK * NGP_GRAM8_LD];
+    __shared__ __attribute__((aligned(16))) uint8_t tt[NGP_BLK * NGP_GRAM8_LD];
+    const int s = blockIdx.x, tb = blockIdx.y, tid = threadIdx.x;
+    const int t = t0 + tb;
+    if (t - d < 0) return;  // block-uniform
+    const size_t tile_bytes = (size_t)R * NGP_BLK;
+    const uint8_t *src_t = tiles8 + ((size_t)t * S + s) * tile_bytes;
+    const uint8_t *src_a = tiles8 + ((size_t)(t - d) * S + s) * tile_bytes;
+    const int tk = tid >> 4, tj = tid & 15;
+    uint32_t acc[4][4];
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) acc[a][b] = 0u;
+    for (int i0 = 0; i0 < R; i0 += NGP_GRAM8_RC) {
+        const int rc = min(NGP_GRAM8_RC, R - i0);  // multiple of 16
+        __syncthreads();
+        for (int idx = tid; idx < NGP_BLK * (rc >> 2); idx += 256) {  // words of 4 rows: unit-major source, lanes run over the columns
+            const int j = idx & (NGP_BLK - 1), q4 = idx >> 6;          // q4: group of 4 rows inside the chunk
+            const int i = i0 + 4 * q4;
+            *(uint32_t *)(tt + j * NGP_GRAM8_LD + 4 * q4) = *(const uint32_t *)(src_t + tile8_off(i, j));
+            *(uint32_t *)(ta + j * NGP_GRAM8_LD + 4 * q4) = *(const uint32_t *)(src_a + tile8_off(i, j));
+        }
+        __syncthreads();
+        for (int i = 0; i < rc; i += 4) {
+            uint32_t xk[4], xj[4];
+#pragma unroll
+            for (int a = 0; a < 4; a++) {
+                xk[a] = *(const uint32_t *)(ta + (4 * tk + a) * NGP_GRAM8_LD + i);
+                xj[a] = *(const uint32_t *)(tt + (4 * tj + a) * NGP_GRAM8_LD + i);
+            }
+#pragma unroll
+            for (int a = 0; a < 4; a++)
+#pragma unroll
+                for (int b = 0; b < 4; b++) acc[a][b] = __builtin_amdgcn_udot4(xk[a], xj[b], acc[a][b], false);
+        }
+    }
+    uint32_t *out = gpart + ((size_t)tb * S + s) * (NGP_BLK * NGP_BLK);
+#pragma unroll
+    for (int a = 0; a < 4; a++)
+#pragma unroll
+        for (int b = 0; b < 4; b++) out[(4 * tk + a) * NGP_BLK + 4 * tj + b] = acc[a][b];
+}
+// sum over shards (exact, 64-bit) -> G = dot - N (m_k m_j) -> gramx[t][d][k][j] in the layout of k_gram_reduce; d == 0 also fills mpm
+__global__ __launch_bounds__(256) void k_gram8_reduce(const uint32_t *__restrict__ gpart, double *__restrict__ gramx, double *__restrict__ mpm,
+                                                      const double *__restrict__ mean, long long N, int S, int t0, int nb, int d, int D) {
+    long long e = (long long)blockIdx.x * 256 + threadIdx.x;  // (tb, k, j)
+    if (e >= (long long)nb * NGP_BLK * NGP_BLK) return;
+    int tb = (int)(e / (NGP_BLK * NGP_BLK)), kj = (int)(e % (NGP_BLK * NGP_BLK));
+    if (t0 + tb - d < 0) return;
+    const uint32_t *p = gpart + (size_t)tb * S * (NGP_BLK * NGP_BLK) + kj;
+    unsigned long long dot = 0;
+    for (int s = 0; s < S; s++) dot += p[(size_t)s * (NGP_BLK * NGP_BLK)];
+    const int k = kj / NGP_BLK, j = kj % NGP_BLK;
+    const double mm = mean[(size_t)(t0 + tb - d) * NGP_BLK + k] * mean[(size_t)(t0 + tb) * NGP_BLK + j];
+    const double nm = (double)N * mm;
+    const double tot = (double)dot - nm;
+    if (d == 0 && k == j) mpm[(size_t)(t0 + tb) * NGP_BLK + k] = tot;
+    const size_t off = (d == 0) ? (size_t)kj : ((size_t)(k >> 1) * NGP_BLK + j) * 2 + (k & 1);
+    gramx[((size_t)(t0 + tb) * D + d) * (NGP_BLK * NGP_BLK) + off] = (d == 0 && j <= k) ? 0.0 : tot;
+}
+
+// out_i = sum_k (g_ik - m_k) beta_k = sum_k g_ik beta_k - sum_k m_k beta_k, k ascending (utility, not on the hot path)
+__global__ __launch_bounds__(256) void k_xbeta8(const uint8_t *__restrict__ tiles8, const double *__restrict__ mean,
+                                                const double *__restrict__ beta, double *__restrict__ out, int R, int S, long long NBLK,
+                                                long long N) {
+    const int s = blockIdx.x;
+    for (int i = threadIdx.x; i < R; i += 256) {
+        double acc = 0.0, accm = 0.0;
+        for (long long t = 0; t < NBLK; t++) {
+            const uint8_t *tp = tiles8 + ((size_t)t * S + s) * ((size_t)R * NGP_BLK);
+            for (int j = 0; j < NGP_BLK; j++) {
+                acc = __builtin_fma((double)tp[tile8_off(i, j)], beta[t * NGP_BLK + j], acc);
+                accm = __builtin_fma(mean[t * NGP_BLK + j], beta[t * NGP_BLK + j], accm);
+            }
+        }
+        out[(size_t)s * R + i] = ((long long)s * R + i < N) ? acc - accm : 0.0;
+    }
+}
+
 // out_i = sum_k x_ik beta_k, k ascending (utility, not on the hot path)
 __global__ __launch_bounds__(256) void k_xbeta(const float *__restrict__ tiles, const double *__restrict__ beta,
                                                double *__restrict__ out, int R, int S, long long NBLK) {

@@ -29,7 +29,7 @@
 #pragma clang fp contract(off)
 
 #define NGP_RING 16        // slots of every communication ring (>= lag D)
-#define NGP_MAX_LAG 8
+#define NGP_MAX_LAG 12     // lags above 8: compact storage only (8 VGPRs of delay line per lag and task)
 #define NGP_SPIN_LIMIT (1u << 21)
 #define NGP_WG 512          // threads per workgroup of the persistent kernel
 #define NGP_DBG_WAVES (1u << 19)   // sampler: 8 words per block, end-of-work stamp of every wave
@@ -67,6 +67,9 @@ struct SweepArgs {
     const double *rhs0;
     const DScal *scal;
     long long Ppad;
+    // compact storage (variant 3): tiles are bytes (genotype codes), centred analytically with the Float64 column means
+    const double *mean;  // [Ppad]
+    long long N;         // rows of the panel (the last shards carry padding rows, which must stay zero)
     // communication (zeroed before every launch)
     double *part;        // [RING][S][64]
     double *gsum;        // [RING][NG][64]
@@ -175,7 +178,7 @@ __device__ inline void dma16_lds(const void *gsrc_lane, const void *lds_base_uni
 // per-lane 64-bit addresses and a v_readfirstlane per request (dma16_lds) ONE wave issues about 18 KiB per us, below a CU's
 // share of the stream; in this form it keeps up (tools/microbench/dma_bench.hip: 2.69 -> 2.16 us per 51 KiB tile, every CU
 // streaming; a second issuing wave would give 2.04).
-__device__ inline void dma16_s(unsigned lds_addr_uniform, const void *gbase_uniform, unsigned voff) {
+__device__ __attribute__((always_inline)) inline void dma16_s(unsigned lds_addr_uniform, const void *gbase_uniform, unsigned voff) {
     unsigned keep_m0;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep_m0)
@@ -187,7 +190,7 @@ __device__ inline void dma16_s(unsigned lds_addr_uniform, const void *gbase_unif
 // instruction's immediate offset walks the source (0, 1024, 2048, 3072).  The immediate is added to the LDS address too, so M0
 // carries slot address minus offset: M0 advances by NGP_QS - 1024 per request.  About six scalar instructions per request
 // instead of seventeen: the loader is then bound by memory, not by its own instruction stream (51 requests took 2.2 us).
-__device__ inline void dma16_s4(unsigned lds_addr_uniform, const void *gbase_uniform, unsigned voff) {
+__device__ __attribute__((always_inline)) inline void dma16_s4(unsigned lds_addr_uniform, const void *gbase_uniform, unsigned voff) {
     unsigned keep_m0;
     const unsigned m1 = lds_addr_uniform + (NGP_QS - 1024), m2 = lds_addr_uniform + 2 * (NGP_QS - 1024), m3 = lds_addr_uniform + 3 * (NGP_QS - 1024);
     asm volatile(
@@ -577,6 +580,7 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
 //   // quads of tile u+2 requested during block u (the counted wait keeps them in flight)
 #define NGP_ROWS_PUBW 2
 #define NGP_ROWS_POLLW 6
+#define NGP_DLS 72            // doubles per parity of the dlt buffer: 64 + the scalar of the compact update
 
 __device__ inline double dpp_f64(double v, const int ctrl_sel) {
     int lo = __double2loint(v), hi = __double2hiint(v);
@@ -605,34 +609,50 @@ __device__ inline void wait_vmcnt_le(int n) {
 #undef NGP_VMC
 }
 
-template <bool DBG, int DT>
-__device__ inline void role_streamer_rows(const SweepArgs &A, const int s, char *smem) {
+// update tasks (4 rows x 8 columns) a lane of a row-owning wave carries in compact storage: 4 per unit, ceil(NU / 7) units per
+// wave, 8 lane slots -> 1, 2 or 4 (the template parameter; 3 runs as 4)
+__host__ __device__ inline int ngp_u8_tasks(int R) {
+    const int nuw = ((R >> 4) + NGP_ROWS_NW - 1) / NGP_ROWS_NW;
+    const int nt = (4 * nuw + 7) / 8;
+    return nt <= 1 ? 1 : (nt == 2 ? 2 : 4);
+}
+#define NGP_U8_MAX_R 896  // 7 waves x 8 units x 16 rows
+// ST = 0: fp32 tiles, a ring slot holds a quad (4 rows x 64 columns x 4 bytes).  ST = 1, 2, 4: compact storage, a ring slot
+// holds a unit of 16 rows x 64 columns x 1 byte, wave w owns units w, w+7, ..., and a lane carries ST update tasks of
+// 4 rows x 8 columns (8 VGPRs per task and lag instead of 32: lags 3, 4, 6, 8, 12 with one task, 4 and 8 with two, 4 with four; shards of up to 896 rows).  Centring is
+// analytic: the shard partial is sum_i g_ij y_i - m_j sum_i y_i, the update subtracts
+// sum_j g_ij dlt_j - sum_j m_j dlt_j from the valid rows.
+template <bool DBG, int DT, int ST>
+__device__ __attribute__((always_inline)) inline void role_streamer_rows(const SweepArgs &A, const int s, char *smem) {
     NGP_DBG_ROWS
+    constexpr bool U8 = (ST != 0);
+    constexpr int NT = U8 ? ST : 1;
     const int R = A.R, S = A.S, tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int NQ = R >> 2;                                   // quads per tile
+    const int NQ = U8 ? (R >> 4) : (R >> 2);                 // 1 KiB ring slots per tile: quads (fp32) or units of 16 rows (bytes)
     const int H = min(NGP_ROWS_HMAX, (NQ + 1) >> 1);         // quads of a tile requested one block earlier than the rest
     const int RQ = 2 * NQ + H;                               // ring slots: tile u in use, tile u+1 complete, H quads of tile u+2
     char *ring = smem;
     double *ys = (double *)(smem + (size_t)RQ * NGP_QS);     // the shard of ycorr, resident for the whole sweep
     double *red = ys + ((R + 7) & ~7);                       // 2 (block parity) x 7 chains x 64 columns
-    double *dl = red + 2 * NGP_ROWS_NW * NGP_BLK;            // 2 (block parity) x 64: dlt of the block being applied
-    int *sflag = (int *)(dl + 2 * NGP_BLK);
-    char *scratch = (char *)(dl + 2 * NGP_BLK) + 64;         // 1 KiB sink of the L2-warming DMA
+    double *dl = red + 2 * NGP_ROWS_NW * NGP_BLK;            // 2 (block parity) x 72: dlt of the block being applied (+ sum_j m_j dlt_j)
+    double *rsy = dl + 2 * NGP_DLS;                          // 2 (block parity) x 8: the waves' sums of their rows of ycorr (compact storage)
+    int *sflag = (int *)(rsy + 16);
+    char *scratch = (char *)(rsy + 16) + 64;                 // 1 KiB sink of the L2-warming DMA
     unsigned long long *fine = (unsigned long long *)(scratch + 1024);  // diagnostic timeline (DBG only, if it fits)
     const bool fine_on = DBG && dbg && s == 1 && A.fine_ok == 1;
 #define NGP_FINE(k)                                                                                              \
     do {                                                                                                         \
         if (fine_on && (unsigned)(u - 800) < 16u && lane == 0) fine[(((u - 800) * 8 + wv) << 3) + (k)] = wall_clock64(); \
     } while (0)
-    const size_t tile_elems = (size_t)R * NGP_BLK;
+    const size_t tile_bytes = (size_t)NQ * 1024;
     double *yg = A.ycorr + (size_t)s * R;
     const int g = s / NGP_GRP;
     const int nb = A.t1 - A.t0;
     for (int i = tid; i < R; i += NGP_WG) ys[i] = yg[i];
     if (tid == 0) *sflag = 1;
     int base = 0;  // ring slot of quad 0 of tile u
-    auto wrap = [&](int p) { return p >= RQ ? p - RQ : p; };
+    auto wrap = [&](int p) __attribute__((always_inline)) { return p >= RQ ? p - RQ : p; };
     if (wv == NGP_ROWS_NW) {
         // ------------------------------ loader ------------------------------
         const unsigned ring0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)ring;
@@ -645,9 +665,9 @@ __device__ inline void role_streamer_rows(const SweepArgs &A, const int s, char 
         // loop, not by the stream.  Capping the outstanding requests with counted vmcnt waits instead was far worse (4.9 us).
         const int pace = A.knob & 7;
         // quads [q0, q1) of local tile `tile` into ring slots tbase + q (everything wave-uniform: scalar registers only)
-        auto dma_quads = [&](int tile, int q0, int q1, int tbase) {
+        auto dma_quads = [&](int tile, int q0, int q1, int tbase) __attribute__((always_inline)) {
             if (no_dma || q0 >= q1) return 0;
-            const char *g = (const char *)(A.tiles + ((size_t)(A.t0 + tile) * S + s) * tile_elems) + (size_t)q0 * 1024;
+            const char *g = (const char *)A.tiles + ((size_t)(A.t0 + tile) * S + s) * tile_bytes + (size_t)q0 * 1024;
             int p = wrap(tbase + q0);
             int q = q0;
             for (; q + 4 <= q1; q += 4) {
@@ -721,19 +741,49 @@ __device__ inline void role_streamer_rows(const SweepArgs &A, const int s, char 
     } else {
         // ------------------------------ row-owning waves ------------------------------
         const int c = lane & 7, ql = lane >> 3;
-        const int nqw = (NQ - wv + NGP_ROWS_NW - 1) / NGP_ROWS_NW;  // quads of this wave (wave-uniform)
-        const int qt = wv + NGP_ROWS_NW * ql;                       // the quad of this lane's update task
-        const bool has_task = qt < NQ;
-        const int qtc = has_task ? qt : wv;                         // idle lanes shadow a valid quad (nothing is stored)
-        float4 keep[DT][8];  // tile elements of the update task: rows 4 qt..4 qt+3 (x, y, z, w) of columns 8 c + jj
+        const int nqw = (NQ - wv + NGP_ROWS_NW - 1) / NGP_ROWS_NW;  // ring slots (quads / units) of this wave (wave-uniform)
+        // fp32: the update task of this lane is quad wv + 7 ql.  Compact: task i is tau = ql + 8 i -> unit wv + 7 (tau >> 2), row quad
+        // tau & 3 of that unit.  Idle lanes shadow a valid slot (nothing is stored).
+        int tslot[NT], trow[NT];   // ring slot (relative to the tile) and first row of task i
+        bool thas[NT];
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            if constexpr (U8) {
+                const int tau = ql + 8 * i;
+                thas[i] = (tau >> 2) < nqw;
+                tslot[i] = thas[i] ? wv + NGP_ROWS_NW * (tau >> 2) : wv;
+                trow[i] = 16 * tslot[i] + 4 * (tau & 3);
+            } else {
+                const int qt = wv + NGP_ROWS_NW * ql;
+                thas[i] = qt < NQ;
+                tslot[i] = thas[i] ? qt : wv;
+                trow[i] = 4 * qt;
+            }
+        }
+        const int nvalid = U8 ? (int)max(0ll, min((long long)R, A.N - (long long)s * R)) : R;  // rows of this shard inside the panel
+        // tile elements of the update tasks: fp32 rows 4 qt..4 qt+3 (x, y, z, w) of columns 8 c + jj; compact: the same four rows as
+        // the bytes of one word
+        float4 keep[U8 ? 1 : DT][8];
+        unsigned keep8[U8 ? DT : 1][NT][8];
 #pragma unroll
         for (int d = 0; d < DT; d++)
 #pragma unroll
-            for (int jj = 0; jj < 8; jj++) keep[d][jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int jj = 0; jj < 8; jj++) {
+                if constexpr (U8) {
+#pragma unroll
+                    for (int i = 0; i < NT; i++) keep8[d][i][jj] = 0u;
+                } else {
+                    keep[d][jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
         unsigned long long pg0 = 0, pg1 = 0;  // poller: granules of the next dlt as read just before the previous barrier
+        double pm = 0.0;                      // poller, compact storage: column mean of (block pm_blk, column lane)
+        int pm_blk = -1;
+        double mpub = 0.0;                    // publisher, compact storage: column mean of the block published next
+        if (U8 && wv == NGP_ROWS_PUBW && nb > 0) mpub = A.mean[(size_t)A.t0 * NGP_BLK + lane];
         // publisher: the stored, not yet counted partial (ring slot), counted once VM_CNT of this wave reads zero
         int sig_pending = -1;
-        auto try_signal = [&](bool force) {
+        auto try_signal = [&](bool force) __attribute__((always_inline)) {
             if (wv != NGP_ROWS_PUBW || sig_pending < 0) return;
             if (force) drain_vm();
             else if ((__builtin_amdgcn_s_getreg((23 << 11) | 7) & 0xC0000Fu) != 0u) return;  // VM_CNT [3:0] and [23:22]
@@ -762,10 +812,12 @@ __device__ inline void role_streamer_rows(const SweepArgs &A, const int s, char 
                         pg0 = ld_u64(gp);
                         pg1 = ld_u64(gp + 1);
                     }
+                    if (U8 && pm_blk != pa) { pm = A.mean[(size_t)(A.t0 + pa) * NGP_BLK + lane]; pm_blk = pa; }
                 }
                 // ---- ycorr -= X_a dlt_a for the rows of this wave ----
+                if constexpr (!U8) {
                 if (a >= 0 && !(DBG && dbg_mode == 1)) {
-                    const double *dq = dl + (u & 1) * NGP_BLK + 8 * c;
+                    const double *dq = dl + (u & 1) * NGP_DLS + 8 * c;
                     double dqv[8];
 #pragma unroll
                     for (int jj = 0; jj < 8; jj++) dqv[jj] = dq[jj];
@@ -781,35 +833,107 @@ __device__ inline void role_streamer_rows(const SweepArgs &A, const int s, char 
                     p0 = p0 + dpp_f64(p0, 0); p1 = p1 + dpp_f64(p1, 0); p2 = p2 + dpp_f64(p2, 0); p3 = p3 + dpp_f64(p3, 0);
                     p0 = p0 + dpp_f64(p0, 1); p1 = p1 + dpp_f64(p1, 1); p2 = p2 + dpp_f64(p2, 1); p3 = p3 + dpp_f64(p3, 1);
                     p0 = p0 + dpp_f64(p0, 2); p1 = p1 + dpp_f64(p1, 2); p2 = p2 + dpp_f64(p2, 2); p3 = p3 + dpp_f64(p3, 2);
-                    if (c == 0 && has_task) {
-                        double *yq = ys + 4 * qt;
+                    if (c == 0 && thas[0]) {
+                        double *yq = ys + trow[0];
                         const double y0 = yq[0], y1 = yq[1], y2 = yq[2], y3 = yq[3];
                         yq[0] = y0 - p0; yq[1] = y1 - p1; yq[2] = y2 - p2; yq[3] = y3 - p3;
+                    }
+                }
+                } else if (!(DBG && dbg_mode == 1)) {
+                    // compact storage: y_i -= (sum_j g_ij dlt_j - sum_j m_j dlt_j) for the rows inside the panel, and the sum of
+                    // this wave's rows of y as the GEMV below sees them (lane slots in task order, then a fixed tree over the slots)
+                    const double *dq = dl + (u & 1) * NGP_DLS + 8 * c;
+                    double dqv[8];
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) dqv[jj] = (a >= 0) ? dq[jj] : 0.0;
+                    const double cm = (a >= 0) ? dl[(u & 1) * NGP_DLS + NGP_BLK] : 0.0;
+                    double vsum = 0.0;
+#pragma unroll
+                    for (int i = 0; i < NT; i++) {
+                        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+                        if (a >= 0) {
+#pragma unroll
+                            for (int jj = 0; jj < 8; jj++) {
+                                const unsigned w = keep8[d][i][jj];
+                                p0 = __builtin_fma((double)(float)(w & 0xffu), dqv[jj], p0);
+                                p1 = __builtin_fma((double)(float)((w >> 8) & 0xffu), dqv[jj], p1);
+                                p2 = __builtin_fma((double)(float)((w >> 16) & 0xffu), dqv[jj], p2);
+                                p3 = __builtin_fma((double)(float)(w >> 24), dqv[jj], p3);
+                            }
+                            p0 = p0 + dpp_f64(p0, 0); p1 = p1 + dpp_f64(p1, 0); p2 = p2 + dpp_f64(p2, 0); p3 = p3 + dpp_f64(p3, 0);
+                            p0 = p0 + dpp_f64(p0, 1); p1 = p1 + dpp_f64(p1, 1); p2 = p2 + dpp_f64(p2, 1); p3 = p3 + dpp_f64(p3, 1);
+                            p0 = p0 + dpp_f64(p0, 2); p1 = p1 + dpp_f64(p1, 2); p2 = p2 + dpp_f64(p2, 2); p3 = p3 + dpp_f64(p3, 2);
+                        }
+                        if (c == 0 && thas[i]) {
+                            double *yq = ys + trow[i];
+                            double y0 = yq[0], y1 = yq[1], y2 = yq[2], y3 = yq[3];
+                            if (a >= 0) {
+                                const int r0 = trow[i];
+                                const double t0 = p0 - cm, t1 = p1 - cm, t2 = p2 - cm, t3 = p3 - cm;
+                                if (r0 + 0 < nvalid) y0 = y0 - t0;
+                                if (r0 + 1 < nvalid) y1 = y1 - t1;
+                                if (r0 + 2 < nvalid) y2 = y2 - t2;
+                                if (r0 + 3 < nvalid) y3 = y3 - t3;
+                                yq[0] = y0; yq[1] = y1; yq[2] = y2; yq[3] = y3;
+                            }
+                            const double q4 = (y0 + y1) + (y2 + y3);
+                            vsum = (i == 0) ? q4 : vsum + q4;
+                        }
+                    }
+                    if (u < nb) {  // ((v_0+v_1)+(v_2+v_3))+((v_4+v_5)+(v_6+v_7)) over the lane slots (lanes 0, 8, ..., 56)
+                        vsum = vsum + __shfl_xor(vsum, 8);
+                        vsum = vsum + __shfl_xor(vsum, 16);
+                        vsum = vsum + __shfl_xor(vsum, 32);
+                        if (lane == 0) rsy[(u & 1) * 8 + wv] = vsum;
                     }
                 }
                 NGP_FINE(1);
                 try_signal(false);
                 if (u < nb) {
-                    // ---- GEMV chain of this wave: quads wv, wv+7, ... (lane = column); LDS serves a wave in order, so the
+                    // ---- GEMV chain of this wave: slots wv, wv+7, ... (lane = column); LDS serves a wave in order, so the
                     //      rows written above are read back without a barrier ----
                     double acc = 0.0;
                     for (int k = 0; k < nqw; k++) {
                         const int q = wv + NGP_ROWS_NW * k;
-                        const float4 x = *(const float4 *)(ring + (size_t)wrap(base + q) * NGP_QS + (size_t)lane * 16);
-                        const double *yq = ys + 4 * q;
-                        const double y0 = yq[0], y1 = yq[1], y2 = yq[2], y3 = yq[3];
-                        acc = __builtin_fma((double)x.x, y0, acc);
-                        acc = __builtin_fma((double)x.y, y1, acc);
-                        acc = __builtin_fma((double)x.z, y2, acc);
-                        acc = __builtin_fma((double)x.w, y3, acc);
+                        if constexpr (U8) {
+                            const uint4 x = *(const uint4 *)(ring + (size_t)wrap(base + q) * NGP_QS + (size_t)lane * 16);
+                            const double *yq = ys + 16 * q;
+                            const unsigned xw[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+                            for (int e4 = 0; e4 < 4; e4++) {
+                                const unsigned w = xw[e4];
+                                const double y0 = yq[4 * e4], y1 = yq[4 * e4 + 1], y2 = yq[4 * e4 + 2], y3 = yq[4 * e4 + 3];
+                                acc = __builtin_fma((double)(float)(w & 0xffu), y0, acc);
+                                acc = __builtin_fma((double)(float)((w >> 8) & 0xffu), y1, acc);
+                                acc = __builtin_fma((double)(float)((w >> 16) & 0xffu), y2, acc);
+                                acc = __builtin_fma((double)(float)(w >> 24), y3, acc);
+                            }
+                        } else {
+                            const float4 x = *(const float4 *)(ring + (size_t)wrap(base + q) * NGP_QS + (size_t)lane * 16);
+                            const double *yq = ys + 4 * q;
+                            const double y0 = yq[0], y1 = yq[1], y2 = yq[2], y3 = yq[3];
+                            acc = __builtin_fma((double)x.x, y0, acc);
+                            acc = __builtin_fma((double)x.y, y1, acc);
+                            acc = __builtin_fma((double)x.z, y2, acc);
+                            acc = __builtin_fma((double)x.w, y3, acc);
+                        }
                     }
                     red[((u & 1) * NGP_ROWS_NW + wv) * NGP_BLK + lane] = acc;
                     NGP_FINE(2);
                     try_signal(false);
-                    // ---- tile u into the delay line (task view of the same quads) ----
-                    const char *tq = ring + (size_t)wrap(base + qtc) * NGP_QS + c * 128;
+                    // ---- tile u into the delay line (task view of the same slots) ----
+                    if constexpr (U8) {
 #pragma unroll
-                    for (int jj = 0; jj < 8; jj++) keep[d][jj] = *(const float4 *)(tq + jj * 16);
+                        for (int i = 0; i < NT; i++) {
+                            const char *tq = ring + (size_t)wrap(base + tslot[i]) * NGP_QS + c * 128 + (trow[i] & 15);
+#pragma unroll
+                            for (int jj = 0; jj < 8; jj++) keep8[d][i][jj] = *(const unsigned *)(tq + jj * 16);
+                        }
+                    } else {
+                        const char *tq = ring + (size_t)wrap(base + tslot[0]) * NGP_QS + c * 128;
+#pragma unroll
+                        for (int jj = 0; jj < 8; jj++) keep[d][jj] = *(const float4 *)(tq + jj * 16);
+                    }
                 }
                 NGP_FINE(3);
                 if (pollw) {
@@ -818,13 +942,23 @@ __device__ inline void role_streamer_rows(const SweepArgs &A, const int s, char 
                         ok = wait_dlt_granules_all(A.dltg, A.nonce, pa, lane, A.abort_w, 1u, pg0, pg1) ? 1 : 0;
                         if (!ok && lane == 0) *sflag = 0;
                     }
-                    if (ok) dl[((u + 1) & 1) * NGP_BLK + lane] = dlt_granules_value(pg0, pg1);
+                    if (ok) {
+                        const double dv = dlt_granules_value(pg0, pg1);
+                        dl[((u + 1) & 1) * NGP_DLS + lane] = dv;
+                        if constexpr (U8) {  // sum_j m_j dlt_j: butterfly over the 64 lanes, xor 32 .. 1
+                            double v = pm * dv;
+#pragma unroll
+                            for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off);
+                            if (lane == 0) dl[((u + 1) & 1) * NGP_DLS + NGP_BLK] = v;
+                        }
+                    }
                 }
                 if (wv == NGP_ROWS_POLLW && pa + 1 >= 0 && u + 2 < nb + DT && !(DBG && dbg_mode == 1)) {
                     // dlt of the block after that: looked at behind the barrier (if the sampler is that far, the next block pays nothing)
                     const unsigned long long *gp = A.dltg + ((size_t)((pa + 1) % NGP_RING) * NGP_BLK + lane) * 2;
                     pg0 = ld_u64(gp);
                     pg1 = ld_u64(gp + 1);
+                    if (U8 && pa + 1 < nb) { pm = A.mean[(size_t)(A.t0 + pa + 1) * NGP_BLK + lane]; pm_blk = pa + 1; }
                 }
                 NGP_FINE(4);
                 // Lag 3: dlt of block u-2, which the poller of this workgroup waits for before this barrier, needs the partial of
@@ -837,10 +971,17 @@ __device__ inline void role_streamer_rows(const SweepArgs &A, const int s, char 
                 if (wv == NGP_ROWS_PUBW && u < nb && !(DBG && dbg_mode == 1)) {
                     const int slot = u % NGP_RING;
                     const double *rp = red + (u & 1) * NGP_ROWS_NW * NGP_BLK + lane;
-                    const double p = ((rp[0] + rp[NGP_BLK]) + (rp[2 * NGP_BLK] + rp[3 * NGP_BLK])) + ((rp[4 * NGP_BLK] + rp[5 * NGP_BLK]) + rp[6 * NGP_BLK]);
+                    double p = ((rp[0] + rp[NGP_BLK]) + (rp[2 * NGP_BLK] + rp[3 * NGP_BLK])) + ((rp[4 * NGP_BLK] + rp[5 * NGP_BLK]) + rp[6 * NGP_BLK]);
+                    if constexpr (U8) {  // partial = sum_i g_ij y_i - m_j sum_i y_i
+                        const double *sp = rsy + (u & 1) * 8;
+                        const double sy = ((sp[0] + sp[1]) + (sp[2] + sp[3])) + ((sp[4] + sp[5]) + sp[6]);
+                        const double ms = mpub * sy;
+                        p = p - ms;
+                    }
                     try_signal(true);  // the previous partial, if its store was still under way at every look
                     st_f64(&A.part[((size_t)slot * S + s) * NGP_BLK + lane], p);
                     sig_pending = slot;
+                    if (U8 && u + 1 < nb) mpub = A.mean[(size_t)(A.t0 + u + 1) * NGP_BLK + lane];
                     if (DBG && dbg && s == 0 && lane == 0) dbg[NGP_DBG_STREAM + 2 * (size_t)u] = wall_clock64();
                 }
                 base = wrap(base + NQ);
@@ -1385,10 +1526,28 @@ __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #ifndef NGP_AB_NO_ROWS
         if (A.variant == 2) {  // row-owning waves + loader wave (host: R <= NGP_ROWS_MAX_R, lag 3..6)
             switch (A.D) {
-                case 3: role_streamer_rows<DBG, 3>(A, s, smem); break;
-                case 4: role_streamer_rows<DBG, 4>(A, s, smem); break;
-                case 5: role_streamer_rows<DBG, 5>(A, s, smem); break;
-                default: role_streamer_rows<DBG, 6>(A, s, smem); break;  // (lag 7 was built: 58 VGPRs of the delay line spill, 2.58 -> 3.08 us per block)
+                case 3: role_streamer_rows<DBG, 3, 0>(A, s, smem); break;
+                case 4: role_streamer_rows<DBG, 4, 0>(A, s, smem); break;
+                case 5: role_streamer_rows<DBG, 5, 0>(A, s, smem); break;
+                default: role_streamer_rows<DBG, 6, 0>(A, s, smem); break;  // (lag 7 was built: 58 VGPRs of the delay line spill, 2.58 -> 3.08 us per block)
+            }
+            return;
+        }
+        if (A.variant == 3) {  // compact storage: the same roles over byte tiles (host: R a multiple of 16, lag from the lists below)
+            const int nt = ngp_u8_tasks(A.R);
+            if (nt == 1) {
+                switch (A.D) {
+                    case 3: role_streamer_rows<DBG, 3, 1>(A, s, smem); break;
+                    case 4: role_streamer_rows<DBG, 4, 1>(A, s, smem); break;
+                    case 6: role_streamer_rows<DBG, 6, 1>(A, s, smem); break;
+                    case 8: role_streamer_rows<DBG, 8, 1>(A, s, smem); break;
+                    default: role_streamer_rows<DBG, 12, 1>(A, s, smem); break;
+                }
+            } else if (nt == 2) {
+                if (A.D == 4) role_streamer_rows<DBG, 4, 2>(A, s, smem);
+                else role_streamer_rows<DBG, 8, 2>(A, s, smem);
+            } else {
+                role_streamer_rows<DBG, 4, 4>(A, s, smem);  // (192 VGPRs of delay line at lag 6 spill)
             }
             return;
         }

@@ -313,6 +313,9 @@ typedef struct {
     int64_t nchain;           /* GEMV chains of a shard partial: 8 (phase streamer, per-block engine) or 7 (row-owning waves) */
     double *gramx;            /* [t][d][k][j], d = 1..D-1: x_{t-d,k}' x_{t,j} */
     float *tiles;             /* [s][t][j][i] */
+    int storage;              /* 0: fp32 centred tiles; 1: compact -- one byte per genotype + fp64 column means, centred analytically */
+    uint8_t *tiles8;          /* [s][t][j][i] genotype codes (storage 1; rows beyond N are 0) */
+    double *mean;             /* Ppad column means (storage 1) */
     double *gram;             /* [t][64][64] */
     double *mpm;              /* Ppad (reference order: P) */
     double *lhs0, *rhs0;      /* Ppad */
@@ -369,7 +372,7 @@ static void free_sets(ora_t *h) {
 }
 void ora_destroy(ora_t *h) {
     if (!h) return;
-    free(h->data); free(h->Mp); free(h->tiles); free(h->gram); free(h->gramx); free(h->mpm); free(h->lhs0); free(h->rhs0);
+    free(h->data); free(h->Mp); free(h->tiles); free(h->tiles8); free(h->mean); free(h->gram); free(h->gramx); free(h->mpm); free(h->lhs0); free(h->rhs0);
     free_sets(h); free(h->varBeta); free(h->sum_varBeta); free(h->y); free(h->ycorr); free(h->beta); free(h->delta);
     free(h->sum_beta); free(h->sum_beta2); free(h->sum_delta); free(h->tr_varE); free(h->tr_b);
     free(h->c); free(h->w); free(h->q); free(h->T); free(h->chi); free(h->rcls);
@@ -474,6 +477,78 @@ int ora_set_panel_f32(ora_t *h, const float *X, int64_t N, int64_t P, int64_t R,
     h->c = (double *)calloc(h->Ppad, sizeof(double)); h->w = (double *)calloc(h->Ppad, sizeof(double));
     h->q = (double *)calloc(h->Ppad, sizeof(double)); h->T = (double *)calloc(h->Ppad, sizeof(double));
     h->chi = (double *)calloc(h->Ppad, sizeof(double));
+    return ORA_OK;
+}
+
+/* Compact storage (blocked order only): the panel stays one byte per genotype, the centred value
+   x_ij = g_ij - m_j (prepMatVec.jl:129) is never formed -- m_j = (sum_i g_ij) / N in Float64 as the reference computes it, and
+   every product with a centred column is taken analytically:
+     x_j' y        = sum_i g_ij y_i - m_j sum_i y_i                     (per shard: chains over the rows + the shard's sum of y)
+     y -= x_j dlt  = y_i - (sum_j g_ij dlt_j - sum_j m_j dlt_j)          (valid rows only; padding rows stay zero)
+     x_k' x_j      = (exact integer dot product) - N (m_k m_j)
+   R must be a multiple of 16 (a row-owning wave holds units of 16 rows); 7 GEMV chains as in the row-owning streamer. */
+int ora_set_panel_u8(ora_t *h, const uint8_t *G, int64_t N, int64_t P, int64_t R, int64_t S, int64_t D, int centre) {
+    if (h->order != 1) { snprintf(h->err, 256, "compact panel: blocked order only (reference order: pass g - mean as Float64)"); return ORA_ERR; }
+    if (R % 16 || R * S < N || R <= 0) { snprintf(h->err, 256, "bad layout R=%lld S=%lld", (long long)R, (long long)S); return ORA_ERR; }
+    if (D < 1 || D > 16) { snprintf(h->err, 256, "bad lag D=%lld", (long long)D); return ORA_ERR; }
+    h->N = N; h->P = P; h->storage = 1; h->nchain = 7;
+    h->R = R; h->S = S; h->D = D; h->NBLK = (P + BLK - 1) / BLK; h->Ppad = h->NBLK * BLK;
+    const size_t tile = (size_t)R * BLK;
+    h->tiles8 = (uint8_t *)calloc((size_t)S * h->NBLK * tile, 1);
+    h->mean = (double *)calloc(h->Ppad, sizeof(double));
+    h->gram = (double *)calloc((size_t)h->NBLK * BLK * BLK, sizeof(double));
+    h->mpm = (double *)calloc(h->Ppad, sizeof(double));
+    if (!h->tiles8 || !h->mean || !h->gram || !h->mpm) { snprintf(h->err, 256, "out of memory"); return ORA_ERR; }
+    for (int64_t j = 0; j < P; j++) {
+        const int64_t t = j / BLK, jj = j % BLK;
+        uint64_t sum = 0;
+        for (int64_t i = 0; i < N; i++) {
+            const int64_t s = i / R, ii = i % R;
+            h->tiles8[((size_t)s * h->NBLK + t) * tile + jj * R + ii] = G[j * N + i];
+            sum += G[j * N + i];
+        }
+        h->mean[j] = centre ? (double)sum / (double)N : 0.0;
+    }
+    const double Nd = (double)N;
+    if (D > 1) {
+        h->gramx = (double *)calloc((size_t)h->NBLK * D * BLK * BLK, sizeof(double));
+        if (!h->gramx) { snprintf(h->err, 256, "out of memory"); return ORA_ERR; }
+    }
+    for (int64_t t = 0; t < h->NBLK; t++)
+        for (int64_t d = 0; d < D && d <= t; d++)
+            for (int k = 0; k < BLK; k++)
+                for (int j = 0; j < BLK; j++) {
+                    uint64_t dot = 0;
+                    for (int64_t s = 0; s < S; s++) {
+                        const uint8_t *ta = h->tiles8 + ((size_t)s * h->NBLK + (t - d)) * tile + (size_t)k * R;
+                        const uint8_t *tt = h->tiles8 + ((size_t)s * h->NBLK + t) * tile + (size_t)j * R;
+                        uint32_t acc = 0;
+                        for (int64_t i = 0; i < R; i++) acc += (uint32_t)ta[i] * (uint32_t)tt[i];
+                        dot += acc;
+                    }
+                    const double mm = h->mean[(t - d) * BLK + k] * h->mean[t * BLK + j];
+                    const double nm = Nd * mm;
+                    const double g = (double)dot - nm;
+                    if (d == 0) h->gram[((size_t)t * BLK + k) * BLK + j] = g;
+                    else h->gramx[(((size_t)t * D + d) * BLK + k) * BLK + j] = g;
+                }
+    for (int64_t k = 0; k < h->Ppad; k++) h->mpm[k] = h->gram[((size_t)(k / BLK) * BLK + k % BLK) * BLK + k % BLK];
+    h->lhs0 = (double *)calloc(h->Ppad, sizeof(double));
+    h->rhs0 = (double *)calloc(h->Ppad, sizeof(double));
+    h->beta = (double *)calloc(h->Ppad, sizeof(double));
+    h->delta = (int64_t *)malloc(sizeof(int64_t) * h->Ppad);
+    for (int64_t k = 0; k < h->Ppad; k++) h->delta[k] = 1;
+    h->sum_beta = (double *)calloc(h->Ppad, sizeof(double));
+    h->sum_beta2 = (double *)calloc(h->Ppad, sizeof(double));
+    h->sum_delta = (double *)calloc(h->Ppad, sizeof(double));
+    h->c = (double *)calloc(h->Ppad, sizeof(double)); h->w = (double *)calloc(h->Ppad, sizeof(double));
+    h->q = (double *)calloc(h->Ppad, sizeof(double)); h->T = (double *)calloc(h->Ppad, sizeof(double));
+    h->chi = (double *)calloc(h->Ppad, sizeof(double));
+    return ORA_OK;
+}
+int ora_get_means(ora_t *h, double *out, int64_t P) {
+    if (!h->mean || P != h->P) { snprintf(h->err, 256, "no compact panel / size mismatch"); return ORA_ERR; }
+    memcpy(out, h->mean, sizeof(double) * P);
     return ORA_OK;
 }
 
@@ -1066,6 +1141,27 @@ static void iter_blocked(ora_t *h) {
     double *part = (double *)malloc(sizeof(double) * S * BLK);
     double *hist = (double *)calloc((size_t)NBLK * BLK, sizeof(double)); /* dlt of every block */
     for (int64_t tb = 0; tb < NBLK + D; tb++) {
+        if (tb >= D && h->storage == 1) { /* compact storage: y_i -= (sum_j g_ij dlt_j - sum_j m_j dlt_j), valid rows only */
+            const int64_t a = tb - D;
+            double md[64];
+            for (int j = 0; j < BLK; j++) md[j] = h->mean[a * BLK + j] * hist[a * BLK + j];
+            const double cm = wave_butterfly(md);
+            for (int64_t s = 0; s < S; s++) {
+                const uint8_t *tl = h->tiles8 + ((size_t)s * NBLK + a) * tile;
+                double *ys = h->ycorr + s * R;
+                for (int64_t i = 0; i < R && s * R + i < N; i++) {
+                    double p8[8];
+                    for (int c = 0; c < 8; c++) {
+                        double p = 0.0;
+                        for (int jj = 0; jj < 8; jj++) p = __builtin_fma((double)tl[(8 * c + jj) * R + i], hist[a * BLK + 8 * c + jj], p);
+                        p8[c] = p;
+                    }
+                    double T = ((p8[0] + p8[1]) + (p8[2] + p8[3])) + ((p8[4] + p8[5]) + (p8[6] + p8[7]));
+                    double Tc = T - cm;
+                    ys[i] = ys[i] - Tc;
+                }
+            }
+        } else
         if (tb >= D) { /* y update with block a = tb - D: per row, columns ascending */
             const int64_t a = tb - D;
             for (int64_t s = 0; s < S; s++) {
@@ -1086,6 +1182,38 @@ static void iter_blocked(ora_t *h) {
         }
         if (tb >= NBLK) continue;
         const int64_t k0 = tb * BLK;
+        /* compact storage: 7 chains over strided units of 16 rows (lane = column), the shard's sum of y in task order, then
+           partial = A - m_j Sy */
+        if (h->storage == 1) for (int64_t s = 0; s < S; s++) {
+            const uint8_t *tl = h->tiles8 + ((size_t)s * NBLK + tb) * tile;
+            const double *ys = h->ycorr + s * R;
+            const int64_t NU = R / 16;
+            double syw[7];
+            for (int wv = 0; wv < 7; wv++) {
+                const int64_t nu = (NU - wv + 6) / 7;   /* units of this wave */
+                double v[8] = {0, 0, 0, 0, 0, 0, 0, 0}; /* lane slots: task tau = slot + 8 pass -> unit wv + 7 (tau >> 2), quad tau & 3 */
+                for (int64_t tau = 0; tau < 4 * nu; tau++) {
+                    const int64_t i0 = 16 * (wv + 7 * (tau >> 2)) + 4 * (tau & 3);
+                    const double q4 = (ys[i0] + ys[i0 + 1]) + (ys[i0 + 2] + ys[i0 + 3]);
+                    v[tau & 7] = (tau < 8) ? q4 : v[tau & 7] + q4;
+                }
+                syw[wv] = ((v[0] + v[1]) + (v[2] + v[3])) + ((v[4] + v[5]) + (v[6] + v[7]));
+            }
+            const double Sy = ((syw[0] + syw[1]) + (syw[2] + syw[3])) + ((syw[4] + syw[5]) + syw[6]);
+            for (int j = 0; j < BLK; j++) {
+                double a7[7];
+                for (int wv = 0; wv < 7; wv++) {
+                    double acc = 0.0;
+                    for (int64_t u16 = wv; u16 < NU; u16 += 7)
+                        for (int e = 0; e < 16; e++) { int64_t i = 16 * u16 + e; acc = __builtin_fma((double)tl[j * R + i], ys[i], acc); }
+                    a7[wv] = acc;
+                }
+                const double A = ((a7[0] + a7[1]) + (a7[2] + a7[3])) + ((a7[4] + a7[5]) + a7[6]);
+                const double ms = h->mean[k0 + j] * Sy;
+                part[s * BLK + j] = A - ms;
+            }
+        }
+        else
         /* GEMV partials: 8 chains over strided row quads, lane = column */
         for (int64_t s = 0; s < S; s++) {
             const float *tl = h->tiles + ((size_t)s * NBLK + tb) * tile;

@@ -117,6 +117,23 @@ class Oracle:
         self._chk(self.L.ora_set_panel_f32(self.h, _p(X, C.c_float), C.c_int64(self.N), C.c_int64(self.P), C.c_int64(R),
                                            C.c_int64(S), C.c_int64(D)))
 
+    def set_panel_u8(self, G, R=0, S=0, D=1, near=3, centre=True):
+        """Compact storage (one byte per genotype, analytic centring).  Blocked order: the layout the library reports; reference
+        order: the Float64 panel the reference would hold for these genotypes (g - mean, mean = integer column sum / N)."""
+        G = np.asfortranarray(G, dtype=np.uint8)
+        self.N, self.P = G.shape
+        if self.order == 0:
+            mu = G.sum(axis=0, dtype=np.int64).astype(np.float64) / float(self.N) if centre else np.zeros(self.P)
+            return self.set_panel_f64(G.astype(np.float64) - mu[None, :])
+        self._chk(self.L.ora_set_near(self.h, C.c_int64(near)))
+        self._chk(self.L.ora_set_panel_u8(self.h, _p(G, C.c_uint8), C.c_int64(self.N), C.c_int64(self.P), C.c_int64(R), C.c_int64(S),
+                                          C.c_int64(D), C.c_int(1 if centre else 0)))
+
+    def means(self):
+        out = np.zeros(self.P)
+        self._chk(self.L.ora_get_means(self.h, _p(out, C.c_double), C.c_int64(self.P)))
+        return out
+
     def set_panel_f64(self, X):
         """Reference order only: the Float64 panel of the reference (already centred in Float64)."""
         X = np.asfortranarray(X, dtype=np.float64)

@@ -9,7 +9,9 @@ iters = int(sys.argv[4]) if len(sys.argv) > 4 else 10
 mode = int(sys.argv[5]) if len(sys.argv) > 5 else 1
 streamer = int(sys.argv[6]) if len(sys.argv) > 6 else None
 dbgmode = int(os.environ.get("NGP_TOOL_DEBUG_MODE", "0"))  # tools only: the library itself never reads the environment
-s = ngp.Sampler(device=0, seed=1001, chain=0, mode=mode, lag=lag, streamer=streamer if ("NGP_HIP_LIB" not in os.environ or "NGP_FORCE_STREAMER" in os.environ) else None)
+s = ngp.Sampler(device=0, seed=1001, chain=0, mode=mode, lag=lag, streamer=streamer if ("NGP_HIP_LIB" not in os.environ or "NGP_FORCE_STREAMER" in os.environ) else None,
+                storage=os.environ.get("NGP_TOOL_STORAGE"))
+if "NGP_TOOL_SHARDS" in os.environ: s.set_max_shards(int(os.environ["NGP_TOOL_SHARDS"]))
 if dbgmode: s.debug_set_mode(dbgmode)
 if "NGP_TOOL_KNOB" in os.environ: s.debug_set_knob(int(os.environ["NGP_TOOL_KNOB"]))
 if "NGP_TOOL_NEAR" in os.environ: s.set_near(int(os.environ["NGP_TOOL_NEAR"]))
@@ -28,7 +30,8 @@ s.run(2)
 t = time.perf_counter(); s.run(iters); dt = (time.perf_counter() - t) / iters
 R, S, nb = s.layout()
 stv = s.streamer() if hasattr(s.L, "ngp_get_streamer") else "r01"
-gbs = 4.0 * N * P / dt / 1e9
-print(f"N={N} P={P} mode={mode} lag={s.config()[1]} streamer={stv} dbg={dbgmode} layout R={R} S={S} nblk={nb}: {dt*1e3:.3f} ms/iter, {dt/nb*1e6:.2f} us/block, {gbs:.0f} GB/s = {gbs/80:.1f}% of 8 TB/s, setup {setup:.2f}s")
+bpe = 1.0 if os.environ.get("NGP_TOOL_STORAGE") == "u8" else 4.0
+gbs = bpe * N * P / dt / 1e9
+print(f"N={N} P={P} mode={mode} lag={s.config()[1]} near={s.near()} streamer={stv} dbg={dbgmode} layout R={R} S={S} nblk={nb}: {dt*1e3:.3f} ms/iter, {dt/nb*1e6:.2f} us/block, {gbs:.0f} GB/s = {gbs/80:.1f}% of 8 TB/s, setup {setup:.2f}s")
 st = s.get_state(); resid = y - st["b"] - s.xbeta(st["beta"])
 print("   invariant |ycorr - (y - b - X beta)| max:", np.abs(st["ycorr"] - resid).max(), " varE", st["varE"])
