@@ -278,7 +278,7 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
     dfree(h->d_rcls);
     dfree(h->d_varBeta); dfree(h->d_sum_varBeta); h->vb_cap = 0;
     h->have_y = false; h->iter = 0;
-    HCHK(hipFuncSetAttribute((const void *)k_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_step));
+    if (h->storage == 0) HCHK(hipFuncSetAttribute((const void *)k_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_step));
     if (h->mode == 1) {
         const size_t lds_sampler = (size_t)(3 * 4096 + 2 * NGP_RING * NGP_BLK + 6 * NGP_BLK) * sizeof(double) + 2 * NGP_BLK * sizeof(int) + 320;
         const size_t lds_max = 160 * 1024;

@@ -590,9 +590,15 @@ __device__ inline double dpp_f64(double v, const int ctrl_sel) {
     } else if (ctrl_sel == 1) {  // quad_perm [2,3,0,1]: lane ^ 2
         lo = __builtin_amdgcn_update_dpp(lo, lo, 0x4E, 0xF, 0xF, false);
         hi = __builtin_amdgcn_update_dpp(hi, hi, 0x4E, 0xF, 0xF, false);
-    } else {  // row_half_mirror: lane i of each group of 8 reads lane 7 - i (the other group of four)
+    } else if (ctrl_sel == 2) {  // row_half_mirror: lane i of each group of 8 reads lane 7 - i (the other group of four)
         lo = __builtin_amdgcn_update_dpp(lo, lo, 0x141, 0xF, 0xF, false);
         hi = __builtin_amdgcn_update_dpp(hi, hi, 0x141, 0xF, 0xF, false);
+    } else if (ctrl_sel == 3) {  // row_mirror: lane i of each row of 16 reads lane 15 - i (the other group of eight)
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x140, 0xF, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(hi, hi, 0x140, 0xF, 0xF, false);
+    } else {  // row_ror:8: lane i of each row of 16 reads lane (i + 8) mod 16 = lane ^ 8
+        lo = __builtin_amdgcn_update_dpp(lo, lo, 0x128, 0xF, 0xF, false);
+        hi = __builtin_amdgcn_update_dpp(hi, hi, 0x128, 0xF, 0xF, false);
     }
     return __hiloint2double(hi, lo);
 }
@@ -881,10 +887,9 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows(const S
                         }
                     }
                     if (u < nb) {  // ((v_0+v_1)+(v_2+v_3))+((v_4+v_5)+(v_6+v_7)) over the lane slots (lanes 0, 8, ..., 56)
-                        vsum = vsum + __shfl_xor(vsum, 8);
-                        vsum = vsum + __shfl_xor(vsum, 16);
-                        vsum = vsum + __shfl_xor(vsum, 32);
-                        if (lane == 0) rsy[(u & 1) * 8 + wv] = vsum;
+                        vsum = vsum + dpp_f64(vsum, 4);  // slots 2r, 2r+1 live in lanes 0 and 8 of row r
+                        const double r0 = readlane_d(vsum, 0), r1 = readlane_d(vsum, 16), r2 = readlane_d(vsum, 32), r3 = readlane_d(vsum, 48);
+                        if (lane == 0) rsy[(u & 1) * 8 + wv] = (r0 + r1) + (r2 + r3);
                     }
                 }
                 NGP_FINE(1);
@@ -945,11 +950,14 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows(const S
                     if (ok) {
                         const double dv = dlt_granules_value(pg0, pg1);
                         dl[((u + 1) & 1) * NGP_DLS + lane] = dv;
-                        if constexpr (U8) {  // sum_j m_j dlt_j: butterfly over the 64 lanes, xor 32 .. 1
+                        if constexpr (U8) {  // sum_j m_j dlt_j: butterfly over the 64 lanes, xor 1, 2, 4, 8 (DPP), then 16, 32 (the four rows)
                             double v = pm * dv;
-#pragma unroll
-                            for (int off = 32; off >= 1; off >>= 1) v = v + __shfl_xor(v, off);
-                            if (lane == 0) dl[((u + 1) & 1) * NGP_DLS + NGP_BLK] = v;
+                            v = v + dpp_f64(v, 0);
+                            v = v + dpp_f64(v, 1);
+                            v = v + dpp_f64(v, 2);  // quads are uniform by now: the mirror is lane ^ 4
+                            v = v + dpp_f64(v, 3);  // groups of eight are uniform: lane ^ 8
+                            const double r0 = readlane_d(v, 0), r1 = readlane_d(v, 16), r2 = readlane_d(v, 32), r3 = readlane_d(v, 48);
+                            if (lane == 0) dl[((u + 1) & 1) * NGP_DLS + NGP_BLK] = (r0 + r1) + (r2 + r3);
                         }
                     }
                 }

@@ -1032,6 +1032,15 @@ static double wave_butterfly(double *v) { /* 64 lanes, xor 32..1 */
     return v[0];
 }
 
+static double wave_butterfly_up(double *v) { /* 64 lanes, xor 1..32 (compact storage: sum_j m_j dlt_j) */
+    double t[64];
+    for (int off = 1; off <= 32; off <<= 1) {
+        for (int l = 0; l < 64; l++) t[l] = v[l] + v[l ^ off];
+        memcpy(v, t, sizeof(t));
+    }
+    return v[0];
+}
+
 static void iter_blocked(ora_t *h) {
     const int64_t N = h->N, R = h->R, S = h->S, L = R * S, NBLK = h->NBLK;
     const int64_t it = h->iter + 1;
@@ -1145,7 +1154,7 @@ static void iter_blocked(ora_t *h) {
             const int64_t a = tb - D;
             double md[64];
             for (int j = 0; j < BLK; j++) md[j] = h->mean[a * BLK + j] * hist[a * BLK + j];
-            const double cm = wave_butterfly(md);
+            const double cm = wave_butterfly_up(md);
             for (int64_t s = 0; s < S; s++) {
                 const uint8_t *tl = h->tiles8 + ((size_t)s * NBLK + a) * tile;
                 double *ys = h->ycorr + s * R;

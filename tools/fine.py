@@ -6,7 +6,8 @@ ngp = load_pkg()
 lag = int(sys.argv[1]) if len(sys.argv) > 1 else 8
 N = int(sys.argv[2]) if len(sys.argv) > 2 else 10000
 P = int(sys.argv[3]) if len(sys.argv) > 3 else 100000
-s = ngp.Sampler(device=0, seed=1001, chain=0, mode=1, lag=lag, streamer=int(sys.argv[4]) if len(sys.argv) > 4 else None)
+s = ngp.Sampler(device=0, seed=1001, chain=0, mode=1, lag=lag, streamer=int(sys.argv[4]) if len(sys.argv) > 4 else None,
+                storage=os.environ.get("NGP_TOOL_STORAGE"))
 if "NGP_TOOL_KNOB" in os.environ: s.debug_set_knob(int(os.environ["NGP_TOOL_KNOB"]))
 if "NGP_TOOL_NEAR" in os.environ: s.set_near(int(os.environ["NGP_TOOL_NEAR"]))
 s.generate_panel(N, P)
@@ -21,7 +22,7 @@ d = s.debug_stamps(True, n=base + 1024).astype(np.int64)
 F = d[base:base + 1024].reshape(16, 8, 8)
 t0 = F[:, :, 0].min(axis=1)  # earliest wave start of each iteration
 names = ["start", "A done", "B1 (pp written)", "B2 (ys updated)", "C gemv done", "C poll done", "iter end", "A: tile drained (w4-6)"]
-if s.streamer()[0] == 2:  # row-owning waves (waves 0-6) + loader (wave 7: start, requests issued, counted wait done)
+if s.streamer()[0] >= 2:  # row-owning waves (waves 0-6) + loader (wave 7: start, requests issued, counted wait done)
     names = ["start", "update done | w7 issued", "gemv done | w7 landed", "keep filled", "dlt fetched", "past barrier", "published", "-"]
 print("stamp (us after the first wave's start of the iteration), median over 16 iterations; rows = waves 0..7")
 for k in range(8):

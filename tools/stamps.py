@@ -6,7 +6,8 @@ ngp = load_pkg()
 lag = int(sys.argv[1]) if len(sys.argv)>1 else 6
 N = int(sys.argv[2]) if len(sys.argv)>2 else 10000
 P = int(sys.argv[3]) if len(sys.argv)>3 else 100000
-s = ngp.Sampler(device=0, seed=1001, chain=0, mode=1, lag=lag, streamer=int(sys.argv[4]) if len(sys.argv) > 4 else None)
+s = ngp.Sampler(device=0, seed=1001, chain=0, mode=1, lag=lag, streamer=int(sys.argv[4]) if len(sys.argv) > 4 else None,
+              storage=os.environ.get("NGP_TOOL_STORAGE"))
 if "NGP_TOOL_KNOB" in os.environ: s.debug_set_knob(int(os.environ["NGP_TOOL_KNOB"]))
 if "NGP_TOOL_NEAR" in os.environ: s.set_near(int(os.environ["NGP_TOOL_NEAR"]))
 s.generate_panel(N,P)
