@@ -158,6 +158,11 @@ __device__ inline bool wait_dlt_granules_all(const unsigned long long *dltg, con
 // XCC (XCD) id of the executing wave: HW_REG_XCC_ID (id 20), bits 3:0
 __device__ inline unsigned xcc_id() { return (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xFu; }
 __device__ inline void drain_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Flags in LDS, read and written as LDS (ds_read / ds_write).  Through a generic pointer the atomics of a flag become FLAT
+// instructions, and every poll then waits for ALL global loads the wave has in flight (a flat access counts on vmcnt too).
+typedef __attribute__((address_space(3))) int lds_int_t;
+__device__ inline int lds_flag_ld(const int *p) { return *(volatile lds_int_t *)(lds_int_t *)p; }
+__device__ inline void lds_flag_st(int *p, int v) { *(volatile lds_int_t *)(lds_int_t *)p = v; }
 // workgroup barrier that leaves VMEM traffic in flight (__syncthreads() drains vmcnt, which would serialise every
 // LDS-DMA issued just before it); LDS traffic of the wave is complete
 __device__ inline void wg_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
@@ -1222,14 +1227,15 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
                 while (__hip_atomic_load(totflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != u + 1) __builtin_amdgcn_s_sleep(0);
 #else
                 // bounded like every other spin: an abort raised by another wave of this workgroup ends the wait
-                for (unsigned sp = 0; __hip_atomic_load(totflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != u + 1; ++sp) {
-                    if ((sp & 255u) == 255u && (*(volatile int *)sabort != 0 || sp > (NGP_SPIN_LIMIT << 4))) {
+                for (unsigned sp = 0; lds_flag_ld(totflag) != u + 1; ++sp) {
+                    if ((sp & 255u) == 255u && (lds_flag_ld(sabort) != 0 || sp > (NGP_SPIN_LIMIT << 4))) {
                         if (j == 0) *sabort = 1;
                         break;
                     }
                     __builtin_amdgcn_s_sleep(0);
                 }
 #endif
+                asm volatile("" ::: "memory");  // r0 is read after the flag (LDS serves a wave in order)
                 tot = r0[rs * NGP_BLK + j];
             }
             const double *gdb = Gd + (u % 3) * 4096 + j;
@@ -1478,7 +1484,7 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
                 if (have_far || have_one) tot = tot - cor;
                 r0[rs * NGP_BLK + j] = tot;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                if (j == 0) __hip_atomic_store(totflag, u + 1, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+                if (j == 0) lds_flag_st(totflag, u + 1);
                 if (u + 1 < nb) {
                     load_rows_pair(A.gramx + ((size_t)(A.t0 + u + 1) * D + 1) * bsz, j, gxr);
                 }
