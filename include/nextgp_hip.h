@@ -74,6 +74,17 @@ int32_t ngp_set_panel_f32(ngp_handle *h, const float *M, int64_t N, int64_t P, i
  * of the PCIe transfer; centring and the fp32 conversion happen on the device and give bit for bit the tiles of
  * ngp_set_panel_f64 on the same values (integer column sum / N). */
 int32_t ngp_set_panel_u8(ngp_handle *h, const uint8_t *G, int64_t N, int64_t P, int64_t ld, int32_t centre);
+/* Binary panel file -- replaces the text genotype file the reference parses into a Float64 matrix (CSV.read + Matrix,
+ * src/prepMatVec.jl:116-131: hours at 50k x 600k) by a header and the genotype codes, column after column:
+ *   bytes 0-7 "NGPPNL01" | int64 N | int64 P | int32 bits (8 or 2) | int32 0 | P columns of N bytes (bits 8) or of
+ *   ceil(N/4) bytes, individual i in bits 2(i mod 4)..2(i mod 4)+1 of byte i/4 (bits 2: allele counts 0, 1, 2; code 3 refused).
+ * ngp_write_panel_file writes one (no handle, host only; 0 or NGP_ERR_ARG), ngp_read_panel_header reads N, P, bits,
+ * ngp_load_panel_file streams the file through a pinned buffer in chunks of whole column blocks straight into the tiles of the
+ * handle's storage (fp32 centred tiles or, with NGP_STORAGE_U8, the bytes themselves): same tiles, bit for bit, as
+ * ngp_set_panel_u8 on the same codes. */
+int32_t ngp_write_panel_file(const char *path, const uint8_t *G, int64_t N, int64_t P, int64_t ld, int32_t bits);
+int32_t ngp_read_panel_header(const char *path, int64_t *N, int64_t *P, int32_t *bits);
+int32_t ngp_load_panel_file(ngp_handle *h, const char *path, int32_t centre);
 /* Synthetic panel generated on the device: g_ij ~ Binomial(2,p_j), p_j ~ U(maf_lo,maf_hi). */
 int32_t ngp_generate_panel(ngp_handle *h, int64_t N, int64_t P, double maf_lo, double maf_hi, uint64_t panel_seed);
 /* Device tiling chosen for the panel: rows per shard R, shards S, 64-SNP blocks NBLK (the blocked

@@ -21,7 +21,7 @@ SYMBOLS = [
     "ngp_set_residual_prior", "ngp_set_intercept", "ngp_set_schedule", "ngp_run", "ngp_get_state", "ngp_set_state",
     "ngp_get_trace", "ngp_get_posterior_sums", "ngp_posterior_len", "ngp_export_posterior_device", "ngp_sweep_set",
     "ngp_get_timing", "ngp_profile_iteration", "ngp_draws_indexed", "ngp_eval_math", "ngp_configure", "ngp_get_config", "ngp_debug_stamps", "ngp_set_near_lags", "ngp_get_near_lags",
-    "ngp_set_streamer", "ngp_get_streamer", "ngp_set_storage", "ngp_get_storage", "ngp_set_max_shards", "ngp_debug_set_mode", "ngp_debug_set_knob", "ngp_set_posterior_sums", "ngp_save_snapshot", "ngp_load_snapshot",
+    "ngp_set_streamer", "ngp_get_streamer", "ngp_set_storage", "ngp_get_storage", "ngp_set_max_shards", "ngp_write_panel_file", "ngp_read_panel_header", "ngp_load_panel_file", "ngp_debug_set_mode", "ngp_debug_set_knob", "ngp_set_posterior_sums", "ngp_save_snapshot", "ngp_load_snapshot",
     "ngp_set_trace_loci", "ngp_get_trace_ext", "ngp_allreduce_posterior", "ngp_add_marker_set_r", "ngp_get_class_state", "ngp_set_class_state", "ngp_add_fixed_set", "ngp_get_fixed", "ngp_set_fixed",
 ]
 
@@ -49,6 +49,23 @@ def load():
 
 def _p(a, t):
     return a.ctypes.data_as(C.POINTER(t)) if a is not None else None
+
+
+def write_panel_file(path, G, bits=8):
+    """Genotype codes (N x P, uint8) as a binary panel file: 8 bits per genotype, or 2 (allele counts 0/1/2 only)."""
+    G = np.asfortranarray(G, dtype=np.uint8)
+    rc = load().ngp_write_panel_file(str(path).encode(), _p(G, C.c_uint8), C.c_int64(G.shape[0]), C.c_int64(G.shape[1]),
+                                     C.c_int64(G.shape[0]), C.c_int32(bits))
+    if rc != 0:
+        raise NextGPHipError(f"ngp_write_panel_file failed ({rc}): path not writable, or codes above 2 with bits=2")
+
+
+def read_panel_header(path):
+    n, p, b = C.c_int64(), C.c_int64(), C.c_int32()
+    rc = load().ngp_read_panel_header(str(path).encode(), C.byref(n), C.byref(p), C.byref(b))
+    if rc != 0:
+        raise NextGPHipError(f"not a panel file: {path}")
+    return n.value, p.value, b.value
 
 
 class Sampler:
@@ -143,6 +160,12 @@ class Sampler:
             pass
 
     # ---- panel -------------------------------------------------------------------------
+    def load_panel_file(self, path, centre=True):
+        """Binary panel file (write_panel_file) straight into the tiles of this handle's storage."""
+        n, p, _ = read_panel_header(path)
+        self._chk(self.L.ngp_load_panel_file(self.h, str(path).encode(), C.c_int32(1 if centre else 0)))
+        self.N, self.P = n, p
+
     def set_panel(self, M, centre=False):
         M = np.asarray(M)
         if M.dtype == np.uint8:  # one byte per genotype: converted and centred on the device

@@ -617,6 +617,27 @@ int32_t ngp_set_panel_f32(ngp_handle *h, const float *M, int64_t N, int64_t P, i
     return set_panel_host<float>(h, M, N, P, ld, centre);
 }
 
+}  // extern "C" (helpers below are C++)
+
+// one staged chunk of genotype bytes (whole 64-column blocks, column-major with leading dimension ld, already on the device)
+// into the tiles: fp32 centred tiles, or the bytes as they are plus the column means (compact storage)
+static void ingest_u8_chunk(ngp_handle *h, const uint8_t *d_g, int64_t N, int64_t ld, int64_t t0, int64_t nb, int64_t ncols, int centre,
+                            double *d_mu) {
+    const int64_t c0 = t0 * NGP_BLK;
+    if (h->storage == 1) {  // the bytes stay bytes; the means go to the handle
+        hipLaunchKernelGGL(k_u8_colmean, dim3((unsigned)ncols), dim3(256), 0, h->stream, d_g, (long long)N, (long long)ld, (int)centre,
+                           h->d_mean + c0);
+        hipLaunchKernelGGL(k_u8_fill8, dim3((unsigned)h->S, (unsigned)nb), dim3(256), 0, h->stream, (uint8_t *)h->d_tiles, d_g, (long long)N,
+                           (long long)ld, (long long)ncols, (int)h->R, (int)h->S, (long long)t0);
+    } else {
+        hipLaunchKernelGGL(k_u8_colmean, dim3((unsigned)ncols), dim3(256), 0, h->stream, d_g, (long long)N, (long long)ld, (int)centre, d_mu);
+        hipLaunchKernelGGL(k_u8_fill, dim3((unsigned)h->S, (unsigned)nb), dim3(256), 0, h->stream, h->d_tiles, d_g, (long long)N,
+                           (long long)ld, (long long)ncols, (int)h->R, (int)h->S, (long long)t0, d_mu);
+    }
+}
+
+extern "C" {
+
 int32_t ngp_set_panel_u8(ngp_handle *h, const uint8_t *G, int64_t N, int64_t P, int64_t ld, int32_t centre) {
     int rc;
     if ((rc = enter(h))) return rc;
@@ -638,21 +659,116 @@ int32_t ngp_set_panel_u8(ngp_handle *h, const uint8_t *G, int64_t N, int64_t P, 
         const size_t bytes = (size_t)(ncols - 1) * ld + (size_t)N;
         e = hipMemcpyAsync(d_g, G + (size_t)c0 * ld, bytes, hipMemcpyHostToDevice, h->stream);
         if (e != hipSuccess) break;
-        if (h->storage == 1) {  // the bytes stay bytes; the means go to the handle
-            hipLaunchKernelGGL(k_u8_colmean, dim3((unsigned)ncols), dim3(256), 0, h->stream, d_g, (long long)N, (long long)ld, (int)centre,
-                               h->d_mean + c0);
-            hipLaunchKernelGGL(k_u8_fill8, dim3((unsigned)h->S, (unsigned)nb), dim3(256), 0, h->stream, (uint8_t *)h->d_tiles, d_g, (long long)N,
-                               (long long)ld, (long long)ncols, (int)h->R, (int)h->S, (long long)t0);
-        } else {
-        hipLaunchKernelGGL(k_u8_colmean, dim3((unsigned)ncols), dim3(256), 0, h->stream, d_g, (long long)N, (long long)ld, (int)centre, d_mu);
-        hipLaunchKernelGGL(k_u8_fill, dim3((unsigned)h->S, (unsigned)nb), dim3(256), 0, h->stream, h->d_tiles, d_g, (long long)N,
-                           (long long)ld, (long long)ncols, (int)h->R, (int)h->S, (long long)t0, d_mu);
-        }
+        ingest_u8_chunk(h, d_g, N, ld, t0, nb, ncols, centre, d_mu);
         e = hipStreamSynchronize(h->stream);  // the staging buffer is reused by the next chunk
     }
     (void)hipFree(d_g);
     dfree(d_mu);
     if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("set_panel_u8: ") + hipGetErrorString(e));
+    return build_gram(h);
+}
+
+// ---- binary panel file (replaces the text genotype file of src/prepMatVec.jl:116-131 for large panels) ----
+// header (32 bytes): magic "NGPPNL01", int64 N, int64 P, int32 bits (8 or 2), int32 0.  Then P columns: N bytes (bits 8), or
+// ceil(N / 4) bytes with four genotypes per byte, individual i in bits 2 (i mod 4) .. 2 (i mod 4) + 1 (bits 2; code 3 is refused).
+namespace {
+struct PanelHeader { char magic[8]; int64_t N, P; int32_t bits, zero; };
+}
+
+int32_t ngp_write_panel_file(const char *path, const uint8_t *G, int64_t N, int64_t P, int64_t ld, int32_t bits) {
+    if (!path || !G || N <= 0 || P <= 0 || ld < N || (bits != 8 && bits != 2)) return NGP_ERR_ARG;
+    FILE *f = std::fopen(path, "wb");
+    if (!f) return NGP_ERR_ARG;
+    PanelHeader hd;
+    std::memcpy(hd.magic, "NGPPNL01", 8);
+    hd.N = N; hd.P = P; hd.bits = bits; hd.zero = 0;
+    bool ok = std::fwrite(&hd, sizeof hd, 1, f) == 1;
+    std::vector<uint8_t> packed((size_t)(N + 3) / 4);
+    for (int64_t j = 0; j < P && ok; j++) {
+        const uint8_t *col = G + (size_t)j * ld;
+        if (bits == 8) {
+            ok = std::fwrite(col, 1, (size_t)N, f) == (size_t)N;
+        } else {
+            std::fill(packed.begin(), packed.end(), 0);
+            for (int64_t i = 0; i < N; i++) {
+                if (col[i] > 2) { ok = false; break; }  // two bits hold the allele counts 0, 1, 2
+                packed[(size_t)i >> 2] |= (uint8_t)(col[i] << (2 * (i & 3)));
+            }
+            if (ok) ok = std::fwrite(packed.data(), 1, packed.size(), f) == packed.size();
+        }
+    }
+    ok = (std::fclose(f) == 0) && ok;
+    return ok ? NGP_OK : NGP_ERR_ARG;
+}
+
+int32_t ngp_read_panel_header(const char *path, int64_t *N, int64_t *P, int32_t *bits) {
+    if (!path) return NGP_ERR_ARG;
+    FILE *f = std::fopen(path, "rb");
+    if (!f) return NGP_ERR_ARG;
+    PanelHeader hd;
+    const bool ok = std::fread(&hd, sizeof hd, 1, f) == 1 && std::memcmp(hd.magic, "NGPPNL01", 8) == 0 && hd.N > 0 && hd.P > 0 &&
+                    (hd.bits == 8 || hd.bits == 2);
+    std::fclose(f);
+    if (!ok) return NGP_ERR_ARG;
+    if (N) *N = hd.N;
+    if (P) *P = hd.P;
+    if (bits) *bits = hd.bits;
+    return NGP_OK;
+}
+
+int32_t ngp_load_panel_file(ngp_handle *h, const char *path, int32_t centre) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(path != nullptr, NGP_ERR_ARG, "null path");
+    FILE *f = std::fopen(path, "rb");
+    REQUIRE(f != nullptr, NGP_ERR_ARG, std::string("cannot open panel file ") + path);
+    PanelHeader hd;
+    if (std::fread(&hd, sizeof hd, 1, f) != 1 || std::memcmp(hd.magic, "NGPPNL01", 8) != 0 || hd.N <= 0 || hd.P <= 0 || (hd.bits != 8 && hd.bits != 2)) {
+        std::fclose(f);
+        return fail(h, NGP_ERR_ARG, std::string("not a panel file (magic NGPPNL01, bits 8 or 2): ") + path);
+    }
+    const int64_t N = hd.N, P = hd.P;
+    if ((rc = alloc_panel(h, N, P))) { std::fclose(f); return rc; }
+    // the file streams through a pinned host buffer in chunks of whole 64-column blocks; two-bit columns are unpacked on the host
+    const int64_t colbytes = (hd.bits == 8) ? N : (N + 3) / 4;
+    const int64_t blk_bytes = (int64_t)NGP_BLK * N;
+    const int64_t nb_chunk = std::max<int64_t>(1, std::min<int64_t>(h->NBLK, ((int64_t)64 << 20) / blk_bytes));
+    uint8_t *d_g = nullptr, *h_g = nullptr;
+    double *d_mu = nullptr;
+    std::vector<uint8_t> packed((hd.bits == 2) ? (size_t)colbytes : 0);
+    hipError_t e = hipMalloc((void **)&d_g, (size_t)nb_chunk * blk_bytes);
+    if (e == hipSuccess) e = hipHostMalloc((void **)&h_g, (size_t)nb_chunk * blk_bytes, hipHostMallocDefault);
+    if (e != hipSuccess) { std::fclose(f); if (d_g) (void)hipFree(d_g); return fail(h, NGP_ERR_NOMEM, "staging buffers"); }
+    if ((rc = dalloc(h, &d_mu, (size_t)nb_chunk * NGP_BLK))) { std::fclose(f); (void)hipFree(d_g); (void)hipHostFree(h_g); return rc; }
+    std::string why;
+    for (int64_t t0 = 0; t0 < h->NBLK && e == hipSuccess && why.empty(); t0 += nb_chunk) {
+        const int64_t nb = std::min<int64_t>(nb_chunk, h->NBLK - t0);
+        const int64_t c0 = t0 * NGP_BLK, ncols = std::min<int64_t>(nb * NGP_BLK, P - c0);
+        for (int64_t jc = 0; jc < ncols && why.empty(); jc++) {
+            uint8_t *dst = h_g + (size_t)jc * N;
+            if (hd.bits == 8) {
+                if (std::fread(dst, 1, (size_t)N, f) != (size_t)N) why = "panel file truncated";
+            } else {
+                if (std::fread(packed.data(), 1, packed.size(), f) != packed.size()) { why = "panel file truncated"; break; }
+                for (int64_t i = 0; i < N; i++) {
+                    const uint8_t g = (uint8_t)((packed[(size_t)i >> 2] >> (2 * (i & 3))) & 3u);
+                    if (g == 3) { why = "panel file holds a missing genotype (code 3): impute before loading"; break; }
+                    dst[i] = g;
+                }
+            }
+        }
+        if (!why.empty()) break;
+        e = hipMemcpyAsync(d_g, h_g, (size_t)ncols * N, hipMemcpyHostToDevice, h->stream);
+        if (e != hipSuccess) break;
+        ingest_u8_chunk(h, d_g, N, N, t0, nb, ncols, centre, d_mu);
+        e = hipStreamSynchronize(h->stream);  // both staging buffers are reused by the next chunk
+    }
+    std::fclose(f);
+    (void)hipFree(d_g);
+    (void)hipHostFree(h_g);
+    dfree(d_mu);
+    if (!why.empty()) { dfree(h->d_tiles); return fail(h, NGP_ERR_ARG, why); }
+    if (e != hipSuccess) { dfree(h->d_tiles); return fail(h, NGP_ERR_HIP, std::string("load_panel_file: ") + hipGetErrorString(e)); }
     return build_gram(h);
 }
 

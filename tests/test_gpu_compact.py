@@ -163,3 +163,68 @@ def test_compact_refuses_centred_input_and_mode0(ngp, O):
     s = ngp.Sampler(device=0, seed=1, chain=0, mode=0, lag=1, storage="u8")
     with pytest.raises(ngp.NextGPHipError, match="persistent sweep"):
         s.set_panel(np.zeros((10, 10), dtype=np.uint8), centre=True)
+
+
+@pytest.mark.parametrize("bits", [8, 2])
+@pytest.mark.parametrize("storage", ["f32", "u8"])
+def test_panel_file_gives_the_tiles_of_set_panel_u8(ngp, O, tmp_path, bits, storage):
+    """Binary panel file (include/nextgp_hip.h ngp_load_panel_file) in place of the text file of src/prepMatVec.jl:116-131."""
+    N, P = 333, 150   # N not a multiple of 4: the last byte of a two-bit column is partly empty
+    G, y, v = make_codes(O, N, P)
+    path = tmp_path / f"panel{bits}.bin"
+    ngp.write_panel_file(path, G, bits=bits)
+    assert ngp.read_panel_header(path) == (N, P, bits)
+    assert path.stat().st_size == 32 + P * (N if bits == 8 else (N + 3) // 4)
+    outs = []
+    for via_file in (True, False):
+        s = ngp.Sampler(device=0, seed=3, chain=0, mode=1, lag=6, storage=storage)
+        if via_file:
+            s.load_panel_file(path, centre=True)
+        else:
+            s.set_panel(G, centre=True)
+        add_sets(s, [(0, P, "PR")], v)
+        s.set_y(y)
+        s.set_residual_prior(4.0, 0.25 * y.var())
+        s.run(5)
+        outs.append((s.mpm(), s.get_state()))
+    assert np.array_equal(outs[0][0], outs[1][0])
+    for k in ("ycorr", "beta", "varBeta"):
+        assert np.array_equal(outs[0][1][k], outs[1][1][k]), k
+
+
+def test_panel_file_errors(ngp, O, tmp_path):
+    G = np.full((8, 4), 3, dtype=np.uint8)
+    with pytest.raises(ngp.NextGPHipError):
+        ngp.write_panel_file(tmp_path / "x.bin", G, bits=2)        # code 3 does not fit two bits
+    bad = tmp_path / "bad.bin"
+    bad.write_bytes(b"not a panel")
+    with pytest.raises(ngp.NextGPHipError):
+        ngp.read_panel_header(bad)
+    s = ngp.Sampler(device=0, seed=1, chain=0)
+    with pytest.raises(ngp.NextGPHipError, match="not a panel file"):
+        s._chk(s.L.ngp_load_panel_file(s.h, str(bad).encode(), 1))
+    ok = tmp_path / "trunc.bin"
+    ngp.write_panel_file(ok, np.ones((100, 70), dtype=np.uint8), bits=8)
+    ok.write_bytes(ok.read_bytes()[:-50])
+    with pytest.raises(ngp.NextGPHipError, match="truncated"):
+        s._chk(s.L.ngp_load_panel_file(s.h, str(ok).encode(), 1))
+
+
+def test_compact_snapshot_resume(ngp, O, tmp_path):
+    G, y, v = make_codes(O, 500, 400)
+    def build():
+        s = ngp.Sampler(device=0, seed=21, chain=2, mode=1, lag=8, storage="u8")
+        s.set_panel(G, centre=True)
+        add_sets(s, [(0, 250, "PR"), (250, 150, "B")], v)
+        s.set_y(y)
+        s.set_residual_prior(4.0, 0.25 * y.var())
+        s.set_schedule(12, 2, 2)
+        return s
+    a = build(); a.run(12)
+    b = build(); b.run(5); b.save_snapshot(tmp_path / "c.snap")
+    c = build(); c.load_snapshot(tmp_path / "c.snap"); c.run(7)
+    sa, sc = a.get_state(), c.get_state()
+    for k in ("ycorr", "beta", "varBeta", "piHat"):
+        assert np.array_equal(sa[k], sc[k]), k
+    pa, pc = a.get_posterior_sums(), c.get_posterior_sums()
+    assert np.array_equal(pa["sum_beta"], pc["sum_beta"]) and pa["nKept"] == pc["nKept"]

@@ -397,3 +397,34 @@ def test_numpy_restatement_fixed_effect_sets(O):
         for o in (o0, o1):
             assert np.abs(o.get_fixed()["b"] - bref).max() <= 1e-10 * max(1.0, np.abs(bref).max()), it
             assert np.abs(o.get_state()["beta"] - ref.state()["beta"]).max() <= 1e-10, it
+
+
+def test_compact_blocked_arithmetic_matches_the_reference_float64_panel(O):
+    """oracle/ngp_oracle.c ora_set_panel_u8 (bytes + analytic centring, the arithmetic the product's compact storage follows)
+    against the reference order on the Float64 panel the reference itself would hold for these genotypes (g - mean,
+    src/prepMatVec.jl:129): agreement to rounding of the sums, where fp32 tiles are ~1e-7 away."""
+    rng = np.random.default_rng(3)
+    N, P = 210, 300
+    maf = rng.uniform(0.05, 0.5, P)
+    G = ((rng.random((N, P)) < maf).astype(np.uint8) + (rng.random((N, P)) < maf).astype(np.uint8))
+    Xc = G - G.mean(0)
+    bt = np.zeros(P); idx = rng.choice(P, 20, replace=False); bt[idx] = rng.normal(size=20)
+    y = 10 + Xc @ bt + rng.normal(size=N)
+    v = 0.5 * y.var() / (Xc ** 2).sum(0).mean()
+    res = {}
+    for name, order, kw in (("ref", 0, {}), ("blk", 1, dict(R=32, S=7, D=4, near=2)), ("blk12", 1, dict(R=16, S=14, D=12, near=3))):
+        o = O.Oracle(order=order, seed=7, chain=0)
+        o.set_panel_u8(G, **kw)
+        o.add_marker_set(0, 150, 0, 4.0, v * 0.5, [(0, 150)], [v])
+        o.add_marker_set(150, P - 150, 1, 4.0, v * 0.5, [(j, j + 1) for j in range(P - 150)], [v] * (P - 150), pi0=0.3, estPi=True)
+        o.set_y(y); o.set_residual_prior(4.0, 0.25 * y.var()); o.set_schedule(15, 3, 2); o.run(15)
+        res[name] = o.get_state()
+    for name in ("blk", "blk12"):
+        a, b = res["ref"], res[name]
+        assert np.array_equal(a["delta"][:P], b["delta"][:P])
+        assert np.abs(a["beta"][:P] - b["beta"][:P]).max() < 1e-12 * np.abs(a["beta"]).max()   # rounding of fp64 sums, 15 iterations
+        assert abs(a["varE"] - b["varE"]) < 1e-12 * a["varE"]
+        assert np.abs(a["ycorr"][:N] - b["ycorr"][:N]).max() < 1e-11
+    # padding rows (224 > 210) never leave zero: the residual invariant holds on the real rows
+    st = res["blk"]
+    assert np.abs(st["ycorr"][:N] - (y - st["b"] - Xc @ st["beta"][:P])).max() < 1e-11
