@@ -5,5 +5,6 @@ The directory name contains a dot, so it is loaded by path (see `ngp_pkg.py` at 
 """
 from ._lib import (LIB_PATH, METHOD_BAYESB, METHOD_BAYESC, METHOD_BAYESPR, METHOD_BAYESR, SYMBOLS, NextGPHipError, Sampler, load,  # noqa: F401
                    read_panel_header, write_panel_file)
-from .api import BayesB, BayesC, BayesPR, BayesR, Random, SNP, design_columns, parse_formula, prep2RegionData, read_genotypes, runLMEM, summaryMCMC  # noqa: F401,E402
+from .api import (BayesB, BayesC, BayesPR, BayesR, Random, SNP, design_columns, is_panel_file, parse_formula, prep2RegionData,
+                  read_genotypes, read_panel_file, runLMEM, summaryMCMC)  # noqa: F401,E402
 from . import multichain  # noqa: F401,E402

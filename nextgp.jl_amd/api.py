@@ -24,7 +24,7 @@ import numpy as np
 
 from ._lib import METHOD_BAYESB, METHOD_BAYESC, METHOD_BAYESPR, Sampler
 
-__all__ = ["BayesPR", "BayesB", "BayesC", "BayesR", "Random", "SNP", "runLMEM", "summaryMCMC", "read_genotypes", "prep2RegionData", "parse_formula", "design_columns"]
+__all__ = ["BayesPR", "BayesB", "BayesC", "BayesR", "Random", "SNP", "runLMEM", "summaryMCMC", "read_genotypes", "read_panel_file", "is_panel_file", "prep2RegionData", "parse_formula", "design_columns"]
 
 
 # ----------------------------------------------------------------------------------------------
@@ -170,6 +170,8 @@ def read_genotypes(path):
     uint8 (one byte per genotype; at 50k x 600k the text parse alone would take hours)."""
     if isinstance(path, (str, os.PathLike)) and str(path).endswith(".npy"):
         path = np.load(path, mmap_mode="r")
+    elif isinstance(path, (str, os.PathLike)) and is_panel_file(path):
+        return read_panel_file(path)
     if isinstance(path, np.ndarray):
         if path.dtype == np.uint8:
             return np.asfortranarray(path)
@@ -180,6 +182,41 @@ def read_genotypes(path):
             M = M[:, None]
     keep = ~np.isnan(M).any(axis=0)
     return np.asfortranarray(M[:, keep])
+
+
+def is_panel_file(path):
+    """True for the binary panel format of include/nextgp_hip.h (magic NGPPNL01)."""
+    try:
+        with open(path, "rb") as f:
+            return f.read(8) == b"NGPPNL01"
+    except OSError:
+        return False
+
+
+def read_panel_file(path):
+    """Binary panel file -> (N, P) uint8 Fortran-ordered codes (host side; Sampler.load_panel_file streams the same file
+    straight to the device)."""
+    with open(path, "rb") as f:
+        hd = f.read(32)
+        if hd[:8] != b"NGPPNL01":
+            raise ValueError(f"not a panel file: {path}")
+        N, P = np.frombuffer(hd, dtype="<i8", count=2, offset=8)
+        bits = int(np.frombuffer(hd, dtype="<i4", count=1, offset=24)[0])
+        N, P = int(N), int(P)
+        if bits == 8:
+            G = np.fromfile(f, dtype=np.uint8, count=N * P).reshape((N, P), order="F")
+        elif bits == 2:
+            nb = (N + 3) // 4
+            raw = np.fromfile(f, dtype=np.uint8, count=nb * P).reshape((nb, P), order="F")
+            G = np.empty((4 * nb, P), dtype=np.uint8, order="F")
+            for k in range(4):
+                G[k::4, :] = (raw >> (2 * k)) & 3
+            G = np.asfortranarray(G[:N, :])
+            if (G == 3).any():
+                raise ValueError("panel file holds a missing genotype (code 3): impute before loading")
+        else:
+            raise ValueError(f"panel file with {bits} bits per genotype")
+    return G
 
 
 def prep2RegionData(outPutFolder, markerSet, mapFile, fixedRegSize):
@@ -260,12 +297,15 @@ def summaryMCMC(param, outFolder=None):
 # runLMEM (src/MCMC.jl:31-41)
 # ----------------------------------------------------------------------------------------------
 def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=None, outFolder="outMCMC", VCV=None, userPedData=None,
-            summaryStat=None, seed=1, chain=0, device=0, samples="text", overwrite=False, engine=None):
+            summaryStat=None, seed=1, chain=0, device=0, samples="text", overwrite=False, engine=None, storage=None):
     """Runs the chain on the GPU and writes the reference's *Out files.
 
     Differences from the reference, all deliberate: (1) `seed`/`chain` key the random streams (the reference never
     seeds); (2) an existing non-empty outFolder is refused unless overwrite=True (the reference deletes it,
-    src/misc.jl:221-227); (3) samples="none" skips the per-iteration text rows and only returns posterior means.
+    src/misc.jl:221-227); (3) samples="none" skips the per-iteration text rows and only returns posterior means;
+    (4) storage="u8" keeps the panel one byte per genotype on the device, centred analytically (ngp_set_storage: a quarter of
+    the memory, no fp32 rounding of the panel) -- every SNP set must then hold integer codes 0..255 (uint8 arrays, binary panel
+    files, or text files whose values are such integers).
     Returns a dict of posterior means taken from the on-device sums."""
     if userPedData is not None and len(userPedData):
         raise NotImplementedError("userPedData: pedigree effects stay on the Julia path (src/mme.jl:26-46)")
@@ -287,10 +327,19 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
     for M in mats:
         if M.shape[0] != len(y):
             raise ValueError("genotype rows must match the phenotype records (marker files are ordered as the data, runTime.jl:23)")
+    if storage in ("u8", 1):  # codes stay codes: integer-valued float input is converted, anything else refused
+        conv = []
+        for M in mats:
+            if M.dtype != np.uint8:
+                if not (np.all(M == np.rint(M)) and M.min() >= 0 and M.max() <= 255):
+                    raise ValueError('storage="u8" needs integer genotype codes in 0..255 in every SNP set')
+                M = np.asfortranarray(M.astype(np.uint8))
+            conv.append(M)
+        mats = conv
     if not all(M.dtype == np.uint8 for M in mats):  # one byte per genotype only when every set comes that way
         mats = [np.asarray(M, dtype=np.float64) for M in mats]
     panel = np.asfortranarray(np.concatenate(mats, axis=1))
-    smp = Sampler(device=device, seed=seed, chain=chain, **(dict(mode=engine[0], lag=engine[1]) if engine else {}))
+    smp = Sampler(device=device, seed=seed, chain=chain, storage=storage, **(dict(mode=engine[0], lag=engine[1]) if engine else {}))
     smp.set_panel(panel, centre=True)  # centring: src/prepMatVec.jl:129
     # residual prior (src/mme.jl:63-94)
     e_prior = VCV.get("e", Random("I", 100.0))

@@ -158,3 +158,60 @@ def test_default_engine_at_full_size(ngp, lag):
     c, y2 = _chain(ngp, "PR", 12, engine=(1, lag))
     st = c.get_state()
     assert np.abs(st["ycorr"] - (y2 - st["b"] - c.xbeta(st["beta"]))).max() <= 1e-9 * np.abs(y2).max()
+
+
+def test_north_star_shape_in_compact_storage(ngp):
+    """50k x 600k with one byte per genotype (30 GB instead of 120 GB): residual invariant, bitwise reproducibility, and the distance
+    to the fp32-storage chain of the same seed on the same generated genotypes -- the fp32 rounding of the panel, nothing else."""
+    N_, P_ = 50000, 600000
+    out = []
+    for storage in ("u8", "u8", None):
+        s = ngp.Sampler(device=0, seed=1001, chain=0, storage=storage)
+        s.generate_panel(N_, P_)
+        if not out:
+            R, S, nblk = s.layout()
+            assert (R, S, nblk) == (208, 241, 9375) and s.config() == (1, 8) and s.streamer() == (3, 7) and s.storage() == 1
+            rng = np.random.default_rng(1)
+            bt = np.zeros(P_); idx = rng.choice(P_, P_ // 100, replace=False); bt[idx] = rng.normal(size=len(idx))
+            g = s.xbeta(bt)
+            y = 10.0 + g + np.random.default_rng(2).normal(size=N_) * np.sqrt(g.var())
+            v = 0.5 * y.var() / (s.mpm().sum() / N_)
+        for c in range(3):
+            s.add_marker_set(c * 200000, 200000, 0, 4.0, v * 0.5, [(0, 200000)], [v])
+        s.set_y(y); s.set_residual_prior(4.0, 0.25 * y.var()); s.set_schedule(6, 0, 1)
+        s.run(6)
+        st = s.get_state()
+        if not out:
+            resid = y - st["b"] - s.xbeta(st["beta"])
+            assert np.abs(st["ycorr"] - resid).max() <= 1e-9 * np.abs(y).max()
+            assert np.isfinite(st["beta"]).all() and st["varE"] > 0 and st["iter"] == 6
+        out.append(st)
+        s.close()
+    a, b, c = out
+    for k in ("ycorr", "beta", "varBeta"):
+        assert np.array_equal(a[k], b[k]), k
+    dev = np.abs(a["beta"] - c["beta"]).max() / np.abs(a["beta"]).max()
+    assert 0 < dev < 1e-3, dev     # fp32 panel rounding (~6e-8 per element) through 6 iterations of 600k updates
+    assert abs(a["varE"] - c["varE"]) < 1e-5 * a["varE"]
+
+
+def test_compact_storage_takes_panels_the_fp32_sweep_cannot(ngp):
+    """150,000 rows: above the 63k-row limit of the persistent sweep on fp32 tiles; 624-row shards, four update tasks per lane."""
+    N_, P_ = 150000, 30016
+    s = ngp.Sampler(device=0, seed=5, chain=0, storage="u8")
+    s.generate_panel(N_, P_)
+    R, S, nblk = s.layout()
+    assert R % 16 == 0 and R > 448 and R * S >= N_ and s.config()[0] == 1
+    rng = np.random.default_rng(1)
+    bt = np.zeros(P_); idx = rng.choice(P_, 300, replace=False); bt[idx] = rng.normal(size=300)
+    g = s.xbeta(bt)
+    y = 10.0 + g + np.random.default_rng(2).normal(size=N_) * np.sqrt(g.var())
+    v = 0.5 * y.var() / (s.mpm().sum() / N_)
+    s.add_marker_set(0, P_, 0, 4.0, v * 0.5, [(0, P_)], [v])
+    s.set_y(y); s.set_residual_prior(4.0, 0.25 * y.var())
+    s.run(5)
+    st = s.get_state()
+    assert np.abs(st["ycorr"] - (y - st["b"] - s.xbeta(st["beta"]))).max() <= 1e-9 * np.abs(y).max()
+    assert np.isfinite(st["beta"]).all() and st["varE"] > 0
+    # the effects found are the simulated ones (a sampler that mixed up rows or columns would not correlate)
+    assert np.corrcoef(st["beta"], bt)[0, 1] > 0.3

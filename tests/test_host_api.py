@@ -181,3 +181,48 @@ def test_runLMEM_covariates_and_blocks(ngp, O, tmp_path):
     assert abs(res["fixed"][0] - 0.3) < 0.15                      # the covariate's effect is recovered (the factor's needs a longer chain)
     lines = (out / "bOut").read_text().splitlines()
     assert len(lines) == 11 and lines[0].split("\t") == res["fixed_names"] and len(lines[1].split("\t")) == 5
+
+
+def test_panel_file_round_trip_on_the_host(ngp, tmp_path):
+    """Binary panel files (include/nextgp_hip.h: ngp_write_panel_file / ngp_read_panel_header; api.read_panel_file) -- host only."""
+    rng = np.random.default_rng(4)
+    G = rng.integers(0, 3, size=(37, 11), dtype=np.uint8)      # 37: the last byte of a two-bit column is partly empty
+    for bits in (8, 2):
+        p = tmp_path / f"p{bits}.bin"
+        ngp.write_panel_file(p, G, bits=bits)
+        assert ngp.is_panel_file(p) and ngp.read_panel_header(p) == (37, 11, bits)
+        assert np.array_equal(ngp.read_panel_file(p), G)
+        assert np.array_equal(ngp.read_genotypes(str(p)), G) and ngp.read_genotypes(str(p)).dtype == np.uint8
+    txt = tmp_path / "g.txt"
+    np.savetxt(txt, G, fmt="%d", delimiter=" ")
+    assert not ngp.is_panel_file(txt)
+    G2 = G.copy(); G2[3, 2] = 200
+    ngp.write_panel_file(tmp_path / "q.bin", G2, bits=8)       # any byte value with 8 bits
+    assert np.array_equal(ngp.read_panel_file(tmp_path / "q.bin"), G2)
+    with pytest.raises(ngp.NextGPHipError):
+        ngp.write_panel_file(tmp_path / "r.bin", G2, bits=2)
+
+
+@pytest.mark.gpu
+def test_runLMEM_compact_storage(ngp, O, tmp_path):
+    """storage="u8" through the reference's interface: text codes, a uint8 array and a two-bit panel file give the same chain, and
+    that chain is the fp32-storage chain up to the fp32 rounding of the panel."""
+    N, P = 150, 200
+    X, y, bt, v = make_problem(O, N, P, seed=4)
+    X1 = O.generate_panel(N, P, seed=6)[0]
+    G = np.rint(X1.astype(np.float64) - X1.astype(np.float64).min(axis=0)).astype(np.uint8)
+    txt, pf = tmp_path / "g.txt", tmp_path / "g.bin"
+    np.savetxt(txt, G, fmt="%d", delimiter=" ")
+    ngp.write_panel_file(pf, G, bits=2)
+    VCV = {"M": ngp.BayesPR(9999, v), "e": ngp.Random("I", 0.5 * y.var())}
+    res = {}
+    for name, src, storage in (("txt8", f'"{txt}"', "u8"), ("bin8", f'"{pf}"', "u8"), ("txt32", f'"{txt}"', None)):
+        res[name] = ngp.runLMEM(f"y ~ 1 + SNP(M,{src})", {"y": y}, 16, 4, 3, outFolder=str(tmp_path / name), VCV=VCV, seed=5,
+                                storage=storage, samples="none")
+    assert np.array_equal(res["txt8"]["sets"]["M"]["beta"], res["bin8"]["sets"]["M"]["beta"]) and res["txt8"]["varE"] == res["bin8"]["varE"]
+    a, b = res["txt8"]["sets"]["M"]["beta"], res["txt32"]["sets"]["M"]["beta"]
+    assert 0 < np.abs(a - b).max() < 1e-4 * np.abs(a).max()     # fp32 rounding of the panel, amplified over 16 iterations
+    frac = tmp_path / "frac.txt"
+    np.savetxt(frac, G + 0.25, fmt="%.2f", delimiter=" ")
+    with pytest.raises(ValueError, match="integer genotype codes"):
+        ngp.runLMEM(f'y ~ 1 + SNP(M,"{frac}")', {"y": y}, 4, 1, 1, outFolder=str(tmp_path / "bad"), VCV=VCV, storage="u8")
