@@ -1242,7 +1242,8 @@ int32_t ngp_profile_iteration(ngp_handle *h, double *avg_ms, int64_t *launches, 
     if (rc == NGP_OK) rc = check_abort(h);
     if (avg_ms) *avg_ms = tot / (double)n;
     if (launches) *launches = n;
-    if (bytes_per_launch) *bytes_per_launch = (h->mode == 1) ? (double)h->N * (double)h->P * 4.0 : (double)h->N * NGP_BLK * 4.0;
+    const double bpe = (h->storage == 1) ? 1.0 : 4.0;  // algorithmic bytes per genotype: the panel is read once per iteration
+    if (bytes_per_launch) *bytes_per_launch = (h->mode == 1) ? (double)h->N * (double)h->P * bpe : (double)h->N * NGP_BLK * bpe;
     return rc;
 }
 

@@ -32,3 +32,5 @@ def test_bench_line_has_the_contract_fields():
     e = d["effective_samples"]
     assert 0 < e["ess_min"] <= 8 and e["ess_min_per_sec"] > 0 and len(e["ess"]["varBeta"]) == 3 and "beta_min_of_128" in e["ess"]
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    cs = d["compact_storage"]   # the extra leg, beside the fp32 headline
+    assert cs["value"] > 0 and cs["panel_bytes"] == 2000 * 6400 and cs["layout"]["streamer"] == 3 and cs["roofline"]["peak"] == 8000.0
