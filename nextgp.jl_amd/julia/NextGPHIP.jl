@@ -48,6 +48,23 @@ set_panel!(h::Handle, data::Matrix{UInt8}; centre::Bool=true) =
     check(h, ccall((:ngp_set_panel_u8, LIB), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Int64, Int64, Int64, Int32),
                    h.ptr, data, size(data, 1), size(data, 2), stride(data, 2), centre))
 
+# Storage of the panel on the device, before it is set: :f32 (centred fp32 tiles) or :u8 (the codes themselves, one byte per
+# genotype, centred analytically with the Float64 column means -- include/nextgp_hip.h "panel storage").  :u8 takes codes only:
+# set_panel!(h, ::Matrix{UInt8}) or load_panel_file!; the centred Float64 M[set].data of the seam cannot be turned back into codes.
+set_storage!(h::Handle, storage::Symbol) =
+    check(h, ccall((:ngp_set_storage, LIB), Int32, (Ptr{Cvoid}, Int32), h.ptr, storage === :u8 ? 1 : 0))
+# at most n streamer workgroups (taller shards, CUs left free for a second chain on the same device); 0 = automatic
+set_max_shards!(h::Handle, n::Integer) = check(h, ccall((:ngp_set_max_shards, LIB), Int32, (Ptr{Cvoid}, Int32), h.ptr, n))
+
+# Binary panel file in place of the text genotype file (src/prepMatVec.jl:116-131): header + codes, 8 or 2 bits per genotype
+function write_panel_file(path::AbstractString, G::Matrix{UInt8}; bits::Integer=8)
+    rc = ccall((:ngp_write_panel_file, LIB), Int32, (Cstring, Ptr{UInt8}, Int64, Int64, Int64, Int32),
+               path, G, size(G, 1), size(G, 2), stride(G, 2), bits)
+    rc == 0 || error("ngp_write_panel_file ($rc): path not writable, or codes above 2 with bits = 2")
+end
+load_panel_file!(h::Handle, path::AbstractString; centre::Bool=true) =
+    check(h, ccall((:ngp_load_panel_file, LIB), Int32, (Ptr{Cvoid}, Cstring, Int32), h.ptr, path, centre))
+
 # regionArray::Vector{UnitRange{Int}} (1-based, src/mme.jl:335-358) -> 0-based [start, stop)
 function add_marker_set!(h::Handle, col0::Integer, ncol::Integer, method::Integer, df::Float64, scale::Float64,
                          regionArray, varBeta0::Vector{Float64}; pi0::Float64=0.0, estPi::Bool=false,
