@@ -176,6 +176,8 @@ def main():
     ap.add_argument("--P", type=int, default=None, help="override the number of SNPs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-compact", action="store_true", help="skip the extra leg in compact (one byte per genotype) storage")
+    ap.add_argument("--storage", default="f32", choices=["f32", "u8"],
+                    help="panel storage of the MAIN measurement (default f32 = the headline; u8 = compact storage, for profiling that mode)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on one GPU)")
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0 (the persistent kernels then run one after the other)")
     ap.add_argument("--cpu-cols", type=int, default=None, help="columns of the CPU baseline sample (default: about 1.6e8 / N)")
@@ -212,7 +214,8 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    s, setup_s = build_chain(ngp, local_rank, 1001 + rank, N, P, sets)
+    compact_main = args.storage == "u8"
+    s, setup_s = build_chain(ngp, local_rank, 1001 + rank, N, P, sets, storage="u8" if compact_main else None)
     K, W = args.steps, args.warmup
     loci = np.unique(np.linspace(0, P - 1, N_TRACE_LOCI).astype(np.int64))
     ntvb = min(s.nvb, 8)
@@ -242,14 +245,14 @@ def main():
     profs = [s.profile_iteration() for _ in range(5)]
     prof = dict(profs[0], avg_ms=float(np.mean([p["avg_ms"] for p in profs])))
     achieved = prof["bytes_per_launch"] / (prof["avg_ms"] * 1e-3) / 1e9
-    bytes_iter = 4.0 * N * P
+    bytes_iter = (1.0 if compact_main else 4.0) * N * P
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the committed rocprofv3
     # summary of the SAME workload (tools/profile_round.sh) is quoted when the configuration matches, else null
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", f"r02_pmc_k_sweep_{args.config}.json")
+    pmc = os.path.join(ROOT, "profiles", f"r02_pmc_k_sweep_{args.config}{'u8' if compact_main else ''}.json")
     if os.path.exists(pmc) and not overridden and prof["launches"] == 1:
         pj = json.load(open(pmc))
-        traffic, traffic_src = pj["hbm_bytes_per_launch"], f"profiles/r02_pmc_k_sweep_{args.config}.json (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
+        traffic, traffic_src = pj["hbm_bytes_per_launch"], f"profiles/{os.path.basename(pmc)} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
     # posterior means across chains: ONE all-reduce of the packed sums over RCCL / xGMI
     allreduce_ms = None
     n = s.posterior_len()
@@ -284,18 +287,18 @@ def main():
             "dtype": "f64",
             "data": "synthetic",
             "config": {
-                "workload": f"single-trait Gibbs sweep, N={N} individuals x P={P} SNPs, marker sets {setdesc}, fp32 panel in HBM "
+                "workload": f"single-trait Gibbs sweep, N={N} individuals x P={P} SNPs, marker sets {setdesc}, {'u8 genotype codes + f64 column means (compact storage)' if compact_main else 'fp32 panel'} in HBM "
                             + (f"(BASELINE.json {cdesc})" if not overridden else f"(shape overridden from {args.config})"),
                 "name": args.config if not overridden else f"{args.config}-override", "N": N, "P": P,
                 "sets": [{"method": m, "col0": c0, "ncol": n} for m, c0, n in sets], "chains": world,
                 "parallelism": "independent chains, one per GPU; one RCCL all-reduce of posterior sums at the end",
-                "panel_dtype": "f32", "accumulate_dtype": "f64",
+                "panel_dtype": "u8" if compact_main else "f32", "accumulate_dtype": "f64",
                 "layout": {"rows_per_shard": R, "shards": S, "blocks": nblk, "engine": mode, "lag": lag, "near_lags": s.near(),
                            "streamer": variant, "gemv_chains": nchain},
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "ngp::k_sweep (persistent sweep: one launch streams the whole N x P fp32 panel once)" if prof["launches"] == 1 else "ngp::k_step (one 64-SNP column block per launch)",
+                "kernel": "ngp::k_sweep (persistent sweep: one launch streams the whole N x P panel once)" if prof["launches"] == 1 else "ngp::k_step (one 64-SNP column block per launch)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -322,7 +325,7 @@ def main():
             "posterior_mean_varE": post_mean_varE,
             "pooled_kept_samples": nkept,
         }
-        if world == 1 and not args.no_compact:
+        if world == 1 and not args.no_compact and not compact_main:
             # the same workload with the panel kept one byte per genotype (ngp_set_storage: analytic centring, no fp32 rounding of
             # the panel) -- reported BESIDE the fp32 headline above, never instead of it
             s.close()

@@ -208,7 +208,10 @@ int32_t ngp_get_streamer(ngp_handle *h, int32_t *variant, int32_t *gemv_chains);
 /* ngp_set_max_shards: the persistent sweep normally splits the rows over every CU but the sampler's and the reducers' (one
  * streamer workgroup per CU, all co-resident).  A smaller number makes the shards taller and leaves CUs free -- for a second
  * chain on the same device (each chain's whole grid must be resident at once), or to exercise tall-shard layouts on small
- * panels.  0 = automatic.  Before the panel is set. */
+ * panels.  0 = automatic.  Before the panel is set.  Chains of ONE process that share a device (one handle and one host thread
+ * each) are kept apart by the library: a call that launches sweeps leases ceil(grid / 8) CUs of every XCD for its duration, and
+ * a call whose grid does not fit beside the running ones waits for them to return (the chains then take turns); sweeps of other
+ * processes cannot be seen -- against those the bounded waits of the kernel remain (NGP_ERR_HIP, chain to be set again). */
 int32_t ngp_set_max_shards(ngp_handle *h, int32_t max_shards);
 #define NGP_STORAGE_F32 0
 #define NGP_STORAGE_U8 1

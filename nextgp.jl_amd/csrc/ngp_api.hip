@@ -10,7 +10,9 @@
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
+#include <condition_variable>
 #include <cstring>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -149,6 +151,33 @@ int fail(ngp_handle *h, int code, const std::string &msg) {
     do {                                        \
         if (!(cond)) return fail(h, code, msg); \
     } while (0)
+
+// Persistent sweeps of SEVERAL handles of this process on one device (chains in their own host threads, ngp_set_max_shards):
+// every workgroup of a sweep waits for others of its grid, so two sweeps may only run together if both grids fit the device at
+// once.  A call that launches sweeps leases its grid's CUs for its duration; a lease that does not fit waits for the running
+// calls to return (the chains then take turns instead of giving up on their spins).  Other processes cannot be seen from here:
+// against them the bounded spins and the abort word remain.
+struct CuLease {
+    static std::mutex &mu() { static std::mutex m; return m; }
+    static std::condition_variable &cv() { static std::condition_variable c; return c; }
+    static int *in_use() { static int u[64] = {0}; return u; }
+    int dev = -1, n = 0;
+    CuLease(ngp_handle *h) {
+        if (h->mode != 1) return;
+        // workgroups are handed to the 8 XCDs in turn, so a grid occupies ceil(grid / 8) CUs of EVERY XCD: the unit of the lease
+        // (three grids of 85 workgroups -- 255 of 256 CUs -- do not fit: 3 x 11 > 32 per XCD; measured, they wait for each other)
+        dev = h->device & 63; n = (int)((1 + h->NG + h->S + 7) / 8);
+        const int cap = std::max(1, h->cu_count / 8);
+        std::unique_lock<std::mutex> lk(mu());
+        cv().wait(lk, [&] { return in_use()[dev] == 0 || in_use()[dev] + n <= cap; });
+        in_use()[dev] += n;
+    }
+    ~CuLease() {
+        if (dev < 0) return;
+        { std::lock_guard<std::mutex> lk(mu()); in_use()[dev] -= n; }
+        cv().notify_all();
+    }
+};
 
 int enter(ngp_handle *h) {
     if (!h) return fail(nullptr, NGP_ERR_ARG, "null handle");
@@ -1019,6 +1048,7 @@ int32_t ngp_run(ngp_handle *h, int64_t niter) {
         h->trace_cap = niter;
     }
     h->ntrace = niter;
+    CuLease lease(h);
     HCHK(hipEventRecord(h->ev0, h->stream));
     for (int64_t n = 0; n < niter; n++) {
         if ((rc = one_iteration(h, n, nullptr))) return rc;
@@ -1183,6 +1213,7 @@ int32_t ngp_sweep_set(ngp_handle *h, int32_t set_id, double varE, double *ycorr,
                        h->d_vbidx, h->d_sets, h->d_scal, h->d_varBeta, h->d_mpm, h->d_lhs0, h->d_rhs0, h->d_beta, h->d_c, h->d_w,
                        h->d_q, h->d_T, h->d_chi, (int)set_id, h->seed, (uint64_t)h->chain, it, (long long)h->h_regs.size(), h->d_regs, h->d_regchi, h->d_rcls);
     const int64_t tb0 = hs.col0 / NGP_BLK, tb1 = (hs.col0 + hs.ncol - 1) / NGP_BLK + 1;
+    CuLease lease(h);
     launch_sweep(h, tb0, tb1, nullptr);
     launch_variance(h, (int)set_id, it);
     HCHK(hipMemcpyAsync(ycorr, h->d_ycorr, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
@@ -1228,6 +1259,7 @@ int32_t ngp_profile_iteration(ngp_handle *h, double *avg_ms, int64_t *launches, 
         h->trace_cap = 1;
     }
     h->ntrace = 1;
+    CuLease lease(h);
     rc = one_iteration(h, 0, evs.data());
     hipError_t e = hipStreamSynchronize(h->stream);
     double tot = 0.0;

@@ -567,3 +567,47 @@ def test_fixed_effect_sets_beyond_the_intercept(ngp, O, engine, tmp_path):
     s.run(10); s2.run(10)
     assert np.array_equal(s.get_fixed()["b"], s2.get_fixed()["b"]) and np.array_equal(s.get_fixed()["sum_b"], s2.get_fixed()["sum_b"])
     assert np.array_equal(s.get_state()["beta"], s2.get_state()["beta"])
+
+
+@pytest.mark.parametrize("shards", [100, 0], ids=["disjoint_cus", "oversubscribed_take_turns"])
+def test_chains_of_one_process_share_a_device(ngp, O, shards):
+    """Several chains on ONE GPU, each in its own host thread (the reference's one-Julia-task-per-chain, here per handle): with
+    ngp_set_max_shards their persistent sweeps run side by side on disjoint CUs; grids that do not fit together take turns (the
+    library leases CUs per call) instead of waiting for each other's workgroups.  Either way every chain is bit for bit the
+    chain it is when it has the device to itself."""
+    import threading
+    X, y, bt, v = make_problem(O, 3000, 3200, seed=5)
+
+    def build(seed):
+        s = ngp.Sampler(device=0, seed=seed, chain=seed - 1001, mode=1, lag=8)
+        if shards:
+            s.set_max_shards(shards)
+        s.set_panel(X)
+        add_sets(s, [(0, 2000, "PR"), (2000, 1200, "B")], v)
+        s.set_y(y); s.set_residual_prior(4.0, 0.25 * y.var())
+        return s
+
+    alone = []
+    for seed in (1001, 1002, 1003):
+        s = build(seed); s.run(40); alone.append(s.get_state()); s.close()
+    chains = [build(seed) for seed in (1001, 1002, 1003)]
+    if shards:
+        assert all(c.layout()[1] <= shards for c in chains)
+    errs = []
+
+    def work(c):
+        try:
+            for _ in range(4):
+                c.run(10)
+        except Exception as e:  # noqa: BLE001
+            errs.append(e)
+
+    ths = [threading.Thread(target=work, args=(c,)) for c in chains]
+    for t in ths: t.start()
+    for t in ths: t.join()
+    assert not errs, errs
+    for c, ref in zip(chains, alone):
+        st = c.get_state()
+        for k in ("ycorr", "beta", "delta", "varBeta", "piHat"):
+            assert np.array_equal(st[k], ref[k]), k
+        assert st["varE"] == ref["varE"] and st["iter"] == 40

@@ -6,6 +6,8 @@ import csv, glob, json, os, shutil, sys
 
 tag = sys.argv[1] if len(sys.argv) > 1 else "r02"
 cfg = sys.argv[2] if len(sys.argv) > 2 else "C4"
+base_cfg = sys.argv[3] if len(sys.argv) > 3 else cfg
+storage = sys.argv[4] if len(sys.argv) > 4 else "f32"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "gpurun_out")
 KERNELS = ("ngp::k_sweep(ngp::SweepArgs)", "void ngp::k_sweep<false>(ngp::SweepArgs)", "void ngp::k_sweep<true>(ngp::SweepArgs)")
@@ -24,7 +26,7 @@ def counter(kind, name):
 fetch, write = counter("fetch", "FETCH_SIZE"), counter("write", "WRITE_SIZE")
 bench = json.loads(open(os.path.join(out, f"{tag}_{cfg}_bench.json")).read().strip().splitlines()[-1])
 summary = {
-    "command": f"rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --config {cfg} --steps 10 --warmup 2 --no-cpu-baseline (two separate passes)",
+    "command": f"rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --config {base_cfg} --storage {storage} --steps 10 --warmup 2 --no-cpu-baseline --no-compact (two separate passes)",
     "workload": bench["config"]["workload"],
     "kernel": "ngp::k_sweep",
     "FETCH_SIZE_KB_per_launch_raw": sum(fetch) / max(len(fetch), 1),
