@@ -52,6 +52,22 @@ template <int K> struct Steps2 {  // V2: the row step as ONE instruction (v_fmac
         }
     }
 };
+template <int K> struct Steps3 {  // V3: two steps per readlane trip -- every lane also carries its right neighbour's value
+    // (en = e_{j+1}, kept up to date with the neighbour's own coefficients), so lane k forms d_{k+1} itself and both d_k, d_{k+1}
+    // leave lane k in ONE trip.  Same fma sequence per lane => bit-identical.
+    __device__ static inline void run(double &e, double &en, const double *G, const double *Gn, const double cc, const double ccn) {
+        if constexpr (K < 64) {
+            const double Hk = -(cc * G[K]), Hk1 = -(cc * G[K + 1]), Hnk = -(ccn * Gn[K]), Hnk1 = -(ccn * Gn[K + 1]);
+            const double t = __builtin_fma(Hnk, e, en);  // in lane K: e_{K+1} after step K = d_{K+1}
+            const double dk = readlane_d(e, K), dk1 = readlane_d(t, K);
+            e = __builtin_fma(Hk, dk, e);
+            en = __builtin_fma(Hnk, dk, en);
+            e = __builtin_fma(Hk1, dk1, e);
+            en = __builtin_fma(Hnk1, dk1, en);
+            Steps3<K + 2>::run(e, en, G, Gn, cc, ccn);
+        }
+    }
+};
 template <int V>
 __global__ __launch_bounds__(64) void k(const double *Gm, const double *e0, const double *c0, double *out, int n, long long *cyc) {
     const int j = threadIdx.x;
@@ -60,6 +76,10 @@ __global__ __launch_bounds__(64) void k(const double *Gm, const double *e0, cons
     for (int kk = 0; kk < 64; kk++) G[kk] = (j > kk) ? Gm[kk * 64 + j] : 0.0;
     const double cc = c0[j];
     double e = e0[j];
+    double Gn[64];
+#pragma unroll
+    for (int kk = 0; kk < 64; kk++) Gn[kk] = (V == 3 && j + 1 < 64 && j + 1 > kk) ? Gm[kk * 64 + j + 1] : 0.0;
+    const double ccn = (j + 1 < 64) ? c0[j + 1] : 0.0;
     long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < n; it++) {
         if (V == 0) {
@@ -76,6 +96,10 @@ __global__ __launch_bounds__(64) void k(const double *Gm, const double *e0, cons
             double ea = e, el = e;
             Steps<0>::run(ea, el, G, cc);
             e = el;
+        } else if (V == 3) {
+            double en = __shfl_down(e, 1);
+            if (j == 63) en = 0.0;
+            Steps3<0>::run(e, en, G, Gn, cc, ccn);
         } else {
             double ea = e, el = e;
             double sq[4] = {0, 0, 0, 0}, hq[4] = {0, 0, 0, 0};
@@ -108,6 +132,10 @@ int main() {
     for (int rep = 0; rep < 2; rep++) hipLaunchKernelGGL(k<2>, dim3(1), dim3(64), 0, 0, G, e, c, out, n, cyc);
     hipDeviceSynchronize(); hipMemcpy(&cy, cyc, 8, hipMemcpyDeviceToHost); hipMemcpy(o1, out, 512, hipMemcpyDeviceToHost);
     printf("V2 fmac_dpp + tail     : %7.1f clocks per block of 64 steps (%.1f per step)\n", (double)cy / n, (double)cy / n / 64);
+    printf("bit-identical: %s\n", memcmp(o0, o1, 512) == 0 ? "yes" : "NO");
+    for (int rep = 0; rep < 2; rep++) hipLaunchKernelGGL(k<3>, dim3(1), dim3(64), 0, 0, G, e, c, out, n, cyc);
+    hipDeviceSynchronize(); hipMemcpy(&cy, cyc, 8, hipMemcpyDeviceToHost); hipMemcpy(o1, out, 512, hipMemcpyDeviceToHost);
+    printf("V3 two steps per trip  : %7.1f clocks per block of 64 steps (%.1f per step)\n", (double)cy / n, (double)cy / n / 64);
     printf("bit-identical: %s\n", memcmp(o0, o1, 512) == 0 ? "yes" : "NO");
     return 0;
 }
