@@ -101,11 +101,7 @@ struct SweepArgs {
     unsigned long long *const dbg = A.dbg;                               \
     const int dbg_mode = A.dbg_mode;                                     \
     (void)dbg; (void)dbg_mode;
-#ifdef NGP_AB_ROWS_RUNTIME_DBG
-#define NGP_DBG_ROWS NGP_DBG_LOCALS
-#else
 #define NGP_DBG_ROWS NGP_DBG_FOLD
-#endif
 
 __device__ inline unsigned ld_u32(const unsigned *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
 __device__ inline void st_u32(unsigned *p, unsigned v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -1223,9 +1219,6 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
                 if (u >= 1) okc = fetch_group_sums<DBG>(A, u, j, &tot);
                 if (!okc && j == 0) *sabort = 1;
             } else {       // wave 5 applies the look-ahead corrections and leaves the final total in r0[buf]
-#ifdef NGP_AB_OLD_TOTFLAG
-                while (__hip_atomic_load(totflag, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP) != u + 1) __builtin_amdgcn_s_sleep(0);
-#else
                 // bounded like every other spin: an abort raised by another wave of this workgroup ends the wait
                 for (unsigned sp = 0; lds_flag_ld(totflag) != u + 1; ++sp) {
                     if ((sp & 255u) == 255u && (lds_flag_ld(sabort) != 0 || sp > (NGP_SPIN_LIMIT << 4))) {
@@ -1234,7 +1227,6 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
                     }
                     __builtin_amdgcn_s_sleep(0);
                 }
-#endif
                 asm volatile("" ::: "memory");  // r0 is read after the flag (LDS serves a wave in order)
                 tot = r0[rs * NGP_BLK + j];
             }
@@ -1537,7 +1529,6 @@ __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         role_reducer<DBG>(A, b - 1);
     else {
         const int s = b - 1 - A.NG;
-#ifndef NGP_AB_NO_ROWS
         if (A.variant == 2) {  // row-owning waves + loader wave (host: R <= NGP_ROWS_MAX_R, lag 3..6)
             switch (A.D) {
                 case 3: role_streamer_rows<DBG, 3, 0>(A, s, smem); break;
@@ -1565,7 +1556,6 @@ __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
             }
             return;
         }
-#endif
         const int tpt = (8 * A.R + NGP_WG - 1) / NGP_WG;  // 1..4
 #define NGP_DISPATCH_D(T)                                      \
     switch (A.D) {                                             \

@@ -228,3 +228,20 @@ def test_compact_snapshot_resume(ngp, O, tmp_path):
         assert np.array_equal(sa[k], sc[k]), k
     pa, pc = a.get_posterior_sums(), c.get_posterior_sums()
     assert np.array_equal(pa["sum_beta"], pc["sum_beta"]) and pa["nKept"] == pc["nKept"]
+
+
+@pytest.mark.parametrize("N", [16, 17, 3568, 3569, 6000])
+def test_compact_row_count_edges(ngp, O, N):
+    """Shards that are exactly full (16 x 223 rows), one row over (32-row shards, the last one nearly empty), a single unit."""
+    P = 70
+    G, y, v = make_codes(O, N, P)
+    s, o = _pair(ngp, O, G, lag=6)
+    R, S, _ = s.layout()
+    assert R * S >= N and (N > 3568 or R == 16)
+    for m in (s, o):
+        add_sets(m, [(0, P, "PR")], v)
+        m.set_y(y)
+        m.set_residual_prior(4.0, max(0.25 * y.var(), 1e-3))
+        m.set_schedule(6, 0, 1)
+        m.run(6)
+    _same_chain(s, o, 6)
