@@ -121,14 +121,19 @@ function sweep!(h::Handle, set_id::Integer, mSet, M, beta, delta, ycorr::Vector{
     b = vec(beta[M[mSet].pos])                 # 1 x P Matrix{Float64}: vec() shares the memory
     d = vec(delta[M[mSet].pos])                # 1 x P Matrix{Int64}
     vb = varBeta[mSet] isa Vector{Float64} ? varBeta[mSet] : Float64.(varBeta[mSet])
-    pih = haskey(M[mSet], :piHat) ? vec(M[mSet].piHat) : Float64[0.0, 0.0]
+    isR = M[mSet].method == "BayesR"          # K class probabilities (1 x K piHat, src/mme.jl:374-383): read through ngp_get_class_state
+    pih = (haskey(M[mSet], :piHat) && !isR) ? vec(M[mSet].piHat) : Float64[0.0, 0.0]
     check(h, ccall((:ngp_sweep_set, LIB), Int32,
                    (Ptr{Cvoid}, Int32, Float64, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}),
                    h.ptr, set_id, varE, ycorr, b, d, vb, pih))
     varBeta[mSet] isa Vector{Float64} || (varBeta[mSet] .= vb)
     if haskey(M[mSet], :piHat)
-        M[mSet].piHat .= reshape(pih, size(M[mSet].piHat))
-        M[mSet].logPi .= log.(M[mSet].piHat)  # src/functions.jl:193
+        if isR
+            M[mSet].piHat .= reshape(class_state(h, set_id)[1], size(M[mSet].piHat))   # src/functions.jl:284-288
+        else
+            M[mSet].piHat .= reshape(pih, size(M[mSet].piHat))
+        end
+        M[mSet].logPi .= log.(M[mSet].piHat)  # src/functions.jl:193, :289
     end
     return nothing
 end
