@@ -6,10 +6,11 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from ngp_pkg import load_pkg
 ngp = load_pkg()
 iters = int(sys.argv[1]) if len(sys.argv) > 1 else 2000
+storage = os.environ.get("NGP_TOOL_STORAGE")   # "u8": the same soak in compact storage (lags are rounded to the instantiated ones)
 cases = [(10000, 100000, 6, [("PR", 100000)]), (10000, 100000, 8, [("B", 100000)]), (3000, 40000, 3, [("C", 20000), ("PR", 20000)]),
          (20000, 60000, 6, [("PR", 30000), ("B", 30000)]), (777, 9999, 4, [("B", 5000), ("C", 4999)]), (50000, 40000, 5, [("PR", 40000)])]
 for N, P, lag, sets in cases:
-    s = ngp.Sampler(device=0, seed=77, chain=0, mode=1, lag=lag)
+    s = ngp.Sampler(device=0, seed=77, chain=0, mode=1, lag=lag, storage=storage)
     s.generate_panel(N, P)
     rng = np.random.default_rng(1); bt = np.zeros(P); idx = rng.choice(P, max(10, P // 100), replace=False); bt[idx] = rng.normal(size=len(idx))
     g = s.xbeta(bt); y = 10 + g + np.random.default_rng(2).normal(size=N) * np.sqrt(g.var())
