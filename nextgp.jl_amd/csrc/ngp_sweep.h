@@ -657,7 +657,12 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows(const S
     const int g = s / NGP_GRP;
     const int nb = A.t1 - A.t0;
     for (int i = tid; i < R; i += NGP_WG) ys[i] = yg[i];
-    if (tid == 0) *sflag = 1;
+    // chains of the current block that have left their sum in `red` (two parities; the eighth slots of rsy are free)
+    int *gcnt0 = (int *)(rsy + 7), *gcnt1 = (int *)(rsy + 15);
+    // the publisher does not wait for the barrier (see below).  fp32 tiles, where the streamers wait for the loader: 50k x 600k
+    // 2.66-2.69 -> 2.57 us per block (same box); byte tiles, where their own arithmetic is the bound: 2.05 -> 2.31, so not there
+    const bool early = U8 ? ((A.knob & 256) != 0) : ((A.knob & 256) == 0);
+    if (tid == 0) { *sflag = 1; *gcnt0 = 0; *gcnt1 = 0; }
     int base = 0;  // ring slot of quad 0 of tile u
     auto wrap = [&](int p) __attribute__((always_inline)) { return p >= RQ ? p - RQ : p; };
     if (wv == NGP_ROWS_NW) {
@@ -797,6 +802,23 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows(const S
             if (lane == 0) atomicAdd(&A.cnt_part[((size_t)sig_pending * A.NG + g) * 32], 1u);
             sig_pending = -1;
         };
+        // the 64 partial dot products of block u: the 7 chains in their fixed tree (compact storage: minus m_j x the shard's sum of y)
+        auto publish = [&](const int u) __attribute__((always_inline)) {
+            const int slot = u % NGP_RING;
+            const double *rp = red + (u & 1) * NGP_ROWS_NW * NGP_BLK + lane;
+            double p = ((rp[0] + rp[NGP_BLK]) + (rp[2 * NGP_BLK] + rp[3 * NGP_BLK])) + ((rp[4 * NGP_BLK] + rp[5 * NGP_BLK]) + rp[6 * NGP_BLK]);
+            if constexpr (U8) {  // partial = sum_i g_ij y_i - m_j sum_i y_i
+                const double *sp = rsy + (u & 1) * 8;
+                const double sy = ((sp[0] + sp[1]) + (sp[2] + sp[3])) + ((sp[4] + sp[5]) + sp[6]);
+                const double ms = mpub * sy;
+                p = p - ms;
+            }
+            try_signal(true);  // the previous partial, if its store was still under way at every look
+            st_f64(&A.part[((size_t)slot * S + s) * NGP_BLK + lane], p);
+            sig_pending = slot;
+            if (U8 && u + 1 < nb) mpub = A.mean[(size_t)(A.t0 + u + 1) * NGP_BLK + lane];
+            if (DBG && dbg && s == 0 && lane == 0) dbg[NGP_DBG_STREAM + 2 * (size_t)u] = wall_clock64();
+        };
         wg_barrier();
         for (int u0 = 0; u0 < nb + DT; u0 += DT) {
 #pragma unroll
@@ -925,6 +947,10 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows(const S
                         }
                     }
                     red[((u & 1) * NGP_ROWS_NW + wv) * NGP_BLK + lane] = acc;
+                    if (early) {
+                        asm volatile("" ::: "memory");  // LDS serves a wave in order: the count follows the sum
+                        if (lane == 0) __hip_atomic_fetch_add((lds_int_t *)((u & 1) ? gcnt1 : gcnt0), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                     NGP_FINE(2);
                     try_signal(false);
                     // ---- tile u into the delay line (task view of the same slots) ----
@@ -942,6 +968,22 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows(const S
                     }
                 }
                 NGP_FINE(3);
+                // The publisher does not wait for the block's barrier (which the loader reaches a microsecond after the chains are
+                // done): it waits for the seven chains through a counter in LDS and publishes at once -- the partial enters the
+                // hand-off loop that much earlier, and the period of the sweep is that loop's latency / (lag - 1).
+                if (early && wv == NGP_ROWS_PUBW && u < nb && !(DBG && dbg_mode == 1)) {
+                    const int *gc = (u & 1) ? gcnt1 : gcnt0;
+                    for (unsigned sp = 0; lds_flag_ld(gc) < NGP_ROWS_NW; ++sp) {
+                        if ((sp & 255u) == 255u && (lds_flag_ld(sflag) == 0 || sp > (NGP_SPIN_LIMIT << 4))) {
+                            if (lane == 0) *sflag = 0;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(0);
+                    }
+                    asm volatile("" ::: "memory");
+                    if (lane == 0) lds_flag_st((u & 1) ? gcnt0 : gcnt1, 0);  // the other parity: counted in the next block, behind the barrier
+                    publish(u);
+                }
                 if (pollw) {
                     int ok = 1;
                     if (!have_dnext && !(DBG && (dbg_mode == 3 || dbg_mode == 4))) {
@@ -977,22 +1019,7 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows(const S
                 wg_barrier();
                 if (!*sflag) return;
                 NGP_FINE(5);
-                if (wv == NGP_ROWS_PUBW && u < nb && !(DBG && dbg_mode == 1)) {
-                    const int slot = u % NGP_RING;
-                    const double *rp = red + (u & 1) * NGP_ROWS_NW * NGP_BLK + lane;
-                    double p = ((rp[0] + rp[NGP_BLK]) + (rp[2 * NGP_BLK] + rp[3 * NGP_BLK])) + ((rp[4 * NGP_BLK] + rp[5 * NGP_BLK]) + rp[6 * NGP_BLK]);
-                    if constexpr (U8) {  // partial = sum_i g_ij y_i - m_j sum_i y_i
-                        const double *sp = rsy + (u & 1) * 8;
-                        const double sy = ((sp[0] + sp[1]) + (sp[2] + sp[3])) + ((sp[4] + sp[5]) + sp[6]);
-                        const double ms = mpub * sy;
-                        p = p - ms;
-                    }
-                    try_signal(true);  // the previous partial, if its store was still under way at every look
-                    st_f64(&A.part[((size_t)slot * S + s) * NGP_BLK + lane], p);
-                    sig_pending = slot;
-                    if (U8 && u + 1 < nb) mpub = A.mean[(size_t)(A.t0 + u + 1) * NGP_BLK + lane];
-                    if (DBG && dbg && s == 0 && lane == 0) dbg[NGP_DBG_STREAM + 2 * (size_t)u] = wall_clock64();
-                }
+                if (!early && wv == NGP_ROWS_PUBW && u < nb && !(DBG && dbg_mode == 1)) publish(u);
                 base = wrap(base + NQ);
                 NGP_FINE(6);
             }
