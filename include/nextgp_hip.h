@@ -248,6 +248,11 @@ int32_t ngp_get_trace_ext(ngp_handle *h, double *beta_tr, double *varBeta_tr, do
  * every handle holds the sums over all chains.  Handles on different devices: ONE RCCL all-reduce (fp64 sum) over xGMI, RCCL
  * loaded on first use; handles sharing a device are added on the device.  Errors are reported on hs[0]. */
 int32_t ngp_allreduce_posterior(ngp_handle **hs, int32_t n);
+/* niter iterations of n chains at once, one host thread per handle inside the library (what n Julia tasks calling ngp_run
+ * would do).  Chains on different devices run in parallel; chains sharing a device run side by side when their grids fit it
+ * together (ngp_set_max_shards: e.g. three chains of 10k x 100k on one MI355X, 801 instead of 346 iterations/s in all) and in
+ * turns otherwise.  Every chain is bit for bit what it is alone.  Returns the first non-zero status (message on that handle). */
+int32_t ngp_run_many(ngp_handle **hs, int32_t n, int64_t niter);
 
 #ifdef __cplusplus
 }

@@ -21,7 +21,7 @@ SYMBOLS = [
     "ngp_set_residual_prior", "ngp_set_intercept", "ngp_set_schedule", "ngp_run", "ngp_get_state", "ngp_set_state",
     "ngp_get_trace", "ngp_get_posterior_sums", "ngp_posterior_len", "ngp_export_posterior_device", "ngp_sweep_set",
     "ngp_get_timing", "ngp_profile_iteration", "ngp_draws_indexed", "ngp_eval_math", "ngp_configure", "ngp_get_config", "ngp_debug_stamps", "ngp_set_near_lags", "ngp_get_near_lags",
-    "ngp_set_streamer", "ngp_get_streamer", "ngp_set_storage", "ngp_get_storage", "ngp_set_max_shards", "ngp_write_panel_file", "ngp_read_panel_header", "ngp_load_panel_file", "ngp_debug_set_mode", "ngp_debug_set_knob", "ngp_set_posterior_sums", "ngp_save_snapshot", "ngp_load_snapshot",
+    "ngp_set_streamer", "ngp_get_streamer", "ngp_set_storage", "ngp_get_storage", "ngp_set_max_shards", "ngp_run_many", "ngp_write_panel_file", "ngp_read_panel_header", "ngp_load_panel_file", "ngp_debug_set_mode", "ngp_debug_set_knob", "ngp_set_posterior_sums", "ngp_save_snapshot", "ngp_load_snapshot",
     "ngp_set_trace_loci", "ngp_get_trace_ext", "ngp_allreduce_posterior", "ngp_add_marker_set_r", "ngp_get_class_state", "ngp_set_class_state", "ngp_add_fixed_set", "ngp_get_fixed", "ngp_set_fixed",
 ]
 
@@ -375,6 +375,16 @@ class Sampler:
         L = samplers[0].L
         arr = (C.c_void_p * len(samplers))(*[s.h for s in samplers])
         samplers[0]._chk(L.ngp_allreduce_posterior(arr, C.c_int32(len(samplers))))
+
+    @staticmethod
+    def run_many(samplers, niter):
+        """niter iterations of every chain of `samplers` at once, one thread per chain inside the library (ngp_run_many)."""
+        L = samplers[0].L
+        arr = (C.c_void_p * len(samplers))(*[s.h for s in samplers])
+        rc = L.ngp_run_many(arr, C.c_int32(len(samplers)), C.c_int64(niter))
+        if rc != 0:
+            msgs = [(s.L.ngp_last_error(s.h) or b"").decode() for s in samplers]
+            raise NextGPHipError(f"libnextgp_hip error {rc}: " + " | ".join(m for m in msgs if m))
 
     def profile_iteration(self):
         ms, by = C.c_double(), C.c_double()

@@ -14,6 +14,7 @@
 #include <cstring>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/nextgp_hip.h"
@@ -1644,6 +1645,26 @@ int import_posterior_device(ngp_handle *h, const double *o) {  // inverse of ngp
     return NGP_OK;
 }
 }  // namespace
+
+int32_t ngp_run_many(ngp_handle **hs, int32_t n, int64_t niter) {
+    if (!hs || n < 1) return fail(nullptr, NGP_ERR_ARG, "ngp_run_many: no handles");
+    for (int i = 0; i < n; i++) {
+        if (!hs[i]) return fail(nullptr, NGP_ERR_ARG, "ngp_run_many: null handle");
+        for (int k = 0; k < i; k++)
+            if (hs[k] == hs[i]) return fail(hs[0], NGP_ERR_ARG, "ngp_run_many: the same handle twice");
+    }
+    // one host thread per chain, as a caller would do it (src/samplers.jl:23: one chain per Julia task); the chains of a device run
+    // side by side when their grids fit it together (ngp_set_max_shards), in turns otherwise (CuLease)
+    std::vector<int32_t> rcs((size_t)n, NGP_OK);
+    std::vector<std::thread> th;
+    th.reserve((size_t)n);
+    for (int i = 1; i < n; i++) th.emplace_back([&, i] { rcs[(size_t)i] = ngp_run(hs[i], niter); });
+    rcs[0] = ngp_run(hs[0], niter);
+    for (auto &t : th) t.join();
+    for (int i = 0; i < n; i++)
+        if (rcs[(size_t)i] != NGP_OK) return rcs[(size_t)i];  // the message is on that handle (ngp_last_error)
+    return NGP_OK;
+}
 
 int32_t ngp_allreduce_posterior(ngp_handle **hs, int32_t n) {
     if (!hs || n < 1) return fail(nullptr, NGP_ERR_ARG, "ngp_allreduce_posterior: no handles");

@@ -100,6 +100,14 @@ save_snapshot(h::Handle, path::AbstractString) = check(h, ccall((:ngp_save_snaps
 load_snapshot!(h::Handle, path::AbstractString) = check(h, ccall((:ngp_load_snapshot, LIB), Int32, (Ptr{Cvoid}, Cstring), h.ptr, path))
 
 # pooled posterior sums of several chains (one Handle per chain / device): ONE RCCL all-reduce inside the library
+# niter iterations of every chain at once, one host thread per handle inside the library (chains sharing a device run side by side
+# when their grids fit it together -- set_max_shards! -- and in turns otherwise)
+function run_many!(hs::Vector{Handle}, niter::Integer)
+    ptrs = [h.ptr for h in hs]
+    rc = ccall((:ngp_run_many, LIB), Int32, (Ptr{Ptr{Cvoid}}, Int32, Int64), ptrs, length(ptrs), niter)
+    rc == 0 || error("ngp_run_many ($rc): " * join((unsafe_string(ccall((:ngp_last_error, LIB), Cstring, (Ptr{Cvoid},), h.ptr)) for h in hs), " | "))
+end
+
 function allreduce_posterior!(hs::Vector{Handle})
     ptrs = Ptr{Cvoid}[x.ptr for x in hs]
     check(hs[1], ccall((:ngp_allreduce_posterior, LIB), Int32, (Ptr{Ptr{Cvoid}}, Int32), ptrs, length(ptrs)))

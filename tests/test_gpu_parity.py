@@ -602,10 +602,12 @@ def test_chains_of_one_process_share_a_device(ngp, O, shards):
         except Exception as e:  # noqa: BLE001
             errs.append(e)
 
-    ths = [threading.Thread(target=work, args=(c,)) for c in chains]
+    ths = [threading.Thread(target=work, args=(c,)) for c in chains[:2]]
     for t in ths: t.start()
     for t in ths: t.join()
     assert not errs, errs
+    chains[2].run(10)
+    ngp.Sampler.run_many(chains[2:] + [build(1004)], 30)      # the same through the library's own threads (ngp_run_many)
     for c, ref in zip(chains, alone):
         st = c.get_state()
         for k in ("ycorr", "beta", "delta", "varBeta", "piHat"):
