@@ -462,7 +462,7 @@ bool is_kept(const ngp_handle *h, int64_t it) {  // src/samplers.jl:26
 void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
     const int R = (int)h->R, S = (int)h->S;
     if (h->mode == 1) {
-        (void)hipMemsetAsync(h->d_ccnt, 0, h->ccnt_words * sizeof(unsigned), h->stream);
+        // (the hand-off counters were zeroed by k_prep, which precedes every sweep in the stream)
         SweepArgs A;
         A.tiles = h->d_tiles; A.ycorr = h->d_ycorr; A.gramx = h->d_gramx;
         A.D = h->D; A.R = R; A.S = S; A.NG = h->NG; A.near = h->near; A.fine_ok = 0; A.t0 = (int)tb0; A.t1 = (int)tb1;
@@ -543,20 +543,22 @@ int one_iteration(ngp_handle *h, int64_t trace_idx, hipEvent_t *evs) {
                            (uint64_t)h->chain, it);
     hipLaunchKernelGGL(k_prep, dim3((unsigned)(h->Ppad / 256 + 1)), dim3(256), 0, h->stream, (long long)h->Ppad, h->d_setof, h->d_loc,
                        h->d_vbidx, h->d_sets, h->d_scal, h->d_varBeta, h->d_mpm, h->d_lhs0, h->d_rhs0, h->d_beta, h->d_c, h->d_w,
-                       h->d_q, h->d_T, h->d_chi, -1, h->seed, (uint64_t)h->chain, it, (long long)h->h_regs.size(), h->d_regs, h->d_regchi, h->d_rcls);
+                       h->d_q, h->d_T, h->d_chi, -1, h->seed, (uint64_t)h->chain, it, (long long)h->h_regs.size(), h->d_regs, h->d_regchi, h->d_rcls,
+                       h->d_ccnt, (long long)(h->mode == 1 ? h->ccnt_words : 0));
     launch_sweep(h, 0, h->NBLK, evs);
     launch_variance(h, -1, it);
     h->iter += 1;
-    if (h->d_trace_loci && trace_idx < h->trace_ext_cap) {
-        const long long nt = std::max<long long>(std::max<long long>(h->ntl, h->ntvb), (long long)h->sets.size());
-        hipLaunchKernelGGL(k_trace, dim3((unsigned)((nt + 255) / 256)), dim3(256), 0, h->stream, (long long)h->ntl, (const long long *)h->d_trace_loci, (long long)h->ntvb,
-                           (int)h->sets.size(), h->d_beta, h->d_varBeta, h->d_sets, h->d_tr_beta, h->d_tr_vb, h->d_tr_pi, (long long)trace_idx);
-    }
-    if (is_kept(h, h->iter)) {
-        long long n = std::max<long long>(std::max<long long>(h->P, h->nvb), 16);
-        hipLaunchKernelGGL(k_accum, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (long long)h->P, (long long)h->nvb,
+    const bool do_trace = h->d_trace_loci && trace_idx < h->trace_ext_cap, do_accum = is_kept(h, h->iter);
+    if (do_trace || do_accum) {
+        long long n = 16;
+        if (do_trace) n = std::max<long long>(n, std::max<long long>(std::max<long long>(h->ntl, h->ntvb), (long long)h->sets.size()));
+        if (do_accum) n = std::max<long long>(n, std::max<long long>(h->P, h->nvb));
+        hipLaunchKernelGGL(k_post, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (int)do_accum, (long long)h->P, (long long)h->nvb,
                            (int)h->sets.size(), h->d_beta, h->d_delta, h->d_varBeta, h->d_sum_beta, h->d_sum_beta2, h->d_sum_delta,
-                           h->d_sum_varBeta, h->d_sets, h->d_scal);
+                           h->d_sum_varBeta, h->d_sets, h->d_scal, (int)do_trace, (long long)h->ntl, (const long long *)h->d_trace_loci,
+                           (long long)h->ntvb, h->d_tr_beta, h->d_tr_vb, h->d_tr_pi, (long long)trace_idx);
+    }
+    if (do_accum) {
         if (h->nfixcol > 0)
             hipLaunchKernelGGL(k_accum_fixed, dim3((unsigned)((h->nfixcol + 255) / 256)), dim3(256), 0, h->stream, (long long)h->nfixcol, h->d_bfix,
                                h->d_sum_bfix);
@@ -1212,7 +1214,8 @@ int32_t ngp_sweep_set(ngp_handle *h, int32_t set_id, double varE, double *ycorr,
     hipLaunchKernelGGL(k_set_varE, dim3(1), dim3(1), 0, h->stream, h->d_scal, varE);
     hipLaunchKernelGGL(k_prep, dim3((unsigned)(h->Ppad / 256 + 1)), dim3(256), 0, h->stream, (long long)h->Ppad, h->d_setof, h->d_loc,
                        h->d_vbidx, h->d_sets, h->d_scal, h->d_varBeta, h->d_mpm, h->d_lhs0, h->d_rhs0, h->d_beta, h->d_c, h->d_w,
-                       h->d_q, h->d_T, h->d_chi, (int)set_id, h->seed, (uint64_t)h->chain, it, (long long)h->h_regs.size(), h->d_regs, h->d_regchi, h->d_rcls);
+                       h->d_q, h->d_T, h->d_chi, (int)set_id, h->seed, (uint64_t)h->chain, it, (long long)h->h_regs.size(), h->d_regs, h->d_regchi, h->d_rcls,
+                       h->d_ccnt, (long long)(h->mode == 1 ? h->ccnt_words : 0));
     const int64_t tb0 = hs.col0 / NGP_BLK, tb1 = (hs.col0 + hs.ncol - 1) / NGP_BLK + 1;
     CuLease lease(h);
     launch_sweep(h, tb0, tb1, nullptr);

@@ -290,7 +290,10 @@ __global__ __launch_bounds__(256) void k_prep(long long Ppad, const int8_t *__re
                                               double *__restrict__ c, double *__restrict__ w, double *__restrict__ q,
                                               double *__restrict__ T, double *__restrict__ chi, int active_set, uint64_t seed,
                                               uint64_t chain, uint64_t it, long long nreg, const DReg *__restrict__ regs,
-                                              double *__restrict__ regchi, double *__restrict__ rcls) {
+                                              double *__restrict__ regchi, double *__restrict__ rcls, unsigned *__restrict__ ccnt,
+                                              long long ccnt_words) {
+    // the hand-off counters of the persistent sweep that follows in the stream start from zero (was a memset launch of its own)
+    for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < ccnt_words; i += (long long)gridDim.x * 256) ccnt[i] = 0u;
     long long k = (long long)blockIdx.x * 256 + threadIdx.x;
     if (k < nreg) {  // data-independent draws of the region variances (functions.jl:509-511): off the post-sweep path
         const DReg Rg = regs[k];
@@ -736,16 +739,6 @@ __global__ void k_set_sum_pi(DSet *__restrict__ sets, int si, double s0, double 
     sets[si].sum_pi1 = s1;
 }
 // per-iteration traces of selected effects, the first ntvb variances and pi of every set (bench.py: effective sample sizes)
-__global__ __launch_bounds__(256) void k_trace(long long ntl, const long long *__restrict__ loci, long long ntvb, int nsets,
-                                               const double *__restrict__ beta, const double *__restrict__ varBeta,
-                                               const DSet *__restrict__ sets, double *__restrict__ tr_beta,
-                                               double *__restrict__ tr_vb, double *__restrict__ tr_pi, long long idx) {
-    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (k < ntl) tr_beta[idx * ntl + k] = beta[loci[k]];
-    if (k < ntvb) tr_vb[idx * ntvb + k] = varBeta[k];
-    if (k < nsets) tr_pi[idx * nsets + k] = sets[k].piHat1;
-}
-// out += in (pooling of posterior sums of handles that share a device)
 __global__ __launch_bounds__(256) void k_add_inplace(double *__restrict__ out, const double *__restrict__ in, long long n) {
     const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
     if (k < n) out[k] = out[k] + in[k];
@@ -756,12 +749,22 @@ __global__ void k_set_varE(DScal *__restrict__ sc, double varE) {
 }
 
 // posterior sums of a kept iteration (samplers.jl:56-103 writes rows; misc.jl:241-244 averages)
-__global__ __launch_bounds__(256) void k_accum(long long P, long long nvb, int nsets, const double *__restrict__ beta,
-                                               const uint8_t *__restrict__ delta, const double *__restrict__ varBeta,
-                                               double *__restrict__ sum_beta, double *__restrict__ sum_beta2,
-                                               double *__restrict__ sum_delta, double *__restrict__ sum_varBeta,
-                                               DSet *__restrict__ sets, DScal *__restrict__ sc) {
-    long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+// end of an iteration, one launch: the per-iteration traces of selected effects / variances / pi (every iteration, if asked for)
+// and the posterior sums (kept iterations only; src/samplers.jl:56-104)
+__global__ __launch_bounds__(256) void k_post(int do_accum, long long P, long long nvb, int nsets, const double *__restrict__ beta,
+                                              const uint8_t *__restrict__ delta, const double *__restrict__ varBeta,
+                                              double *__restrict__ sum_beta, double *__restrict__ sum_beta2,
+                                              double *__restrict__ sum_delta, double *__restrict__ sum_varBeta,
+                                              DSet *__restrict__ sets, DScal *__restrict__ sc, int do_trace, long long ntl,
+                                              const long long *__restrict__ loci, long long ntvb, double *__restrict__ tr_beta,
+                                              double *__restrict__ tr_vb, double *__restrict__ tr_pi, long long idx) {
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (do_trace) {
+        if (k < ntl) tr_beta[idx * ntl + k] = beta[loci[k]];
+        if (k < ntvb) tr_vb[idx * ntvb + k] = varBeta[k];
+        if (k < nsets) tr_pi[idx * nsets + k] = sets[k].piHat1;
+    }
+    if (!do_accum) return;
     if (k < P) {
         double b = beta[k];
         sum_beta[k] += b;
