@@ -213,6 +213,9 @@ int32_t ngp_get_streamer(ngp_handle *h, int32_t *variant, int32_t *gemv_chains);
  * a call whose grid does not fit beside the running ones waits for them to return (the chains then take turns); sweeps of other
  * processes cannot be seen -- against those the bounded waits of the kernel remain (NGP_ERR_HIP, chain to be set again). */
 int32_t ngp_set_max_shards(ngp_handle *h, int32_t max_shards);
+/* The largest max_shards with which `chains` chains of this handle's device are co-resident (256 CUs: 247 for one chain, 123
+ * for two, 76 for three, 61 for four). */
+int32_t ngp_shards_for_chains(ngp_handle *h, int32_t chains, int32_t *max_shards);
 #define NGP_STORAGE_F32 0
 #define NGP_STORAGE_U8 1
 int32_t ngp_set_storage(ngp_handle *h, int32_t storage);

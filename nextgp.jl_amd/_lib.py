@@ -21,7 +21,7 @@ SYMBOLS = [
     "ngp_set_residual_prior", "ngp_set_intercept", "ngp_set_schedule", "ngp_run", "ngp_get_state", "ngp_set_state",
     "ngp_get_trace", "ngp_get_posterior_sums", "ngp_posterior_len", "ngp_export_posterior_device", "ngp_sweep_set",
     "ngp_get_timing", "ngp_profile_iteration", "ngp_draws_indexed", "ngp_eval_math", "ngp_configure", "ngp_get_config", "ngp_debug_stamps", "ngp_set_near_lags", "ngp_get_near_lags",
-    "ngp_set_streamer", "ngp_get_streamer", "ngp_set_storage", "ngp_get_storage", "ngp_set_max_shards", "ngp_run_many", "ngp_write_panel_file", "ngp_read_panel_header", "ngp_load_panel_file", "ngp_debug_set_mode", "ngp_debug_set_knob", "ngp_set_posterior_sums", "ngp_save_snapshot", "ngp_load_snapshot",
+    "ngp_set_streamer", "ngp_get_streamer", "ngp_set_storage", "ngp_get_storage", "ngp_set_max_shards", "ngp_shards_for_chains", "ngp_run_many", "ngp_write_panel_file", "ngp_read_panel_header", "ngp_load_panel_file", "ngp_debug_set_mode", "ngp_debug_set_knob", "ngp_set_posterior_sums", "ngp_save_snapshot", "ngp_load_snapshot",
     "ngp_set_trace_loci", "ngp_get_trace_ext", "ngp_allreduce_posterior", "ngp_add_marker_set_r", "ngp_get_class_state", "ngp_set_class_state", "ngp_add_fixed_set", "ngp_get_fixed", "ngp_set_fixed",
 ]
 
@@ -104,6 +104,12 @@ class Sampler:
 
     def set_max_shards(self, n):
         self._chk(self.L.ngp_set_max_shards(self.h, C.c_int32(int(n))))
+
+    def shards_for_chains(self, chains):
+        """The largest max_shards with which `chains` chains share this device side by side."""
+        v = C.c_int32()
+        self._chk(self.L.ngp_shards_for_chains(self.h, C.c_int32(int(chains)), C.byref(v)))
+        return v.value
 
     def set_storage(self, storage):
         """0 / "f32": centred fp32 tiles; 1 / "u8": compact storage (bytes + Float64 column means, analytic centring)."""

@@ -1397,6 +1397,19 @@ int32_t ngp_set_max_shards(ngp_handle *h, int32_t max_shards) {
     return NGP_OK;
 }
 
+int32_t ngp_shards_for_chains(ngp_handle *h, int32_t chains, int32_t *max_shards) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(chains >= 1 && max_shards, NGP_ERR_ARG, "chains must be >= 1");
+    // workgroups go to the 8 XCDs in turn: `chains` grids are co-resident when each takes at most (CUs / 8) / chains CUs per XCD;
+    // a grid is 1 sampler + ceil(S / 32) reducers + S streamers
+    const int per = 8 * ((h->cu_count / 8) / chains);
+    const int s = per - 1 - (per + NGP_GRP - 1) / NGP_GRP;
+    REQUIRE(s >= 1, NGP_ERR_ARG, "too many chains for this device");
+    *max_shards = s;
+    return NGP_OK;
+}
+
 int32_t ngp_set_storage(ngp_handle *h, int32_t storage) {
     int rc;
     if ((rc = enter(h))) return rc;

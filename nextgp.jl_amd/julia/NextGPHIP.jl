@@ -55,6 +55,11 @@ set_storage!(h::Handle, storage::Symbol) =
     check(h, ccall((:ngp_set_storage, LIB), Int32, (Ptr{Cvoid}, Int32), h.ptr, storage === :u8 ? 1 : 0))
 # at most n streamer workgroups (taller shards, CUs left free for a second chain on the same device); 0 = automatic
 set_max_shards!(h::Handle, n::Integer) = check(h, ccall((:ngp_set_max_shards, LIB), Int32, (Ptr{Cvoid}, Int32), h.ptr, n))
+function shards_for_chains(h::Handle, chains::Integer)   # the largest max_shards with which `chains` chains share the device side by side
+    v = Ref{Int32}(0)
+    check(h, ccall((:ngp_shards_for_chains, LIB), Int32, (Ptr{Cvoid}, Int32, Ref{Int32}), h.ptr, chains, v))
+    return Int(v[])
+end
 
 # Binary panel file in place of the text genotype file (src/prepMatVec.jl:116-131): header + codes, 8 or 2 bits per genotype
 function write_panel_file(path::AbstractString, G::Matrix{UInt8}; bits::Integer=8)

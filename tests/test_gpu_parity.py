@@ -593,6 +593,7 @@ def test_chains_of_one_process_share_a_device(ngp, O, shards):
     chains = [build(seed) for seed in (1001, 1002, 1003)]
     if shards:
         assert all(c.layout()[1] <= shards for c in chains)
+        assert [chains[0].shards_for_chains(k) for k in (1, 2, 3, 4)] == [247, 123, 76, 61]   # 256 CUs
     errs = []
 
     def work(c):

@@ -10,16 +10,12 @@ ngp = load_pkg()
 N, P, K, iters = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4])
 storage = sys.argv[5] if len(sys.argv) > 5 else None
 lag = int(os.environ.get("NGP_TOOL_LAG", "0"))
-import torch
-torch.cuda.init()
-ncu = torch.cuda.get_device_properties(0).multi_processor_count
-# a chain's grid = 1 sampler + ceil(S / 32) reducers + S streamers; K grids must be co-resident
-per = 8 * ((ncu // 8) // K)   # workgroups go to the 8 XCDs in turn: a grid takes ceil(grid / 8) CUs of every XCD
-shards = per - 1 - (per + 31) // 32
 chains = []
+shards = None
 for k in range(K):
     s = ngp.Sampler(device=0, seed=1001 + k, chain=k, storage=storage, **({"mode": 1, "lag": lag} if lag else {}))
     if K > 1:
+        shards = s.shards_for_chains(K)   # a chain's grid = 1 sampler + ceil(S / 32) reducers + S streamers; K grids co-resident
         s.set_max_shards(shards)
     s.generate_panel(N, P)
     rng = np.random.default_rng(1); bt = np.zeros(P); idx = rng.choice(P, max(10, P // 100), replace=False); bt[idx] = rng.normal(size=len(idx))
