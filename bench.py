@@ -61,8 +61,10 @@ def simulate_y(xbeta, N, P):
     return 10.0 + g + e
 
 
-def build_chain(ngp, device, seed, N, P, sets, panel_seed=20250509, storage=None):
+def build_chain(ngp, device, seed, N, P, sets, panel_seed=20250509, storage=None, share=0):
     s = ngp.Sampler(device=device, seed=seed, chain=seed - 1001, storage=storage)
+    if share > 1:  # this chain is one of `share` that run side by side on the device
+        s.set_max_shards(s.shards_for_chains(share))
     t0 = time.time()
     s.generate_panel(N, P, 0.05, 0.5, panel_seed)
     setup_s = time.time() - t0
@@ -176,6 +178,8 @@ def main():
     ap.add_argument("--P", type=int, default=None, help="override the number of SNPs")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-compact", action="store_true", help="skip the extra leg in compact (one byte per genotype) storage")
+    ap.add_argument("--chains-per-gpu", type=int, default=0,
+                    help="extra leg: that many independent chains side by side on the GPU (aggregate it/s; pays where one chain is not bandwidth-bound)")
     ap.add_argument("--storage", default="f32", choices=["f32", "u8"],
                     help="panel storage of the MAIN measurement (default f32 = the headline; u8 = compact storage, for profiling that mode)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on one GPU)")
@@ -353,6 +357,29 @@ def main():
                 "speedup_vs_fp32_storage": (K / cdt) / (K / dt), "setup_s": csetup,
             }
             c.close()
+        if world == 1 and args.chains_per_gpu > 1 and not compact_main:
+            # independent chains side by side on ONE GPU (disjoint CU shares, one thread each inside the library): the aggregate
+            # rate of the same metric where a single chain is bound by its sampler workgroup -- beside the single-chain value
+            try:
+                s.close()
+            except Exception:  # noqa: BLE001
+                pass
+            torch.cuda.empty_cache()
+            kc = args.chains_per_gpu
+            cs = [build_chain(ngp, local_rank, 1001 + i, N, P, sets, share=kc)[0] for i in range(kc)]
+            for c in cs:
+                c.set_schedule(W + K, W, 1)
+            ngp.Sampler.run_many(cs, W)
+            torch.cuda.synchronize()
+            tk = time.perf_counter()
+            ngp.Sampler.run_many(cs, K)
+            torch.cuda.synchronize()
+            kdt = time.perf_counter() - tk
+            out["chains_per_gpu"] = {"chains": kc, "value": kc * K / kdt, "unit": "it/s (aggregate over the chains of this GPU)",
+                                     "ms_per_step_of_a_chain": kdt / K * 1e3, "rows_per_shard": cs[0].layout()[0], "shards_per_chain": cs[0].layout()[1],
+                                     "speedup_vs_single_chain": (kc * K / kdt) / its}
+            for c in cs:
+                c.close()
         if world == 1 and not args.no_cpu_baseline:
             cols = args.cpu_cols or int(max(256, min(P, 1.6e8 // N)))
             out["cpu_baseline"] = cpu_baseline(N, P, sets, min(cols, P), args.cpu_seconds)
