@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_line_has_the_contract_fields():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C4", "--N", "2000", "--P", "6400", "--steps", "8", "--warmup", "1",
-                          "--cpu-cols", "640", "--cpu-seconds", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                          "--cpu-cols", "640", "--cpu-seconds", "2", "--chains-per-gpu", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -32,5 +32,7 @@ def test_bench_line_has_the_contract_fields():
     e = d["effective_samples"]
     assert 0 < e["ess_min"] <= 8 and e["ess_min_per_sec"] > 0 and len(e["ess"]["varBeta"]) == 3 and "beta_min_of_128" in e["ess"]
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
+    kc = d["chains_per_gpu"]    # optional leg: two chains side by side on the GPU, aggregate rate
+    assert kc["chains"] == 2 and kc["value"] > 0 and kc["shards_per_chain"] <= 123
     cs = d["compact_storage"]   # the extra leg, beside the fp32 headline
     assert cs["value"] > 0 and cs["panel_bytes"] == 2000 * 6400 and cs["layout"]["streamer"] == 3 and cs["roofline"]["peak"] == 8000.0

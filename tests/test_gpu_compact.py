@@ -245,3 +245,19 @@ def test_compact_row_count_edges(ngp, O, N):
         m.set_schedule(6, 0, 1)
         m.run(6)
     _same_chain(s, o, 6)
+
+
+def test_compact_without_centring(ngp, O):
+    """centre = 0: the means are zero and the codes are the panel (the reference always centres, src/prepMatVec.jl:129; the flag
+    exists for callers that centre themselves) -- same chain as the fp32 storage of the same uncentred values, to rounding."""
+    G, y, v = make_codes(O, 300, 200)
+    outs = []
+    for storage in ("u8", None):
+        s = ngp.Sampler(device=0, seed=4, chain=0, mode=1, lag=6, storage=storage)
+        s.set_panel(G, centre=False)
+        if storage == "u8":
+            assert np.all(s.means() == 0.0)
+        add_sets(s, [(0, 200, "PR")], v)
+        s.set_y(y); s.set_residual_prior(4.0, 0.25 * y.var()); s.run(8)
+        outs.append(s.get_state())
+    assert np.abs(outs[0]["beta"] - outs[1]["beta"]).max() < 1e-9 * max(1.0, np.abs(outs[1]["beta"]).max())
