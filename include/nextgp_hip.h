@@ -57,8 +57,8 @@ const char *ngp_last_error(ngp_handle *h);
 int32_t ngp_configure(ngp_handle *h, int32_t mode, int32_t lag);
 int32_t ngp_get_config(ngp_handle *h, int32_t *mode, int32_t *lag);
 /* Persistent sweep only: look-ahead lags 1..near are corrected inside the sampler workgroup, lags near+1..lag-1 by the
- * reducer workgroups (another summation order, which the blocked oracle needs to know).  1..4, 0 = automatic (3; on shards
- * taller than 128 rows 2 for the row-owning streamer and 4 for the phase streamer); to be chosen before the panel is set.  ngp_get_near_lags reports the value in force. */
+ * reducer workgroups (another summation order, which the blocked oracle needs to know).  1..4, 0 = automatic (3 with the phase streamer,
+ * 4 on its shards taller than 128 rows; 2 with the row-owning streamer from 64-row shards on); to be chosen before the panel is set.  ngp_get_near_lags reports the value in force. */
 int32_t ngp_set_near_lags(ngp_handle *h, int32_t near);
 int32_t ngp_get_near_lags(ngp_handle *h, int32_t *near);
 /* Diagnostic only: enable != 0 makes the persistent kernel write 100 MHz time stamps (sampler: 4 words per
@@ -188,7 +188,7 @@ int32_t ngp_eval_math(ngp_handle *h, int32_t which, const double *in, int64_t n,
 
 /* ---- streamer variants of the persistent sweep (before the panel is set) ----
  * 0 = automatic, 1 = phase streamer (every shard height), 2 = row-owning waves + loader wave (shards of at most 224 rows,
- * lags 3..6; the default for shards taller than 128 rows).  Both replace the loop of src/functions.jl:124-136; they differ in
+ * lags 3..6; the default for shards of 64 to 224 rows).  Both replace the loop of src/functions.jl:124-136; they differ in
  * the summation order of the shard partial of X_t'ycorr only: ngp_get_streamer reports the variant in force and the number of
  * GEMV chains per partial (8 or 7), which the blocked oracle needs like R, S, lag and near lags. */
 int32_t ngp_set_streamer(ngp_handle *h, int32_t variant);

@@ -252,9 +252,11 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
     h->NG = (int)((h->S + NGP_GRP - 1) / NGP_GRP);
     h->D = (h->mode == 1) ? std::min(h->lag, 8) : 1;
     // streamer variant (ngp_sweep.h): the row-owning waves serve shards of up to NGP_ROWS_MAX_R rows at lags 3..6 and are the
-    // default where the phase streamer is bound by its barriers (shards taller than 128 rows)
+    // default from 64-row shards on
     h->streamer = 1;
-    if (h->mode == 1 && h->R <= NGP_ROWS_MAX_R && h->lag >= 3 && (h->streamer_req == 2 || (h->streamer_req == 0 && h->R > 128))) h->streamer = 2;
+    // (from 64-row shards on since the publisher stopped waiting for the block's barrier: 20k x 100k 3.66 -> 3.26 ms, 28k x 100k
+    // 3.97 -> 3.45, 16k x 100k 3.38 -> 3.16, equal at 52-60 rows, the phase streamer ahead at 44 rows: 1.86 against 1.99 us per block)
+    if (h->mode == 1 && h->R <= NGP_ROWS_MAX_R && h->lag >= 3 && (h->streamer_req == 2 || (h->streamer_req == 0 && h->R >= 64))) h->streamer = 2;
     h->nchain = (h->streamer == 2) ? NGP_ROWS_NW : 8;
     if (h->streamer == 2) {
         if (h->D > 6) h->D = 6;  // register delay line: 32 VGPRs per lag
@@ -263,7 +265,7 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
     // where with lag 5 nothing is left for the reducers then, saves 8 % with it; with the row-owning streamer (lag 6) the sampler
     // CU is again the busier end (its Gram traffic: 32 KB per near lag and block) and three near lags measure better
     // (row-owning streamer on tall shards: two near lags measured 1.5 % better still -- the far path is one hop since dlt travels as granules)
-    h->near = h->near_req ? h->near_req : ((h->mode == 1 && h->R > 128) ? (h->streamer == 2 ? 2 : 4) : 3);
+    h->near = h->near_req ? h->near_req : ((h->mode == 1 && h->streamer == 2 && h->R >= 64) ? 2 : ((h->mode == 1 && h->R > 128) ? 4 : 3));
     }
     h->NBLK = (P + NGP_BLK - 1) / NGP_BLK;
     h->Ppad = h->NBLK * NGP_BLK;
