@@ -1038,7 +1038,7 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows(const S
 // ------------------------------------------------------------------------------------------
 // reducer g: every wave works on its own blocks (u = wave, wave+8, ...), no workgroup barrier
 template <bool DBG>
-__device__ inline void role_reducer(const SweepArgs &A, const int g) {
+__device__ inline void role_reducer(const SweepArgs &A, const int g, char *smem) {
     NGP_DBG_LOCALS
     const int S = A.S, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int s0 = g * NGP_GRP, s1 = min(s0 + NGP_GRP, S), gsize = s1 - s0;
@@ -1074,13 +1074,27 @@ __device__ inline void role_reducer(const SweepArgs &A, const int g) {
             }
             if (!(dbg_mode == 3 || dbg_mode == 4 || dbg_mode == 6) && !wait_dlt_granules_all(A.dltg, A.nonce, a, lane, A.abort_w, 4u, q0, q1)) return;
             const double dreg = dlt_granules_value(q0, q1);  // lane k holds dlt_k
+            // dlt goes through this wave's 512 bytes of LDS and comes back as broadcast reads (every lane the same 16 bytes): 32 LDS
+            // instructions instead of 128 v_readlane, each of which is a 20-clock trip through an SGPR, in front of the 64 fma --
+            // this term sits in the hand-off loop between the sampler's dlt and the group sum it waits for
+            double *ldw = (double *)smem + (size_t)wv * NGP_BLK;
+            ldw[lane] = dreg;
+            typedef const __attribute__((address_space(3))) double *lds_cdp;
+            const lds_cdp dk = (lds_cdp)ldw;
             double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
 #pragma unroll
-            for (int kk = 0; kk < NGP_BLK; kk += 4) {
-                s0 = __builtin_fma(gr[kk + 0], readlane_d(dreg, kk + 0), s0);
-                s1 = __builtin_fma(gr[kk + 1], readlane_d(dreg, kk + 1), s1);
-                s2 = __builtin_fma(gr[kk + 2], readlane_d(dreg, kk + 2), s2);
-                s3 = __builtin_fma(gr[kk + 3], readlane_d(dreg, kk + 3), s3);
+            for (int kk = 0; kk < NGP_BLK; kk += 16) {
+                double dv[16];
+#pragma unroll
+                for (int i = 0; i < 16; i++) dv[i] = dk[kk + i];
+#pragma unroll
+                for (int i = 0; i < 16; i += 4) {
+                    s0 = __builtin_fma(gr[kk + i + 0], dv[i + 0], s0);
+                    s1 = __builtin_fma(gr[kk + i + 1], dv[i + 1], s1);
+                    s2 = __builtin_fma(gr[kk + i + 2], dv[i + 2], s2);
+                    s3 = __builtin_fma(gr[kk + i + 3], dv[i + 3], s3);
+                }
+                asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));
             }
             v = v - ((s0 + s1) + (s2 + s3));
         }
@@ -1553,7 +1567,7 @@ __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     if (b == 0)
         role_sampler<DBG>(A, smem);
     else if (b <= A.NG)
-        role_reducer<DBG>(A, b - 1);
+        role_reducer<DBG>(A, b - 1, smem);
     else {
         const int s = b - 1 - A.NG;
         if (A.variant == 2) {  // row-owning waves + loader wave (host: R <= NGP_ROWS_MAX_R, lag 3..6)
