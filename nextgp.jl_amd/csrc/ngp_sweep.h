@@ -315,7 +315,7 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
             if (dbg && s == 0) dbg[NGP_DBG_STREAM + 2 * (size_t)uu + 1] = wall_clock64();
             if (!ok) *sflag = 0;
         }
-        ok = __shfl(ok, 0);
+        ok = __builtin_amdgcn_readfirstlane(ok);
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
         if (ok) dl[(uu & 1) * 64 + j] = ld_f64(&A.dlt[(size_t)(aa % NGP_RING) * NGP_BLK + j]);
     };
@@ -490,12 +490,12 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
                 bool have_dnext = false;
                 if (pollw) {
                     int ok = 1;
-                    if (__shfl((int)fl, 0) < pa + 1 && dbg_mode != 3 && dbg_mode != 4) {
+                    if (__builtin_amdgcn_readfirstlane((int)fl) < pa + 1 && dbg_mode != 3 && dbg_mode != 4) {
                         if (j == 0) {
                             ok = wait_ge(A.flag_dlt, (unsigned)(pa + 1), A.abort_w, 1u) ? 1 : 0;
                             if (!ok) *sflag = 0;
                         }
-                        ok = __shfl(ok, 0);
+                        ok = __builtin_amdgcn_readfirstlane(ok);
                     }
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     if (ok) {
@@ -1047,7 +1047,7 @@ __device__ inline void role_reducer(const SweepArgs &A, const int g, char *smem)
         const int slot = u % NGP_RING, round = u / NGP_RING;
         int ok = 1;
         if (lane == 0) ok = wait_ge(&A.cnt_part[((size_t)slot * A.NG + g) * 32], (unsigned)((round + 1) * gsize), A.abort_w, 2u) ? 1 : 0;
-        ok = __shfl(ok, 0);
+        ok = __builtin_amdgcn_readfirstlane(ok);
         if (!ok) return;
         if (dbg && g == 0 && lane == 0) dbg[NGP_DBG_RED + 2 * (size_t)u] = wall_clock64();
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
@@ -1130,7 +1130,7 @@ __device__ inline bool fetch_group_sums(const SweepArgs &A, int u, int j, double
     const int NG = A.NG, slot = u % NGP_RING;
     int ok = 1;
     if (j == 0) ok = (dbg_mode == 2 || wait_ge(&A.cnt_gs[(size_t)slot * 32], (unsigned)((u / NGP_RING + 1) * NG), A.abort_w, 3u)) ? 1 : 0;
-    ok = __shfl(ok, 0);
+    ok = __builtin_amdgcn_readfirstlane(ok);
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
     if (!ok) return false;
     const double *gp = A.gsum + (size_t)slot * NG * NGP_BLK + j;
@@ -1426,10 +1426,10 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
                 if (next_fetch < nb && next_fetch <= u + 2) {  // r0[(u+2) & 3] is free: block u-2 is done
                     const bool must = (next_fetch == u + 1);    // the next block needs these sums
                     int ok = 1;
-                    bool ready = (__shfl((int)probe, 0) >= (int)target_of(next_fetch)) || dbg_mode == 2;
+                    bool ready = (__builtin_amdgcn_readfirstlane((int)probe) >= (int)target_of(next_fetch)) || dbg_mode == 2;
                     if (!ready && must) {
                         if (j == 0) ok = wait_ge(&A.cnt_gs[(size_t)(next_fetch % NGP_RING) * 32], target_of(next_fetch), A.abort_w, 3u) ? 1 : 0;
-                        ok = __shfl(ok, 0);
+                        ok = __builtin_amdgcn_readfirstlane(ok);
                         ready = true;
                     }
                     if (!ok) {
