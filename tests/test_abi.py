@@ -43,3 +43,12 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".h", ".hip", ".cpp", ".jl")):
                 txt = open(os.path.join(dp, f), errors="ignore").read()
                 assert "libngp_oracle" not in txt and "import oracle" not in txt and "from oracle" not in txt, f
+
+
+def test_tools_and_bench_compile():
+    """Every script that is sent to the GPU box parses on this interpreter (a syntax error there costs a GPU call)."""
+    import glob
+    import py_compile
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for f in sorted(glob.glob(os.path.join(root, "tools", "*.py"))) + [os.path.join(root, "bench.py"), os.path.join(root, "__graft_entry__.py")]:
+        py_compile.compile(f, doraise=True)
