@@ -1,5 +1,5 @@
 """Randomised parity: random shapes, method mixes, lags, near lags, streamers, storages and shard limits, the device against the
-blocked oracle with the layout the library reports, bit for bit.  python tools/fuzz_parity.py [cases] [seed]"""
+blocked oracle with the layout the library reports, bit for bit.  python tests/fuzz_parity.py [cases] [seed]"""
 import os, sys
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))

@@ -1,5 +1,5 @@
 """Runs one of the BASELINE.json configurations end to end and prints a JSON line (diagnostic / report tool).
-   python tools/run_config.py C1|C2|C3|C3c|C4|C4s [iters] [warm]   (C3c = C3 with BayesC)"""
+   python tests/run_config.py C1|C2|C3|C3c|C4|C4s [iters] [warm]   (C3c = C3 with BayesC)"""
 import json, os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
