@@ -19,7 +19,7 @@
 
 #include "../../include/nextgp_hip.h"
 #include "ngp_kernels.h"
-#include "ngp_sweep.h"
+#include "ngp_sweep_args.h"
 
 using namespace ngp;
 
@@ -326,12 +326,12 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
             if (need + 8192 <= lds_max) h->lds_sweep = std::max(h->lds_sweep, need + 8192);
         }
         if (h->lds_sweep > lds_max) return fail(h, NGP_ERR_ARG, "panel too tall for the persistent sweep (LDS)");
-        HCHK(hipFuncSetAttribute((const void *)k_sweep<false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_sweep));
-        HCHK(hipFuncSetAttribute((const void *)k_sweep<true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_sweep));
+        HCHK(sweep_set_max_lds_0((int)h->lds_sweep));
+        HCHK(sweep_set_max_lds_1((int)h->lds_sweep));
         // every workgroup of the persistent kernel waits for others: the whole grid must be resident at once, one workgroup
         // per CU.  Checked here, not assumed (a grid that does not fit would only show up as a spin timeout).
         int wg_per_cu = 0;
-        HCHK(hipOccupancyMaxActiveBlocksPerMultiprocessor(&wg_per_cu, (const void *)k_sweep<false>, NGP_WG, h->lds_sweep));
+        HCHK(sweep_occupancy_0(&wg_per_cu, h->lds_sweep));
         if (wg_per_cu < 1 || 1 + h->NG + h->S > (int64_t)wg_per_cu * h->cu_count)
             return fail(h, NGP_ERR_STATE, "persistent sweep: grid of " + std::to_string(1 + h->NG + h->S) + " workgroups cannot be co-resident (" +
                                               std::to_string(wg_per_cu) + " per CU x " + std::to_string(h->cu_count) + " CUs); use ngp_configure(mode 0)");
@@ -484,9 +484,9 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
         A.mean = h->d_mean; A.N = h->N;
         A.dbg_mode = h->dbg_mode;
         if (h->d_dbg || h->dbg_mode)  // diagnostic instantiation: stamps and timing modes exist only there
-            hipLaunchKernelGGL(k_sweep<true>, dim3((unsigned)(1 + h->NG + S)), dim3(NGP_WG), h->lds_sweep, h->stream, A);
+            sweep_launch_1((unsigned)(1 + h->NG + S), h->lds_sweep, h->stream, A);
         else
-            hipLaunchKernelGGL(k_sweep<false>, dim3((unsigned)(1 + h->NG + S)), dim3(NGP_WG), h->lds_sweep, h->stream, A);
+            sweep_launch_0((unsigned)(1 + h->NG + S), h->lds_sweep, h->stream, A);
         if (evs) (void)hipEventRecord(evs[1], h->stream);
         h->sweep_launches += 1;
         return;

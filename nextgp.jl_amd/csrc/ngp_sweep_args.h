@@ -1,0 +1,92 @@
+// ngp_sweep_args.h -- launch arguments and layout constants of the persistent sweep kernel (ngp_sweep.h), shared with the host side
+#pragma once
+#include "ngp_common.h"
+
+#define NGP_RING 16        // slots of every communication ring (>= lag D)
+#define NGP_MAX_LAG 12     // lags above 8: compact storage only (8 VGPRs of delay line per lag and task)
+#define NGP_SPIN_LIMIT (1u << 21)
+#define NGP_WG 512          // threads per workgroup of the persistent kernel
+#define NGP_DBG_WAVES (1u << 19)   // sampler: 8 words per block, end-of-work stamp of every wave
+#define NGP_DBG_RED (3u << 18)     // reducer 0: 2 words per block (counter complete, group sum published)
+#define NGP_DBG_ALL (7u << 17)     // every streamer: publish time of local block 800 and its XCC id
+#define NGP_SPARSE_MAX 16  // BayesB / BayesC blocks with at most this many active lanes take the sparse chain
+// LDS distance of two quads of a tile: 1 KiB of data + 16 B, so that the update tasks (lanes = consecutive quads, same
+// columns) read conflict-free
+#ifndef NGP_LAZY_LAG
+#define NGP_LAZY_LAG 7  // streamers count their partials lazily from this lag on
+#endif
+#define NGP_QS 1040
+#define NGP_DBG_STREAM (1u << 20)  // offset of streamer 0's stamps in the debug buffer
+
+namespace ngp {
+
+struct SweepArgs {
+    const float *tiles;
+    double *ycorr;
+    const double *gramx;  // [block][lag d < D][64][64]: d = 0 one-sided diagonal block (natural order), d >= 1 cross blocks with
+                          // row pairs interleaved (gram_pair_index)
+    int knob;     // tuning knob of the streamers (ngp_debug_set_knob), see role_streamer_rows
+    int variant;  // streamer variant: 1 = phase streamer (role_streamer), 2 = row-owning waves + loader wave (role_streamer_rows)
+    int D, R, S, NG, near, fine_ok, t0, t1;  // near: look-ahead lags 1..near are corrected by the sampler, farther ones by the reducers
+     // fine_ok: the streamers' LDS has room for the diagnostic timeline
+    double *beta;
+    uint8_t *delta;
+    const double *c, *w, *q, *mpm, *chi;
+    const int8_t *setof;
+    const int32_t *vbidx;
+    DSet *sets;
+    double *varBeta;
+    // BayesR (null / unused when the model has no BayesR set): per-class coefficients of k_prep, M.rhs, chain scalars
+    const double *rcls;
+    const double *rhs0;
+    const DScal *scal;
+    long long Ppad;
+    // compact storage (variant 3): tiles are bytes (genotype codes), centred analytically with the Float64 column means
+    const double *mean;  // [Ppad]
+    long long N;         // rows of the panel (the last shards carry padding rows, which must stay zero)
+    // communication (zeroed before every launch)
+    double *part;        // [RING][S][64]
+    double *gsum;        // [RING][NG][64]
+    double *dlt;         // [RING][64]
+    unsigned long long *dltg;  // [RING][64][2] the same values as self-validating 8-byte granules {32 data bits, 32-bit tag}
+    unsigned nonce;      // 12-bit launch number inside every tag (the granule ring is not cleared between launches)
+    unsigned *cnt_part;  // [RING][NG] counters, one 128-B line each
+    unsigned *cnt_gs;    // [RING] counters, one 128-B line each
+    unsigned *flag_dlt;  // number of blocks the sampler has finished
+    unsigned *abort_w;   // != 0: a spin timed out (code = role)
+    unsigned *xcc_w;     // sampler's XCC id + 1 (speed only: same-XCD streamers warm the L2 with Gram blocks)
+    unsigned long long *dbg;  // optional time stamps (diagnostic runs only), else nullptr
+    int dbg_mode;             // diagnostic timing runs, results invalid: 1 = streamers only move tiles, 2 = sampler alone
+                              // (never waits), 3 = streamers + reducers alone (never wait for dlt), 4 = as 3 without the tile DMA,
+                              // 5 = whole pipeline, BayesPR blocks without the recursion, 6 = whole pipeline, reducers never wait for dlt
+};
+
+#define NGP_ROWS_MAX_R 224
+#define NGP_ROWS_NW 7       // row-owning waves
+#ifndef NGP_ROWS_HMAX
+#define NGP_ROWS_HMAX 32
+#endif
+//   // quads of tile u+2 requested during block u (the counted wait keeps them in flight)
+#define NGP_ROWS_PUBW 2
+#define NGP_ROWS_POLLW 6
+#define NGP_DLS 72            // doubles per parity of the dlt buffer: 64 + the scalar of the compact update
+
+// update tasks (4 rows x 8 columns) a lane of a row-owning wave carries in compact storage: 4 per unit, ceil(NU / 7) units per
+// wave, 8 lane slots -> 1, 2 or 4 (the template parameter; 3 runs as 4)
+__host__ __device__ inline int ngp_u8_tasks(int R) {
+    const int nuw = ((R >> 4) + NGP_ROWS_NW - 1) / NGP_ROWS_NW;
+    const int nt = (4 * nuw + 7) / 8;
+    return nt <= 1 ? 1 : (nt == 2 ? 2 : 4);
+}
+#define NGP_U8_MAX_R 896  // 7 waves x 8 units x 16 rows
+
+// Host entry points of the two instantiations of the persistent kernel (ngp_sweep_inst.hip is compiled twice, once per value of
+// NGP_INST_DBG, so that the production kernel and the diagnostic one build in parallel and apart from the API's own kernels):
+// _0 = k_sweep<false>, _1 = k_sweep<true> (time stamps and timing modes exist only there).
+hipError_t sweep_set_max_lds_0(int bytes);
+hipError_t sweep_set_max_lds_1(int bytes);
+hipError_t sweep_occupancy_0(int *wg_per_cu, size_t lds_bytes);
+void sweep_launch_0(unsigned grid, size_t lds_bytes, hipStream_t stream, const SweepArgs &A);
+void sweep_launch_1(unsigned grid, size_t lds_bytes, hipStream_t stream, const SweepArgs &A);
+
+}  // namespace ngp

@@ -1,0 +1,32 @@
+// ngp_sweep_inst.hip -- one instantiation of the persistent sweep kernel (ngp_sweep.h) and its host-side launch stubs.
+// Compiled twice: -DNGP_INST_DBG=0 (production kernel) and -DNGP_INST_DBG=1 (diagnostic kernel: time stamps, timing modes).
+#include <hip/hip_runtime.h>
+
+#include "ngp_sweep.h"
+
+#ifndef NGP_INST_DBG
+#error "compile with -DNGP_INST_DBG=0 or -DNGP_INST_DBG=1"
+#endif
+
+namespace ngp {
+
+#if NGP_INST_DBG
+#define NGP_SFX(name) name##_1
+#else
+#define NGP_SFX(name) name##_0
+#endif
+static constexpr bool kDbg = (NGP_INST_DBG != 0);
+
+hipError_t NGP_SFX(sweep_set_max_lds)(int bytes) {
+    return hipFuncSetAttribute((const void *)k_sweep<kDbg>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+#if !NGP_INST_DBG
+hipError_t sweep_occupancy_0(int *wg_per_cu, size_t lds_bytes) {
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(wg_per_cu, (const void *)k_sweep<false>, NGP_WG, lds_bytes);
+}
+#endif
+void NGP_SFX(sweep_launch)(unsigned grid, size_t lds_bytes, hipStream_t stream, const SweepArgs &A) {
+    hipLaunchKernelGGL(k_sweep<kDbg>, dim3(grid), dim3(NGP_WG), lds_bytes, stream, A);
+}
+
+}  // namespace ngp
