@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define NGP_ABI_VERSION 2
+#define NGP_ABI_VERSION 3
 
 #define NGP_OK 0
 #define NGP_ERR_ARG (-1)     /* bad argument (null, size mismatch, non-finite value) */
@@ -161,8 +161,9 @@ int32_t ngp_get_trace(ngp_handle *h, double *varE, double *b, int64_t n);
 int32_t ngp_get_posterior_sums(ngp_handle *h, double *sum_beta, double *sum_beta2, double *sum_delta, double *sum_varBeta,
                                double *sum_pi, double *sum_varE, double *sum_b, int64_t *nKept);
 /* Same sums packed into a DEVICE buffer [sum_beta P | sum_beta2 P | sum_delta P | sum_varBeta nvb |
- * sum_pi 2*nsets | class-probability sums of the BayesR sets, K each | sum_varE | sum_b | nKept] so the host can
- * all-reduce them over RCCL without a PCIe round trip.  len = 3P + nvb + 2 nsets + sum K + 3 doubles. */
+ * sum_pi 2*nsets | class-probability sums of the BayesR sets, K each | sums of the fixed effects beyond the intercept, all
+ * columns of all sets in order (ngp_get_fixed) | sum_varE | sum_b | nKept] so the host can all-reduce them over RCCL without a
+ * PCIe round trip.  len = 3P + nvb + 2 nsets + sum K + nfixcol + 3 doubles. */
 int32_t ngp_posterior_len(ngp_handle *h, int64_t *len);
 int32_t ngp_export_posterior_device(ngp_handle *h, void *device_ptr, int64_t len);
 
@@ -256,6 +257,10 @@ int32_t ngp_allreduce_posterior(ngp_handle **hs, int32_t n);
  * together (ngp_set_max_shards: e.g. three chains of 10k x 100k on one MI355X, 801 instead of 346 iterations/s in all) and in
  * turns otherwise.  Every chain is bit for bit what it is alone.  Returns the first non-zero status (message on that handle). */
 int32_t ngp_run_many(ngp_handle **hs, int32_t n, int64_t niter);
+
+/* Test hook of the exception barrier: throws a C++ exception inside an entry point (kind 0 std::bad_alloc, 1 std::length_error,
+ * 2 a non-standard one); what comes back is a negative status and a message -- never an unwind into the caller.  h may be NULL. */
+int32_t ngp_debug_throw(ngp_handle *h, int32_t kind);
 
 #ifdef __cplusplus
 }

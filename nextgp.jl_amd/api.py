@@ -104,8 +104,19 @@ def SNP(name, path, map=""):
 # ----------------------------------------------------------------------------------------------
 # formula (the subset of the StatsModels DSL the marker path uses, src/prepMatVec.jl:112-169)
 # ----------------------------------------------------------------------------------------------
+class ParsedFormula(tuple):
+    """(lhs, intercept, [GenomicTerm, ...]) with the plain covariate / factor terms as `.covariates` -- the parse result carries
+    everything itself (no state is left on the function: two models parsed in turn, or from threads, cannot pick up each other's
+    covariates)."""
+
+    def __new__(cls, lhs, intercept, snps, covariates):
+        t = super().__new__(cls, (lhs, intercept, snps))
+        t.covariates = list(covariates)
+        return t
+
+
 def parse_formula(formula):
-    """'y ~ 1 + SNP(M, "geno.txt", "map.txt")' -> (lhs, intercept, [GenomicTerm, ...])."""
+    """'y ~ 1 + x + SNP(M, "geno.txt", "map.txt")' -> ParsedFormula (lhs, intercept, [GenomicTerm, ...]; .covariates = ['x'])."""
     if "~" not in formula:
         raise ValueError("formula needs a '~'")
     lhs, rhs = [t.strip() for t in formula.split("~", 1)]
@@ -142,8 +153,7 @@ def parse_formula(formula):
         else:
             raise NotImplementedError(f"term '{t}': interactions / function terms stay on the reference's Julia path (StatsModels, "
                                       "src/prepMatVec.jl:150-165); use the fine seam (ngp_sweep_set) to combine them with the GPU sweep")
-    parse_formula.last_covariates = covs
-    return lhs, intercept, snps
+    return ParsedFormula(lhs, intercept, snps, covs)
 
 
 def design_columns(name, col):
@@ -311,7 +321,8 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
         raise NotImplementedError("userPedData: pedigree effects stay on the Julia path (src/mme.jl:26-46)")
     VCV = dict(VCV or {})
     summaryStat = dict(summaryStat or {})
-    lhs, intercept, snps = parse_formula(formula)
+    parsed = parse_formula(formula)
+    lhs, intercept, snps = parsed
     if not snps:
         raise ValueError("the accelerated path needs at least one SNP(...) term")
     y = np.asarray(userData[lhs], dtype=np.float64)
@@ -352,7 +363,7 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
     # fixed effects beyond the intercept (src/prepMatVec.jl:150-165, blocks src/mme.jl:96-108): every term its own set, the terms of a
     # blockThese group one multi-column set (sampleb!, src/functions.jl:22-36); blocks first, in the user's order, then the rest in
     # model order (the reference walks a Julia Dict, whose order is not defined: documented difference)
-    covs = list(getattr(parse_formula, "last_covariates", []))
+    covs = list(parsed.covariates)
     fixed_names = ["(Intercept)"] if intercept else []
     designs = {c: design_columns(c, userData[c]) for c in covs}
     used = set()

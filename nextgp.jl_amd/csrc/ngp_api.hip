@@ -140,6 +140,31 @@ int fail(ngp_handle *h, int code, const std::string &msg) {
     if (h) h->err = msg; else g_create_err = msg;
     return code;
 }
+// the same for the exception barrier of the C ABI: storing the message must not throw a second time
+int fail_nothrow(ngp_handle *h, int code, const char *what) noexcept {
+    try {
+        std::string &dst = h ? h->err : g_create_err;
+        dst.assign(what ? what : "?");
+    } catch (...) {  // out of memory while storing the message: keep the code, drop the text
+        try { (h ? h->err : g_create_err).clear(); } catch (...) {}
+    }
+    return code;
+}
+
+// Exception barrier (include/nextgp_hip.h: "no C++ exception crosses this boundary"; SURVEY.md section 8b, error conventions):
+// every extern "C" body runs inside NGP_TRY ... NGP_CATCH(handle).  std::vector / std::string / std::thread can throw
+// (bad_alloc, length_error, system_error); unwinding into the caller's ccall frame would abort the Julia process, so they become
+// a negative status and a message for ngp_last_error, like every other failure (the reference's error(...) style, src/mme.jl:77,343).
+#define NGP_TRY try {
+#define NGP_CATCH(H)                                                                                                 \
+    }                                                                                                                \
+    catch (const std::bad_alloc &) { return fail_nothrow((H), NGP_ERR_NOMEM, "out of host memory (std::bad_alloc)"); } \
+    catch (const std::exception &e_) {                                                                               \
+        char b_[256];                                                                                                \
+        std::snprintf(b_, sizeof b_, "internal error (C++ exception stopped at the C ABI): %s", e_.what());          \
+        return fail_nothrow((H), NGP_ERR_HIP, b_);                                                                   \
+    }                                                                                                                \
+    catch (...) { return fail_nothrow((H), NGP_ERR_HIP, "internal error (unknown C++ exception stopped at the C ABI)"); }
 
 #define HCHK(call)                                                                                          \
     do {                                                                                                    \
@@ -309,7 +334,13 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
     h->sets.clear(); h->nvb = 0; h->h_regs.clear(); h->h_seg_k0.clear(); h->h_seg_len.clear(); h->h_seg_set.clear(); h->nclass_total = 0;
     dfree(h->d_rcls);
     dfree(h->d_varBeta); dfree(h->d_sum_varBeta); h->vb_cap = 0;
-    h->have_y = false; h->iter = 0;
+    // a new panel is a new model: the fixed-effect sets (N rows of the OLD panel) and the trace selection (loci of the old P) go
+    // with the marker sets -- k_fixed would read d_X of the old N, k_post beta[loci[k]] beyond the new P
+    for (auto &fx : h->fix) { dfree(fx.d_X); dfree(fx.d_xpx0); dfree(fx.d_xpxR); dfree(fx.d_lhs0); dfree(fx.d_rhs0); }
+    h->fix.clear(); h->nfixcol = 0; dfree(h->d_bfix); dfree(h->d_sum_bfix);
+    dfree(h->d_trace_loci); dfree(h->d_tr_beta); dfree(h->d_tr_vb); dfree(h->d_tr_pi);
+    h->ntl = 0; h->ntvb = 0; h->trace_ext_cap = 0;
+    h->have_y = false; h->iter = 0; h->poisoned = false;
     if (h->storage == 0) HCHK(hipFuncSetAttribute((const void *)k_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_step));
     if (h->mode == 1) {
         const size_t lds_sampler = (size_t)(3 * 4096 + 2 * NGP_RING * NGP_BLK + 6 * NGP_BLK) * sizeof(double) + 2 * NGP_BLK * sizeof(int) + 320;
@@ -583,6 +614,11 @@ int set_class_state_dev(ngp_handle *h, int si, const double *pi, const double *s
     return NGP_OK;
 }
 
+// doubles of the packed posterior (ngp_export_posterior_device): 3P + nvb + 2 nsets + sum K + fixed-effect columns + 3
+int64_t posterior_words(const ngp_handle *h) {
+    return 3 * h->P + h->nvb + 2 * (int64_t)h->sets.size() + h->nclass_total + h->nfixcol + 3;
+}
+
 int ready(ngp_handle *h) {
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
     REQUIRE(h->have_y, NGP_ERR_STATE, "y not set");
@@ -597,6 +633,7 @@ extern "C" {
 int32_t ngp_abi_version(void) { return NGP_ABI_VERSION; }
 
 int32_t ngp_create(int32_t device, uint64_t seed, uint32_t chain_id, ngp_handle **out) {
+    NGP_TRY
     if (!out) return fail(nullptr, NGP_ERR_ARG, "null out pointer");
     *out = nullptr;
     int ndev = 0;
@@ -621,9 +658,11 @@ int32_t ngp_create(int32_t device, uint64_t seed, uint32_t chain_id, ngp_handle 
     }
     *out = h;
     return NGP_OK;
+    NGP_CATCH(nullptr)
 }
 
 int32_t ngp_destroy(ngp_handle *h) {
+    NGP_TRY
     if (!h) return NGP_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
@@ -640,15 +679,20 @@ int32_t ngp_destroy(ngp_handle *h) {
     if (h->stream) (void)hipStreamDestroy(h->stream);
     delete h;
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 const char *ngp_last_error(ngp_handle *h) { return h ? h->err.c_str() : g_create_err.c_str(); }
 
 int32_t ngp_set_panel_f64(ngp_handle *h, const double *M, int64_t N, int64_t P, int64_t ld, int32_t centre) {
+    NGP_TRY
     return set_panel_host<double>(h, M, N, P, ld, centre);
+    NGP_CATCH(h)
 }
 int32_t ngp_set_panel_f32(ngp_handle *h, const float *M, int64_t N, int64_t P, int64_t ld, int32_t centre) {
+    NGP_TRY
     return set_panel_host<float>(h, M, N, P, ld, centre);
+    NGP_CATCH(h)
 }
 
 }  // extern "C" (helpers below are C++)
@@ -673,6 +717,7 @@ static void ingest_u8_chunk(ngp_handle *h, const uint8_t *d_g, int64_t N, int64_
 extern "C" {
 
 int32_t ngp_set_panel_u8(ngp_handle *h, const uint8_t *G, int64_t N, int64_t P, int64_t ld, int32_t centre) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(G != nullptr, NGP_ERR_ARG, "null panel pointer");
@@ -700,6 +745,7 @@ int32_t ngp_set_panel_u8(ngp_handle *h, const uint8_t *G, int64_t N, int64_t P, 
     dfree(d_mu);
     if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("set_panel_u8: ") + hipGetErrorString(e));
     return build_gram(h);
+    NGP_CATCH(h)
 }
 
 // ---- binary panel file (replaces the text genotype file of src/prepMatVec.jl:116-131 for large panels) ----
@@ -710,14 +756,15 @@ struct PanelHeader { char magic[8]; int64_t N, P; int32_t bits, zero; };
 }
 
 int32_t ngp_write_panel_file(const char *path, const uint8_t *G, int64_t N, int64_t P, int64_t ld, int32_t bits) {
+    NGP_TRY
     if (!path || !G || N <= 0 || P <= 0 || ld < N || (bits != 8 && bits != 2)) return NGP_ERR_ARG;
+    std::vector<uint8_t> packed(bits == 2 ? (size_t)(N + 3) / 4 : 0);  // before the file is opened: an allocation failure leaves nothing behind
     FILE *f = std::fopen(path, "wb");
     if (!f) return NGP_ERR_ARG;
     PanelHeader hd;
     std::memcpy(hd.magic, "NGPPNL01", 8);
     hd.N = N; hd.P = P; hd.bits = bits; hd.zero = 0;
     bool ok = std::fwrite(&hd, sizeof hd, 1, f) == 1;
-    std::vector<uint8_t> packed((size_t)(N + 3) / 4);
     for (int64_t j = 0; j < P && ok; j++) {
         const uint8_t *col = G + (size_t)j * ld;
         if (bits == 8) {
@@ -733,9 +780,11 @@ int32_t ngp_write_panel_file(const char *path, const uint8_t *G, int64_t N, int6
     }
     ok = (std::fclose(f) == 0) && ok;
     return ok ? NGP_OK : NGP_ERR_ARG;
+    NGP_CATCH(nullptr)
 }
 
 int32_t ngp_read_panel_header(const char *path, int64_t *N, int64_t *P, int32_t *bits) {
+    NGP_TRY
     if (!path) return NGP_ERR_ARG;
     FILE *f = std::fopen(path, "rb");
     if (!f) return NGP_ERR_ARG;
@@ -748,9 +797,11 @@ int32_t ngp_read_panel_header(const char *path, int64_t *N, int64_t *P, int32_t 
     if (P) *P = hd.P;
     if (bits) *bits = hd.bits;
     return NGP_OK;
+    NGP_CATCH(nullptr)
 }
 
 int32_t ngp_load_panel_file(ngp_handle *h, const char *path, int32_t centre) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(path != nullptr, NGP_ERR_ARG, "null path");
@@ -804,9 +855,11 @@ int32_t ngp_load_panel_file(ngp_handle *h, const char *path, int32_t centre) {
     if (!why.empty()) { dfree(h->d_tiles); return fail(h, NGP_ERR_ARG, why); }
     if (e != hipSuccess) { dfree(h->d_tiles); return fail(h, NGP_ERR_HIP, std::string("load_panel_file: ") + hipGetErrorString(e)); }
     return build_gram(h);
+    NGP_CATCH(h)
 }
 
 int32_t ngp_generate_panel(ngp_handle *h, int64_t N, int64_t P, double maf_lo, double maf_hi, uint64_t panel_seed) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(maf_lo > 0.0 && maf_hi < 1.0 && maf_lo <= maf_hi, NGP_ERR_ARG, "maf range must satisfy 0 < lo <= hi < 1");
@@ -828,9 +881,11 @@ int32_t ngp_generate_panel(ngp_handle *h, int64_t N, int64_t P, double maf_lo, d
     dfree(d_mu); dfree(d_thr);
     if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("generate_panel: ") + hipGetErrorString(e));
     return build_gram(h);
+    NGP_CATCH(h)
 }
 
 int32_t ngp_get_layout(ngp_handle *h, int64_t *R, int64_t *S, int64_t *nblk) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
@@ -838,18 +893,22 @@ int32_t ngp_get_layout(ngp_handle *h, int64_t *R, int64_t *S, int64_t *nblk) {
     if (S) *S = h->S;
     if (nblk) *nblk = h->NBLK;
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_get_mpm(ngp_handle *h, double *out, int64_t P) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
     REQUIRE(out && P == h->P, NGP_ERR_ARG, "mpm buffer must hold P entries");
     HCHK(hipMemcpy(out, h->d_mpm, (size_t)P * sizeof(double), hipMemcpyDeviceToHost));
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_get_gram(ngp_handle *h, int64_t t, double *out) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
@@ -863,9 +922,11 @@ int32_t ngp_get_gram(ngp_handle *h, int64_t t, double *out) {
         for (int j = k + 1; j < NGP_BLK; j++) out[j * NGP_BLK + k] = out[k * NGP_BLK + j];
     }
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_xbeta(ngp_handle *h, const double *beta, int64_t P, double *out, int64_t N) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
@@ -886,11 +947,13 @@ int32_t ngp_xbeta(ngp_handle *h, const double *beta, int64_t P, double *out, int
     dfree(d_b); dfree(d_o);
     if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("xbeta: ") + hipGetErrorString(e));
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_add_marker_set(ngp_handle *h, int64_t col0, int64_t ncol, int32_t method, double df, double scale,
                            const int64_t *reg_start, const int64_t *reg_stop, int64_t nreg, const double *varBeta0, double pi0,
                            int32_t estPi, const double *lhs0, const double *rhs0, int32_t *set_id) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
@@ -973,11 +1036,14 @@ int32_t ngp_add_marker_set(ngp_handle *h, int64_t col0, int64_t ncol, int32_t me
     h->nvb = new_nvb;
     h->sets.push_back(hs);
     h->tables_dirty = true;
+    h->trace_ext_cap = 0;  // d_tr_pi holds one column per set: sized again by the next traced ngp_run
     if (set_id) *set_id = si;
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_set_y(ngp_handle *h, const double *y, int64_t N) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
@@ -1011,30 +1077,38 @@ int32_t ngp_set_y(ngp_handle *h, const double *y, int64_t N) {
     h->iter = 0; h->have_y = true; h->poisoned = false; h->ntrace = 0;
     for (auto &hs : h->sets) hs.fine_calls = 0;
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_set_residual_prior(ngp_handle *h, double df, double scale) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(std::isfinite(df) && std::isfinite(scale) && df > 0 && scale >= 0, NGP_ERR_ARG, "bad residual prior");
     h->e_df = df; h->e_scale = scale;
     return NGP_OK;
+    NGP_CATCH(h)
 }
 int32_t ngp_set_intercept(ngp_handle *h, int32_t on) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     h->intercept = on ? 1 : 0;
     return NGP_OK;
+    NGP_CATCH(h)
 }
 int32_t ngp_set_schedule(ngp_handle *h, int64_t chainLength, int64_t burnIn, int64_t thin) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(chainLength >= 0 && burnIn >= 0 && thin >= 1, NGP_ERR_ARG, "bad schedule");
     h->chainLength = chainLength; h->burnIn = burnIn; h->thin = thin;
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_run(ngp_handle *h, int64_t niter) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     if ((rc = ready(h))) return rc;
@@ -1071,10 +1145,12 @@ int32_t ngp_run(ngp_handle *h, int64_t niter) {
     h->iter_ms += ms; h->iters_timed += niter;
     if (h->dbg_mode != 0) return fail(h, NGP_ERR_DEBUG, "diagnostic timing mode " + std::to_string(h->dbg_mode) + " is active: the chain is invalid (ngp_debug_set_mode(h, 0) ends it)");
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_get_state(ngp_handle *h, double *ycorr, double *beta, int64_t *delta, double *varBeta, double *piHat, double *varE,
                       double *b, int64_t *iter) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr && h->have_y, NGP_ERR_STATE, "panel / y not set");
@@ -1098,14 +1174,18 @@ int32_t ngp_get_state(ngp_handle *h, double *ycorr, double *beta, int64_t *delta
     if (b) *b = sc.b;
     if (iter) *iter = h->iter;
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_set_state(ngp_handle *h, const double *ycorr, const double *beta, const int64_t *delta, const double *varBeta,
                       const double *piHat, double varE, double b, int64_t iter) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr && h->have_y, NGP_ERR_STATE, "panel / y not set");
-    REQUIRE(std::isfinite(varE) && std::isfinite(b) && iter >= 0, NGP_ERR_ARG, "bad scalar state");
+    // (varE is 0 before the first iteration -- ngp_set_y -- and drawn before it is used; any later state has varE > 0)
+    REQUIRE(std::isfinite(varE) && (varE > 0.0 || (varE == 0.0 && iter == 0)) && std::isfinite(b) && iter >= 0, NGP_ERR_ARG,
+            "bad scalar state (varE must be finite and positive)");
     if (ycorr) HCHK(hipMemcpy(h->d_ycorr, ycorr, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice));
     if (beta) HCHK(hipMemcpy(h->d_beta, beta, (size_t)h->P * sizeof(double), hipMemcpyHostToDevice));
     if (delta) {
@@ -1125,9 +1205,11 @@ int32_t ngp_set_state(ngp_handle *h, const double *ycorr, const double *beta, co
     h->iter = iter;
     if (ycorr && beta) h->poisoned = false;
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_get_trace(ngp_handle *h, double *varE, double *b, int64_t n) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     n = std::min(n, h->ntrace);
@@ -1135,10 +1217,12 @@ int32_t ngp_get_trace(ngp_handle *h, double *varE, double *b, int64_t n) {
     if (varE) HCHK(hipMemcpy(varE, h->d_tr_varE, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     if (b) HCHK(hipMemcpy(b, h->d_tr_b, (size_t)n * sizeof(double), hipMemcpyDeviceToHost));
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_get_posterior_sums(ngp_handle *h, double *sum_beta, double *sum_beta2, double *sum_delta, double *sum_varBeta,
                                double *sum_pi, double *sum_varE, double *sum_b, int64_t *nKept) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
@@ -1159,21 +1243,25 @@ int32_t ngp_get_posterior_sums(ngp_handle *h, double *sum_beta, double *sum_beta
     if (sum_b) *sum_b = sc.sum_b;
     if (nKept) *nKept = sc.nKept;
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_posterior_len(ngp_handle *h, int64_t *len) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(len != nullptr, NGP_ERR_ARG, "null len");
-    *len = 3 * h->P + h->nvb + 2 * (int64_t)h->sets.size() + h->nclass_total + 3;
+    *len = posterior_words(h);
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_export_posterior_device(ngp_handle *h, void *device_ptr, int64_t len) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
-    const int64_t need = 3 * h->P + h->nvb + 2 * (int64_t)h->sets.size() + h->nclass_total + 3;
+    const int64_t need = posterior_words(h);
     REQUIRE(device_ptr && len == need, NGP_ERR_ARG, "export buffer length mismatch (see ngp_posterior_len)");
     double *o = (double *)device_ptr;
     const size_t pb = (size_t)h->P * sizeof(double);
@@ -1189,13 +1277,18 @@ int32_t ngp_export_posterior_device(ngp_handle *h, void *device_ptr, int64_t len
     std::vector<double> tail;
     for (auto &s : ds) { tail.push_back(s.sum_pi0); tail.push_back(s.sum_pi1); }
     for (auto &s : ds) for (int v = 0; v < s.K; v++) tail.push_back(s.sum_pic[v]);  // BayesR class probabilities, set by set
+    const size_t nfix_at = tail.size();
+    tail.resize(nfix_at + (size_t)h->nfixcol);  // fixed-effect sums beyond the intercept (all columns of all sets, in order)
+    if (h->nfixcol > 0) HCHK(hipMemcpy(tail.data() + nfix_at, h->d_sum_bfix, (size_t)h->nfixcol * sizeof(double), hipMemcpyDeviceToHost));
     tail.push_back(sc.sum_varE); tail.push_back(sc.sum_b); tail.push_back((double)sc.nKept);
     HCHK(hipMemcpy(o + 3 * h->P + h->nvb, tail.data(), tail.size() * sizeof(double), hipMemcpyHostToDevice));
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_sweep_set(ngp_handle *h, int32_t set_id, double varE, double *ycorr, double *beta, int64_t *delta, double *varBeta,
                       double *piHat) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
@@ -1240,9 +1333,11 @@ int32_t ngp_sweep_set(ngp_handle *h, int32_t set_id, double varE, double *ycorr,
         piHat[0] = ds.piHat0; piHat[1] = ds.piHat1;
     }
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_get_timing(ngp_handle *h, int64_t *sweep_launches, double *iter_ms, int64_t *iters) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     if (sweep_launches) *sweep_launches = h->sweep_launches;
@@ -1250,9 +1345,11 @@ int32_t ngp_get_timing(ngp_handle *h, int64_t *sweep_launches, double *iter_ms, 
     if (iters) *iters = h->iters_timed;
     h->sweep_launches = 0; h->iter_ms = 0; h->iters_timed = 0;
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_profile_iteration(ngp_handle *h, double *avg_ms, int64_t *launches, double *bytes_per_launch) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     if ((rc = ready(h))) return rc;
@@ -1283,9 +1380,11 @@ int32_t ngp_profile_iteration(ngp_handle *h, double *avg_ms, int64_t *launches, 
     const double bpe = (h->storage == 1) ? 1.0 : 4.0;  // algorithmic bytes per genotype: the panel is read once per iteration
     if (bytes_per_launch) *bytes_per_launch = (h->mode == 1) ? (double)h->N * (double)h->P * bpe : (double)h->N * NGP_BLK * bpe;
     return rc;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_debug_stamps(ngp_handle *h, int32_t enable, uint64_t *out, int64_t n) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     const size_t words = (size_t)2 << 20;
@@ -1293,9 +1392,11 @@ int32_t ngp_debug_stamps(ngp_handle *h, int32_t enable, uint64_t *out, int64_t n
     if (out && h->d_dbg) HCHK(hipMemcpy(out, h->d_dbg, std::min<size_t>((size_t)n, words) * sizeof(uint64_t), hipMemcpyDeviceToHost));
     if (!enable && h->d_dbg) { HCHK(hipStreamSynchronize(h->stream)); dfree(h->d_dbg); }
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_configure(ngp_handle *h, int32_t mode, int32_t lag) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles == nullptr, NGP_ERR_STATE, "ngp_configure must precede the panel upload");
@@ -1303,34 +1404,42 @@ int32_t ngp_configure(ngp_handle *h, int32_t mode, int32_t lag) {
     REQUIRE(lag >= 1 && lag <= NGP_MAX_LAG, NGP_ERR_ARG, "lag must be in 1..12 (above 8: compact storage)");
     h->mode = mode; h->lag = lag; h->lag_auto = false;
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_set_near_lags(ngp_handle *h, int32_t near) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles == nullptr, NGP_ERR_STATE, "ngp_set_near_lags must precede the panel upload");
     REQUIRE(near >= 0 && near <= 4, NGP_ERR_ARG, "near lags: 0 (automatic) or 1..4");
     h->near_req = near;
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_get_near_lags(ngp_handle *h, int32_t *near) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     if (near) *near = h->near;
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_get_config(ngp_handle *h, int32_t *mode, int32_t *lag) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     if (mode) *mode = h->mode;
     if (lag) *lag = h->D;
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_draws_indexed(ngp_handle *h, uint64_t iter, uint64_t kind, uint64_t index0, int32_t what, double p1, double p2, int64_t n,
                           double *out) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(out && n > 0, NGP_ERR_ARG, "bad output buffer");
@@ -1343,9 +1452,11 @@ int32_t ngp_draws_indexed(ngp_handle *h, uint64_t iter, uint64_t kind, uint64_t 
     dfree(d);
     if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("draws: ") + hipGetErrorString(e));
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_eval_math(ngp_handle *h, int32_t which, const double *in, int64_t n, double *out) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(in && out && n > 0, NGP_ERR_ARG, "bad buffers");
@@ -1359,6 +1470,7 @@ int32_t ngp_eval_math(ngp_handle *h, int32_t which, const double *in, int64_t n,
     dfree(di); dfree(dout);
     if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("eval_math: ") + hipGetErrorString(e));
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 
@@ -1367,39 +1479,48 @@ int32_t ngp_eval_math(ngp_handle *h, int32_t which, const double *in, int64_t n,
  * streamer variants, pooled posterior sums
  * ---------------------------------------------------------------------------------------------- */
 int32_t ngp_debug_set_mode(ngp_handle *h, int32_t mode) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(mode >= 0 && mode <= 6, NGP_ERR_ARG, "diagnostic mode must be in 0..6");
     h->dbg_mode = mode;
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_debug_set_knob(ngp_handle *h, int32_t knob) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     h->knob = knob;
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_set_streamer(ngp_handle *h, int32_t variant) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles == nullptr, NGP_ERR_STATE, "ngp_set_streamer must precede the panel upload");
     REQUIRE(variant >= 0 && variant <= 2, NGP_ERR_ARG, "streamer variant: 0 (automatic), 1 (phase streamer) or 2 (row-owning waves)");
     h->streamer_req = variant;
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_set_max_shards(ngp_handle *h, int32_t max_shards) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles == nullptr, NGP_ERR_STATE, "ngp_set_max_shards must precede the panel upload");
     REQUIRE(max_shards >= 0, NGP_ERR_ARG, "max_shards: 0 (automatic) or a positive number of streamer workgroups");
     h->max_shards_req = max_shards;
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_shards_for_chains(ngp_handle *h, int32_t chains, int32_t *max_shards) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(chains >= 1 && max_shards, NGP_ERR_ARG, "chains must be >= 1");
@@ -1410,18 +1531,22 @@ int32_t ngp_shards_for_chains(ngp_handle *h, int32_t chains, int32_t *max_shards
     REQUIRE(s >= 1, NGP_ERR_ARG, "too many chains for this device");
     *max_shards = s;
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_set_storage(ngp_handle *h, int32_t storage) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles == nullptr, NGP_ERR_STATE, "ngp_set_storage must precede the panel upload");
     REQUIRE(storage == NGP_STORAGE_F32 || storage == NGP_STORAGE_U8, NGP_ERR_ARG, "storage: 0 (fp32 tiles) or 1 (compact: bytes + column means)");
     h->storage = storage;
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_get_storage(ngp_handle *h, int32_t *storage, double *means, int64_t P) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     if (storage) *storage = h->storage;
@@ -1432,18 +1557,22 @@ int32_t ngp_get_storage(ngp_handle *h, int32_t *storage, double *means, int64_t 
         HCHK(hipMemcpy(means, h->d_mean, (size_t)P * sizeof(double), hipMemcpyDeviceToHost));
     }
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_get_streamer(ngp_handle *h, int32_t *variant, int32_t *gemv_chains) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     if (variant) *variant = (h->mode == 1) ? h->streamer : 0;
     if (gemv_chains) *gemv_chains = h->nchain;
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_set_posterior_sums(ngp_handle *h, const double *sum_beta, const double *sum_beta2, const double *sum_delta,
                                const double *sum_varBeta, const double *sum_pi, double sum_varE, double sum_b, int64_t nKept) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr && h->have_y, NGP_ERR_STATE, "panel / y not set");
@@ -1464,16 +1593,19 @@ int32_t ngp_set_posterior_sums(ngp_handle *h, const double *sum_beta, const doub
     sc.sum_varE = sum_varE; sc.sum_b = sum_b; sc.nKept = nKept;
     HCHK(hipMemcpy(h->d_scal, &sc, sizeof(DScal), hipMemcpyHostToDevice));
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 /* Snapshot file: the chain state and the posterior sums, little-endian, no padding:
- *   char[8] "NGPSNAP1" | int64 N, P, nvb, nsets, iter, nKept | uint64 seed | uint64 chain |
+ *   char[8] "NGPSNAP2" | int64 N, P, nvb, nsets, iter, nKept | uint64 seed | uint64 chain |
+ *   model signature: per marker set int64 {method, K, nreg, col0, ncol} | int64 nfixsets | per fixed-effect set int64 ncol |
  *   double varE, b, sum_varE, sum_b | ycorr[N] | beta[P] | delta[P] (uint8) | varBeta[nvb] | piHat[2 nsets] |
  *   sum_beta[P] | sum_beta2[P] | sum_delta[P] | sum_varBeta[nvb] | sum_pi[2 nsets] | fine_calls[nsets] (uint64) |
  *   int64 nfix | b_fixed[nfix] | sum_b_fixed[nfix] | per BayesR set: piHat[K] | sum_pi[K]
  * It plays the role of the reference's append-only *Out files for a resumed run (src/outFiles.jl:17-21): what was kept
  * before the interruption is not lost. */
 int32_t ngp_save_snapshot(ngp_handle *h, const char *path) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr && h->have_y, NGP_ERR_STATE, "panel / y not set");
@@ -1497,7 +1629,14 @@ int32_t ngp_save_snapshot(ngp_handle *h, const char *path) {
     const int64_t hdr[6] = {h->N, h->P, h->nvb, (int64_t)ns, iter, nk};
     const uint64_t ids[2] = {h->seed, (uint64_t)h->chain};
     const double scal[4] = {varE, b, svE, sbb};
-    W("NGPSNAP1", 8); W(hdr, sizeof(hdr)); W(ids, sizeof(ids)); W(scal, sizeof(scal));
+    W("NGPSNAP2", 8); W(hdr, sizeof(hdr)); W(ids, sizeof(ids));
+    {   // model signature: a snapshot only loads into the model it was taken from (equal counts are not enough)
+        for (auto &hs : h->sets) { const int64_t sg[5] = {hs.method, hs.K, hs.nreg, hs.col0, hs.ncol}; W(sg, sizeof(sg)); }
+        const int64_t nfs = (int64_t)h->fix.size();
+        W(&nfs, 8);
+        for (auto &fx : h->fix) W(&fx.ncol, 8);
+    }
+    W(scal, sizeof(scal));
     W(yc.data(), N * 8); W(be.data(), P * 8); W(d8.data(), P); W(vb.data(), nvb * 8); W(pi.data(), 2 * ns * 8);
     W(sb.data(), P * 8); W(sb2.data(), P * 8); W(sd.data(), P * 8); W(sv.data(), nvb * 8); W(sp.data(), 2 * ns * 8);
     for (auto &hs : h->sets) W(&hs.fine_calls, 8);
@@ -1517,9 +1656,11 @@ int32_t ngp_save_snapshot(ngp_handle *h, const char *path) {
     if (fclose(f) != 0) ok = false;
     if (!ok || rename(tmp.c_str(), path) != 0) { remove(tmp.c_str()); return fail(h, NGP_ERR_ARG, std::string("writing the snapshot failed: ") + path); }
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_load_snapshot(ngp_handle *h, const char *path) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr && h->have_y, NGP_ERR_STATE, "panel / y not set (build the model first, then load the snapshot)");
@@ -1529,12 +1670,31 @@ int32_t ngp_load_snapshot(ngp_handle *h, const char *path) {
     bool ok = true;
     auto Rd = [&](void *p, size_t n) { if (n && fread(p, 1, n, f) != n) ok = false; };
     char magic[8]; int64_t hdr[6] = {0, 0, 0, 0, 0, 0}; uint64_t ids[2] = {0, 0}; double scal[4] = {0, 0, 0, 0};
-    Rd(magic, 8); Rd(hdr, sizeof(hdr)); Rd(ids, sizeof(ids)); Rd(scal, sizeof(scal));
-    if (!ok || memcmp(magic, "NGPSNAP1", 8) != 0) { fclose(f); return fail(h, NGP_ERR_ARG, "not a snapshot file (bad magic or truncated header)"); }
+    Rd(magic, 8); Rd(hdr, sizeof(hdr)); Rd(ids, sizeof(ids));
+    if (!ok || memcmp(magic, "NGPSNAP2", 8) != 0) { fclose(f); return fail(h, NGP_ERR_ARG, "not a snapshot file (bad magic or truncated header)"); }
     if (hdr[0] != h->N || hdr[1] != h->P || hdr[2] != h->nvb || hdr[3] != (int64_t)h->sets.size() || hdr[4] < 0 || hdr[5] < 0) {
         fclose(f);
         return fail(h, NGP_ERR_ARG, "snapshot does not match the model of this handle (N, P, variance components or marker sets differ)");
     }
+    {   // model signature
+        bool same = true;
+        for (auto &hs : h->sets) {
+            int64_t sg[5] = {-1, -1, -1, -1, -1};
+            Rd(sg, sizeof(sg));
+            same = same && sg[0] == hs.method && sg[1] == hs.K && sg[2] == hs.nreg && sg[3] == hs.col0 && sg[4] == hs.ncol;
+        }
+        int64_t nfs = -1;
+        Rd(&nfs, 8);
+        same = same && ok && nfs == (int64_t)h->fix.size();
+        if (same)
+            for (auto &fx : h->fix) { int64_t nc = -1; Rd(&nc, 8); same = same && nc == fx.ncol; }
+        if (!ok || !same) {
+            fclose(f);
+            return fail(h, NGP_ERR_ARG, "snapshot does not match the model of this handle (methods, classes, regions or fixed-effect sets differ)");
+        }
+    }
+    Rd(scal, sizeof(scal));
+    if (ok && !(std::isfinite(scal[0]) && (scal[0] > 0.0 || (scal[0] == 0.0 && hdr[4] == 0)))) { fclose(f); return fail(h, NGP_ERR_ARG, "snapshot holds an invalid residual variance"); }
     const size_t N = (size_t)h->N, P = (size_t)h->P, nvb = (size_t)h->nvb, ns = h->sets.size();
     std::vector<double> yc(N), be(P), vb(std::max<size_t>(nvb, 1)), pi(2 * std::max<size_t>(ns, 1)), sb(P), sb2(P), sd(P), sv(std::max<size_t>(nvb, 1)),
         sp(2 * std::max<size_t>(ns, 1));
@@ -1555,7 +1715,9 @@ int32_t ngp_load_snapshot(ngp_handle *h, const char *path) {
     if (!ok || !at_end) return fail(h, NGP_ERR_ARG, "snapshot file is truncated or has trailing bytes");
     std::vector<int64_t> de(P);
     for (size_t k = 0; k < P; k++) de[k] = d8[k];
-    if ((rc = ngp_set_state(h, yc.data(), be.data(), de.data(), vb.data(), pi.data(), scal[0], scal[1], hdr[4]))) return rc;
+    h->poisoned = true;  // until the whole restore has gone through: a failure half-way must not leave a mixed state behind as valid
+    if ((rc = ngp_set_state(h, yc.data(), be.data(), de.data(), vb.data(), pi.data(), scal[0], scal[1], hdr[4]))) { h->poisoned = true; return rc; }
+    h->poisoned = true;  // (ngp_set_state has just declared the state valid: not before the sums, fixed effects and classes are in)
     if ((rc = ngp_set_posterior_sums(h, sb.data(), sb2.data(), sd.data(), sv.data(), sp.data(), scal[2], scal[3], hdr[5]))) return rc;
     for (size_t si = 0; si < ns; si++) h->sets[si].fine_calls = fc[si];
     if (h->nfixcol > 0 && (rc = ngp_set_fixed(h, fb.data(), fs.data(), h->nfixcol))) return rc;
@@ -1569,10 +1731,13 @@ int32_t ngp_load_snapshot(ngp_handle *h, const char *path) {
             }
     }
     h->seed = ids[0]; h->chain = (uint32_t)ids[1];  // the draws continue the interrupted chain's streams
+    h->poisoned = false;
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_set_trace_loci(ngp_handle *h, const int64_t *loci, int64_t n, int64_t n_varBeta) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
@@ -1585,9 +1750,11 @@ int32_t ngp_set_trace_loci(ngp_handle *h, const int64_t *loci, int64_t n, int64_
     if ((rc = dalloc(h, &h->d_trace_loci, (size_t)std::max<int64_t>(n, 1)))) return rc;
     if (n) HCHK(hipMemcpy(h->d_trace_loci, loci, (size_t)n * sizeof(int64_t), hipMemcpyHostToDevice));
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_get_trace_ext(ngp_handle *h, double *beta_tr, double *varBeta_tr, double *pi_tr, int64_t n) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_trace_loci != nullptr, NGP_ERR_STATE, "no traces requested (ngp_set_trace_loci)");
@@ -1600,6 +1767,7 @@ int32_t ngp_get_trace_ext(ngp_handle *h, double *beta_tr, double *varBeta_tr, do
     if (varBeta_tr && h->ntvb) HCHK(hipMemcpy(varBeta_tr, h->d_tr_vb, (size_t)(n * h->ntvb) * sizeof(double), hipMemcpyDeviceToHost));
     if (pi_tr && !h->sets.empty()) HCHK(hipMemcpy(pi_tr, h->d_tr_pi, (size_t)n * h->sets.size() * sizeof(double), hipMemcpyDeviceToHost));
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 
@@ -1640,7 +1808,7 @@ int import_posterior_device(ngp_handle *h, const double *o) {  // inverse of ngp
     HCHK(hipMemcpyAsync(h->d_sum_beta2, o + h->P, pb, hipMemcpyDeviceToDevice, h->stream));
     HCHK(hipMemcpyAsync(h->d_sum_delta, o + 2 * h->P, pb, hipMemcpyDeviceToDevice, h->stream));
     if (h->nvb) HCHK(hipMemcpyAsync(h->d_sum_varBeta, o + 3 * h->P, (size_t)h->nvb * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
-    std::vector<double> tail(2 * h->sets.size() + (size_t)h->nclass_total + 3);
+    std::vector<double> tail(2 * h->sets.size() + (size_t)h->nclass_total + (size_t)h->nfixcol + 3);
     HCHK(hipMemcpyAsync(tail.data(), o + 3 * h->P + h->nvb, tail.size() * sizeof(double), hipMemcpyDeviceToHost, h->stream));
     HCHK(hipStreamSynchronize(h->stream));
     for (size_t si = 0; si < h->sets.size(); si++)
@@ -1654,9 +1822,11 @@ int import_posterior_device(ngp_handle *h, const double *o) {  // inverse of ngp
                 off += (size_t)h->sets[si].K;
             }
     }
+    const size_t tf = 2 * h->sets.size() + (size_t)h->nclass_total;
+    if (h->nfixcol > 0) HCHK(hipMemcpy(h->d_sum_bfix, tail.data() + tf, (size_t)h->nfixcol * sizeof(double), hipMemcpyHostToDevice));
     DScal sc;
     HCHK(hipMemcpy(&sc, h->d_scal, sizeof(DScal), hipMemcpyDeviceToHost));
-    const size_t t0 = 2 * h->sets.size() + (size_t)h->nclass_total;
+    const size_t t0 = tf + (size_t)h->nfixcol;
     sc.sum_varE = tail[t0]; sc.sum_b = tail[t0 + 1]; sc.nKept = (long long)std::llround(tail[t0 + 2]);
     HCHK(hipMemcpy(h->d_scal, &sc, sizeof(DScal), hipMemcpyHostToDevice));
     HCHK(hipStreamSynchronize(h->stream));
@@ -1665,6 +1835,7 @@ int import_posterior_device(ngp_handle *h, const double *o) {  // inverse of ngp
 }  // namespace
 
 int32_t ngp_run_many(ngp_handle **hs, int32_t n, int64_t niter) {
+    NGP_TRY
     if (!hs || n < 1) return fail(nullptr, NGP_ERR_ARG, "ngp_run_many: no handles");
     for (int i = 0; i < n; i++) {
         if (!hs[i]) return fail(nullptr, NGP_ERR_ARG, "ngp_run_many: null handle");
@@ -1674,17 +1845,23 @@ int32_t ngp_run_many(ngp_handle **hs, int32_t n, int64_t niter) {
     // one host thread per chain, as a caller would do it (src/samplers.jl:23: one chain per Julia task); the chains of a device run
     // side by side when their grids fit it together (ngp_set_max_shards), in turns otherwise (CuLease)
     std::vector<int32_t> rcs((size_t)n, NGP_OK);
-    std::vector<std::thread> th;
-    th.reserve((size_t)n);
-    for (int i = 1; i < n; i++) th.emplace_back([&, i] { rcs[(size_t)i] = ngp_run(hs[i], niter); });
+    struct Joiner {  // a std::thread constructor that throws (system_error) must not unwind past joinable threads
+        std::vector<std::thread> th;
+        ~Joiner() { for (auto &t : th) if (t.joinable()) t.join(); }
+    } jn;
+    jn.th.reserve((size_t)n);
+    // ngp_run is itself an entry point behind the exception barrier: nothing can leave a worker's lambda
+    for (int i = 1; i < n; i++) jn.th.emplace_back([&rcs, hs, niter, i]() noexcept { rcs[(size_t)i] = ngp_run(hs[i], niter); });
     rcs[0] = ngp_run(hs[0], niter);
-    for (auto &t : th) t.join();
+    for (auto &t : jn.th) t.join();
     for (int i = 0; i < n; i++)
         if (rcs[(size_t)i] != NGP_OK) return rcs[(size_t)i];  // the message is on that handle (ngp_last_error)
     return NGP_OK;
+    NGP_CATCH((hs ? hs[0] : nullptr))
 }
 
 int32_t ngp_allreduce_posterior(ngp_handle **hs, int32_t n) {
+    NGP_TRY
     if (!hs || n < 1) return fail(nullptr, NGP_ERR_ARG, "ngp_allreduce_posterior: no handles");
     for (int i = 0; i < n; i++)
         if (!hs[i]) return fail(nullptr, NGP_ERR_ARG, "ngp_allreduce_posterior: null handle");
@@ -1694,8 +1871,9 @@ int32_t ngp_allreduce_posterior(ngp_handle **hs, int32_t n) {
     if ((rc = ngp_posterior_len(h, &len))) return rc;
     for (int i = 0; i < n; i++) {
         REQUIRE(hs[i]->d_tiles != nullptr, NGP_ERR_STATE, "ngp_allreduce_posterior: a handle has no panel");
-        REQUIRE(hs[i]->P == h->P && hs[i]->nvb == h->nvb && hs[i]->sets.size() == h->sets.size(), NGP_ERR_ARG,
-                "ngp_allreduce_posterior: the chains do not share one model");
+        REQUIRE(hs[i]->P == h->P && hs[i]->nvb == h->nvb && hs[i]->sets.size() == h->sets.size() && hs[i]->nfixcol == h->nfixcol &&
+                    hs[i]->nclass_total == h->nclass_total,
+                NGP_ERR_ARG, "ngp_allreduce_posterior: the chains do not share one model");
         for (int k = 0; k < i; k++) REQUIRE(hs[k] != hs[i], NGP_ERR_ARG, "ngp_allreduce_posterior: a handle is listed twice");
     }
     std::vector<double *> buf((size_t)n, nullptr);
@@ -1749,6 +1927,7 @@ int32_t ngp_allreduce_posterior(ngp_handle **hs, int32_t n) {
     }
     cleanup();
     return NGP_OK;
+    NGP_CATCH((hs ? hs[0] : nullptr))
 }
 
 
@@ -1758,6 +1937,7 @@ int32_t ngp_allreduce_posterior(ngp_handle **hs, int32_t n) {
  * counted from 1 as the reference writes it. */
 int32_t ngp_add_marker_set_r(ngp_handle *h, int64_t col0, int64_t ncol, double df, double scale, double varBeta0, const double *vClass,
                              const double *pi, int32_t K, int32_t estPi, const double *lhs0, const double *rhs0, int32_t *set_id) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
@@ -1790,9 +1970,11 @@ int32_t ngp_add_marker_set_r(ngp_handle *h, int64_t col0, int64_t ncol, double d
     h->nclass_total += K;
     if (set_id) *set_id = sid;
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_get_class_state(ngp_handle *h, int32_t set_id, double *piHat, double *sum_pi, int64_t *K) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(set_id >= 0 && set_id < (int)h->sets.size(), NGP_ERR_ARG, "unknown set id");
@@ -1805,15 +1987,18 @@ int32_t ngp_get_class_state(ngp_handle *h, int32_t set_id, double *piHat, double
         if (sum_pi) sum_pi[v] = ds.sum_pic[v];
     }
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_set_class_state(ngp_handle *h, int32_t set_id, const double *piHat, const double *sum_pi, int64_t K) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(set_id >= 0 && set_id < (int)h->sets.size(), NGP_ERR_ARG, "unknown set id");
     REQUIRE(h->sets[(size_t)set_id].K > 0 && K == h->sets[(size_t)set_id].K, NGP_ERR_ARG, "not a BayesR set, or another number of classes");
     if (piHat) for (int64_t v = 0; v < K; v++) REQUIRE(std::isfinite(piHat[v]) && piHat[v] > 0.0, NGP_ERR_ARG, "class probabilities must be > 0");
     return set_class_state_dev(h, set_id, piHat, sum_pi);
+    NGP_CATCH(h)
 }
 
 
@@ -1824,6 +2009,7 @@ int32_t ngp_set_class_state(ngp_handle *h, int32_t set_id, const double *piHat, 
  * several: sampleb! (src/functions.jl:22-36), Gauss-Seidel over X'X + min|diag| / 10000 (src/mme.jl:149-152). */
 int32_t ngp_add_fixed_set(ngp_handle *h, const double *X, int64_t N, int64_t ncol, int64_t ld, const double *lhs0, const double *rhs0,
                           int32_t *set_id) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
@@ -1876,9 +2062,11 @@ int32_t ngp_add_fixed_set(ngp_handle *h, const double *X, int64_t N, int64_t nco
     if (set_id) *set_id = (int32_t)h->fix.size();
     h->fix.push_back(fx);
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_get_fixed(ngp_handle *h, double *b, double *sum_b, int64_t *ncols_total) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     if (ncols_total) *ncols_total = h->nfixcol;
@@ -1887,9 +2075,11 @@ int32_t ngp_get_fixed(ngp_handle *h, double *b, double *sum_b, int64_t *ncols_to
     if (b) HCHK(hipMemcpy(b, h->d_bfix, (size_t)h->nfixcol * sizeof(double), hipMemcpyDeviceToHost));
     if (sum_b) HCHK(hipMemcpy(sum_b, h->d_sum_bfix, (size_t)h->nfixcol * sizeof(double), hipMemcpyDeviceToHost));
     return NGP_OK;
+    NGP_CATCH(h)
 }
 
 int32_t ngp_set_fixed(ngp_handle *h, const double *b, const double *sum_b, int64_t ncols_total) {
+    NGP_TRY
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(ncols_total == h->nfixcol, NGP_ERR_ARG, "fixed-effect column count mismatch");
@@ -1898,6 +2088,19 @@ int32_t ngp_set_fixed(ngp_handle *h, const double *b, const double *sum_b, int64
     if (b) HCHK(hipMemcpy(h->d_bfix, b, (size_t)h->nfixcol * sizeof(double), hipMemcpyHostToDevice));
     if (sum_b) HCHK(hipMemcpy(h->d_sum_bfix, sum_b, (size_t)h->nfixcol * sizeof(double), hipMemcpyHostToDevice));
     return NGP_OK;
+    NGP_CATCH(h)
+}
+
+/* Test hook of the exception barrier (tests/test_abi.py): throws inside an entry point, past the same NGP_TRY / NGP_CATCH every
+ * other one runs in.  kind 0: std::bad_alloc, 1: std::length_error (a std::vector asked for more than max_size), 2: a
+ * non-standard exception.  h may be NULL (the message then goes where ngp_create's go).  Never returns NGP_OK. */
+int32_t ngp_debug_throw(ngp_handle *h, int32_t kind) {
+    NGP_TRY
+    if (kind == 0) throw std::bad_alloc();
+    if (kind == 1) { std::vector<double> v; v.resize(v.max_size() + 1); }
+    if (kind == 2) throw 42;
+    return fail(h, NGP_ERR_ARG, "ngp_debug_throw: kind must be 0, 1 or 2");
+    NGP_CATCH(h)
 }
 
 }  // extern "C"

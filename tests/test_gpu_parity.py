@@ -465,6 +465,31 @@ def test_export_posterior_device_equals_packed_host_sums(ngp, O):
     torch.cuda.synchronize()
     exp = ngp.multichain.pack_posterior(s.get_posterior_sums(), s.P, s.nvb, s.nsets)
     assert np.array_equal(buf.cpu().numpy(), exp)
+    # with a BayesR set and a fixed-effect set: their sums travel in the packed vector too
+    s, X, y, v = _model_with_fixed_and_classes(ngp, O, seed=3)
+    s.set_schedule(12, 2, 2); s.run(12)
+    n = s.posterior_len()
+    buf = torch.zeros(n, device="cuda", dtype=torch.float64)
+    s.export_posterior_device(buf.data_ptr(), n)
+    torch.cuda.synchronize()
+    exp = ngp.multichain.pack_posterior(s.get_posterior_sums(), s.P, s.nvb, s.nsets, class_sums=s.get_class_state(1)["sum_pi"],
+                                        fixed_sums=s.get_fixed()["sum_b"])
+    assert n == len(exp) == ngp.multichain.posterior_len(s.P, s.nvb, s.nsets, 4, 2)
+    assert np.array_equal(buf.cpu().numpy(), exp)
+    m = ngp.multichain.unpack_means(exp, s.P, s.nvb, s.nsets, 4, 2)
+    assert np.array_equal(m["b_fixed"], s.get_fixed()["sum_b"] / 5) and m["nKept"] == 5
+
+
+def _model_with_fixed_and_classes(ngp, O, seed):
+    """BayesPR set + BayesR set + a two-column fixed-effect block (beyond the intercept)."""
+    N, P = 200, 192
+    X, y, bt, v = make_problem(O, N, P, seed=4)
+    s = ngp.Sampler(device=0, seed=seed, chain=0)
+    s.set_panel(X); add_sets(s, [(0, 100, "PR"), (100, 92, "R")], v)
+    rng = np.random.default_rng(77)
+    s.add_fixed_set(rng.normal(size=(N, 2)))
+    s.set_y(y); s.set_residual_prior(4.0, 1.0)
+    return s, X, y, v
 
 
 def test_allreduce_posterior_pools_chains_inside_the_library(ngp, O):
@@ -483,6 +508,21 @@ def test_allreduce_posterior_pools_chains_inside_the_library(ngp, O):
         for k in ("sum_beta", "sum_beta2", "sum_delta", "sum_varBeta", "sum_pi"):
             assert np.array_equal(p[k], (sums[0][k] + sums[1][k]) + sums[2][k]), k
         assert p["sum_varE"] == (sums[0]["sum_varE"] + sums[1]["sum_varE"]) + sums[2]["sum_varE"]
+    # fixed-effect sums and BayesR class sums are pooled with the rest (every handle ends with the pooled nKept, so a caller that
+    # divides ngp_get_fixed's sum_b by nKept -- runLMEM does -- needs them pooled too)
+    chains, fx, cl = [], [], []
+    for c in range(3):
+        s, *_ = _model_with_fixed_and_classes(ngp, O, seed=2001 + c)
+        s.set_schedule(10, 2, 2); s.run(10)
+        chains.append(s); fx.append(s.get_fixed()["sum_b"]); cl.append(s.get_class_state(1)["sum_pi"])
+    ngp.Sampler.allreduce_posterior(chains)
+    for s in chains:
+        assert s.get_posterior_sums()["nKept"] == 12
+        assert np.array_equal(s.get_fixed()["sum_b"], (fx[0] + fx[1]) + fx[2])
+        assert np.array_equal(s.get_class_state(1)["sum_pi"], (cl[0] + cl[1]) + cl[2])
+    other, *_ = _small_model(ngp, O, seed=9)                  # another model (no fixed set, no classes) is refused
+    with pytest.raises(ngp.NextGPHipError, match="do not share one model"):
+        ngp.Sampler.allreduce_posterior([chains[0], other])
     single, *_ = _small_model(ngp, O, seed=5)                 # n = 1 is the identity
     single.set_schedule(4, 0, 1); single.run(4)
     before = single.get_posterior_sums()
@@ -522,7 +562,9 @@ def test_diagnostic_mode_is_explicit_and_flagged(ngp, O):
     c.debug_set_mode(0)
     c.set_y(y)                                               # a fresh, valid chain again
     c.run(2)
-    assert np.array_equal(c.get_state()["beta"], _small_model(ngp, O)[0].get_state()["beta"]) is False or True
+    ref, *_ = _small_model(ngp, O)                           # ... bit for bit the chain a handle that never saw the mode draws
+    ref.run(2)
+    assert np.array_equal(c.get_state()["beta"], ref.get_state()["beta"]) and c.get_state()["varE"] == ref.get_state()["varE"]
 
 
 @pytest.mark.parametrize("engine", [(0, 1), (1, 6), (1, 4, 3, 2)], ids=["blocklaunch", "persist_lag6", "rows_lag4"])

@@ -16,8 +16,10 @@ def test_parse_formula(ngp):
     for bad in ("y ~ 1 + x1&x2 + SNP(M,\"g\")", "y ~ 1 + PED(ID) + SNP(M,\"g\")", "y ~ 1 + (1|herd) + SNP(M,\"g\")"):
         with pytest.raises(NotImplementedError, match="Julia path"):
             ngp.parse_formula(bad)
-    ngp.parse_formula('y ~ 1 + age + herd + SNP(M,"g")')
-    assert ngp.parse_formula.last_covariates == ["age", "herd"]      # covariates / factors: fixed-effect sets on the device
+    first = ngp.parse_formula('y ~ 1 + age + herd + SNP(M,"g")')
+    second = ngp.parse_formula('y ~ 1 + SNP(M,"g")')                  # a later parse does not change what an earlier one returned
+    assert first.covariates == ["age", "herd"] and second.covariates == []   # covariates / factors: fixed-effect sets on the device
+    assert not hasattr(ngp.parse_formula, "last_covariates")
     Xd, names = ngp.design_columns("herd", np.array(["a", "c", "b", "a"]))
     assert names == ["herd: b", "herd: c"] and np.array_equal(Xd, [[0, 0], [0, 1], [1, 0], [0, 0]])
     Xc, _ = ngp.design_columns("age", np.array([1.0, 2.0, 6.0]))
