@@ -258,6 +258,19 @@ int32_t ngp_allreduce_posterior(ngp_handle **hs, int32_t n);
  * turns otherwise.  Every chain is bit for bit what it is alone.  Returns the first non-zero status (message on that handle). */
 int32_t ngp_run_many(ngp_handle **hs, int32_t n, int64_t niter);
 
+/* Placement census of the last persistent-sweep launch: out[b] = (XCC id + 1) << 32 | HW_REG_HW_ID of workgroup b (0: never resident),
+ * n >= *grid entries.  Every launch of the persistent kernel opens with a census of its own grid (all of its workgroups wait for
+ * each other, so all must be resident at once); a launch whose grid is not complete within 20 ms ends before any role has touched
+ * the chain, and the call runs it again with the whole device leased (the chains of one process then take turns) -- *retries counts
+ * those, *exclusive says whether this handle now always leases the whole device.  Any pointer may be NULL. */
+int32_t ngp_get_census(ngp_handle *h, uint64_t *out, int64_t n, int64_t *grid, int64_t *retries, int32_t *exclusive);
+/* Test hook of that fallback: the sweep of iteration `iteration` (counted as ngp_get_state's iter) closes its own census as timed
+ * out, once; the call must resume it and end bit for bit where an undisturbed chain ends.  0 = off. */
+int32_t ngp_debug_fail_census(ngp_handle *h, int64_t iteration);
+/* Test hook of ngp_allreduce_posterior: group this handle under virtual device vdev (-1: its real device).  Handles of ONE GPU with
+ * different virtual devices then take the multi-device branch (leaders, packing, unpacking); the collective itself is a sum on that
+ * GPU instead of ncclAllReduce. */
+int32_t ngp_debug_set_virtual_device(ngp_handle *h, int32_t vdev);
 /* Test hook of the exception barrier: throws a C++ exception inside an entry point (kind 0 std::bad_alloc, 1 std::length_error,
  * 2 a non-standard one); what comes back is a negative status and a message -- never an unwind into the caller.  h may be NULL. */
 int32_t ngp_debug_throw(ngp_handle *h, int32_t kind);

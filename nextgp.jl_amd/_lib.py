@@ -22,7 +22,7 @@ SYMBOLS = [
     "ngp_get_trace", "ngp_get_posterior_sums", "ngp_posterior_len", "ngp_export_posterior_device", "ngp_sweep_set",
     "ngp_get_timing", "ngp_profile_iteration", "ngp_draws_indexed", "ngp_eval_math", "ngp_configure", "ngp_get_config", "ngp_debug_stamps", "ngp_set_near_lags", "ngp_get_near_lags",
     "ngp_set_streamer", "ngp_get_streamer", "ngp_set_storage", "ngp_get_storage", "ngp_set_max_shards", "ngp_shards_for_chains", "ngp_run_many", "ngp_write_panel_file", "ngp_read_panel_header", "ngp_load_panel_file", "ngp_debug_set_mode", "ngp_debug_set_knob", "ngp_set_posterior_sums", "ngp_save_snapshot", "ngp_load_snapshot",
-    "ngp_set_trace_loci", "ngp_get_trace_ext", "ngp_allreduce_posterior", "ngp_add_marker_set_r", "ngp_get_class_state", "ngp_set_class_state", "ngp_add_fixed_set", "ngp_get_fixed", "ngp_set_fixed", "ngp_debug_throw",
+    "ngp_set_trace_loci", "ngp_get_trace_ext", "ngp_allreduce_posterior", "ngp_add_marker_set_r", "ngp_get_class_state", "ngp_set_class_state", "ngp_add_fixed_set", "ngp_get_fixed", "ngp_set_fixed", "ngp_debug_throw", "ngp_get_census", "ngp_debug_set_virtual_device", "ngp_debug_fail_census",
 ]
 
 _lib = None
@@ -374,6 +374,22 @@ class Sampler:
         bt = np.empty((n, max(self.ntl, 1))); vt = np.empty((n, max(self.ntvb, 1))); pt = np.empty((n, max(self.nsets, 1)))
         self._chk(self.L.ngp_get_trace_ext(self.h, _p(bt, C.c_double), _p(vt, C.c_double), _p(pt, C.c_double), C.c_int64(n)))
         return dict(beta=bt[:, :self.ntl], varBeta=vt[:, :self.ntvb], pi=pt[:, :self.nsets])
+
+    def census(self):
+        """Placement of the workgroups of the last persistent-sweep launch (ngp_get_census): dict(grid, retries, exclusive,
+        xcc[grid] (0-7, -1 = never resident), hw_id[grid])."""
+        g, r, e = C.c_int64(), C.c_int64(), C.c_int32()
+        self._chk(self.L.ngp_get_census(self.h, None, C.c_int64(0), C.byref(g), C.byref(r), C.byref(e)))
+        tb = np.zeros(g.value, dtype=np.uint64)
+        self._chk(self.L.ngp_get_census(self.h, _p(tb, C.c_uint64), C.c_int64(g.value), None, None, None))
+        return dict(grid=g.value, retries=r.value, exclusive=bool(e.value), xcc=(tb >> np.uint64(32)).astype(np.int64) - 1,
+                    hw_id=(tb & np.uint64(0xFFFFFFFF)).astype(np.int64))
+
+    def debug_fail_census(self, iteration):
+        self._chk(self.L.ngp_debug_fail_census(self.h, C.c_int64(iteration)))
+
+    def debug_set_virtual_device(self, vdev):
+        self._chk(self.L.ngp_debug_set_virtual_device(self.h, C.c_int32(vdev)))
 
     @staticmethod
     def allreduce_posterior(samplers):

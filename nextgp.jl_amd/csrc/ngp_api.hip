@@ -126,6 +126,12 @@ struct ngp_handle {
     int knob = 0;  // pacing of the loader wave of the row-owning streamer: s_sleep units after every four requests (ngp_debug_set_knob)
     bool adding_r = false;  // ngp_add_marker_set is being called by ngp_add_marker_set_r
     bool poisoned = false;  // a sweep gave up half-way (abort word): the chain state is unusable until ngp_set_y / ngp_set_state
+    bool exclusive = false;  // a grid of this handle was once not co-resident beside other chains' grids: its calls now lease the whole device
+    int64_t census_retries = 0;  // launches that ended at the census and were run again with the device to themselves
+    int64_t dbg_census_fail_iter = 0;  // ngp_debug_fail_census: the sweep of this iteration ends at its census (once)
+    int vdev = -1;           // ngp_debug_set_virtual_device: the device ngp_allreduce_posterior groups this handle under (-1: the real one)
+    unsigned long long *d_census_tbl = nullptr;  // placement of the workgroups of the last sweep launch (inside d_ccnt)
+    size_t census_off = 0;   // word offset of the census counters inside d_ccnt
     // optional per-iteration traces of selected effects, variances and pi (ngp_set_trace_loci)
     int64_t *d_trace_loci = nullptr;
     int64_t ntl = 0, ntvb = 0;
@@ -187,22 +193,32 @@ struct CuLease {
     static std::mutex &mu() { static std::mutex m; return m; }
     static std::condition_variable &cv() { static std::condition_variable c; return c; }
     static int *in_use() { static int u[64] = {0}; return u; }
-    int dev = -1, n = 0;
+    int dev = -1, n = 0, cap = 0, want = 0;
+    bool excl = false;
     CuLease(ngp_handle *h) {
         if (h->mode != 1) return;
         // workgroups are handed to the 8 XCDs in turn, so a grid occupies ceil(grid / 8) CUs of EVERY XCD: the unit of the lease
         // (three grids of 85 workgroups -- 255 of 256 CUs -- do not fit: 3 x 11 > 32 per XCD; measured, they wait for each other)
-        dev = h->device & 63; n = (int)((1 + h->NG + h->S + 7) / 8);
-        const int cap = std::max(1, h->cu_count / 8);
+        dev = h->device & 63; want = (int)((1 + h->NG + h->S + 7) / 8);
+        cap = std::max(1, h->cu_count / 8);
+        acquire(h->exclusive);
+    }
+    void acquire(bool exclusive) {
+        if (dev < 0) return;
+        excl = exclusive; n = exclusive ? cap : want;  // exclusive: the whole device, i.e. nobody else's sweep beside this call's
         std::unique_lock<std::mutex> lk(mu());
         cv().wait(lk, [&] { return in_use()[dev] == 0 || in_use()[dev] + n <= cap; });
         in_use()[dev] += n;
     }
-    ~CuLease() {
-        if (dev < 0) return;
+    void release() {
+        if (dev < 0 || n == 0) return;
         { std::lock_guard<std::mutex> lk(mu()); in_use()[dev] -= n; }
+        n = 0;
         cv().notify_all();
     }
+    // the count fitted and the grids still were not all resident (census): give the share back and wait for the device to be free
+    void make_exclusive() { release(); acquire(true); }
+    ~CuLease() { release(); }
 };
 
 int enter(ngp_handle *h) {
@@ -370,10 +386,13 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
         if ((rc = dalloc(h, &h->d_cgsum, (size_t)NGP_RING * h->NG * NGP_BLK))) return rc;
         if ((rc = dalloc(h, &h->d_cdlt, (size_t)NGP_RING * NGP_BLK))) return rc;
         if ((rc = dalloc(h, &h->d_cdltg, (size_t)NGP_RING * NGP_BLK * 2))) return rc;
-        h->ccnt_words = (size_t)NGP_RING * h->NG * 32 + (size_t)NGP_RING * 32 + 32;
+        // hand-off counters | census counters (one line) | census table (placement of each workgroup, 2 words each); all zeroed by k_prep
+        h->census_off = (size_t)NGP_RING * h->NG * 32 + (size_t)NGP_RING * 32 + 32;
+        h->ccnt_words = h->census_off + 32 + 2 * (size_t)(1 + h->NG + h->S);
         if ((rc = dalloc(h, &h->d_ccnt, h->ccnt_words))) return rc;
-        if ((rc = dalloc(h, &h->d_abort, 32))) return rc;
+        h->d_census_tbl = (unsigned long long *)(h->d_ccnt + h->census_off + 32);
     }
+    if ((rc = dalloc(h, &h->d_abort, 32))) return rc;
     HCHK(hipStreamSynchronize(h->stream));
     return NGP_OK;
 }
@@ -507,6 +526,9 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
         A.nonce = h->launch_seq;
         A.cnt_part = h->d_ccnt; A.cnt_gs = h->d_ccnt + (size_t)NGP_RING * h->NG * 32;
         A.flag_dlt = A.cnt_gs + (size_t)NGP_RING * 32; A.abort_w = h->d_abort; A.xcc_w = h->d_abort + 16;
+        A.census = (h->dbg_mode == 0) ? h->d_ccnt + h->census_off : nullptr;  // timing modes leave roles out: no census there
+        A.census_tbl = h->d_census_tbl; A.iter_tag = (unsigned)(h->iter + 1);
+        A.census_fail = (h->dbg_census_fail_iter > 0 && !h->exclusive) ? (unsigned)h->dbg_census_fail_iter : 0u;
         if (evs) (void)hipEventRecord(evs[0], h->stream);
         A.dbg = h->d_dbg;
         A.fine_ok = ((size_t)2 * (R / 4) * NGP_QS + (size_t)R * 80 + 8320 + 8192 <= h->lds_sweep) ? 1 : 0;  // diagnostic timeline fits in LDS
@@ -537,47 +559,87 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
     h->sweep_launches += 2 * (tb1 - tb0) + 1;
 }
 
-int check_abort(ngp_handle *h) {
-    if (h->mode != 1) return NGP_OK;
-    unsigned code = 0;
-    HCHK(hipMemcpy(&code, h->d_abort, sizeof(unsigned), hipMemcpyDeviceToHost));
-    if (code != 0) {
-        (void)hipMemset(h->d_abort, 0, sizeof(unsigned));
-        h->poisoned = true;  // ycorr / beta were left half-way through a sweep
-        return fail(h, NGP_ERR_HIP, "persistent sweep kernel gave up waiting (role code " + std::to_string(code) +
-                                        "): workgroups not co-resident (another kernel holding CUs?) or a hand-off was lost; the chain "
-                                        "state is invalid until ngp_set_y / ngp_set_state");
+// placement census of the last sweep launch (SweepArgs.census_tbl): who arrived, and where
+std::string census_report(ngp_handle *h) {
+    const size_t grid = (size_t)(1 + h->NG + h->S);
+    std::vector<unsigned long long> tb(grid, 0ull);
+    if (!h->d_census_tbl || hipMemcpy(tb.data(), h->d_census_tbl, grid * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return "(no census)";
+    int per_xcc[16] = {0}, per_se[16][8] = {{0}};
+    size_t arrived = 0;
+    std::string missing;
+    for (size_t b = 0; b < grid; b++) {
+        if (tb[b] == 0ull) { if (missing.size() < 120) missing += (missing.empty() ? "" : ",") + std::to_string(b); continue; }
+        arrived++;
+        const unsigned x = ((unsigned)(tb[b] >> 32) - 1u) & 15u, hw = (unsigned)tb[b];
+        per_xcc[x]++; per_se[x][(hw >> 13) & 7u]++;  // HW_REG_HW_ID: cu_id [11:8], sh_id [12], se_id [15:13]
     }
-    return NGP_OK;
+    std::string r = std::to_string(arrived) + " of " + std::to_string(grid) + " workgroups resident; per XCD";
+    for (int x = 0; x < 8; x++) {
+        r += " " + std::to_string(per_xcc[x]) + "(";
+        for (int e = 0; e < 4; e++) r += (e ? "/" : "") + std::to_string(per_se[x][e]);
+        r += ")";
+    }
+    if (!missing.empty()) r += "; missing blocks " + missing;
+    return r;
+}
+
+// status of the sweeps launched so far: NGP_OK, NGP_RETRY_CENSUS (a launch ended at its census with nothing changed: *iter_failed
+// says which iteration; the abort words are cleared, the caller runs it again with the device to itself) or an error (poisoned)
+#define NGP_RETRY_CENSUS 1
+int check_abort(ngp_handle *h, int64_t *iter_failed = nullptr) {
+    if (h->mode != 1) return NGP_OK;
+    unsigned w[2] = {0, 0};
+    HCHK(hipMemcpy(w, h->d_abort, sizeof(w), hipMemcpyDeviceToHost));
+    if (w[0] == 0) return NGP_OK;
+    (void)hipMemset(h->d_abort, 0, sizeof(w));
+    if (w[0] == NGP_ABORT_CENSUS && iter_failed && !h->exclusive) {
+        // iter_tag holds the low 32 bits of the iteration: the launches in flight are at most 16 iterations ahead of it
+        const int64_t base = (h->iter + 1) & ~(int64_t)0xFFFFFFFF;
+        int64_t it = base | (int64_t)w[1];
+        if (it > h->iter + 1) it -= ((int64_t)1 << 32);
+        *iter_failed = it;
+        return NGP_RETRY_CENSUS;
+    }
+    h->poisoned = true;  // ycorr / beta were left half-way through a sweep (or a grid was not resident even alone on the device)
+    if (w[0] == NGP_ABORT_CENSUS)
+        return fail(h, NGP_ERR_HIP, "persistent sweep: the grid did not become resident although this call had leased the whole device (" +
+                                        census_report(h) + "): another process holding CUs?  The chain state is invalid until ngp_set_y / ngp_set_state");
+    return fail(h, NGP_ERR_HIP, "persistent sweep kernel gave up waiting (role code " + std::to_string(w[0]) +
+                                    "): workgroups not co-resident (another kernel holding CUs?) or a hand-off was lost; the chain "
+                                    "state is invalid until ngp_set_y / ngp_set_state");
 }
 
 void launch_variance(ngp_handle *h, int active_set, uint64_t it) {
     const long long nseg = (long long)h->h_seg_k0.size(), nreg = (long long)h->h_regs.size();
     if (nseg > 0) {
         hipLaunchKernelGGL(k_regssq, dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, h->stream, nseg, h->d_seg_k0, h->d_seg_len,
-                           h->d_beta, h->d_segpart);
+                           h->d_beta, h->d_segpart, h->d_abort);
         if (h->nclass_total > 0)
             hipLaunchKernelGGL(k_rssq, dim3((unsigned)((nseg + 3) / 4)), dim3(256), 0, h->stream, nseg, h->d_seg_k0, h->d_seg_len, h->d_seg_set,
-                               h->d_sets, h->d_beta, h->d_delta, h->d_segpart);
+                               h->d_sets, h->d_beta, h->d_delta, h->d_segpart, h->d_abort);
         hipLaunchKernelGGL(k_regdraw, dim3((unsigned)((nreg + 63) / 64)), dim3(64), 0, h->stream, nreg, h->d_regs, h->d_segpart,
-                           h->d_sets, h->d_varBeta, active_set, h->d_regchi, h->seed, (uint64_t)h->chain, it);
+                           h->d_sets, h->d_varBeta, active_set, h->d_regchi, h->seed, (uint64_t)h->chain, it, h->d_abort);
     }
     hipLaunchKernelGGL(k_pidraw, dim3(1), dim3(64), 0, h->stream, (int)h->sets.size(), h->d_sets, active_set, h->seed,
-                       (uint64_t)h->chain, it);
+                       (uint64_t)h->chain, it, h->d_abort);
 }
 
-int one_iteration(ngp_handle *h, int64_t trace_idx, hipEvent_t *evs) {
+// resume_mid: the head of this iteration (varE, intercept, fixed-effect sets) has run already -- its sweep ended at the census
+// with nothing changed and is launched again, k_prep first (it redraws the same keyed numbers and clears the hand-off counters)
+int one_iteration(ngp_handle *h, int64_t trace_idx, hipEvent_t *evs, bool resume_mid = false) {
     const uint64_t it = (uint64_t)(h->iter + 1);
+    if (!resume_mid) {
     hipLaunchKernelGGL(k_head, dim3(1), dim3(1024), 0, h->stream, h->d_ycorr, (long long)h->L, (long long)h->N, h->d_scal, h->e_df,
-                       h->e_scale, h->intercept, 1, h->seed, (uint64_t)h->chain, it, h->d_tr_varE, h->d_tr_b, (long long)trace_idx);
+                       h->e_scale, h->intercept, 1, h->seed, (uint64_t)h->chain, it, h->d_tr_varE, h->d_tr_b, (long long)trace_idx, h->d_abort);
     for (size_t f = 0; f < h->fix.size(); f++)  // the other fixed-effect sets, in the order they were added (src/samplers.jl:39-41)
         hipLaunchKernelGGL(k_fixed, dim3(1), dim3(1024), 0, h->stream, h->d_ycorr, (long long)h->N, h->fix[f].d_X, (int)h->fix[f].ncol, h->fix[f].d_xpx0,
                            h->fix[f].d_xpxR, h->fix[f].d_lhs0, h->fix[f].d_rhs0, h->d_bfix + h->fix[f].off, h->d_scal, (int)f, h->seed,
-                           (uint64_t)h->chain, it);
+                           (uint64_t)h->chain, it, h->d_abort);
+    }
     hipLaunchKernelGGL(k_prep, dim3((unsigned)(h->Ppad / 256 + 1)), dim3(256), 0, h->stream, (long long)h->Ppad, h->d_setof, h->d_loc,
                        h->d_vbidx, h->d_sets, h->d_scal, h->d_varBeta, h->d_mpm, h->d_lhs0, h->d_rhs0, h->d_beta, h->d_c, h->d_w,
                        h->d_q, h->d_T, h->d_chi, -1, h->seed, (uint64_t)h->chain, it, (long long)h->h_regs.size(), h->d_regs, h->d_regchi, h->d_rcls,
-                       h->d_ccnt, (long long)(h->mode == 1 ? h->ccnt_words : 0));
+                       h->d_ccnt, (long long)(h->mode == 1 ? h->ccnt_words : 0), h->d_abort);
     launch_sweep(h, 0, h->NBLK, evs);
     launch_variance(h, -1, it);
     h->iter += 1;
@@ -589,12 +651,42 @@ int one_iteration(ngp_handle *h, int64_t trace_idx, hipEvent_t *evs) {
         hipLaunchKernelGGL(k_post, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, (int)do_accum, (long long)h->P, (long long)h->nvb,
                            (int)h->sets.size(), h->d_beta, h->d_delta, h->d_varBeta, h->d_sum_beta, h->d_sum_beta2, h->d_sum_delta,
                            h->d_sum_varBeta, h->d_sets, h->d_scal, (int)do_trace, (long long)h->ntl, (const long long *)h->d_trace_loci,
-                           (long long)h->ntvb, h->d_tr_beta, h->d_tr_vb, h->d_tr_pi, (long long)trace_idx);
+                           (long long)h->ntvb, h->d_tr_beta, h->d_tr_vb, h->d_tr_pi, (long long)trace_idx, h->d_abort);
     }
     if (do_accum) {
         if (h->nfixcol > 0)
             hipLaunchKernelGGL(k_accum_fixed, dim3((unsigned)((h->nfixcol + 255) / 256)), dim3(256), 0, h->stream, (long long)h->nfixcol, h->d_bfix,
-                               h->d_sum_bfix);
+                               h->d_sum_bfix, h->d_abort);
+    }
+    return NGP_OK;
+}
+
+// niter iterations from the handle's current state under `lease`, the launch queue bounded to 16 iterations; a launch that ends at
+// its census (grid not co-resident beside another chain's, nothing changed) is run again once the device is this call's alone
+int run_iterations(ngp_handle *h, int64_t niter, CuLease &lease, hipEvent_t *evs_first) {
+    int rc;
+    const int64_t iter0 = h->iter;
+    bool resume_mid = false;
+    int64_t n = 0;
+    while (n < niter) {
+        if ((rc = one_iteration(h, n, (n == 0) ? evs_first : nullptr, resume_mid))) return rc;
+        resume_mid = false;
+        ++n;
+        if ((n & 15) == 0 || n == niter) {  // bound the launch queue
+            HCHK(hipStreamSynchronize(h->stream));
+            int64_t itf = 0;
+            rc = check_abort(h, &itf);
+            if (rc == NGP_RETRY_CENSUS) {
+                // kernels behind the failing launch returned at once (abort word): the chain stands at iteration itf, head done
+                h->exclusive = true; h->census_retries += 1;
+                lease.make_exclusive();
+                h->iter = itf - 1;
+                n = h->iter - iter0;
+                resume_mid = true;
+                continue;
+            }
+            if (rc) return rc;
+        }
     }
     return NGP_OK;
 }
@@ -1129,17 +1221,10 @@ int32_t ngp_run(ngp_handle *h, int64_t niter) {
     h->ntrace = niter;
     CuLease lease(h);
     HCHK(hipEventRecord(h->ev0, h->stream));
-    for (int64_t n = 0; n < niter; n++) {
-        if ((rc = one_iteration(h, n, nullptr))) return rc;
-        if ((n & 15) == 15) {  // bound the launch queue
-            HCHK(hipStreamSynchronize(h->stream));
-            if ((rc = check_abort(h))) return rc;
-        }
-    }
+    if ((rc = run_iterations(h, niter, lease, nullptr))) return rc;
     HCHK(hipEventRecord(h->ev1, h->stream));
     HCHK(hipStreamSynchronize(h->stream));
     HCHK(hipGetLastError());
-    if ((rc = check_abort(h))) return rc;
     float ms = 0.f;
     HCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->iter_ms += ms; h->iters_timed += niter;
@@ -1300,27 +1385,37 @@ int32_t ngp_sweep_set(ngp_handle *h, int32_t set_id, double varE, double *ycorr,
     for (int64_t r = 0; r < hs.nreg; r++) REQUIRE(std::isfinite(varBeta[r]) && varBeta[r] >= 0.0, NGP_ERR_ARG, "varBeta must be finite, >= 0");
     if (hs.method != NGP_METHOD_BAYESPR) REQUIRE(piHat != nullptr, NGP_ERR_ARG, "BayesB / BayesC need piHat");
     const uint64_t it = ++hs.fine_calls;
-    HCHK(hipMemsetAsync(h->d_ycorr, 0, (size_t)h->L * sizeof(double), h->stream));
-    HCHK(hipMemcpyAsync(h->d_ycorr, ycorr, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HCHK(hipMemcpyAsync(h->d_beta + hs.col0, beta, (size_t)hs.ncol * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    HCHK(hipMemcpyAsync(h->d_varBeta + hs.vb_off, varBeta, (size_t)hs.nreg * sizeof(double), hipMemcpyHostToDevice, h->stream));
-    if (hs.method != NGP_METHOD_BAYESPR)
-        hipLaunchKernelGGL(k_set_pi, dim3(1), dim3(1), 0, h->stream, h->d_sets, (int)set_id, piHat[0], piHat[1]);
-    hipLaunchKernelGGL(k_set_varE, dim3(1), dim3(1), 0, h->stream, h->d_scal, varE);
-    hipLaunchKernelGGL(k_prep, dim3((unsigned)(h->Ppad / 256 + 1)), dim3(256), 0, h->stream, (long long)h->Ppad, h->d_setof, h->d_loc,
-                       h->d_vbidx, h->d_sets, h->d_scal, h->d_varBeta, h->d_mpm, h->d_lhs0, h->d_rhs0, h->d_beta, h->d_c, h->d_w,
-                       h->d_q, h->d_T, h->d_chi, (int)set_id, h->seed, (uint64_t)h->chain, it, (long long)h->h_regs.size(), h->d_regs, h->d_regchi, h->d_rcls,
-                       h->d_ccnt, (long long)(h->mode == 1 ? h->ccnt_words : 0));
     const int64_t tb0 = hs.col0 / NGP_BLK, tb1 = (hs.col0 + hs.ncol - 1) / NGP_BLK + 1;
     CuLease lease(h);
-    launch_sweep(h, tb0, tb1, nullptr);
-    launch_variance(h, (int)set_id, it);
-    HCHK(hipMemcpyAsync(ycorr, h->d_ycorr, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HCHK(hipMemcpyAsync(beta, h->d_beta + hs.col0, (size_t)hs.ncol * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HCHK(hipMemcpyAsync(varBeta, h->d_varBeta + hs.vb_off, (size_t)hs.nreg * sizeof(double), hipMemcpyDeviceToHost, h->stream));
-    HCHK(hipStreamSynchronize(h->stream));
-    HCHK(hipGetLastError());
-    if ((rc = check_abort(h))) return rc;
+    for (int attempt = 0;; ++attempt) {
+        HCHK(hipMemsetAsync(h->d_ycorr, 0, (size_t)h->L * sizeof(double), h->stream));
+        HCHK(hipMemcpyAsync(h->d_ycorr, ycorr, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HCHK(hipMemcpyAsync(h->d_beta + hs.col0, beta, (size_t)hs.ncol * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        HCHK(hipMemcpyAsync(h->d_varBeta + hs.vb_off, varBeta, (size_t)hs.nreg * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        if (hs.method != NGP_METHOD_BAYESPR)
+            hipLaunchKernelGGL(k_set_pi, dim3(1), dim3(1), 0, h->stream, h->d_sets, (int)set_id, piHat[0], piHat[1]);
+        hipLaunchKernelGGL(k_set_varE, dim3(1), dim3(1), 0, h->stream, h->d_scal, varE);
+        hipLaunchKernelGGL(k_prep, dim3((unsigned)(h->Ppad / 256 + 1)), dim3(256), 0, h->stream, (long long)h->Ppad, h->d_setof, h->d_loc,
+                           h->d_vbidx, h->d_sets, h->d_scal, h->d_varBeta, h->d_mpm, h->d_lhs0, h->d_rhs0, h->d_beta, h->d_c, h->d_w,
+                           h->d_q, h->d_T, h->d_chi, (int)set_id, h->seed, (uint64_t)h->chain, it, (long long)h->h_regs.size(), h->d_regs, h->d_regchi, h->d_rcls,
+                           h->d_ccnt, (long long)(h->mode == 1 ? h->ccnt_words : 0), h->d_abort);
+        launch_sweep(h, tb0, tb1, nullptr);
+        launch_variance(h, (int)set_id, it);
+        HCHK(hipStreamSynchronize(h->stream));
+        HCHK(hipGetLastError());
+        int64_t itf = 0;
+        rc = check_abort(h, &itf);
+        if (rc == NGP_RETRY_CENSUS && attempt == 0) {  // nothing was changed (the caller's arrays are the state): once more, alone on the device
+            h->exclusive = true; h->census_retries += 1;
+            lease.make_exclusive();
+            continue;
+        }
+        if (rc) return rc;
+        break;
+    }
+    HCHK(hipMemcpy(ycorr, h->d_ycorr, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost));
+    HCHK(hipMemcpy(beta, h->d_beta + hs.col0, (size_t)hs.ncol * sizeof(double), hipMemcpyDeviceToHost));
+    HCHK(hipMemcpy(varBeta, h->d_varBeta + hs.vb_off, (size_t)hs.nreg * sizeof(double), hipMemcpyDeviceToHost));
     if (h->dbg_mode != 0) return fail(h, NGP_ERR_DEBUG, "diagnostic timing mode is active: the sweep is invalid");
     if (delta) {
         std::vector<uint8_t> d((size_t)hs.ncol);
@@ -1363,7 +1458,7 @@ int32_t ngp_profile_iteration(ngp_handle *h, double *avg_ms, int64_t *launches, 
     }
     h->ntrace = 1;
     CuLease lease(h);
-    rc = one_iteration(h, 0, evs.data());
+    rc = run_iterations(h, 1, lease, evs.data());  // (checks the abort word; a launch that ends at its census is run again)
     hipError_t e = hipStreamSynchronize(h->stream);
     double tot = 0.0;
     if (rc == NGP_OK && e == hipSuccess)
@@ -1374,7 +1469,6 @@ int32_t ngp_profile_iteration(ngp_handle *h, double *avg_ms, int64_t *launches, 
         }
     for (auto &ev : evs) (void)hipEventDestroy(ev);
     if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("profile_iteration: ") + hipGetErrorString(e));
-    if (rc == NGP_OK) rc = check_abort(h);
     if (avg_ms) *avg_ms = tot / (double)n;
     if (launches) *launches = n;
     const double bpe = (h->storage == 1) ? 1.0 : 4.0;  // algorithmic bytes per genotype: the panel is read once per iteration
@@ -1884,11 +1978,12 @@ int32_t ngp_allreduce_posterior(ngp_handle **hs, int32_t n) {
         if ((rc = ngp_export_posterior_device(hs[i], buf[i], len))) { if (hs[i] != h) h->err = hs[i]->err; cleanup(); return rc; }
     }
     // leaders: the first handle of every device; the others are added into their leader on the device
+    auto devof = [](const ngp_handle *x) { return x->vdev >= 0 ? 1000 + x->vdev : x->device; };  // (virtual devices: test hook)
     std::vector<int> leader((size_t)n);
     std::vector<int> leaders;
     for (int i = 0; i < n; i++) {
         leader[i] = i;
-        for (int k = 0; k < i; k++) if (hs[k]->device == hs[i]->device) { leader[i] = leader[k]; break; }
+        for (int k = 0; k < i; k++) if (devof(hs[k]) == devof(hs[i])) { leader[i] = leader[k]; break; }
         if (leader[i] == i) leaders.push_back(i);
     }
     hipError_t e = hipSuccess;
@@ -1901,8 +1996,26 @@ int32_t ngp_allreduce_posterior(ngp_handle **hs, int32_t n) {
         }
     if (e != hipSuccess) { cleanup(); return fail(h, NGP_ERR_HIP, std::string("pooling on one device: ") + hipGetErrorString(e)); }
     if (leaders.size() > 1) {
-        if (!g_rccl.load()) { cleanup(); return fail(h, NGP_ERR_HIP, g_rccl.err); }
         const int nl = (int)leaders.size();
+        bool one_physical = true;
+        for (int i = 1; i < nl; i++) one_physical = one_physical && hs[leaders[i]]->device == hs[leaders[0]]->device;
+        if (one_physical) {
+            // every leader on one GPU (virtual devices, ngp_debug_set_virtual_device): the collective is a sum on that GPU, leader
+            // order -- the same packing, grouping and unpacking as across devices, everything but the ncclAllReduce call
+            ngp_handle *L0 = hs[leaders[0]];
+            (void)hipSetDevice(L0->device);
+            double *tot = nullptr;
+            if (hipMalloc((void **)&tot, (size_t)len * sizeof(double)) != hipSuccess) { cleanup(); return fail(h, NGP_ERR_NOMEM, "posterior buffer"); }
+            e = hipMemcpyAsync(tot, buf[leaders[0]], (size_t)len * sizeof(double), hipMemcpyDeviceToDevice, L0->stream);
+            for (int i = 1; i < nl && e == hipSuccess; i++)
+                hipLaunchKernelGGL(k_add_inplace, dim3((unsigned)((len + 255) / 256)), dim3(256), 0, L0->stream, tot, buf[leaders[i]], (long long)len);
+            for (int i = 0; i < nl && e == hipSuccess; i++)
+                e = hipMemcpyAsync(buf[leaders[i]], tot, (size_t)len * sizeof(double), hipMemcpyDeviceToDevice, L0->stream);
+            if (e == hipSuccess) e = hipStreamSynchronize(L0->stream);
+            (void)hipFree(tot);
+            if (e != hipSuccess) { cleanup(); return fail(h, NGP_ERR_HIP, std::string("pooling leaders on one device: ") + hipGetErrorString(e)); }
+        } else {
+        if (!g_rccl.load()) { cleanup(); return fail(h, NGP_ERR_HIP, g_rccl.err); }
         std::vector<void *> comms((size_t)nl, nullptr);
         std::vector<int> devs((size_t)nl);
         for (int i = 0; i < nl; i++) devs[i] = hs[leaders[i]]->device;
@@ -1920,6 +2033,7 @@ int32_t ngp_allreduce_posterior(ngp_handle **hs, int32_t n) {
         }
         for (int i = 0; i < nl; i++) if (comms[i]) g_rccl.CommDestroy(comms[i]);
         if (r != 0) { cleanup(); return fail(h, NGP_ERR_HIP, std::string("RCCL all-reduce failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(r) : "?")); }
+        }
     }
     for (int i = 0; i < n; i++) {
         (void)hipSetDevice(hs[i]->device);
@@ -2087,6 +2201,55 @@ int32_t ngp_set_fixed(ngp_handle *h, const double *b, const double *sum_b, int64
     HCHK(hipStreamSynchronize(h->stream));
     if (b) HCHK(hipMemcpy(h->d_bfix, b, (size_t)h->nfixcol * sizeof(double), hipMemcpyHostToDevice));
     if (sum_b) HCHK(hipMemcpy(h->d_sum_bfix, sum_b, (size_t)h->nfixcol * sizeof(double), hipMemcpyHostToDevice));
+    return NGP_OK;
+    NGP_CATCH(h)
+}
+
+/* Placement census of the last persistent-sweep launch of this handle: out[b] = (XCC id + 1) << 32 | HW_REG_HW_ID of workgroup b,
+ * 0 for a workgroup that never became resident (n >= grid entries; *grid = 1 sampler + reducers + streamers); *retries = launches of
+ * this handle that ended at the census (grid not co-resident beside another chain's) and were run again with the device to
+ * themselves; *exclusive = whether the handle's calls now lease the whole device. */
+int32_t ngp_get_census(ngp_handle *h, uint64_t *out, int64_t n, int64_t *grid, int64_t *retries, int32_t *exclusive) {
+    NGP_TRY
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(h->d_tiles != nullptr && h->mode == 1, NGP_ERR_STATE, "no persistent sweep on this handle");
+    const int64_t g = 1 + h->NG + h->S;
+    if (grid) *grid = g;
+    if (retries) *retries = h->census_retries;
+    if (exclusive) *exclusive = h->exclusive ? 1 : 0;
+    if (out) {
+        REQUIRE(n >= g, NGP_ERR_ARG, "census buffer smaller than the grid");
+        HCHK(hipStreamSynchronize(h->stream));
+        HCHK(hipMemcpy(out, h->d_census_tbl, (size_t)g * sizeof(uint64_t), hipMemcpyDeviceToHost));
+    }
+    return NGP_OK;
+    NGP_CATCH(h)
+}
+
+/* Test hook of the census fallback: the sweep of iteration `iteration` (1-based, as ngp_get_state counts) closes its own census as
+ * "timed out" -- what a grid that is not co-resident does after 20 ms -- so that the retry path (abort before any role has run,
+ * kernels behind it skipped, whole-device lease, the iteration resumed from k_prep) can be exercised on one chain.  0 = off. */
+int32_t ngp_debug_fail_census(ngp_handle *h, int64_t iteration) {
+    NGP_TRY
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(iteration >= 0, NGP_ERR_ARG, "iteration must be >= 0");
+    h->dbg_census_fail_iter = iteration;
+    if (iteration > 0) h->exclusive = false;
+    return NGP_OK;
+    NGP_CATCH(h)
+}
+
+/* Test hook of ngp_allreduce_posterior's grouping: the handle is treated as living on device `vdev` (-1: its real device) when
+ * leaders are chosen and buffers packed / unpacked -- with several handles of ONE GPU given different virtual devices the
+ * multi-device branch runs up to the collective itself, which is then a sum on that one device instead of ncclAllReduce. */
+int32_t ngp_debug_set_virtual_device(ngp_handle *h, int32_t vdev) {
+    NGP_TRY
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(vdev >= -1 && vdev < 64, NGP_ERR_ARG, "virtual device: -1 (off) or 0..63");
+    h->vdev = vdev;
     return NGP_OK;
     NGP_CATCH(h)
 }

@@ -23,7 +23,8 @@ namespace ngp {
 __global__ __launch_bounds__(1024) void k_head(double *__restrict__ ycorr, long long L, long long N, DScal *__restrict__ sc,
                                                double e_df, double e_scale, int intercept, int draw_varE, uint64_t seed,
                                                uint64_t chain, uint64_t it, double *__restrict__ tr_varE,
-                                               double *__restrict__ tr_b, long long trace_idx) {
+                                               double *__restrict__ tr_b, long long trace_idx, const unsigned *__restrict__ abort_w) {
+    if (abort_w && *abort_w != 0u) return;  // an earlier sweep of this call gave up (ngp_sweep_args.h, abort_w)
     __shared__ double wyy[16], wsy[16];
     __shared__ double s_db;
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -102,7 +103,8 @@ __global__ __launch_bounds__(1024) void k_head(double *__restrict__ ycorr, long 
 __global__ __launch_bounds__(1024) void k_fixed(double *__restrict__ ycorr, long long N, const double *__restrict__ X, int nc,
                                                 const double *__restrict__ xpx0, const double *__restrict__ xpxR,
                                                 const double *__restrict__ lhs0, const double *__restrict__ rhs0, double *__restrict__ b,
-                                                const DScal *__restrict__ sc, int fset, uint64_t seed, uint64_t chain, uint64_t it) {
+                                                const DScal *__restrict__ sc, int fset, uint64_t seed, uint64_t chain, uint64_t it, const unsigned *__restrict__ abort_w) {
+    if (abort_w && *abort_w != 0u) return;  // an earlier sweep of this call gave up (ngp_sweep_args.h, abort_w)
     __shared__ double wsum[16];
     __shared__ double Yi[64], db[64];
     const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
@@ -156,7 +158,8 @@ __global__ __launch_bounds__(1024) void k_fixed(double *__restrict__ ycorr, long
         ycorr[i] = ycorr[i] - t;
     }
 }
-__global__ void k_accum_fixed(long long n, const double *__restrict__ b, double *__restrict__ sum_b) {
+__global__ void k_accum_fixed(long long n, const double *__restrict__ b, double *__restrict__ sum_b, const unsigned *__restrict__ abort_w) {
+    if (abort_w && *abort_w != 0u) return;  // an earlier sweep of this call gave up (ngp_sweep_args.h, abort_w)
     const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (k < n) sum_b[k] += b[k];
 }
@@ -174,7 +177,8 @@ __global__ __launch_bounds__(256) void k_prep(long long Ppad, const int8_t *__re
                                               double *__restrict__ T, double *__restrict__ chi, int active_set, uint64_t seed,
                                               uint64_t chain, uint64_t it, long long nreg, const DReg *__restrict__ regs,
                                               double *__restrict__ regchi, double *__restrict__ rcls, unsigned *__restrict__ ccnt,
-                                              long long ccnt_words) {
+                                              long long ccnt_words, const unsigned *__restrict__ abort_w) {
+    if (abort_w && *abort_w != 0u) return;  // an earlier sweep of this call gave up (ngp_sweep_args.h, abort_w)
     // the hand-off counters of the persistent sweep that follows in the stream start from zero (was a memset launch of its own)
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < ccnt_words; i += (long long)gridDim.x * 256) ccnt[i] = 0u;
     long long k = (long long)blockIdx.x * 256 + threadIdx.x;
@@ -477,7 +481,8 @@ __global__ __launch_bounds__(256) void k_recur(const double *__restrict__ part, 
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_regssq(long long nseg, const long long *__restrict__ seg_k0,
                                                 const int32_t *__restrict__ seg_len, const double *__restrict__ beta,
-                                                double *__restrict__ segpart) {
+                                                double *__restrict__ segpart, const unsigned *__restrict__ abort_w) {
+    if (abort_w && *abort_w != 0u) return;  // an earlier sweep of this call gave up (ngp_sweep_args.h, abort_w)
     // one wave per 256-locus segment: lane l takes loci l, l+64, l+128, l+192 (coalesced), then the xor butterfly
     const long long sg = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (sg >= nseg) return;
@@ -502,7 +507,8 @@ __global__ __launch_bounds__(256) void k_regssq(long long nseg, const long long 
 __global__ __launch_bounds__(256) void k_rssq(long long nseg, const long long *__restrict__ seg_k0, const int32_t *__restrict__ seg_len,
                                               const int32_t *__restrict__ seg_set, const DSet *__restrict__ sets,
                                               const double *__restrict__ beta, const uint8_t *__restrict__ delta,
-                                              double *__restrict__ segpart) {
+                                              double *__restrict__ segpart, const unsigned *__restrict__ abort_w) {
+    if (abort_w && *abort_w != 0u) return;  // an earlier sweep of this call gave up (ngp_sweep_args.h, abort_w)
     const long long sg = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
     if (sg >= nseg) return;
     const int si = seg_set[sg];
@@ -532,7 +538,8 @@ __global__ __launch_bounds__(256) void k_rssq(long long nseg, const long long *_
 
 __global__ __launch_bounds__(64) void k_regdraw(long long nreg, const DReg *__restrict__ regs, const double *__restrict__ segpart,
                                                 const DSet *__restrict__ sets, double *__restrict__ varBeta, int active_set,
-                                                const double *__restrict__ regchi, uint64_t seed, uint64_t chain, uint64_t it) {
+                                                const double *__restrict__ regchi, uint64_t seed, uint64_t chain, uint64_t it, const unsigned *__restrict__ abort_w) {
+    if (abort_w && *abort_w != 0u) return;  // an earlier sweep of this call gave up (ngp_sweep_args.h, abort_w)
     long long rg = (long long)blockIdx.x * 64 + threadIdx.x;
     if (rg >= nreg) return;
     const DReg R = regs[rg];
@@ -568,7 +575,8 @@ __global__ __launch_bounds__(64) void k_regdraw(long long nreg, const DReg *__re
 }
 
 // pi draw of BayesB sets (functions.jl:190-194, :531-533); also clears the inclusion counters
-__global__ void k_pidraw(int nsets, DSet *__restrict__ sets, int active_set, uint64_t seed, uint64_t chain, uint64_t it) {
+__global__ void k_pidraw(int nsets, DSet *__restrict__ sets, int active_set, uint64_t seed, uint64_t chain, uint64_t it, const unsigned *__restrict__ abort_w) {
+    if (abort_w && *abort_w != 0u) return;  // an earlier sweep of this call gave up (ngp_sweep_args.h, abort_w)
     int si = threadIdx.x;
     if (si >= nsets) return;
     if (active_set >= 0 && si != active_set) return;
@@ -639,7 +647,8 @@ __global__ __launch_bounds__(256) void k_post(int do_accum, long long P, long lo
                                               double *__restrict__ sum_delta, double *__restrict__ sum_varBeta,
                                               DSet *__restrict__ sets, DScal *__restrict__ sc, int do_trace, long long ntl,
                                               const long long *__restrict__ loci, long long ntvb, double *__restrict__ tr_beta,
-                                              double *__restrict__ tr_vb, double *__restrict__ tr_pi, long long idx) {
+                                              double *__restrict__ tr_vb, double *__restrict__ tr_pi, long long idx, const unsigned *__restrict__ abort_w) {
+    if (abort_w && *abort_w != 0u) return;  // an earlier sweep of this call gave up (ngp_sweep_args.h, abort_w)
     const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
     if (do_trace) {
         if (k < ntl) tr_beta[idx * ntl + k] = beta[loci[k]];

@@ -1489,6 +1489,36 @@ __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     extern __shared__ __attribute__((aligned(16))) char smem[];
     NGP_DBG_LOCALS
     const int b = blockIdx.x;
+    // an earlier launch of this call gave up: nothing runs until the host has looked (the chain stays where that launch found it)
+    if (ld_u32(A.abort_w) != 0u) return;
+    // Census: every workgroup of this grid waits for others, so the whole grid must be resident at once.  The host checks that
+    // by count (occupancy query, CU lease), but what the dispatcher does with several grids of one process is not ours to
+    // know: each workgroup reports in, the last one opens the gate, and if the gate is still shut after 20 ms the launch ends
+    // BEFORE any role has touched the chain (abort code NGP_ABORT_CENSUS) -- the host then runs it again with the device to itself.
+    if (A.census) {
+        int *cflag = (int *)smem;
+        if (threadIdx.x == 0) {
+            A.census_tbl[b] = ((unsigned long long)(xcc_id() + 1u) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+            if (A.census_fail != 0u && A.census_fail == A.iter_tag) atomicCAS(&A.census[1], 0u, 2u);  // test hook
+            const unsigned old = atomicAdd(&A.census[0], 1u);
+            if (old + 1u == gridDim.x) atomicCAS(&A.census[1], 0u, 1u);
+            const unsigned long long t0 = wall_clock64();
+            unsigned verdict;
+            while ((verdict = ld_u32(&A.census[1])) == 0u) {
+                if (wall_clock64() - t0 > NGP_CENSUS_TICKS) atomicCAS(&A.census[1], 0u, 2u);
+                else __builtin_amdgcn_s_sleep(8);
+            }
+            if (verdict != 1u) {
+                st_u32(A.abort_w + 1, A.iter_tag);
+                st_u32(A.abort_w, NGP_ABORT_CENSUS);
+            }
+            *cflag = (verdict == 1u) ? 1 : 0;
+        }
+        __syncthreads();
+        const int cok = *cflag;
+        __syncthreads();  // the roles overwrite this word
+        if (!cok) return;
+    }
     if (dbg_mode == 1 && b <= A.NG) return;
     if ((dbg_mode == 2 && b != 0) || ((dbg_mode == 3 || dbg_mode == 4) && b == 0)) return;
     if (b == 0)

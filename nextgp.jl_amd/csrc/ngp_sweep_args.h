@@ -16,6 +16,8 @@
 #define NGP_LAZY_LAG 7  // streamers count their partials lazily from this lag on
 #endif
 #define NGP_QS 1040
+#define NGP_ABORT_CENSUS 9u        // abort code: the grid was not co-resident within NGP_CENSUS_TICKS (no state was modified)
+#define NGP_CENSUS_TICKS 2000000ull  // 20 ms of the 100 MHz wall clock
 #define NGP_DBG_STREAM (1u << 20)  // offset of streamer 0's stamps in the debug buffer
 
 namespace ngp {
@@ -53,7 +55,13 @@ struct SweepArgs {
     unsigned *cnt_part;  // [RING][NG] counters, one 128-B line each
     unsigned *cnt_gs;    // [RING] counters, one 128-B line each
     unsigned *flag_dlt;  // number of blocks the sampler has finished
-    unsigned *abort_w;   // != 0: a spin timed out (code = role)
+    unsigned *abort_w;   // [0] != 0: the sweep gave up (code = role whose spin timed out; NGP_ABORT_CENSUS: not every workgroup became
+                         // resident, NOTHING was changed); [1] = iter_tag of the launch that gave up.  Every kernel of the iteration
+                         // sequence returns at once while [0] != 0, so the chain stays where the failing launch found it.
+    unsigned *census;    // [0] arrivals of this launch, [1] verdict (0 open, 1 all resident, 2 timed out); zeroed by k_prep; null: no census
+    unsigned long long *census_tbl;  // [grid] placement of every workgroup that arrived: (XCC id + 1) << 32 | HW_REG_HW_ID
+    unsigned iter_tag;   // low 32 bits of the iteration this launch belongs to
+    unsigned census_fail;  // test hook (ngp_debug_fail_census): the launch with this iter_tag closes its own census as "timed out"
     unsigned *xcc_w;     // sampler's XCC id + 1 (speed only: same-XCD streamers warm the L2 with Gram blocks)
     unsigned long long *dbg;  // optional time stamps (diagnostic runs only), else nullptr
     int dbg_mode;             // diagnostic timing runs, results invalid: 1 = streamers only move tiles, 2 = sampler alone

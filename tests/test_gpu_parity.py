@@ -656,3 +656,64 @@ def test_chains_of_one_process_share_a_device(ngp, O, shards):
         for k in ("ycorr", "beta", "delta", "varBeta", "piHat"):
             assert np.array_equal(st[k], ref[k]), k
         assert st["varE"] == ref["varE"] and st["iter"] == 40
+
+
+def test_census_of_a_sweep_and_resume_after_a_failed_one(ngp, O):
+    """Every launch of the persistent kernel opens with a census of its own grid.  (1) An undisturbed launch: every workgroup
+    reported in, spread over the 8 XCDs.  (2) A launch whose census fails (forced here through ngp_debug_fail_census: the state a
+    grid that is not co-resident reaches after 20 ms) ends before any role has run, the kernels queued behind it return at once,
+    and the call resumes that iteration with the device to itself: the chain ends bit for bit where an undisturbed one ends."""
+    ref, X, y, v = _small_model(ngp, O)
+    ref.set_schedule(40, 4, 2); ref.run(40)
+    c = ref.census()
+    assert c["grid"] == len(c["xcc"]) and (c["xcc"] >= 0).all() and c["retries"] == 0 and not c["exclusive"]
+    assert len(set(c["xcc"].tolist())) == min(8, c["grid"])
+    for fail_at in (1, 19, 40):                       # first launch of the call, the middle of a queue of 16, the last one
+        s, *_ = _small_model(ngp, O)
+        s.set_schedule(40, 4, 2)
+        s.debug_fail_census(fail_at)
+        s.run(40)
+        cs = s.census()
+        assert cs["retries"] == 1 and cs["exclusive"]
+        a, b = ref.get_state(), s.get_state()
+        for k in ("ycorr", "beta", "delta", "varBeta", "piHat"):
+            assert np.array_equal(a[k], b[k]), (fail_at, k)
+        assert a["varE"] == b["varE"] and a["b"] == b["b"] and a["iter"] == b["iter"] == 40
+        pa, pb = ref.get_posterior_sums(), s.get_posterior_sums()
+        assert pa["nKept"] == pb["nKept"] and np.array_equal(pa["sum_beta"], pb["sum_beta"]) and pa["sum_varE"] == pb["sum_varE"]
+        assert np.array_equal(ref.get_trace(40)["varE"], s.get_trace(40)["varE"])
+    # the fine seam takes the same way out
+    s, *_ = _small_model(ngp, O)
+    t, *_ = _small_model(ngp, O)
+    st = s.get_state()
+    res = []
+    for m, forced in ((s, True), (t, False)):
+        yc, be, vb, pi = st["ycorr"].copy(), np.zeros(100), np.array([v]), np.array([0.5, 0.5])
+        if forced:
+            m.debug_fail_census(1)
+        m.sweep_set(0, 1.0, yc, be, vb, pi)
+        res.append((yc, be, vb))
+    assert all(np.array_equal(p, q) for p, q in zip(res[0], res[1])) and s.census()["retries"] == 1
+
+
+def test_allreduce_multi_device_branch_on_one_gpu(ngp, O):
+    """ngp_allreduce_posterior's multi-device branch (one leader per device, the other handles of a device added into it, ONE
+    collective over the leaders, every handle unpacking its leader's buffer) driven on this box's one GPU: five handles grouped
+    under three virtual devices.  Everything but the ncclAllReduce call itself is the code an 8-GPU node runs."""
+    chains, sums, fx = [], [], []
+    vdevs = [0, 1, 0, 2, 1]
+    for c, vd in enumerate(vdevs):
+        s, *_ = _model_with_fixed_and_classes(ngp, O, seed=3001 + c)
+        s.set_schedule(8, 2, 2); s.run(8)
+        s.debug_set_virtual_device(vd)
+        chains.append(s); sums.append(s.get_posterior_sums()); fx.append(s.get_fixed()["sum_b"])
+    ngp.Sampler.allreduce_posterior(chains)
+    # leaders 0 (+2), 1 (+4), 3; collective adds leader buffers in leader order
+    tot = lambda f: ((f(0) + f(2)) + (f(1) + f(4))) + f(3)
+    for s in chains:
+        p = s.get_posterior_sums()
+        assert p["nKept"] == 15
+        for k in ("sum_beta", "sum_beta2", "sum_delta", "sum_varBeta", "sum_pi"):
+            assert np.array_equal(p[k], tot(lambda i: sums[i][k])), k
+        assert p["sum_varE"] == tot(lambda i: sums[i]["sum_varE"])
+        assert np.array_equal(s.get_fixed()["sum_b"], tot(lambda i: fx[i]))

@@ -35,6 +35,11 @@ for t in ths: t.start()
 bar.wait(); t0 = time.perf_counter(); bar.wait(); dt = time.perf_counter() - t0
 for t in ths: t.join()
 print(f"   {K} x {iters} iterations in {dt:.3f} s: {K * iters / dt:.1f} it/s aggregate, {dt / iters * 1e3:.3f} ms per iteration of a chain")
-for s in chains:
+for k, s in enumerate(chains):
     st = s.get_state()
     assert np.isfinite(st["beta"]).all() and st["varE"] > 0
+    c = s.census()   # placement of the chain's last launch: workgroups per XCD, and per shader engine inside each XCD (HW_ID bits 15:13)
+    per = [int((c["xcc"] == x).sum()) for x in range(8)]
+    se = [[int(((c["xcc"] == x) & (((c["hw_id"] >> 13) & 7) == e)).sum()) for e in range(4)] for x in range(8)]
+    print(f"   chain {k}: grid {c['grid']}, launches ended at the census and run again alone: {c['retries']}, whole-device lease now: {c['exclusive']}; "
+          f"workgroups per XCD {per}; per shader engine {se}", flush=True)
