@@ -38,6 +38,7 @@ extern "C" {
 #define NGP_METHOD_BAYESB 1  /* src/runTime.jl:48-61 */
 #define NGP_METHOD_BAYESC 2  /* src/runTime.jl:64-77, sampler src/functions.jl:197-235 */
 #define NGP_METHOD_BAYESR 3  /* src/runTime.jl:78-93, sampler src/functions.jl:238-289; added with ngp_add_marker_set_r */
+#define NGP_METHOD_TUPLE 4   /* correlated sets, BayesPR's Tuple method: src/functions.jl:140-154; added with ngp_add_marker_set_tuple */
 
 typedef struct ngp_handle ngp_handle;
 
@@ -121,6 +122,20 @@ int32_t ngp_add_marker_set_r(ngp_handle *h, int64_t col0, int64_t ncol, double d
                              const double *pi, int32_t K, int32_t estPi, const double *lhs0, const double *rhs0, int32_t *set_id);
 int32_t ngp_get_class_state(ngp_handle *h, int32_t set_id, double *piHat, double *sum_pi, int64_t *K);
 int32_t ngp_set_class_state(ngp_handle *h, int32_t set_id, const double *piHat, const double *sum_pi, int64_t K);
+
+/* Correlated marker sets -- sampleBayesPR!(::Tuple) (src/functions.jl:140-154), sampleVarCovBetaPR (:513-516), set-up
+ * src/mme.jl:448-489: k = 1..4 sets (e.g. breeds) share nloc loci; every locus draws its k effects jointly, beta_l ~ MvNormal(inv(LHS)
+ * RHS, inv(LHS)) with LHS = X_l'X_l / varE + inv(varBeta_r), and every region r draws its k x k variance matrix
+ * varBeta_r ~ InverseWishart(df + n_r, scale + B_r'B_r).  df = 3 + k and scale = v (df - k - 1) (k x k, row-major) are the caller's
+ * (src/mme.jl:493, 501); varBeta0 = v, ONE k x k matrix every region starts from (src/mme.jl:516); regions are ranges of LOCI.
+ * Panel layout: the k columns of a locus are adjacent -- component m of locus l is panel column col0 + 64 (l / Lb) + k (l % Lb) + m,
+ * Lb = floor(64 / k), col0 a multiple of 64 (a locus never straddles a 64-column block; for k = 3 column 63 of every block of the
+ * set is unused and must hold zeros).  In ngp_get_state / ngp_get_posterior_sums the set contributes nreg k x k matrices
+ * (row-major) to varBeta, and its effects sit at their panel columns.  k = 1 is the Symbol method of BayesPR, bit for bit (with
+ * scale = the Symbol path's scale * df).  (In the reference snapshot this method is unreachable -- SURVEY.md fact 6 -- so parity is
+ * against the specification in oracle/.)  MvNormal / InverseWishart: Cholesky and Bartlett constructions on the keyed draws. */
+int32_t ngp_add_marker_set_tuple(ngp_handle *h, int64_t col0, int64_t nloc, int32_t k, double df, const double *scale,
+                                 const int64_t *reg_start, const int64_t *reg_stop, int64_t nreg, const double *varBeta0, int32_t *set_id);
 
 /* A fixed-effect set beyond the intercept (X[xSet] of src/prepMatVec.jl:150-165; set-up src/mme.jl:120-152): the columns of one
  * model term or of one `blockThese` group, N x ncol column-major (ncol <= 64), sampled after the intercept in the order the

@@ -12,7 +12,35 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("NGP_HIP_LIB") or os.path.join(_HERE, "libnextgp_hip.so")  # override: a library built elsewhere
 
-METHOD_BAYESPR, METHOD_BAYESB, METHOD_BAYESC, METHOD_BAYESR = 0, 1, 2, 3
+METHOD_BAYESPR, METHOD_BAYESB, METHOD_BAYESC, METHOD_BAYESR, METHOD_TUPLE = 0, 1, 2, 3, 4
+
+
+def tuple_columns(col0, nloc, k):
+    """Panel columns of a Tuple (correlated BayesPR) set: array [nloc, k], component m of locus l at col0 + 64 (l // Lb) + k (l % Lb) + m
+    with Lb = 64 // k loci per 64-column block (include/nextgp_hip.h, ngp_add_marker_set_tuple)."""
+    if col0 % 64 or not 1 <= k <= 4:
+        raise ValueError("tuple set: col0 on a 64-column boundary, k in 1..4")
+    l = np.arange(nloc, dtype=np.int64)[:, None]
+    Lb = 64 // k
+    return col0 + 64 * (l // Lb) + k * (l % Lb) + np.arange(k, dtype=np.int64)[None, :]
+
+
+def tuple_span(nloc, k):
+    """Panel columns a tuple set occupies from its first column on (holes included)."""
+    Lb = 64 // k
+    nblk = (nloc + Lb - 1) // Lb
+    return 64 * (nblk - 1) + k * (nloc - Lb * (nblk - 1))
+
+
+def tuple_panel(sets):
+    """k matrices (N x nloc, one per correlated set, same loci) -> the interleaved N x span block a tuple set occupies (unused
+    columns zero), same dtype."""
+    k, (N, nloc) = len(sets), sets[0].shape
+    out = np.zeros((N, tuple_span(nloc, k)), dtype=sets[0].dtype, order="F")
+    cols = tuple_columns(0, nloc, k)
+    for m, X in enumerate(sets):
+        out[:, cols[:, m]] = X
+    return out
 
 # every symbol include/nextgp_hip.h declares
 SYMBOLS = [
@@ -22,7 +50,7 @@ SYMBOLS = [
     "ngp_get_trace", "ngp_get_posterior_sums", "ngp_posterior_len", "ngp_export_posterior_device", "ngp_sweep_set",
     "ngp_get_timing", "ngp_profile_iteration", "ngp_draws_indexed", "ngp_eval_math", "ngp_configure", "ngp_get_config", "ngp_debug_stamps", "ngp_set_near_lags", "ngp_get_near_lags",
     "ngp_set_streamer", "ngp_get_streamer", "ngp_set_storage", "ngp_get_storage", "ngp_set_max_shards", "ngp_shards_for_chains", "ngp_run_many", "ngp_write_panel_file", "ngp_read_panel_header", "ngp_load_panel_file", "ngp_debug_set_mode", "ngp_debug_set_knob", "ngp_set_posterior_sums", "ngp_save_snapshot", "ngp_load_snapshot",
-    "ngp_set_trace_loci", "ngp_get_trace_ext", "ngp_allreduce_posterior", "ngp_add_marker_set_r", "ngp_get_class_state", "ngp_set_class_state", "ngp_add_fixed_set", "ngp_get_fixed", "ngp_set_fixed", "ngp_debug_throw", "ngp_get_census", "ngp_debug_set_virtual_device", "ngp_debug_fail_census",
+    "ngp_set_trace_loci", "ngp_get_trace_ext", "ngp_allreduce_posterior", "ngp_add_marker_set_r", "ngp_get_class_state", "ngp_set_class_state", "ngp_add_fixed_set", "ngp_get_fixed", "ngp_set_fixed", "ngp_debug_throw", "ngp_get_census", "ngp_debug_set_virtual_device", "ngp_debug_fail_census", "ngp_add_marker_set_tuple",
 ]
 
 _lib = None
@@ -268,6 +296,19 @@ class Sampler:
         self.nsets += 1
         self.set_shapes.append((ncol, 1))
         self.nclasses = getattr(self, "nclasses", 0) + len(vc)
+        return sid.value
+
+    def add_marker_set_tuple(self, col0, nloc, k, df, scale, regions, varBeta0):
+        """Correlated sets (BayesPR's Tuple method, src/functions.jl:140-154): k sets, nloc loci, columns as tuple_columns(col0, nloc, k);
+        scale and varBeta0 k x k, regions ranges of loci."""
+        rs = np.ascontiguousarray([r[0] for r in regions], dtype=np.int64)
+        re = np.ascontiguousarray([r[1] for r in regions], dtype=np.int64)
+        sc = np.ascontiguousarray(np.asarray(scale, dtype=np.float64).reshape(k, k)); vb = np.ascontiguousarray(np.asarray(varBeta0, dtype=np.float64).reshape(k, k))
+        sid = C.c_int32()
+        self._chk(self.L.ngp_add_marker_set_tuple(self.h, C.c_int64(col0), C.c_int64(nloc), C.c_int32(k), C.c_double(df), _p(sc, C.c_double),
+                                                  _p(rs, C.c_int64), _p(re, C.c_int64), C.c_int64(len(rs)), _p(vb, C.c_double), C.byref(sid)))
+        self.nsets += 1
+        self.set_shapes.append((tuple_span(nloc, k), len(rs) * k * k))
         return sid.value
 
     def get_class_state(self, set_id):

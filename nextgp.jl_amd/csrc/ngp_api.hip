@@ -42,6 +42,8 @@ struct HSet {
     std::vector<double> vb0;  // initial variances (src/mme.jl:516)
     int K = 0;                // BayesR: classes, their multipliers and prior probabilities (src/mme.jl:374-383)
     std::vector<double> vcls, rpi;
+    int tk = 0;               // Tuple (correlated BayesPR) set: number of correlated sets; nreg k x k variance matrices in varBeta
+    int64_t nloc = 0;
 };
 
 std::string g_create_err;
@@ -94,6 +96,16 @@ struct ngp_handle {
     int32_t *d_seg_set = nullptr;    // set of every variance segment
     std::vector<int32_t> h_seg_set;
     int64_t nclass_total = 0;        // sum of K over the BayesR sets (entries of the packed posterior)
+    // Tuple sets (src/functions.jl:140-154): per-set constants, coefficient rows, region tables of the inverse-Wishart draws
+    DTup *d_tup = nullptr;
+    double *d_tupc = nullptr, *d_tupg = nullptr, *d_tsegpart = nullptr;
+    DTReg *d_tregs = nullptr;
+    long long *d_tseg_l0 = nullptr;
+    int32_t *d_tseg_len = nullptr, *d_tseg_set = nullptr;
+    std::vector<DTReg> h_tregs;
+    std::vector<long long> h_tseg_l0;
+    std::vector<int32_t> h_tseg_len, h_tseg_set;
+    int ntuple = 0;
     // PR region tables
     DReg *d_regs = nullptr;
     long long *d_seg_k0 = nullptr;
@@ -349,6 +361,7 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
     h->h_vbidx.assign(pp, 0);
     h->sets.clear(); h->nvb = 0; h->h_regs.clear(); h->h_seg_k0.clear(); h->h_seg_len.clear(); h->h_seg_set.clear(); h->nclass_total = 0;
     dfree(h->d_rcls);
+    dfree(h->d_tup); dfree(h->d_tupc); dfree(h->d_tupg); h->h_tregs.clear(); h->h_tseg_l0.clear(); h->h_tseg_len.clear(); h->h_tseg_set.clear(); h->ntuple = 0;
     dfree(h->d_varBeta); dfree(h->d_sum_varBeta); h->vb_cap = 0;
     // a new panel is a new model: the fixed-effect sets (N rows of the OLD panel) and the trace selection (loci of the old P) go
     // with the marker sets -- k_fixed would read d_X of the old N, k_post beta[loci[k]] beyond the new P
@@ -501,6 +514,17 @@ int sync_tables(ngp_handle *h) {
         HCHK(hipMemcpy(h->d_seg_len, h->h_seg_len.data(), h->h_seg_len.size() * sizeof(int32_t), hipMemcpyHostToDevice));
         HCHK(hipMemcpy(h->d_seg_set, h->h_seg_set.data(), h->h_seg_set.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     }
+    if (!h->h_tregs.empty()) {
+        if ((rc = dalloc(h, &h->d_tregs, h->h_tregs.size()))) return rc;
+        if ((rc = dalloc(h, &h->d_tseg_l0, h->h_tseg_l0.size()))) return rc;
+        if ((rc = dalloc(h, &h->d_tseg_len, h->h_tseg_len.size()))) return rc;
+        if ((rc = dalloc(h, &h->d_tseg_set, h->h_tseg_set.size()))) return rc;
+        if ((rc = dalloc(h, &h->d_tsegpart, h->h_tseg_l0.size() * NGP_TPAIRS))) return rc;
+        HCHK(hipMemcpy(h->d_tregs, h->h_tregs.data(), h->h_tregs.size() * sizeof(DTReg), hipMemcpyHostToDevice));
+        HCHK(hipMemcpy(h->d_tseg_l0, h->h_tseg_l0.data(), h->h_tseg_l0.size() * sizeof(long long), hipMemcpyHostToDevice));
+        HCHK(hipMemcpy(h->d_tseg_len, h->h_tseg_len.data(), h->h_tseg_len.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+        HCHK(hipMemcpy(h->d_tseg_set, h->h_tseg_set.data(), h->h_tseg_set.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    }
     h->tables_dirty = false;
     return NGP_OK;
 }
@@ -521,6 +545,7 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
         A.beta = h->d_beta; A.delta = h->d_delta; A.c = h->d_c; A.w = h->d_w; A.q = h->d_q; A.mpm = h->d_mpm; A.chi = h->d_chi;
         A.setof = h->d_setof; A.vbidx = h->d_vbidx; A.sets = h->d_sets; A.varBeta = h->d_varBeta;
         A.rcls = h->d_rcls; A.rhs0 = h->d_rhs0; A.scal = h->d_scal; A.Ppad = h->Ppad;
+        A.tup = h->ntuple ? h->d_tup : nullptr; A.tupc = h->d_tupc; A.tupg = h->d_tupg;
         A.part = h->d_cpart; A.gsum = h->d_cgsum; A.dlt = h->d_cdlt; A.dltg = h->d_cdltg;
         h->launch_seq = (h->launch_seq % 4095u) + 1u;  // 1..4095: never the zero the ring is born with
         A.nonce = h->launch_seq;
@@ -554,7 +579,7 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
         if (do_gemv)
             hipLaunchKernelGGL(k_recur, dim3(1), dim3(256), 0, h->stream, h->d_part, h->d_gramx, h->D, S, (int)t, h->d_beta, h->d_delta,
                                h->d_c, h->d_w, h->d_q, h->d_mpm, h->d_chi, h->d_setof, h->d_vbidx, h->d_sets, h->d_varBeta, h->d_dlt, h->d_rcls,
-                               (long long)h->Ppad, h->d_rhs0, h->d_scal);
+                               (long long)h->Ppad, h->d_rhs0, h->d_scal, h->d_tup, h->d_tupc, h->d_tupg);
     }
     h->sweep_launches += 2 * (tb1 - tb0) + 1;
 }
@@ -620,6 +645,13 @@ void launch_variance(ngp_handle *h, int active_set, uint64_t it) {
         hipLaunchKernelGGL(k_regdraw, dim3((unsigned)((nreg + 63) / 64)), dim3(64), 0, h->stream, nreg, h->d_regs, h->d_segpart,
                            h->d_sets, h->d_varBeta, active_set, h->d_regchi, h->seed, (uint64_t)h->chain, it, h->d_abort);
     }
+    if (!h->h_tregs.empty()) {  // Tuple sets: Sb = B_r'B_r per region, then the inverse-Wishart draw of its variance matrix
+        const long long ntseg = (long long)h->h_tseg_l0.size(), ntreg = (long long)h->h_tregs.size();
+        hipLaunchKernelGGL(k_tuple_ssq, dim3((unsigned)((ntseg + 3) / 4)), dim3(256), 0, h->stream, ntseg, h->d_tseg_l0, h->d_tseg_len, h->d_tseg_set,
+                           h->d_tup, h->d_beta, h->d_tsegpart, h->d_abort);
+        hipLaunchKernelGGL(k_tuple_draw, dim3((unsigned)((ntreg + 63) / 64)), dim3(64), 0, h->stream, ntreg, h->d_tregs, h->d_tsegpart, h->d_tup,
+                           h->d_varBeta, active_set, h->seed, (uint64_t)h->chain, it, h->d_abort);
+    }
     hipLaunchKernelGGL(k_pidraw, dim3(1), dim3(64), 0, h->stream, (int)h->sets.size(), h->d_sets, active_set, h->seed,
                        (uint64_t)h->chain, it, h->d_abort);
 }
@@ -639,7 +671,7 @@ int one_iteration(ngp_handle *h, int64_t trace_idx, hipEvent_t *evs, bool resume
     hipLaunchKernelGGL(k_prep, dim3((unsigned)(h->Ppad / 256 + 1)), dim3(256), 0, h->stream, (long long)h->Ppad, h->d_setof, h->d_loc,
                        h->d_vbidx, h->d_sets, h->d_scal, h->d_varBeta, h->d_mpm, h->d_lhs0, h->d_rhs0, h->d_beta, h->d_c, h->d_w,
                        h->d_q, h->d_T, h->d_chi, -1, h->seed, (uint64_t)h->chain, it, (long long)h->h_regs.size(), h->d_regs, h->d_regchi, h->d_rcls,
-                       h->d_ccnt, (long long)(h->mode == 1 ? h->ccnt_words : 0), h->d_abort);
+                       h->d_ccnt, (long long)(h->mode == 1 ? h->ccnt_words : 0), h->d_abort, h->d_tup, h->d_tupc, h->d_tupg);
     launch_sweep(h, 0, h->NBLK, evs);
     launch_variance(h, -1, it);
     h->iter += 1;
@@ -765,6 +797,7 @@ int32_t ngp_destroy(ngp_handle *h) {
     dfree(h->d_sum_varBeta); dfree(h->d_regs); dfree(h->d_seg_k0); dfree(h->d_seg_len); dfree(h->d_segpart); dfree(h->d_regchi);
     for (auto &fx : h->fix) { dfree(fx.d_X); dfree(fx.d_xpx0); dfree(fx.d_xpxR); dfree(fx.d_lhs0); dfree(fx.d_rhs0); }
     dfree(h->d_bfix); dfree(h->d_sum_bfix);
+    dfree(h->d_tup); dfree(h->d_tupc); dfree(h->d_tupg); dfree(h->d_tsegpart); dfree(h->d_tregs); dfree(h->d_tseg_l0); dfree(h->d_tseg_len); dfree(h->d_tseg_set);
     dfree(h->d_tr_varE); dfree(h->d_tr_b); dfree(h->d_trace_loci); dfree(h->d_tr_beta); dfree(h->d_tr_vb); dfree(h->d_tr_pi);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
@@ -1056,7 +1089,7 @@ int32_t ngp_add_marker_set(ngp_handle *h, int64_t col0, int64_t ncol, int32_t me
     if (method == NGP_METHOD_BAYESR) REQUIRE(h->adding_r, NGP_ERR_ARG, "BayesR sets are added with ngp_add_marker_set_r (classes and their probabilities)");
     REQUIRE(reg_start && reg_stop && varBeta0 && nreg > 0, NGP_ERR_ARG, "regions / varBeta0 missing");
     REQUIRE(std::isfinite(df) && std::isfinite(scale) && df > 0, NGP_ERR_ARG, "df/scale must be finite, df > 0");
-    for (int64_t k = col0; k < col0 + ncol; k++) REQUIRE(h->h_setof[k] < 0, NGP_ERR_ARG, "marker sets overlap");
+    for (int64_t k = col0; k < col0 + ncol; k++) REQUIRE(h->h_setof[k] == -1, NGP_ERR_ARG, "marker sets overlap");
     if (method == NGP_METHOD_BAYESB) {
         REQUIRE(nreg == ncol, NGP_ERR_ARG, "BayesB needs one region per locus (src/mme.jl:356)");
         REQUIRE(pi0 > 0.0 && pi0 < 1.0, NGP_ERR_ARG, "BayesB pi must be in (0,1)");
@@ -1382,8 +1415,9 @@ int32_t ngp_sweep_set(ngp_handle *h, int32_t set_id, double varE, double *ycorr,
     REQUIRE(std::isfinite(varE) && varE > 0.0, NGP_ERR_ARG, "varE must be finite and positive");
     if ((rc = sync_tables(h))) return rc;
     HSet &hs = h->sets[set_id];
-    for (int64_t r = 0; r < hs.nreg; r++) REQUIRE(std::isfinite(varBeta[r]) && varBeta[r] >= 0.0, NGP_ERR_ARG, "varBeta must be finite, >= 0");
-    if (hs.method != NGP_METHOD_BAYESPR) REQUIRE(piHat != nullptr, NGP_ERR_ARG, "BayesB / BayesC need piHat");
+    const int64_t nvbs = (int64_t)hs.vb0.size();  // variance entries of the set: regions (loci for BayesB), k x k per region for a tuple set
+    for (int64_t r = 0; r < nvbs; r++) REQUIRE(std::isfinite(varBeta[r]) && (varBeta[r] >= 0.0 || hs.tk > 1), NGP_ERR_ARG, "varBeta must be finite, >= 0");
+    if (hs.method != NGP_METHOD_BAYESPR && hs.method != NGP_METHOD_TUPLE) REQUIRE(piHat != nullptr, NGP_ERR_ARG, "BayesB / BayesC need piHat");
     const uint64_t it = ++hs.fine_calls;
     const int64_t tb0 = hs.col0 / NGP_BLK, tb1 = (hs.col0 + hs.ncol - 1) / NGP_BLK + 1;
     CuLease lease(h);
@@ -1391,14 +1425,14 @@ int32_t ngp_sweep_set(ngp_handle *h, int32_t set_id, double varE, double *ycorr,
         HCHK(hipMemsetAsync(h->d_ycorr, 0, (size_t)h->L * sizeof(double), h->stream));
         HCHK(hipMemcpyAsync(h->d_ycorr, ycorr, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
         HCHK(hipMemcpyAsync(h->d_beta + hs.col0, beta, (size_t)hs.ncol * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        HCHK(hipMemcpyAsync(h->d_varBeta + hs.vb_off, varBeta, (size_t)hs.nreg * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        if (hs.method != NGP_METHOD_BAYESPR)
+        HCHK(hipMemcpyAsync(h->d_varBeta + hs.vb_off, varBeta, (size_t)nvbs * sizeof(double), hipMemcpyHostToDevice, h->stream));
+        if (hs.method != NGP_METHOD_BAYESPR && hs.method != NGP_METHOD_TUPLE)
             hipLaunchKernelGGL(k_set_pi, dim3(1), dim3(1), 0, h->stream, h->d_sets, (int)set_id, piHat[0], piHat[1]);
         hipLaunchKernelGGL(k_set_varE, dim3(1), dim3(1), 0, h->stream, h->d_scal, varE);
         hipLaunchKernelGGL(k_prep, dim3((unsigned)(h->Ppad / 256 + 1)), dim3(256), 0, h->stream, (long long)h->Ppad, h->d_setof, h->d_loc,
                            h->d_vbidx, h->d_sets, h->d_scal, h->d_varBeta, h->d_mpm, h->d_lhs0, h->d_rhs0, h->d_beta, h->d_c, h->d_w,
                            h->d_q, h->d_T, h->d_chi, (int)set_id, h->seed, (uint64_t)h->chain, it, (long long)h->h_regs.size(), h->d_regs, h->d_regchi, h->d_rcls,
-                           h->d_ccnt, (long long)(h->mode == 1 ? h->ccnt_words : 0), h->d_abort);
+                           h->d_ccnt, (long long)(h->mode == 1 ? h->ccnt_words : 0), h->d_abort, h->d_tup, h->d_tupc, h->d_tupg);
         launch_sweep(h, tb0, tb1, nullptr);
         launch_variance(h, (int)set_id, it);
         HCHK(hipStreamSynchronize(h->stream));
@@ -1415,7 +1449,7 @@ int32_t ngp_sweep_set(ngp_handle *h, int32_t set_id, double varE, double *ycorr,
     }
     HCHK(hipMemcpy(ycorr, h->d_ycorr, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost));
     HCHK(hipMemcpy(beta, h->d_beta + hs.col0, (size_t)hs.ncol * sizeof(double), hipMemcpyDeviceToHost));
-    HCHK(hipMemcpy(varBeta, h->d_varBeta + hs.vb_off, (size_t)hs.nreg * sizeof(double), hipMemcpyDeviceToHost));
+    HCHK(hipMemcpy(varBeta, h->d_varBeta + hs.vb_off, (size_t)nvbs * sizeof(double), hipMemcpyDeviceToHost));
     if (h->dbg_mode != 0) return fail(h, NGP_ERR_DEBUG, "diagnostic timing mode is active: the sweep is invalid");
     if (delta) {
         std::vector<uint8_t> d((size_t)hs.ncol);
@@ -1725,7 +1759,7 @@ int32_t ngp_save_snapshot(ngp_handle *h, const char *path) {
     const double scal[4] = {varE, b, svE, sbb};
     W("NGPSNAP2", 8); W(hdr, sizeof(hdr)); W(ids, sizeof(ids));
     {   // model signature: a snapshot only loads into the model it was taken from (equal counts are not enough)
-        for (auto &hs : h->sets) { const int64_t sg[5] = {hs.method, hs.K, hs.nreg, hs.col0, hs.ncol}; W(sg, sizeof(sg)); }
+        for (auto &hs : h->sets) { const int64_t sg[5] = {hs.method, hs.K + 16 * hs.tk, hs.nreg, hs.col0, hs.ncol}; W(sg, sizeof(sg)); }
         const int64_t nfs = (int64_t)h->fix.size();
         W(&nfs, 8);
         for (auto &fx : h->fix) W(&fx.ncol, 8);
@@ -1775,14 +1809,15 @@ int32_t ngp_load_snapshot(ngp_handle *h, const char *path) {
         for (auto &hs : h->sets) {
             int64_t sg[5] = {-1, -1, -1, -1, -1};
             Rd(sg, sizeof(sg));
-            same = same && sg[0] == hs.method && sg[1] == hs.K && sg[2] == hs.nreg && sg[3] == hs.col0 && sg[4] == hs.ncol;
+            same = same && sg[0] == hs.method && sg[1] == hs.K + 16 * hs.tk && sg[2] == hs.nreg && sg[3] == hs.col0 && sg[4] == hs.ncol;
         }
         int64_t nfs = -1;
         Rd(&nfs, 8);
         same = same && ok && nfs == (int64_t)h->fix.size();
         if (same)
             for (auto &fx : h->fix) { int64_t nc = -1; Rd(&nc, 8); same = same && nc == fx.ncol; }
-        if (!ok || !same) {
+        if (!ok) { fclose(f); return fail(h, NGP_ERR_ARG, "snapshot file is truncated (model signature)"); }
+        if (!same) {
             fclose(f);
             return fail(h, NGP_ERR_ARG, "snapshot does not match the model of this handle (methods, classes, regions or fixed-effect sets differ)");
         }
@@ -2083,6 +2118,105 @@ int32_t ngp_add_marker_set_r(ngp_handle *h, int64_t col0, int64_t ncol, double d
     if ((rc = set_class_state_dev(h, sid, pi, std::vector<double>((size_t)K, 0.0).data()))) return rc;
     h->nclass_total += K;
     if (set_id) *set_id = sid;
+    return NGP_OK;
+    NGP_CATCH(h)
+}
+
+/* Correlated marker sets -- the Tuple method of BayesPR (src/functions.jl:140-154, sampleVarCovBetaPR :513-516, set-up
+ * src/mme.jl:448-489): k sets (breeds) share nloc loci; per locus a k x k conditional, per region an inverse-Wishart draw of the
+ * k x k variance matrix.  The panel holds the k columns of a locus side by side: component m of locus l is panel column
+ * col0 + 64 (l / Lb) + k (l % Lb) + m with Lb = floor(64 / k) loci per 64-column block and col0 on a block boundary (a locus never
+ * straddles two blocks; for k = 3 column 63 of every block of the set is unused: fill it with zeros). */
+int32_t ngp_add_marker_set_tuple(ngp_handle *h, int64_t col0, int64_t nloc, int32_t k, double df, const double *scale,
+                                 const int64_t *reg_start, const int64_t *reg_stop, int64_t nreg, const double *varBeta0, int32_t *set_id) {
+    NGP_TRY
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
+    REQUIRE(h->sets.size() < 16, NGP_ERR_ARG, "at most 16 marker sets");
+    REQUIRE(k >= 1 && k <= NGP_KMAX, NGP_ERR_ARG, "a tuple holds 1..4 correlated sets");
+    REQUIRE(nloc >= 1 && col0 >= 0 && col0 % NGP_BLK == 0, NGP_ERR_ARG, "tuple set: first column on a 64-column block boundary");
+    REQUIRE(scale && varBeta0 && reg_start && reg_stop && nreg > 0, NGP_ERR_ARG, "scale / varBeta0 / regions missing");
+    REQUIRE(std::isfinite(df) && df > 0, NGP_ERR_ARG, "df must be finite and positive");
+    const int64_t Lb = NGP_BLK / k, nblk = (nloc + Lb - 1) / Lb, span = NGP_BLK * (nblk - 1) + (int64_t)k * (nloc - Lb * (nblk - 1));
+    REQUIRE(col0 + span <= h->P, NGP_ERR_ARG, "tuple set outside the panel");
+    // the set owns its 64-column blocks to the end of the last one (its block chain draws whole loci; no other set's column may sit there)
+    for (int64_t c = col0; c < std::min<int64_t>(col0 + NGP_BLK * nblk, h->Ppad); c++) REQUIRE(h->h_setof[c] == -1, NGP_ERR_ARG, "marker sets overlap");
+    for (int a = 0; a < k * k; a++) REQUIRE(std::isfinite(scale[a]) && std::isfinite(varBeta0[a]), NGP_ERR_ARG, "scale / varBeta0 must be finite");
+    for (int a = 0; a < k; a++) REQUIRE(varBeta0[a * k + a] > 0.0, NGP_ERR_ARG, "varBeta0 must be positive definite");
+    int64_t expect = 0;
+    for (int64_t r = 0; r < nreg; r++) {
+        REQUIRE(reg_start[r] == expect && reg_stop[r] > reg_start[r], NGP_ERR_ARG, "regions must be consecutive and non-empty");
+        expect = reg_stop[r];
+    }
+    REQUIRE(expect == nloc, NGP_ERR_ARG, "regions must cover all loci of the set");
+    const int si = (int)h->sets.size();
+    const int64_t nv = nreg * k * k;
+    std::vector<double> vb0((size_t)nv);
+    for (int64_t r = 0; r < nreg; r++) for (int a = 0; a < k * k; a++) vb0[(size_t)(r * k * k + a)] = varBeta0[a];  // src/mme.jl:516
+    HSet hs{col0, span, NGP_METHOD_TUPLE, df, 0.0, nreg, h->nvb, 0, 0, 0.5, vb0};
+    hs.tk = k; hs.nloc = nloc;
+    const int64_t new_nvb = h->nvb + nv;
+    if (new_nvb > h->vb_cap) {
+        int64_t cap = std::max<int64_t>(new_nvb, 2 * h->vb_cap);
+        double *nvp = nullptr, *nsp = nullptr;
+        if ((rc = dalloc(h, &nvp, (size_t)cap))) return rc;
+        if ((rc = dalloc(h, &nsp, (size_t)cap))) return rc;
+        if (h->nvb > 0) {
+            HCHK(hipMemcpyAsync(nvp, h->d_varBeta, (size_t)h->nvb * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+            HCHK(hipMemcpyAsync(nsp, h->d_sum_varBeta, (size_t)h->nvb * sizeof(double), hipMemcpyDeviceToDevice, h->stream));
+        }
+        HCHK(hipStreamSynchronize(h->stream));
+        dfree(h->d_varBeta); dfree(h->d_sum_varBeta);
+        h->d_varBeta = nvp; h->d_sum_varBeta = nsp; h->vb_cap = cap;
+    }
+    HCHK(hipMemcpy(h->d_varBeta + h->nvb, vb0.data(), (size_t)nv * sizeof(double), hipMemcpyHostToDevice));
+    if (!h->d_tup) {
+        if ((rc = dalloc(h, &h->d_tup, 16))) return rc;
+        if ((rc = dalloc(h, &h->d_tupc, (size_t)NGP_KMAX * (size_t)h->Ppad))) return rc;
+        if ((rc = dalloc(h, &h->d_tupg, (size_t)NGP_KMAX * (size_t)h->Ppad))) return rc;
+    }
+    for (int64_t c = col0; c < std::min<int64_t>(col0 + NGP_BLK * nblk, h->Ppad); c++) h->h_setof[c] = (int8_t)-2;  // owned, no locus (unused lanes)
+    for (int64_t r = 0; r < nreg; r++) {
+        for (int64_t l = reg_start[r]; l < reg_stop[r]; l++)
+            for (int m = 0; m < k; m++) {
+                const int64_t c = tuple_col(col0, k, l, m);
+                h->h_setof[c] = (int8_t)si;
+                h->h_loc[c] = (int32_t)(l * k + m);   // also the key of the component's normal draw
+                h->h_vbidx[c] = (int32_t)(h->nvb + r * k * k);
+            }
+        DTReg tr;
+        tr.seg0 = (long long)h->h_tseg_l0.size(); tr.rg = r; tr.n = reg_stop[r] - reg_start[r]; tr.set = si;
+        int ns = 0;
+        for (int64_t l0 = reg_start[r]; l0 < reg_stop[r]; l0 += NGP_SEG) {
+            h->h_tseg_l0.push_back(l0);
+            h->h_tseg_len.push_back((int32_t)std::min<int64_t>(NGP_SEG, reg_stop[r] - l0));
+            h->h_tseg_set.push_back((int32_t)si);
+            ns++;
+        }
+        tr.nseg = ns;
+        h->h_tregs.push_back(tr);
+    }
+    REQUIRE((int64_t)nloc * k < ((int64_t)1 << 31), NGP_ERR_ARG, "tuple set too large");
+    DTup tp;
+    memset(&tp, 0, sizeof(tp));
+    tp.k = k; tp.col0 = col0; tp.nloc = nloc; tp.vb_off = h->nvb; tp.df = df;
+    for (int a = 0; a < k * k; a++) tp.scale[a] = scale[a];
+    HCHK(hipMemcpy(h->d_tup + si, &tp, sizeof(DTup), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_tuple_gkk, dim3((unsigned)((nloc * k + 255) / 256)), dim3(256), 0, h->stream, h->d_gramx, h->D, h->d_mpm, tp, h->d_tupg,
+                       (long long)h->Ppad);
+    DSet ds;
+    memset(&ds, 0, sizeof(ds));
+    ds.method = NGP_METHOD_TUPLE; ds.df = df; ds.col0 = col0; ds.ncol = span;
+    HCHK(hipMemcpy(h->d_sets + si, &ds, sizeof(DSet), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(k_set_pi, dim3(1), dim3(1), 0, h->stream, h->d_sets, si, 0.5, 0.5);
+    HCHK(hipStreamSynchronize(h->stream));
+    h->nvb = new_nvb;
+    h->sets.push_back(hs);
+    h->ntuple += 1;
+    h->tables_dirty = true;
+    h->trace_ext_cap = 0;
+    if (set_id) *set_id = si;
     return NGP_OK;
     NGP_CATCH(h)
 }

@@ -12,6 +12,8 @@
 #define NGP_SEG 256
 #define NGP_GRP 32
 #define NGP_RMAX 4  // variance classes of a BayesR set (the chain keeps their coefficients in registers)
+#define NGP_KMAX 4  // marker sets of one tuple (correlated BayesPR, src/functions.jl:140-154)
+#define NGP_METHOD_TUPLE_DEV 4
 
 namespace ngp {
 
@@ -28,6 +30,55 @@ struct DSet {  // one marker set (src/mme.jl:324-361, 492-520)
     double vcls[NGP_RMAX], pic[NGP_RMAX], logpic[NGP_RMAX], sum_pic[NGP_RMAX];
     int ncls[NGP_RMAX];  // loci per class of the running sweep
 };
+
+// Correlated (Tuple) BayesPR set (src/functions.jl:140-154, 513-516; set-up src/mme.jl:448-489): k sets share nloc loci, the k
+// columns of a locus adjacent in the panel; the set's marker-set entry (DSet) carries method 4, this the rest.
+struct DTup {
+    int k, pad_;
+    long long col0, nloc, vb_off;  // first panel column (a block boundary), loci, offset of the nreg k x k variance matrices in varBeta
+    double df, scale[NGP_KMAX * NGP_KMAX];
+};
+// panel column of component m of tuple locus l: floor(64 / k) whole loci per 64-column block, component-minor
+__host__ __device__ inline long long tuple_col(long long col0, int k, long long l, int m) {
+    const long long Lb = NGP_BLK / k;
+    return col0 + (long long)NGP_BLK * (l / Lb) + (long long)k * (l % Lb) + m;
+}
+// ---- k x k helpers of the Tuple path (row-major, k <= NGP_KMAX), operation for operation the text of oracle/ngp_oracle.c
+// (t_chol, t_spd_inv, t_chol1): fma where written, everything else separately rounded; k = 1 takes the scalar forms ----
+__device__ inline int t_chol(const double *S, int k, double *L) {
+    for (int a = 0; a < k * k; a++) L[a] = 0.0;
+    for (int i = 0; i < k; i++)
+        for (int j = 0; j <= i; j++) {
+            double s = S[i * k + j];
+            for (int m = 0; m < j; m++) s = __builtin_fma(-L[i * k + m], L[j * k + m], s);
+            if (i == j) { if (!(s > 0.0)) return -1; L[i * k + i] = det_sqrt(s); }
+            else L[i * k + j] = s / L[j * k + j];
+        }
+    return 0;
+}
+__device__ inline int t_spd_inv(const double *S, int k, double *out) {
+    if (k == 1) { out[0] = 1.0 / S[0]; return (S[0] > 0.0) ? 0 : -1; }
+    double L[NGP_KMAX * NGP_KMAX], Li[NGP_KMAX * NGP_KMAX];
+    if (t_chol(S, k, L)) return -1;
+    for (int a = 0; a < k * k; a++) Li[a] = 0.0;
+    for (int c = 0; c < k; c++)
+        for (int i = c; i < k; i++) {
+            double s = (i == c) ? 1.0 : 0.0;
+            for (int m = c; m < i; m++) s = __builtin_fma(-L[i * k + m], Li[m * k + c], s);
+            Li[i * k + c] = s / L[i * k + i];
+        }
+    for (int i = 0; i < k; i++)
+        for (int j = 0; j < k; j++) {
+            double s = 0.0;
+            for (int m = 0; m < k; m++) s = __builtin_fma(Li[m * k + i], Li[m * k + j], s);
+            out[i * k + j] = s;
+        }
+    return 0;
+}
+__device__ inline int t_chol1(const double *S, int k, double *L) {
+    if (k == 1) { L[0] = det_sqrt(S[0]); return (S[0] >= 0.0) ? 0 : -1; }
+    return t_chol(S, k, L);
+}
 
 struct DReg {  // one BayesPR variance region
     long long seg0;
@@ -123,6 +174,67 @@ __device__ inline void eval_rform(const int meth, const double r, const double b
         cand = in ? e1 : -bo;
         cls = in;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// Block chain of a Tuple (correlated BayesPR) block (src/functions.jl:144-151 in 64-column space).
+// Lane j = column j of the block; the k columns of a locus are adjacent, floor(64 / k) loci per block.  tot = x_j'ycorr as the
+// look-ahead pipeline delivers it (group sums minus corrections).  One step per LOCUS: its k effects are drawn together from
+// the r of its k columns, dlt_m = W_m + sum_b C[m][b] r_b (W = L z - beta, C = iVarE inv(LHS): k_prep), then applied component
+// after component to the columns of the later loci, r_j -= G[m][j] dlt_m.  G(kk) returns G[kk][j] of the one-sided diagonal block
+// (0 for j <= kk).  Returns dlt of this lane's column (0 for the unused lanes of the block).
+// ------------------------------------------------------------------------------------------
+struct TupLane {  // per-column coefficients of a tuple lane (prefetched): rows of C and of X_l'X_l, W
+    double crow[NGP_KMAX], grow[NGP_KMAX], ww;
+};
+__device__ inline TupLane load_tuplane(const double *__restrict__ tupc, const double *__restrict__ tupg, const double *__restrict__ w,
+                                       long long Ppad, long long kcol) {
+    TupLane T;
+#pragma unroll
+    for (int b = 0; b < NGP_KMAX; b++) {
+        T.crow[b] = tupc[(size_t)b * Ppad + kcol];
+        T.grow[b] = tupg[(size_t)b * Ppad + kcol];
+    }
+    T.ww = w[kcol];
+    return T;
+}
+template <typename GAt>
+__device__ inline double tuple_chain(const int k, const long long nloc, const long long first_locus, const int j, const double tot,
+                                     const double bo, const TupLane &T, GAt G) {
+    const int Lb = NGP_BLK / k;
+    const long long left = nloc - first_locus;
+    const int nvalid = (int)(left < Lb ? left : Lb) * k;  // used lanes of this block (uniform)
+    const int gbase = (j / k) * k;
+    const bool valid = j < nvalid;
+    // x_m'(ycorr + X_l beta_l): the add-back of all k effects of the locus, components in order
+    double rfull = tot;
+#pragma unroll
+    for (int b = 0; b < NGP_KMAX; b++)
+        if (b < k) {
+            const double bm = __shfl(bo, gbase + b);
+            if (valid) rfull = __builtin_fma(T.grow[b], bm, rfull);
+        }
+    // scaled form, as the Symbol path's chain: e = W + sum_b C[b] r_b is this lane's candidate dlt
+    double e = T.ww;
+#pragma unroll
+    for (int b = 0; b < NGP_KMAX; b++)
+        if (b < k) {
+            const double rb = __shfl(rfull, gbase + b);
+            e = __builtin_fma(rb, T.crow[b], e);
+        }
+    if (!valid) e = 0.0;
+    // a finished column s changes e by H(s) dlt_s, H(s) = -(sum_b C[b] G[s][column b of this lane's locus]), for the columns of
+    // LATER loci only (the k effects of a locus are drawn together)
+    for (int sl = 0; sl < nvalid; ++sl) {
+        const double dk = readlane_d(e, sl);
+        double t = T.crow[0] * G(sl, gbase);
+#pragma unroll
+        for (int b = 1; b < NGP_KMAX; b++)
+            if (b < k) t = __builtin_fma(T.crow[b], G(sl, gbase + b), t);
+        const double Hs = (valid && sl < gbase) ? -t : 0.0;
+        e = __builtin_fma(Hs, dk, e);
+    }
+    return e;
 }
 
 // Tile (t, s) = R rows x 64 columns of fp32, stored QUAD-MAJOR: element (row i, column j) sits at (i >> 2) * 256 + j * 4 + (i & 3).

@@ -177,7 +177,8 @@ __global__ __launch_bounds__(256) void k_prep(long long Ppad, const int8_t *__re
                                               double *__restrict__ T, double *__restrict__ chi, int active_set, uint64_t seed,
                                               uint64_t chain, uint64_t it, long long nreg, const DReg *__restrict__ regs,
                                               double *__restrict__ regchi, double *__restrict__ rcls, unsigned *__restrict__ ccnt,
-                                              long long ccnt_words, const unsigned *__restrict__ abort_w) {
+                                              long long ccnt_words, const unsigned *__restrict__ abort_w, const DTup *__restrict__ tup,
+                                              double *__restrict__ tupc, const double *__restrict__ tupg) {
     if (abort_w && *abort_w != 0u) return;  // an earlier sweep of this call gave up (ngp_sweep_args.h, abort_w)
     // the hand-off counters of the persistent sweep that follows in the stream start from zero (was a memset launch of its own)
     for (long long i = (long long)blockIdx.x * 256 + threadIdx.x; i < ccnt_words; i += (long long)gridDim.x * 256) ccnt[i] = 0u;
@@ -203,6 +204,38 @@ __global__ __launch_bounds__(256) void k_prep(long long Ppad, const int8_t *__re
     const double varE = sc->varE, iVarE = sc->iVarE;
     const uint64_t l = (uint64_t)loc[k];
     const uint64_t key = ((uint64_t)si << 40) | l;
+    if (S.method == NGP_METHOD_TUPLE_DEV) {
+        // Tuple set (src/functions.jl:143-149): the k x k conditional of this column's locus -- every column of the locus forms it
+        // (k <= 4: a few dozen flops) and keeps its own row: C[m][.] = iVarE inv(LHS)[m][.], W_m = (L z)_m - beta_m, L = chol(inv(LHS)),
+        // LHS = X_l'X_l iVarE + inv(varBeta_r).  loc = locus * k + component (also the key of the component's normal draw).
+        const DTup Tp = tup[si];
+        const int kk = Tp.k, m = (int)(l % (uint64_t)kk);
+        const long long base = k - m;
+        double invB[NGP_KMAX * NGP_KMAX], LHS[NGP_KMAX * NGP_KMAX], invLHS[NGP_KMAX * NGP_KMAX], Lc[NGP_KMAX * NGP_KMAX];
+        double vbm[NGP_KMAX * NGP_KMAX];
+        for (int a = 0; a < kk * kk; a++) vbm[a] = varBeta[vbidx[k] + a];
+        int bad = t_spd_inv(vbm, kk, invB);
+        for (int a = 0; a < kk; a++)
+            for (int b = 0; b < kk; b++) {
+                const double t1 = tupg[(size_t)b * Ppad + base + a] * iVarE;
+                LHS[a * kk + b] = t1 + invB[a * kk + b];
+            }
+        bad |= t_spd_inv(LHS, kk, invLHS);
+        bad |= t_chol1(invLHS, kk, Lc);
+        for (int b = 0; b < kk; b++) tupc[(size_t)b * Ppad + k] = iVarE * invLHS[m * kk + b];
+        double acc = 0.0;
+        for (int b = 0; b <= m; b++) {
+            Rng rz = rng_seed(seed, chain, it, NGP_KIND_BETA_NORMAL, ((uint64_t)si << 40) | (l - (uint64_t)m + (uint64_t)b));
+            const double zb = rng_normal(rz);
+            acc = (b == 0) ? Lc[m * kk] * zb : __builtin_fma(Lc[m * kk + b], zb, acc);
+        }
+        c[k] = 0.0;
+        w[k] = bad ? __builtin_nan("") : acc - beta[k];  // a variance matrix that is not positive definite poisons the chain visibly
+        q[k] = -1.0;
+        T[k] = 1.0;
+        chi[k] = 1.0;
+        return;
+    }
     if (S.method == 3) {  // BayesR: per-class coefficients (src/functions.jl:254-255); the class is chosen inside the block chain
         double *rq = rcls, *ra = rcls + (size_t)NGP_RMAX * Ppad, *rt = rcls + (size_t)2 * NGP_RMAX * Ppad, *ru = rcls + (size_t)3 * NGP_RMAX * Ppad;
         const double varB = varBeta[vbidx[k]];
@@ -374,7 +407,8 @@ __global__ __launch_bounds__(256) void k_recur(const double *__restrict__ part, 
                                                const double *__restrict__ chi, const int8_t *__restrict__ setof,
                                                const int32_t *__restrict__ vbidx, DSet *__restrict__ sets,
                                                double *__restrict__ varBeta, double *__restrict__ dlt, const double *__restrict__ rcls,
-                                               long long Ppad, const double *__restrict__ rhs0, const DScal *__restrict__ sc) {
+                                               long long Ppad, const double *__restrict__ rhs0, const DScal *__restrict__ sc,
+                                               const DTup *__restrict__ tup, const double *__restrict__ tupc, const double *__restrict__ tupg) {
     __shared__ double gs[32 * NGP_BLK];
     const int tid = threadIdx.x, j = tid & 63, g4 = tid >> 6;
     const int ngroups = (S + NGP_GRP - 1) / NGP_GRP;
@@ -395,6 +429,20 @@ __global__ __launch_bounds__(256) void k_recur(const double *__restrict__ part, 
     const double r = __builtin_fma(gd, bo, tot);
     const int si0 = setof[k];
     const int meth0 = (si0 >= 0) ? sets[si0].method : -1;
+    {
+        const unsigned long long tm = __ballot(meth0 == NGP_METHOD_TUPLE_DEV);
+        if (tm != 0ull) {  // a block of a Tuple set: one step per locus (tuple_chain)
+            const int sit = __builtin_amdgcn_readfirstlane(__shfl(si0, __builtin_ctzll(tm)));
+            const DTup Tp = tup[sit];
+            const TupLane TL = load_tuplane(tupc, tupg, w, Ppad, k);
+            const long long first_locus = ((long long)t - Tp.col0 / NGP_BLK) * (NGP_BLK / Tp.k);
+            const double dfin = tuple_chain(Tp.k, Tp.nloc, first_locus, j, tot, bo, TL, [&](int sl, int cc2) { return G[(size_t)sl * NGP_BLK + cc2]; });
+            beta[k] = bo + dfin;
+            delta[k] = (uint8_t)1;
+            dlt[j] = dfin;
+            return;
+        }
+    }
     if (__ballot(meth0 == 3) != 0ull) {  // a BayesR locus in the block: r-form chain (eval_rform)
         RLane RL;
         RL.K = 2; RL.rhs0 = 0.0;
@@ -572,6 +620,114 @@ __global__ __launch_bounds__(64) void k_regdraw(long long nreg, const DReg *__re
     double tt = S.scale * S.df;
     tt = tt + tot;
     varBeta[R.vb] = tt / ch;
+}
+
+// ------------------------------------------------------------------------------------------
+// Tuple sets: region variance MATRICES (src/functions.jl:152, :513-516).  Sb = B_r'B_r entry by entry in the segment pattern of
+// k_regssq (a wave per 256 loci of a region; lane l: loci l, l+64, l+128, l+192 by fma; xor butterfly), then one thread per region:
+// segments in order, Psi = scale + Sb, varBeta_r ~ InverseWishart(df + n_r, Psi) by Bartlett's construction on keyed draws
+// (oracle/ngp_oracle.c t_inverse_wishart, operation for operation; k = 1: Psi / chi2, the Symbol path's form and key).
+// ------------------------------------------------------------------------------------------
+struct DTReg {  // one variance region of a tuple set
+    long long seg0, rg, n;
+    int nseg, set;
+};
+#define NGP_TPAIRS 10  // entries a <= b of a symmetric 4 x 4 matrix
+__global__ __launch_bounds__(256) void k_tuple_ssq(long long nseg, const long long *__restrict__ seg_l0, const int32_t *__restrict__ seg_len,
+                                                   const int32_t *__restrict__ seg_set, const DTup *__restrict__ tup,
+                                                   const double *__restrict__ beta, double *__restrict__ tsegpart,
+                                                   const unsigned *__restrict__ abort_w) {
+    if (abort_w && *abort_w != 0u) return;
+    const long long sg = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (sg >= nseg) return;
+    const int lane = threadIdx.x & 63;
+    const DTup Tp = tup[seg_set[sg]];
+    const long long l0 = seg_l0[sg];
+    const int n = seg_len[sg], kk = Tp.k;
+    int pr = 0;
+    for (int a = 0; a < kk; a++)
+        for (int b = a; b < kk; b++, pr++) {
+            double acc = 0.0;
+#pragma unroll
+            for (int m = 0; m < 4; m++) {
+                const int i = lane + 64 * m;
+                if (i < n) {
+                    const double ba = beta[tuple_col(Tp.col0, kk, l0 + i, a)], bb = beta[tuple_col(Tp.col0, kk, l0 + i, b)];
+                    acc = __builtin_fma(ba, bb, acc);
+                }
+            }
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) acc = acc + __shfl_xor(acc, off);
+            if (lane == 0) tsegpart[sg * NGP_TPAIRS + pr] = acc;
+        }
+}
+__global__ __launch_bounds__(64) void k_tuple_draw(long long nreg, const DTReg *__restrict__ regs, const double *__restrict__ tsegpart,
+                                                   const DTup *__restrict__ tup, double *__restrict__ varBeta, int active_set,
+                                                   uint64_t seed, uint64_t chain, uint64_t it, const unsigned *__restrict__ abort_w) {
+    if (abort_w && *abort_w != 0u) return;
+    const long long rgi = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (rgi >= nreg) return;
+    const DTReg Rg = regs[rgi];
+    if (active_set >= 0 && Rg.set != active_set) return;
+    const DTup Tp = tup[Rg.set];
+    const int k = Tp.k;
+    double Psi[NGP_KMAX * NGP_KMAX];
+    int pr = 0;
+    for (int a = 0; a < k; a++)
+        for (int b = a; b < k; b++, pr++) {
+            double tot = tsegpart[Rg.seg0 * NGP_TPAIRS + pr];
+            for (int sg = 1; sg < Rg.nseg; sg++) tot = tot + tsegpart[(Rg.seg0 + sg) * NGP_TPAIRS + pr];
+            const double pab = Tp.scale[a * k + b] + tot, pba = Tp.scale[b * k + a] + tot;
+            Psi[a * k + b] = pab; Psi[b * k + a] = pba;
+        }
+    const double nu = Tp.df + (double)Rg.n;
+    double *out = varBeta + Tp.vb_off + Rg.rg * k * k;
+    if (k == 1) {
+        Rng r = rng_seed(seed, chain, it, NGP_KIND_REGION_CHI2, ((uint64_t)Rg.set << 40) | (uint64_t)Rg.rg);
+        const double ch = rng_chisq(r, nu);
+        out[0] = Psi[0] / ch;
+        return;
+    }
+    double Pi[NGP_KMAX * NGP_KMAX], L[NGP_KMAX * NGP_KMAX], A[NGP_KMAX * NGP_KMAX], LA[NGP_KMAX * NGP_KMAX], W[NGP_KMAX * NGP_KMAX], res[NGP_KMAX * NGP_KMAX];
+    int bad = t_spd_inv(Psi, k, Pi);
+    bad |= t_chol(Pi, k, L);
+    for (int a = 0; a < k * k; a++) A[a] = 0.0;
+    for (int i = 0; i < k; i++)
+        for (int j = 0; j <= i; j++) {
+            Rng r = (i == 0) ? rng_seed(seed, chain, it, NGP_KIND_REGION_CHI2, ((uint64_t)Rg.set << 40) | (uint64_t)Rg.rg)
+                             : rng_seed(seed, chain, it, NGP_KIND_T_WISHART, ((uint64_t)Rg.set << 40) | ((uint64_t)Rg.rg << 8) | ((uint64_t)i << 4) | (uint64_t)j);
+            if (i == j) { const double ch = rng_chisq(r, nu - (double)i); A[i * k + i] = det_sqrt(ch); }
+            else A[i * k + j] = rng_normal(r);
+        }
+    for (int i = 0; i < k; i++)
+        for (int j = 0; j < k; j++) {
+            double s = 0.0;
+            for (int m = 0; m < k; m++) s = __builtin_fma(L[i * k + m], A[m * k + j], s);
+            LA[i * k + j] = s;
+        }
+    for (int i = 0; i < k; i++)
+        for (int j = 0; j < k; j++) {
+            double s = 0.0;
+            for (int m = 0; m < k; m++) s = __builtin_fma(LA[i * k + m], LA[j * k + m], s);
+            W[i * k + j] = s;
+        }
+    bad |= t_spd_inv(W, k, res);
+    for (int a = 0; a < k * k; a++) out[a] = bad ? __builtin_nan("") : res[a];
+}
+// X_l'X_l of every locus of a tuple set, row m for column (l, m): from the one-sided diagonal Gram block (entry [a][b] kept for b > a)
+// and x'x in mpm.  Once per set.
+__global__ __launch_bounds__(256) void k_tuple_gkk(const double *__restrict__ gramx, int D, const double *__restrict__ mpm, DTup Tp,
+                                                   double *__restrict__ tupg, long long Ppad) {
+    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;  // locus * k + component
+    if (idx >= Tp.nloc * Tp.k) return;
+    const int k = Tp.k, m = (int)(idx % k);
+    const long long l = idx / k, c = tuple_col(Tp.col0, k, l, m), t = c / NGP_BLK;
+    const int jm = (int)(c % NGP_BLK);
+    const double *G0 = gramx + (size_t)t * D * NGP_BLK * NGP_BLK;  // plane d = 0
+    for (int b = 0; b < k; b++) {
+        const int jb = jm - m + b;
+        tupg[(size_t)b * Ppad + c] = (b == m) ? mpm[c] : G0[(size_t)min(jm, jb) * NGP_BLK + max(jm, jb)];
+    }
 }
 
 // pi draw of BayesB sets (functions.jl:190-194, :531-533); also clears the inclusion counters

@@ -21,6 +21,7 @@
 #define NGP_KIND_PI_BETA 7
 #define NGP_KIND_R_UNIFORM 8    // BayesR: the fresh uniform of every comparison of the class search (src/functions.jl:261)
 #define NGP_KIND_R_DIRICHLET 9  // BayesR: gamma draws of the Dirichlet (src/functions.jl:536-538)
+#define NGP_KIND_T_WISHART 11   // Tuple sets: Bartlett factor of a region's inverse-Wishart draw, (set << 40) | (region << 8) | (i << 4) | j
 
 #define NGP_GOLD 0x9E3779B97F4A7C15ULL
 

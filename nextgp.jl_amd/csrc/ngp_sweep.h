@@ -1214,11 +1214,21 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
             int isave = 1;
             // BayesR: the lane's set and method (one byte per lane, read only when the model has a BayesR set at all)
             int meth0 = -1, si0 = -1;
-            if (A.rcls) {
+            if (A.rcls || A.tup) {
                 si0 = A.setof[(long long)t * NGP_BLK + j];
                 meth0 = (si0 >= 0) ? smeth[si0] : -1;
             }
-            if (A.rcls && __ballot(meth0 == 3) != 0ull) {
+            unsigned long long tmask = 0ull;
+            if (A.tup) tmask = __ballot(meth0 == NGP_METHOD_TUPLE_DEV);
+            if (tmask != 0ull) {
+                // a block of a Tuple set: one step per locus, its k effects drawn together (tuple_chain, ngp_common.h)
+                const int sit = __builtin_amdgcn_readfirstlane(__shfl(si0, __builtin_ctzll(tmask)));
+                const DTup Tp = A.tup[sit];
+                const TupLane TL = load_tuplane(A.tupc, A.tupg, A.w, A.Ppad, (long long)t * NGP_BLK + j);
+                const long long first_locus = ((long long)t - Tp.col0 / NGP_BLK) * (NGP_BLK / Tp.k);
+                dsave = tuple_chain(Tp.k, Tp.nloc, first_locus, j, tot, bo, TL, [&](int sl, int cc2) { return Gd[(u % 3) * 4096 + sl * NGP_BLK + cc2]; });
+                isave = 1;
+            } else if (A.rcls && __ballot(meth0 == 3) != 0ull) {
                 // r-form chain (eval_rform, ngp_kernels.h): candidates of all lanes from the current r, the first non-zero one at
                 // or behind the cursor takes its step.  With most loci in the zero class that is a few steps per block.
                 RLane RL;

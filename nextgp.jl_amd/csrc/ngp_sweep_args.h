@@ -43,6 +43,9 @@ struct SweepArgs {
     const double *rhs0;
     const DScal *scal;
     long long Ppad;
+    // Tuple (correlated BayesPR) sets; null when the model has none: per-set constants, rows of C (k_prep) and of X_l'X_l per column
+    const DTup *tup;
+    const double *tupc, *tupg;
     // compact storage (variant 3): tiles are bytes (genotype codes), centred analytically with the Float64 column means
     const double *mean;  // [Ppad]
     long long N;         // rows of the panel (the last shards carry padding rows, which must stay zero)

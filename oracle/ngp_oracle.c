@@ -64,6 +64,9 @@
 #define METHOD_C 2 /* BayesC: src/functions.jl:197-235 */
 #define METHOD_R 3 /* BayesR: src/functions.jl:238-289 */
 #define RMAX 4     /* variance classes of a BayesR set (the device keeps them in registers) */
+#define METHOD_T 4 /* correlated (Tuple) BayesPR: src/functions.jl:140-154, 513-516; set-up src/mme.jl:448-489 */
+#define KMAX 4     /* marker sets of one tuple */
+#define KIND_T_WISHART 11 /* Bartlett factor of a region's inverse-Wishart draw: index (set << 40) | (region << 8) | (i << 4) | j */
 
 #define BLK 64
 #define SEG 256
@@ -298,7 +301,92 @@ typedef struct {
     double sum_pi[2];
     /* BayesR (functions.jl:238-289): K variance classes with multipliers vcls of the set's single variance */
     int K; double vcls[RMAX], pic[RMAX], logpic[RMAX], sum_pic[RMAX];
+    /* Tuple BayesPR (functions.jl:140-154): tk correlated sets share nloc loci; the k columns of a locus are adjacent in the panel
+       (tcol); scale tk x tk (mme.jl:501), nreg variance MATRICES (tk x tk each, row-major) in varBeta */
+    int tk; int64_t nloc; double tscale[KMAX * KMAX];
+    double *tmpm;  /* reference order: X_l'X_l of every locus, [nloc][tk][tk] (mme.jl:462) */
 } oset_t;
+
+/* Panel column of component m of tuple locus l: every 64-column block holds floor(64 / k) whole loci, component-minor (a locus
+   never straddles two blocks: the block chain draws its k effects in one step); for k = 3 column 63 of each block stays unused. */
+static inline int64_t tcol(const oset_t *S, int64_t l, int m) {
+    const int64_t Lb = BLK / S->tk;
+    return S->col0 + BLK * (l / Lb) + (int64_t)S->tk * (l % Lb) + m;
+}
+
+/* ---- k x k helpers of the Tuple path (row-major, k <= KMAX).  Every operation is written out (fma where stated, everything
+   else separately rounded): the device repeats this text operation for operation (csrc/ngp_common.h), so both give the same bits.
+   k = 1 takes the scalar forms of the Symbol path (1 / x, sqrt x), which makes a one-set tuple that path, bit for bit. ---- */
+static int t_chol(const double *S, int k, double *L) { /* S = L L', L lower; returns -1 if S is not positive definite */
+    for (int a = 0; a < k * k; a++) L[a] = 0.0;
+    for (int i = 0; i < k; i++)
+        for (int j = 0; j <= i; j++) {
+            double s = S[i * k + j];
+            for (int m = 0; m < j; m++) s = __builtin_fma(-L[i * k + m], L[j * k + m], s);
+            if (i == j) { if (!(s > 0.0)) return -1; L[i * k + i] = sqrt(s); }
+            else L[i * k + j] = s / L[j * k + j];
+        }
+    return 0;
+}
+static int t_spd_inv(const double *S, int k, double *out) { /* inv(S) through the Cholesky factor: inv(L)' inv(L) */
+    if (k == 1) { out[0] = 1.0 / S[0]; return (S[0] > 0.0) ? 0 : -1; }
+    double L[KMAX * KMAX], Li[KMAX * KMAX];
+    if (t_chol(S, k, L)) return -1;
+    for (int a = 0; a < k * k; a++) Li[a] = 0.0;
+    for (int c = 0; c < k; c++)
+        for (int i = c; i < k; i++) {
+            double s = (i == c) ? 1.0 : 0.0;
+            for (int m = c; m < i; m++) s = __builtin_fma(-L[i * k + m], Li[m * k + c], s);
+            Li[i * k + c] = s / L[i * k + i];
+        }
+    for (int i = 0; i < k; i++)
+        for (int j = 0; j < k; j++) {
+            double s = 0.0;
+            for (int m = 0; m < k; m++) s = __builtin_fma(Li[m * k + i], Li[m * k + j], s);
+            out[i * k + j] = s;
+        }
+    return 0;
+}
+static int t_chol1(const double *S, int k, double *L) { /* Cholesky factor with the scalar form for k = 1 */
+    if (k == 1) { L[0] = sqrt(S[0]); return (S[0] >= 0.0) ? 0 : -1; }
+    return t_chol(S, k, L);
+}
+/* varBeta ~ InverseWishart(nu, Psi) (functions.jl:513-516; Distributions.jl is absent: Bartlett's construction on the keyed
+   streams).  W = (L A)(L A)' with L = chol(inv(Psi)), A lower triangular, A_ii = sqrt(chi2(nu - i)), A_ij ~ N(0,1) (i > j);
+   varBeta = inv(W).  k = 1: Psi / chi2(nu), the Symbol path's form.  The (0,0) chi-square is the region's chi-square of the
+   Symbol path (KIND_REGION_CHI2, (set << 40) | region). */
+static int t_inverse_wishart(uint64_t seed, uint64_t chain, uint64_t it, int si, int64_t rg, double nu, const double *Psi, int k, double *out) {
+    rng_t r;
+    if (k == 1) {
+        rng_seed(&r, seed, chain, it, KIND_REGION_CHI2, ((uint64_t)si << 40) | (uint64_t)rg);
+        const double ch = rng_chisq(&r, nu);
+        out[0] = Psi[0] / ch;
+        return 0;
+    }
+    double Pi[KMAX * KMAX], L[KMAX * KMAX], A[KMAX * KMAX], LA[KMAX * KMAX], W[KMAX * KMAX];
+    if (t_spd_inv(Psi, k, Pi) || t_chol(Pi, k, L)) return -1;
+    for (int a = 0; a < k * k; a++) A[a] = 0.0;
+    for (int i = 0; i < k; i++)
+        for (int j = 0; j <= i; j++) {
+            if (i == 0) rng_seed(&r, seed, chain, it, KIND_REGION_CHI2, ((uint64_t)si << 40) | (uint64_t)rg);
+            else rng_seed(&r, seed, chain, it, KIND_T_WISHART, ((uint64_t)si << 40) | ((uint64_t)rg << 8) | ((uint64_t)i << 4) | (uint64_t)j);
+            if (i == j) { const double ch = rng_chisq(&r, nu - (double)i); A[i * k + i] = sqrt(ch); }
+            else A[i * k + j] = rng_normal(&r);
+        }
+    for (int i = 0; i < k; i++)
+        for (int j = 0; j < k; j++) {
+            double s = 0.0;
+            for (int m = 0; m < k; m++) s = __builtin_fma(L[i * k + m], A[m * k + j], s);
+            LA[i * k + j] = s;
+        }
+    for (int i = 0; i < k; i++)
+        for (int j = 0; j < k; j++) {
+            double s = 0.0;
+            for (int m = 0; m < k; m++) s = __builtin_fma(LA[i * k + m], LA[j * k + m], s);
+            W[i * k + j] = s;
+        }
+    return t_spd_inv(W, k, out);
+}
 
 typedef struct {
     int order; /* 0 reference, 1 blocked */
@@ -345,6 +433,7 @@ typedef struct {
     int nfix; struct { int64_t ncol, off; double *X, *xpx0, *xpxR, *lhs0, *rhs0; } fix[16];
     int64_t nfixcol; double *bfix, *sum_bfix;
     double *rcls; /* BayesR per-locus class coefficients of the blocked order: [4][RMAX][Ppad] = 1/lhs, a, sd z, u */
+    double *tupc, *tupg; /* Tuple sets, blocked order: [KMAX][Ppad] row of C = iVarE inv(LHS) and of X_l'X_l of every column */
     char err[256];
 } ora_t;
 
@@ -368,14 +457,14 @@ int ora_set_nchain(ora_t *h, int64_t n) {
     h->nchain = n; return ORA_OK;
 }
 static void free_sets(ora_t *h) {
-    for (int s = 0; s < h->nsets; s++) { free(h->sets[s].reg_start); free(h->sets[s].reg_stop); }
+    for (int s = 0; s < h->nsets; s++) { free(h->sets[s].reg_start); free(h->sets[s].reg_stop); free(h->sets[s].tmpm); }
 }
 void ora_destroy(ora_t *h) {
     if (!h) return;
     free(h->data); free(h->Mp); free(h->tiles); free(h->tiles8); free(h->mean); free(h->gram); free(h->gramx); free(h->mpm); free(h->lhs0); free(h->rhs0);
     free_sets(h); free(h->varBeta); free(h->sum_varBeta); free(h->y); free(h->ycorr); free(h->beta); free(h->delta);
     free(h->sum_beta); free(h->sum_beta2); free(h->sum_delta); free(h->tr_varE); free(h->tr_b);
-    free(h->c); free(h->w); free(h->q); free(h->T); free(h->chi); free(h->rcls);
+    free(h->c); free(h->w); free(h->q); free(h->T); free(h->chi); free(h->rcls); free(h->tupc); free(h->tupg);
     free(h);
 }
 const char *ora_last_error(ora_t *h) { return h->err; }
@@ -586,6 +675,11 @@ int ora_add_marker_set(ora_t *h, int64_t col0, int64_t ncol, int method, double 
                        const double *lhs0, const double *rhs0, int *set_id) {
     if (h->nsets >= 16) { snprintf(h->err, 256, "too many sets"); return ORA_ERR; }
     if (col0 < 0 || col0 + ncol > h->P) { snprintf(h->err, 256, "set outside panel"); return ORA_ERR; }
+    for (int q = 0; q < h->nsets; q++) {  /* a tuple set owns its 64-column blocks to the end of the last one */
+        const oset_t *o = &h->sets[q];
+        const int64_t oend = (o->method == METHOD_T) ? o->col0 + BLK * ((o->ncol + BLK - 1) / BLK) : o->col0 + o->ncol;
+        if (col0 < oend && o->col0 < col0 + ncol) { snprintf(h->err, 256, "marker sets overlap"); return ORA_ERR; }
+    }
     oset_t *s = &h->sets[h->nsets];
     memset(s, 0, sizeof(*s));
     s->col0 = col0; s->ncol = ncol; s->method = method; s->df = df; s->scale = scale; s->nreg = nreg; s->estPi = estPi;
@@ -751,6 +845,52 @@ int ora_add_marker_set_r(ora_t *h, int64_t col0, int64_t ncol, double df, double
     }
     return ORA_OK;
 }
+/* Correlated marker sets (Tuple BayesPR, mme.jl:448-489): k sets share nloc loci; the panel holds them locus-major (tcol), from a
+   block boundary on.  df = 3 + k, scale = v (df - k - 1) as k x k (mme.jl:493, 501: the caller computes them), regions are ranges
+   of LOCI, varBeta0 one k x k matrix (every region starts from it, mme.jl:516). */
+int ora_add_marker_set_tuple(ora_t *h, int64_t col0, int64_t nloc, int k, double df, const double *scale, const int64_t *reg_start,
+                             const int64_t *reg_stop, int64_t nreg, const double *varBeta0, int *set_id) {
+    if (h->nsets >= 16 || k < 1 || k > KMAX || nloc < 1 || col0 % BLK) { snprintf(h->err, 256, "bad tuple set (1..4 sets, first column on a block boundary)"); return ORA_ERR; }
+    const int64_t Lb = BLK / k, nblk = (nloc + Lb - 1) / Lb, span = BLK * (nblk - 1) + (int64_t)k * (nloc - Lb * (nblk - 1));
+    if (col0 < 0 || col0 + span > h->P) { snprintf(h->err, 256, "tuple set outside panel"); return ORA_ERR; }
+    for (int q = 0; q < h->nsets; q++)
+        if (col0 < h->sets[q].col0 + h->sets[q].ncol && h->sets[q].col0 < col0 + BLK * nblk) { snprintf(h->err, 256, "marker sets overlap"); return ORA_ERR; }
+    oset_t *s = &h->sets[h->nsets];
+    memset(s, 0, sizeof(*s));
+    s->col0 = col0; s->ncol = span; s->method = METHOD_T; s->df = df; s->nreg = nreg; s->tk = k; s->nloc = nloc;
+    for (int a = 0; a < k * k; a++) s->tscale[a] = scale[a];
+    s->reg_start = (int64_t *)malloc(sizeof(int64_t) * nreg); s->reg_stop = (int64_t *)malloc(sizeof(int64_t) * nreg);
+    memcpy(s->reg_start, reg_start, sizeof(int64_t) * nreg); memcpy(s->reg_stop, reg_stop, sizeof(int64_t) * nreg);
+    s->vb_off = h->nvb;
+    const int64_t nv = nreg * k * k;
+    h->varBeta = (double *)realloc(h->varBeta, sizeof(double) * (h->nvb + nv));
+    h->sum_varBeta = (double *)realloc(h->sum_varBeta, sizeof(double) * (h->nvb + nv));
+    for (int64_t r = 0; r < nreg; r++)
+        for (int a = 0; a < k * k; a++) { h->varBeta[h->nvb + r * k * k + a] = varBeta0[a]; h->sum_varBeta[h->nvb + r * k * k + a] = 0.0; }
+    h->nvb += nv;
+    s->piHat[0] = 0.5; s->piHat[1] = 0.5;
+    if (h->order == 0) {  /* mme.jl:462: mpm[l] = X_l'X_l */
+        s->tmpm = (double *)malloc(sizeof(double) * nloc * k * k);
+        for (int64_t l = 0; l < nloc; l++)
+            for (int a = 0; a < k; a++)
+                for (int b = 0; b < k; b++)
+                    s->tmpm[(l * k + a) * k + b] = dot8_1(h->data + tcol(s, l, a) * h->N, h->data + tcol(s, l, b) * h->N, h->N);
+    } else {
+        const size_t PP = (size_t)h->Ppad;
+        if (!h->tupc) { h->tupc = (double *)calloc(KMAX * PP, sizeof(double)); h->tupg = (double *)calloc(KMAX * PP, sizeof(double)); }
+        for (int64_t l = 0; l < nloc; l++)
+            for (int m = 0; m < k; m++) {
+                const int64_t c = tcol(s, l, m), t = c / BLK;
+                for (int b = 0; b < k; b++) {
+                    const int64_t cb = tcol(s, l, b);
+                    h->tupg[(size_t)b * PP + c] = h->gram[((size_t)t * BLK + c % BLK) * BLK + cb % BLK];
+                }
+            }
+    }
+    if (set_id) *set_id = h->nsets;
+    h->nsets++;
+    return ORA_OK;
+}
 int ora_get_class_state(ora_t *h, int si, double *piHat, double *sum_pi, int64_t *K) {
     if (si < 0 || si >= h->nsets) return ORA_ERR;
     oset_t *s = &h->sets[si];
@@ -886,6 +1026,40 @@ static void iter_ref(ora_t *h) {
                 rng_seed(&r, h->seed, h->chain, it, KIND_REGION_CHI2, ((uint64_t)si << 40) | (uint64_t)rg);
                 double n_r = (double)(S->reg_stop[rg] - S->reg_start[rg]);
                 vb[rg] = (S->scale * S->df + ssq) / rng_chisq(&r, S->df + n_r);         /* :135, :509-511 */
+            }
+        } else if (S->method == METHOD_T) {
+            /* functions.jl:140-154, the Tuple method, line by line */
+            const int k = S->tk;
+            for (int64_t rg = 0; rg < S->nreg; rg++) {
+                double *vbm = vb + rg * k * k;
+                double invB[KMAX * KMAX], Sb[KMAX * KMAX];
+                if (t_spd_inv(vbm, k, invB)) { snprintf(h->err, 256, "tuple: varBeta not positive definite"); return; }   /* :143 */
+                for (int a = 0; a < k * k; a++) Sb[a] = 0.0;
+                for (int64_t l = S->reg_start[rg]; l < S->reg_stop[rg]; l++) {
+                    const double *col[KMAX]; double bj[KMAX];
+                    for (int m = 0; m < k; m++) { col[m] = h->data + tcol(S, l, m) * N; bj[m] = h->beta[tcol(S, l, m)]; }
+                    for (int64_t i = 0; i < N; i++) { double t = 0.0; for (int m = 0; m < k; m++) t = __builtin_fma(col[m][i], bj[m], t); h->ycorr[i] += t; }  /* :145 */
+                    double RHS[KMAX], LHS[KMAX * KMAX], invLHS[KMAX * KMAX], Lc[KMAX * KMAX], mean[KMAX], z[KMAX];
+                    for (int m = 0; m < k; m++) RHS[m] = dot8(h->Mp + tcol(S, l, m) * N, h->ycorr, N) / varE;                 /* :146 */
+                    for (int a = 0; a < k * k; a++) LHS[a] = S->tmpm[l * k * k + a] / varE + invB[a];                          /* :147 */
+                    if (t_spd_inv(LHS, k, invLHS) || t_chol1(invLHS, k, Lc)) { snprintf(h->err, 256, "tuple: LHS not positive definite"); return; }
+                    for (int a = 0; a < k; a++) { double t = 0.0; for (int b = 0; b < k; b++) t += invLHS[a * k + b] * RHS[b]; mean[a] = t; }  /* :148 */
+                    for (int m = 0; m < k; m++) {
+                        rng_seed(&r, h->seed, h->chain, it, KIND_BETA_NORMAL, ((uint64_t)si << 40) | (uint64_t)(l * k + m));
+                        z[m] = rng_normal(&r);
+                    }
+                    for (int a = 0; a < k; a++) {                                                                             /* :149 MvNormal(mean, invLHS) = mean + L z */
+                        double t = mean[a];
+                        for (int b = 0; b <= a; b++) t += Lc[a * k + b] * z[b];
+                        bj[a] = t; h->beta[tcol(S, l, a)] = t;
+                    }
+                    for (int64_t i = 0; i < N; i++) { double t = 0.0; for (int m = 0; m < k; m++) t = __builtin_fma(col[m][i], bj[m], t); h->ycorr[i] -= t; }  /* :150 */
+                    for (int a = 0; a < k; a++) for (int b = 0; b < k; b++) Sb[a * k + b] += bj[a] * bj[b];                   /* :514 */
+                }
+                double Psi[KMAX * KMAX];
+                for (int a = 0; a < k * k; a++) Psi[a] = S->tscale[a] + Sb[a];
+                const double nu = S->df + (double)(S->reg_stop[rg] - S->reg_start[rg]);
+                if (t_inverse_wishart(h->seed, h->chain, it, si, rg, nu, Psi, k, vbm)) { snprintf(h->err, 256, "tuple: inverse Wishart failed"); return; }  /* :152, :513-516 */
             }
         } else if (S->method == METHOD_C) {
             /* functions.jl:197-235: BayesC = BayesB's inclusion step with ONE variance for the whole set, redrawn after the
@@ -1082,6 +1256,33 @@ static void iter_blocked(ora_t *h) {
     for (int si = 0; si < h->nsets; si++) {
         oset_t *Sx = &h->sets[si];
         double *vb = h->varBeta + Sx->vb_off;
+        if (Sx->method == METHOD_T) {
+            /* Tuple set: per locus the k x k conditional (functions.jl:143-149) with everything the block chain does not need to
+               compute: C = iVarE inv(X_l'X_l iVarE + inv(varBeta_r)) (row m for column (l, m)) and W = L z - beta, L = chol(inv(LHS)) */
+            const int kk = Sx->tk; const size_t PP = (size_t)h->Ppad;
+            for (int64_t rg = 0; rg < Sx->nreg; rg++) {
+                double invB[KMAX * KMAX];
+                if (t_spd_inv(vb + rg * kk * kk, kk, invB)) { snprintf(h->err, 256, "tuple: varBeta not positive definite"); return; }
+                for (int64_t l = Sx->reg_start[rg]; l < Sx->reg_stop[rg]; l++) {
+                    double LHS[KMAX * KMAX], invLHS[KMAX * KMAX], Lc[KMAX * KMAX], z[KMAX];
+                    for (int a = 0; a < kk; a++)
+                        for (int b = 0; b < kk; b++) { double t1 = h->tupg[(size_t)b * PP + tcol(Sx, l, a)] * iVarE; LHS[a * kk + b] = t1 + invB[a * kk + b]; }
+                    if (t_spd_inv(LHS, kk, invLHS) || t_chol1(invLHS, kk, Lc)) { snprintf(h->err, 256, "tuple: LHS not positive definite"); return; }
+                    for (int m = 0; m < kk; m++) {
+                        rng_seed(&r, h->seed, h->chain, it, KIND_BETA_NORMAL, ((uint64_t)si << 40) | (uint64_t)(l * kk + m));
+                        z[m] = rng_normal(&r);
+                    }
+                    for (int m = 0; m < kk; m++) {
+                        const int64_t c = tcol(Sx, l, m);
+                        for (int b = 0; b < kk; b++) h->tupc[(size_t)b * PP + c] = iVarE * invLHS[m * kk + b];
+                        double acc = Lc[m * kk + 0] * z[0];
+                        for (int b = 1; b <= m; b++) acc = __builtin_fma(Lc[m * kk + b], z[b], acc);
+                        h->w[c] = acc - h->beta[c];
+                    }
+                }
+            }
+            continue;
+        }
         for (int64_t rg = 0; rg < Sx->nreg; rg++)
             for (int64_t l = Sx->reg_start[rg]; l < Sx->reg_stop[rg]; l++) {
                 int64_t k = Sx->col0 + l;
@@ -1243,6 +1444,15 @@ static void iter_blocked(ora_t *h) {
         double rr[BLK], dlt[BLK]; int inc[BLK];
         const double *G = h->gram + (size_t)tb * BLK * BLK;
         const int64_t NGq = (S + GRP - 1) / GRP;
+        int has_r = 0, has_t = -1;
+        int lane_set[BLK];
+        for (int j = 0; j < BLK; j++) {
+            lane_set[j] = -1;
+            for (int si = 0; si < h->nsets; si++)
+                if (k0 + j >= h->sets[si].col0 && k0 + j < h->sets[si].col0 + h->sets[si].ncol) lane_set[j] = si;
+            if (lane_set[j] >= 0 && h->sets[lane_set[j]].method == METHOD_R) has_r = 1;
+            if (lane_set[j] >= 0 && h->sets[lane_set[j]].method == METHOD_T) has_t = lane_set[j];
+        }
         for (int j = 0; j < BLK; j++) {
             /* group sums: shards of a group added in order */
             double gs[64];
@@ -1276,19 +1486,53 @@ static void iter_blocked(ora_t *h) {
                 if (have) tot = tot - c;
             }
             rr[j] = __builtin_fma(G[j * BLK + j], h->beta[k0 + j], tot);
+            if (has_t >= 0) {   /* tuple block: x_m'(ycorr + X_l beta_l) -- the add-back of ALL k effects of the locus, components in order */
+                const oset_t *Tx = &h->sets[has_t]; const int kk = Tx->tk;
+                rr[j] = tot;
+                if (j < (BLK / kk) * kk)
+                    for (int b = 0; b < kk; b++) rr[j] = __builtin_fma(h->tupg[(size_t)b * h->Ppad + k0 + j], h->beta[k0 + (j / kk) * kk + b], rr[j]);
+            }
+        }
+        if (has_t >= 0) {
+            /* Tuple block (functions.jl:144-151 in 64-column space): the k effects of a locus are drawn in ONE step from the r of its
+               k columns -- dlt_m = W_m + sum_b C[m][b] r_b -- and then applied, component after component, to the columns of the
+               later loci of the block. */
+            const oset_t *Tx = &h->sets[has_t]; const int kk = Tx->tk; const size_t PP = (size_t)h->Ppad;
+            const int64_t Lb = BLK / kk, lb0 = (tb - Tx->col0 / BLK) * Lb;
+            /* scaled form, as the Symbol path's chain: lane j carries e_j = W_j + sum_b C_j[b] r_b, its candidate dlt; a finished
+               column s changes it by H_j(s) dlt_s, H_j(s) = -(sum_b C_j[b] G[s][column b of j's locus]) -- for the columns of LATER
+               loci only (the k effects of a locus are drawn together: its own columns do not see each other's dlt) */
+            double cand[BLK];
+            int64_t nvalid = (Tx->nloc - lb0 < Lb ? Tx->nloc - lb0 : Lb) * kk;   /* used lanes of this block */
+            for (int j = 0; j < BLK; j++) {
+                cand[j] = 0.0;
+                if (j >= nvalid) continue;
+                const int gb = (j / kk) * kk; const int64_t c = k0 + j;
+                double e = h->w[c];
+                for (int b = 0; b < kk; b++) e = __builtin_fma(rr[gb + b], h->tupc[(size_t)b * PP + c], e);
+                cand[j] = e;
+            }
+            for (int sl = 0; sl < nvalid; sl++) {
+                const double dk = cand[sl];
+                for (int j = (sl / kk + 1) * kk; j < nvalid; j++) {
+                    const int gb = (j / kk) * kk; const int64_t c = k0 + j;
+                    double t = h->tupc[c] * G[(gb) * BLK + sl];
+                    for (int b = 1; b < kk; b++) t = __builtin_fma(h->tupc[(size_t)b * PP + c], G[(gb + b) * BLK + sl], t);
+                    const double Hjs = -t;
+                    cand[j] = __builtin_fma(Hjs, dk, cand[j]);
+                }
+            }
+            for (int k = 0; k < BLK; k++) {
+                hist[tb * BLK + k] = cand[k];
+                h->beta[k0 + k] = h->beta[k0 + k] + cand[k];
+                h->delta[k0 + k] = 1;
+            }
+            continue;
         }
         /* Blocks that hold a BayesR locus: the chain runs on r itself ("r-form").  All lanes form their candidate dlt from the
            current r; the first lane at or behind the cursor whose candidate is not zero takes its step (r_j -= G_jk dlt_k for
            the later lanes) and the candidates behind it are formed again; lanes whose candidate is zero change nothing and
            are passed over.  Lanes of other methods in such a block follow their own rule, written in r. */
-        int has_r = 0;
-        int lane_set[BLK];
-        for (int j = 0; j < BLK; j++) {
-            lane_set[j] = -1;
-            for (int si = 0; si < h->nsets; si++)
-                if (k0 + j >= h->sets[si].col0 && k0 + j < h->sets[si].col0 + h->sets[si].ncol) lane_set[j] = si;
-            if (lane_set[j] >= 0 && h->sets[lane_set[j]].method == METHOD_R) has_r = 1;
-        }
         if (has_r) {
             const size_t PP = (size_t)h->Ppad;
             const double *rq = h->rcls, *ra = h->rcls + RMAX * PP, *rt = h->rcls + 2 * RMAX * PP, *ru = h->rcls + 3 * RMAX * PP;
@@ -1363,6 +1607,37 @@ static void iter_blocked(ora_t *h) {
     for (int si = 0; si < h->nsets; si++) {
         oset_t *Sx = &h->sets[si];
         double *vb = h->varBeta + Sx->vb_off;
+        if (Sx->method == METHOD_T) {
+            /* functions.jl:152, :513-516: Sb = B_r'B_r entry by entry in the segment pattern of the Symbol path (a wave per 256 loci,
+               lane l: loci l, l+64, l+128, l+192 by fma, xor butterfly, segments in order), then the inverse-Wishart draw */
+            const int kk = Sx->tk;
+            for (int64_t rg = 0; rg < Sx->nreg; rg++) {
+                double Sb[KMAX * KMAX], Psi[KMAX * KMAX];
+                for (int a = 0; a < kk; a++)
+                    for (int b = a; b < kk; b++) {
+                        double tot = 0.0; int first = 1;
+                        for (int64_t l0 = Sx->reg_start[rg]; l0 < Sx->reg_stop[rg]; l0 += SEG) {
+                            int64_t l1 = l0 + SEG < Sx->reg_stop[rg] ? l0 + SEG : Sx->reg_stop[rg];
+                            double lane[64];
+                            for (int l = 0; l < 64; l++) {
+                                double acc = 0.0;
+                                for (int m = 0; m < 4; m++) {
+                                    int64_t ll = l0 + l + 64 * m;
+                                    if (ll < l1) acc = __builtin_fma(h->beta[tcol(Sx, ll, a)], h->beta[tcol(Sx, ll, b)], acc);
+                                }
+                                lane[l] = acc;
+                            }
+                            double p = wave_butterfly(lane);
+                            tot = first ? p : tot + p; first = 0;
+                        }
+                        Sb[a * kk + b] = tot; Sb[b * kk + a] = tot;
+                    }
+                for (int a = 0; a < kk * kk; a++) Psi[a] = Sx->tscale[a] + Sb[a];
+                const double nu = Sx->df + (double)(Sx->reg_stop[rg] - Sx->reg_start[rg]);
+                if (t_inverse_wishart(h->seed, h->chain, it, si, rg, nu, Psi, kk, vb + rg * kk * kk)) { snprintf(h->err, 256, "tuple: inverse Wishart failed"); return; }
+            }
+            continue;
+        }
         if (Sx->method == METHOD_R) {
             int64_t nL[RMAX] = {0, 0, 0, 0}, nNonZero = 0;
             for (int64_t l = 0; l < Sx->ncol; l++) nL[h->delta[Sx->col0 + l] - 1]++;
@@ -1551,7 +1826,9 @@ int ora_run(ora_t *h, int64_t niter) {
     h->tr_b = (double *)malloc(sizeof(double) * (niter > 0 ? niter : 1));
     h->ntrace = niter;
     for (int64_t n = 0; n < niter; n++) {
+        const int64_t before = h->iter;
         if (h->order == 0) iter_ref(h); else iter_blocked(h);
+        if (h->iter == before) return ORA_ERR;  /* the iteration gave up (message in h->err) */
         h->tr_varE[n] = h->varE; h->tr_b[n] = h->b;
         if (is_kept(h, h->iter)) accumulate(h);
     }

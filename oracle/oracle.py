@@ -185,6 +185,18 @@ class Oracle:
         self.nsets += 1
         return sid.value
 
+    def add_marker_set_tuple(self, col0, nloc, k, df, scale, regions, varBeta0):
+        """Correlated sets (Tuple BayesPR, mme.jl:448-489): k sets, nloc loci, locus-major columns from col0 (a block boundary) on;
+        scale and varBeta0 are k x k, regions ranges of loci."""
+        rs = np.ascontiguousarray([r[0] for r in regions], dtype=np.int64)
+        re = np.ascontiguousarray([r[1] for r in regions], dtype=np.int64)
+        sc = np.ascontiguousarray(np.asarray(scale, dtype=np.float64).reshape(k, k)); vb = np.ascontiguousarray(np.asarray(varBeta0, dtype=np.float64).reshape(k, k))
+        sid = C.c_int()
+        self._chk(self.L.ora_add_marker_set_tuple(self.h, C.c_int64(col0), C.c_int64(nloc), C.c_int(k), C.c_double(df), _p(sc, C.c_double),
+                                                  _p(rs, C.c_int64), _p(re, C.c_int64), C.c_int64(len(rs)), _p(vb, C.c_double), C.byref(sid)))
+        self.nsets += 1
+        return sid.value
+
     def get_class_state(self, set_id):
         pi = np.empty(8); sp = np.empty(8); K = C.c_int64()
         self._chk(self.L.ora_get_class_state(self.h, C.c_int(set_id), _p(pi, C.c_double), _p(sp, C.c_double), C.byref(K)))

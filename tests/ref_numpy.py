@@ -8,6 +8,7 @@ varBeta[set] a vector -- and every statement cites the line it restates:
     /root/reference/src/samplers.jl:29-53      iteration order (varE, fixed effects, marker sets)
     /root/reference/src/functions.jl:39-47     sampleX!, single column (the intercept)
     /root/reference/src/functions.jl:118-137   sampleBayesPR!(::Symbol)
+    /root/reference/src/functions.jl:140-154   sampleBayesPR!(::Tuple), :513-516 sampleVarCovBetaPR, set-up src/mme.jl:448-489
     /root/reference/src/functions.jl:157-195   sampleBayesB!
     /root/reference/src/functions.jl:197-235   sampleBayesC!
     /root/reference/src/functions.jl:238-289   sampleBayesR!
@@ -22,7 +23,8 @@ import math
 
 import numpy as np
 
-KIND = dict(VARE_CHI2=1, FIXED_NORMAL=2, BETA_NORMAL=3, REGION_CHI2=4, B_UNIFORM=5, B_LOCUS_CHI2=6, PI_BETA=7, R_UNIFORM=8, R_DIRICHLET=9)
+KIND = dict(VARE_CHI2=1, FIXED_NORMAL=2, BETA_NORMAL=3, REGION_CHI2=4, B_UNIFORM=5, B_LOCUS_CHI2=6, PI_BETA=7, R_UNIFORM=8, R_DIRICHLET=9,
+            T_WISHART=11)
 
 
 class RefChain:
@@ -233,6 +235,53 @@ class RefChain:
             M["piHat"][:] = g / g.sum()
             M["logPi"][:] = np.log(M["piHat"])
 
+    def add_set_tuple(self, cols, df, scale, regions, v):    # mme.jl:448-489; cols[l, m] = panel column of component m of locus l
+        cols = np.asarray(cols)
+        nloc, k = cols.shape
+        data = [self.X[:, cols[l, :]] for l in range(nloc)]                                       # :456-457: X_l, N x k
+        m = dict(method=4, k=k, cols=cols, data=data, Mp=[d.T.copy() for d in data],             # :463
+                 mpm=[d.T @ d for d in data],                                                     # :462
+                 regionArray=[range(a, b) for a, b in regions], scale=np.array(scale, float).reshape(k, k), df=df,
+                 piHat=np.array([0.5, 0.5]), span=int(cols.max() - cols.min() + 1), col0=int(cols.min()))
+        self.M.append(m)
+        self.beta.append(np.zeros((k, nloc)))                 # one row vector per set of the tuple (beta[M.pos])
+        self.delta.append(np.ones(m["span"], dtype=np.int64))
+        self.varBeta.append([np.array(v, float).reshape(k, k).copy() for _ in regions])           # :516
+
+    def sampleBayesPR_tuple(self, si, varE):                  # functions.jl:140-154
+        M, beta, vb = self.M[si], self.beta[si], self.varBeta[si]
+        k = M["k"]
+        for r, theseLoci in enumerate(M["regionArray"]):
+            regionSize = len(theseLoci)
+            invB = np.linalg.inv(vb[r])                                                           # :143
+            for locus in theseLoci:
+                self.ycorr += M["data"][locus] @ beta[:, locus]                                   # :145
+                RHS = (M["Mp"][locus] @ self.ycorr) / varE                                        # :146
+                invLHS = np.linalg.inv(M["mpm"][locus] / varE + invB)                             # :147
+                meanBETA = invLHS @ RHS                                                           # :148
+                z = np.array([self.draw("BETA_NORMAL", (si << 40) | (locus * k + m), 1) for m in range(k)])
+                L = np.linalg.cholesky((invLHS + invLHS.T) / 2)                                   # rand(MvNormal(mean, Symmetric(invLHS))) = mean + L z
+                beta[:, locus] = meanBETA + L @ z                                                 # :149
+                self.ycorr -= M["data"][locus] @ beta[:, locus]                                   # :150
+            B = beta[:, theseLoci.start:theseLoci.stop].T                                         # reduce(hcat, ...): regionSize x k
+            Sb = B.T @ B                                                                          # :514
+            vb[r] = self.inverse_wishart(si, r, M["df"] + regionSize, M["scale"] + Sb)            # :515
+
+    def inverse_wishart(self, si, r, nu, Psi):
+        """rand(InverseWishart(nu, Psi)) by Bartlett's construction on the keyed draws (Distributions.jl is absent): W = (L A)(L A)',
+        L = chol(inv(Psi)), A lower, A_ii = sqrt(chi2(nu - i)), A_ij ~ N(0, 1); result inv(W).  k = 1: Psi / chi2(nu)."""
+        k = Psi.shape[0]
+        if k == 1:
+            return Psi / self.draw("REGION_CHI2", (si << 40) | r, 2, nu)
+        L = np.linalg.cholesky(np.linalg.inv(Psi))
+        A = np.zeros((k, k))
+        for i in range(k):
+            for j in range(i + 1):
+                key = ("REGION_CHI2", (si << 40) | r) if i == 0 else ("T_WISHART", (si << 40) | (r << 8) | (i << 4) | j)
+                A[i, j] = math.sqrt(self.draw(key[0], key[1], 2, nu - i)) if i == j else self.draw(key[0], key[1], 1)
+        LA = L @ A
+        return np.linalg.inv(LA @ LA.T)
+
     # ---- samplers.jl:29-53 ----
     def run(self, niter):
         for _ in range(niter):
@@ -244,10 +293,18 @@ class RefChain:
             for f in range(len(getattr(self, "Xfix", []))):
                 self.sampleXset(f, varE)
             for si, M in enumerate(self.M):                  # :50-53
-                {0: self.sampleBayesPR, 1: self.sampleBayesB, 2: self.sampleBayesC, 3: self.sampleBayesR}[M["method"]](si, varE)
+                {0: self.sampleBayesPR, 1: self.sampleBayesB, 2: self.sampleBayesC, 3: self.sampleBayesR, 4: self.sampleBayesPR_tuple}[M["method"]](si, varE)
+
+    def _panel_beta(self, si):
+        M = self.M[si]
+        if M["method"] != 4:
+            return self.beta[si]
+        out = np.zeros(M["span"])                              # the tuple's effects at their panel columns (unused columns 0)
+        out[M["cols"] - M["col0"]] = self.beta[si].T
+        return out
 
     def state(self):
-        return dict(ycorr=self.ycorr.copy(), beta=np.concatenate(self.beta), delta=np.concatenate(self.delta),
-                    varBeta=np.concatenate(self.varBeta),
+        return dict(ycorr=self.ycorr.copy(), beta=np.concatenate([self._panel_beta(si) for si in range(len(self.M))]), delta=np.concatenate(self.delta),
+                    varBeta=np.concatenate([np.concatenate([m.ravel() for m in vb]) if self.M[si]["method"] == 4 else vb for si, vb in enumerate(self.varBeta)]),
                     piHat=np.concatenate([m["piHat"] if m["method"] != 3 else np.array([0.5, 0.5]) for m in self.M]),
                     class_pi=[m["piHat"].copy() if m["method"] == 3 else None for m in self.M], varE=self.varE, b=float(self.b[0]))

@@ -433,6 +433,14 @@ def test_snapshot_resume_reproduces_the_uninterrupted_run(ngp, O, tmp_path):
     other.set_panel(np.zeros((10, 5), dtype=np.float32)); other.add_marker_set(0, 5, 0, 4.0, 0.1, [(0, 5)], [0.1]); other.set_y(np.zeros(10))
     with pytest.raises(ngp.NextGPHipError, match="does not match"):
         other.load_snapshot(path)
+    # the same counts are not enough: a model with BayesC where the snapshot's has BayesB (same N, P, sets; nvb made equal
+    # by regions) is refused by the model signature in the header
+    twin = ngp.Sampler(device=0, seed=3, chain=0)
+    Xs, ys, _, vs = make_problem(O, 200, 192, seed=4)
+    twin.set_panel(Xs); add_sets(twin, [(0, 100, "PR"), (100, 92, "PR1")], vs); twin.set_y(ys)   # BayesPR, one region per locus: 92 variances too
+    assert twin.nvb == full.nvb
+    with pytest.raises(ngp.NextGPHipError, match="methods, classes, regions"):
+        twin.load_snapshot(path)
     open(path, "r+b").truncate(100)
     with pytest.raises(ngp.NextGPHipError, match="truncated|magic"):
         second.load_snapshot(path)
