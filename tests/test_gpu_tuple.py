@@ -106,7 +106,7 @@ def test_tuple_compact_storage_snapshot_and_fine_seam(ngp, O, tmp_path):
     vm = 0.01 * (0.6 * np.eye(k) + 0.4)
     regions = [(0, 25), (25, 60)]
     s = ngp.Sampler(device=0, seed=3, chain=0, storage="u8")
-    s.set_panel(Gt)
+    s.set_panel(Gt, centre=True)
     R, S, _ = s.layout()
     o = O.Oracle(order=1, seed=3, chain=0)
     o.set_panel_u8(Gt, R=R, S=S, D=s.config()[1], near=s.near())
@@ -116,7 +116,7 @@ def test_tuple_compact_storage_snapshot_and_fine_seam(ngp, O, tmp_path):
     path = str(tmp_path / "t.ngpsnap")
     s.save_snapshot(path)
     s2 = ngp.Sampler(device=0, seed=99, chain=7, storage="u8")
-    s2.set_panel(Gt); add_tuple(s2, nloc, k, vm, regions); s2.set_y(y); s2.set_residual_prior(4.0, 0.5); s2.set_schedule(14, 2, 2)
+    s2.set_panel(Gt, centre=True); add_tuple(s2, nloc, k, vm, regions); s2.set_y(y); s2.set_residual_prior(4.0, 0.5); s2.set_schedule(14, 2, 2)
     s2.load_snapshot(path)
     for m in (s2, o):
         m.run(8)
@@ -126,7 +126,7 @@ def test_tuple_compact_storage_snapshot_and_fine_seam(ngp, O, tmp_path):
     assert np.array_equal(s2.get_posterior_sums()["sum_varBeta"], o.get_posterior_sums()["sum_varBeta"])
     # fine seam: one call of the set's callback with the caller's arrays
     f = ngp.Sampler(device=0, seed=3, chain=0, storage="u8")
-    f.set_panel(Gt); add_tuple(f, nloc, k, vm, regions); f.set_y(y)
+    f.set_panel(Gt, centre=True); add_tuple(f, nloc, k, vm, regions); f.set_y(y)
     yc = (y - y.mean()).copy(); be = np.zeros(Gt.shape[1]); vb = np.tile(vm.ravel(), 2)
     f.sweep_set(0, 1.3, yc, be, vb)
     assert np.isfinite(be).all() and np.abs(be).max() > 0 and not np.array_equal(vb, np.tile(vm.ravel(), 2))
