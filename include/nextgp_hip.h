@@ -232,6 +232,17 @@ int32_t ngp_set_max_shards(ngp_handle *h, int32_t max_shards);
 /* The largest max_shards with which `chains` chains of this handle's device are co-resident (256 CUs: 247 for one chain, 123
  * for two, 76 for three, 61 for four). */
 int32_t ngp_shards_for_chains(ngp_handle *h, int32_t chains, int32_t *max_shards);
+/* ---- K chains per pass over the panel ----
+ * Independent chains (one handle each) that share ONE panel run their sweeps in ONE kernel launch per iteration: every streamer
+ * workgroup forms X_t'[y_1 .. y_K] from each tile it reads, so the panel is streamed once for K iterations' worth of sampling;
+ * every chain keeps its own sampler workgroup, reducers, hand-off rings and draws, and stays bit for bit the chain it is alone with
+ * the same layout.  Set-up: the first handle sets the panel (after ngp_set_max_shards(ngp_shards_for_pass(K))), the others call
+ * ngp_share_panel(h, first) in place of a panel upload -- no copy of the panel is made; then each handle gets its own marker sets,
+ * y and seeds, and ngp_run_many(handles, K, niter) runs them fused (engine served: persistent sweep over fp32 tiles, shards of at
+ * most 64 rows, lag 4, 6 or 8 -- e.g. 10k x 100k; other engines run the handles side by side as before).  Independent chains are
+ * the path's own parallelism (src/samplers.jl:23: one chain per Julia task). */
+int32_t ngp_share_panel(ngp_handle *h, ngp_handle *owner);
+int32_t ngp_shards_for_pass(ngp_handle *h, int32_t chains, int32_t *max_shards);
 #define NGP_STORAGE_F32 0
 #define NGP_STORAGE_U8 1
 int32_t ngp_set_storage(ngp_handle *h, int32_t storage);

@@ -50,7 +50,7 @@ SYMBOLS = [
     "ngp_get_trace", "ngp_get_posterior_sums", "ngp_posterior_len", "ngp_export_posterior_device", "ngp_sweep_set",
     "ngp_get_timing", "ngp_profile_iteration", "ngp_draws_indexed", "ngp_eval_math", "ngp_configure", "ngp_get_config", "ngp_debug_stamps", "ngp_set_near_lags", "ngp_get_near_lags",
     "ngp_set_streamer", "ngp_get_streamer", "ngp_set_storage", "ngp_get_storage", "ngp_set_max_shards", "ngp_shards_for_chains", "ngp_run_many", "ngp_write_panel_file", "ngp_read_panel_header", "ngp_load_panel_file", "ngp_debug_set_mode", "ngp_debug_set_knob", "ngp_set_posterior_sums", "ngp_save_snapshot", "ngp_load_snapshot",
-    "ngp_set_trace_loci", "ngp_get_trace_ext", "ngp_allreduce_posterior", "ngp_add_marker_set_r", "ngp_get_class_state", "ngp_set_class_state", "ngp_add_fixed_set", "ngp_get_fixed", "ngp_set_fixed", "ngp_debug_throw", "ngp_get_census", "ngp_debug_set_virtual_device", "ngp_debug_fail_census", "ngp_add_marker_set_tuple",
+    "ngp_set_trace_loci", "ngp_get_trace_ext", "ngp_allreduce_posterior", "ngp_add_marker_set_r", "ngp_get_class_state", "ngp_set_class_state", "ngp_add_fixed_set", "ngp_get_fixed", "ngp_set_fixed", "ngp_debug_throw", "ngp_get_census", "ngp_debug_set_virtual_device", "ngp_debug_fail_census", "ngp_add_marker_set_tuple", "ngp_share_panel", "ngp_shards_for_pass",
 ]
 
 _lib = None
@@ -138,6 +138,18 @@ class Sampler:
         v = C.c_int32()
         self._chk(self.L.ngp_shards_for_chains(self.h, C.c_int32(int(chains)), C.byref(v)))
         return v.value
+
+    def shards_for_pass(self, chains):
+        """The largest max_shards with which `chains` chains share one fused sweep launch (K chains per pass)."""
+        v = C.c_int32()
+        self._chk(self.L.ngp_shards_for_pass(self.h, C.c_int32(int(chains)), C.byref(v)))
+        return v.value
+
+    def share_panel(self, owner):
+        """Take `owner`'s panel by reference (K chains per pass): same tiles, Gram window and layout; chain state is this handle's."""
+        self._chk(self.L.ngp_share_panel(self.h, owner.h))
+        self.N, self.P = owner.N, owner.P
+        self._panel_owner = owner   # keeps the owner's Python object alive as long as this one
 
     def set_storage(self, storage):
         """0 / "f32": centred fp32 tiles; 1 / "u8": compact storage (bytes + Float64 column means, analytic centring)."""

@@ -7,6 +7,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <atomic>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -28,6 +29,11 @@ namespace {
 struct HFix {  // one fixed-effect set beyond the intercept
     int64_t ncol, off;
     double *d_X = nullptr, *d_xpx0 = nullptr, *d_xpxR = nullptr, *d_lhs0 = nullptr, *d_rhs0 = nullptr;
+};
+
+struct PanelMem {  // d_tiles / d_mean / d_gramx / d_mpm of one uploaded panel; handles that share it hold a reference each
+    void *tiles = nullptr, *mean = nullptr, *gramx = nullptr, *mpm = nullptr;
+    std::atomic<int> refs{1};
 };
 
 struct HSet {
@@ -139,8 +145,10 @@ struct ngp_handle {
     bool adding_r = false;  // ngp_add_marker_set is being called by ngp_add_marker_set_r
     bool poisoned = false;  // a sweep gave up half-way (abort word): the chain state is unusable until ngp_set_y / ngp_set_state
     bool exclusive = false;  // a grid of this handle was once not co-resident beside other chains' grids: its calls now lease the whole device
+    int64_t last_grid = 0;       // workgroups of the last sweep launch this handle led (fused launches: K (1 + NG) + S)
     int64_t census_retries = 0;  // launches that ended at the census and were run again with the device to themselves
     int64_t dbg_census_fail_iter = 0;  // ngp_debug_fail_census: the sweep of this iteration ends at its census (once)
+    struct PanelMem *pm = nullptr;      // the panel's device arrays (tiles, Gram window, x'x, means), shared by reference count: ngp_share_panel
     int vdev = -1;           // ngp_debug_set_virtual_device: the device ngp_allreduce_posterior groups this handle under (-1: the real one)
     unsigned long long *d_census_tbl = nullptr;  // placement of the workgroups of the last sweep launch (inside d_ccnt)
     size_t census_off = 0;   // word offset of the census counters inside d_ccnt
@@ -207,11 +215,11 @@ struct CuLease {
     static int *in_use() { static int u[64] = {0}; return u; }
     int dev = -1, n = 0, cap = 0, want = 0;
     bool excl = false;
-    CuLease(ngp_handle *h) {
+    explicit CuLease(ngp_handle *h, int64_t grid_override = 0) {
         if (h->mode != 1) return;
         // workgroups are handed to the 8 XCDs in turn, so a grid occupies ceil(grid / 8) CUs of EVERY XCD: the unit of the lease
         // (three grids of 85 workgroups -- 255 of 256 CUs -- do not fit: 3 x 11 > 32 per XCD; measured, they wait for each other)
-        dev = h->device & 63; want = (int)((1 + h->NG + h->S + 7) / 8);
+        dev = h->device & 63; want = (int)(((grid_override > 0 ? grid_override : 1 + h->NG + h->S) + 7) / 8);
         cap = std::max(1, h->cu_count / 8);
         acquire(h->exclusive);
     }
@@ -267,10 +275,33 @@ void choose_layout(int64_t N, int64_t max_shards, int64_t r_cap, int64_t *R, int
     *S = (N + r - 1) / r;
 }
 
-int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
+// drop this handle's reference to its panel arrays; the last reference frees them
+void release_panel(ngp_handle *h) {
+    if (h->pm) {
+        if (h->pm->refs.fetch_sub(1) == 1) {
+            (void)hipFree(h->pm->tiles); (void)hipFree(h->pm->mean); (void)hipFree(h->pm->gramx); (void)hipFree(h->pm->mpm);
+            delete h->pm;
+        }
+        h->pm = nullptr;
+    } else {  // arrays of an allocation that failed half-way (no store yet)
+        if (h->d_tiles) (void)hipFree(h->d_tiles);
+        if (h->d_mean) (void)hipFree(h->d_mean);
+        if (h->d_gramx) (void)hipFree(h->d_gramx);
+        if (h->d_mpm) (void)hipFree(h->d_mpm);
+    }
+    h->d_tiles = nullptr; h->d_mean = nullptr; h->d_gramx = nullptr; h->d_mpm = nullptr;
+}
+
+int alloc_panel(ngp_handle *h, int64_t N, int64_t P, ngp_handle *owner = nullptr) {
     REQUIRE(N > 0 && P > 0, NGP_ERR_ARG, "panel dimensions must be positive");
     REQUIRE(N <= (int64_t)508 * 1024, NGP_ERR_ARG, "N too large for this build (max 520192)");
+    release_panel(h);  // (handles that share the old panel keep it alive)
     h->N = N; h->P = P;
+    if (owner) {  // the owner's layout, engine and storage, as they are
+        h->mode = owner->mode; h->lag = owner->lag; h->lag_auto = owner->lag_auto; h->near_req = owner->near_req; h->near = owner->near;
+        h->max_shards_req = owner->max_shards_req; h->storage = owner->storage; h->streamer_req = owner->streamer_req;
+        h->streamer = owner->streamer; h->nchain = owner->nchain; h->D = owner->D; h->NG = owner->NG; h->R = owner->R; h->S = owner->S;
+    } else {
     // persistent mode: sampler + reducers + S streamers must all be resident, one workgroup per CU
     int64_t max_shards = 256;
     if (h->storage == 1) {
@@ -320,20 +351,28 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
     // (row-owning streamer on tall shards: two near lags measured 1.5 % better still -- the far path is one hop since dlt travels as granules)
     h->near = h->near_req ? h->near_req : ((h->mode == 1 && h->streamer == 2 && h->R >= 64) ? 2 : ((h->mode == 1 && h->R > 128) ? 4 : 3));
     }
+    }
     h->NBLK = (P + NGP_BLK - 1) / NGP_BLK;
     h->Ppad = h->NBLK * NGP_BLK;
     h->L = h->R * h->S;
     h->lds_step = (size_t)h->R * 264 + 4096;
     int rc;
     size_t tile_elems = (size_t)h->R * NGP_BLK;
+    const size_t pp = (size_t)h->Ppad;
+    if (owner) {
+        h->d_tiles = owner->d_tiles; h->d_mean = owner->d_mean; h->d_gramx = owner->d_gramx; h->d_mpm = owner->d_mpm;
+        h->pm = owner->pm; h->pm->refs.fetch_add(1);
+    } else {
     if (h->storage == 1) {  // one byte per element (R is a multiple of 16), held behind the same pointer
         if ((rc = dalloc(h, &h->d_tiles, (size_t)h->NBLK * h->S * tile_elems / 4))) return rc;
         if ((rc = dalloc(h, &h->d_mean, (size_t)h->Ppad))) return rc;
         HCHK(hipMemsetAsync(h->d_mean, 0, (size_t)h->Ppad * sizeof(double), h->stream));
     } else if ((rc = dalloc(h, &h->d_tiles, (size_t)h->NBLK * h->S * tile_elems))) return rc;
     if ((rc = dalloc(h, &h->d_gramx, (size_t)h->NBLK * h->D * NGP_BLK * NGP_BLK))) return rc;
-    const size_t pp = (size_t)h->Ppad;
     if ((rc = dalloc(h, &h->d_mpm, pp))) return rc;
+    h->pm = new PanelMem();
+    h->pm->tiles = h->d_tiles; h->pm->mean = h->d_mean; h->pm->gramx = h->d_gramx; h->pm->mpm = h->d_mpm;
+    }
     if ((rc = dalloc(h, &h->d_lhs0, pp))) return rc;
     if ((rc = dalloc(h, &h->d_rhs0, pp))) return rc;
     if ((rc = dalloc(h, &h->d_beta, pp))) return rc;
@@ -401,7 +440,7 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P) {
         if ((rc = dalloc(h, &h->d_cdltg, (size_t)NGP_RING * NGP_BLK * 2))) return rc;
         // hand-off counters | census counters (one line) | census table (placement of each workgroup, 2 words each); all zeroed by k_prep
         h->census_off = (size_t)NGP_RING * h->NG * 32 + (size_t)NGP_RING * 32 + 32;
-        h->ccnt_words = h->census_off + 32 + 2 * (size_t)(1 + h->NG + h->S);
+        h->ccnt_words = h->census_off + 32 + 2 * (size_t)320;  // (320 >= any grid, also the fused grid of K chains per pass)
         if ((rc = dalloc(h, &h->d_ccnt, h->ccnt_words))) return rc;
         h->d_census_tbl = (unsigned long long *)(h->d_ccnt + h->census_off + 32);
     }
@@ -535,32 +574,40 @@ bool is_kept(const ngp_handle *h, int64_t it) {  // src/samplers.jl:26
 }
 
 // one sweep over blocks [tb0, tb1): persistent kernel (mode 1) or two launches per block (mode 0)
+// launch arguments of the persistent sweep over blocks [tb0, tb1) of this handle's chain (advances the launch nonce)
+void fill_sweep_args(ngp_handle *h, int64_t tb0, int64_t tb1, SweepArgs &A) {
+    const int R = (int)h->R, S = (int)h->S;
+    A.tiles = h->d_tiles; A.ycorr = h->d_ycorr; A.gramx = h->d_gramx;
+    A.D = h->D; A.R = R; A.S = S; A.NG = h->NG; A.near = h->near; A.fine_ok = 0; A.t0 = (int)tb0; A.t1 = (int)tb1;
+    A.beta = h->d_beta; A.delta = h->d_delta; A.c = h->d_c; A.w = h->d_w; A.q = h->d_q; A.mpm = h->d_mpm; A.chi = h->d_chi;
+    A.setof = h->d_setof; A.vbidx = h->d_vbidx; A.sets = h->d_sets; A.varBeta = h->d_varBeta;
+    A.rcls = h->d_rcls; A.rhs0 = h->d_rhs0; A.scal = h->d_scal; A.Ppad = h->Ppad;
+    A.tup = h->ntuple ? h->d_tup : nullptr; A.tupc = h->d_tupc; A.tupg = h->d_tupg;
+    A.part = h->d_cpart; A.gsum = h->d_cgsum; A.dlt = h->d_cdlt; A.dltg = h->d_cdltg;
+    h->launch_seq = (h->launch_seq % 4095u) + 1u;  // 1..4095: never the zero the ring is born with
+    A.nonce = h->launch_seq;
+    A.cnt_part = h->d_ccnt; A.cnt_gs = h->d_ccnt + (size_t)NGP_RING * h->NG * 32;
+    A.flag_dlt = A.cnt_gs + (size_t)NGP_RING * 32; A.abort_w = h->d_abort; A.xcc_w = h->d_abort + 16;
+    A.census = (h->dbg_mode == 0) ? h->d_ccnt + h->census_off : nullptr;  // timing modes leave roles out: no census there
+    A.census_tbl = h->d_census_tbl; A.iter_tag = (unsigned)(h->iter + 1);
+    A.census_fail = (h->dbg_census_fail_iter > 0 && !h->exclusive) ? (unsigned)h->dbg_census_fail_iter : 0u;
+    A.dbg = h->d_dbg;
+    A.fine_ok = ((size_t)2 * (R / 4) * NGP_QS + (size_t)R * 80 + 8320 + 8192 <= h->lds_sweep) ? 1 : 0;  // diagnostic timeline fits in LDS
+    A.variant = h->streamer; A.knob = h->knob;
+    if (h->streamer >= 2) A.fine_ok = (h->lds_rows + 8192 <= h->lds_sweep) ? 1 : 0;
+    A.mean = h->d_mean; A.N = h->N;
+    A.dbg_mode = h->dbg_mode;
+}
+
+// one sweep over blocks [tb0, tb1): persistent kernel (mode 1) or two launches per block (mode 0)
 void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
     const int R = (int)h->R, S = (int)h->S;
     if (h->mode == 1) {
         // (the hand-off counters were zeroed by k_prep, which precedes every sweep in the stream)
         SweepArgs A;
-        A.tiles = h->d_tiles; A.ycorr = h->d_ycorr; A.gramx = h->d_gramx;
-        A.D = h->D; A.R = R; A.S = S; A.NG = h->NG; A.near = h->near; A.fine_ok = 0; A.t0 = (int)tb0; A.t1 = (int)tb1;
-        A.beta = h->d_beta; A.delta = h->d_delta; A.c = h->d_c; A.w = h->d_w; A.q = h->d_q; A.mpm = h->d_mpm; A.chi = h->d_chi;
-        A.setof = h->d_setof; A.vbidx = h->d_vbidx; A.sets = h->d_sets; A.varBeta = h->d_varBeta;
-        A.rcls = h->d_rcls; A.rhs0 = h->d_rhs0; A.scal = h->d_scal; A.Ppad = h->Ppad;
-        A.tup = h->ntuple ? h->d_tup : nullptr; A.tupc = h->d_tupc; A.tupg = h->d_tupg;
-        A.part = h->d_cpart; A.gsum = h->d_cgsum; A.dlt = h->d_cdlt; A.dltg = h->d_cdltg;
-        h->launch_seq = (h->launch_seq % 4095u) + 1u;  // 1..4095: never the zero the ring is born with
-        A.nonce = h->launch_seq;
-        A.cnt_part = h->d_ccnt; A.cnt_gs = h->d_ccnt + (size_t)NGP_RING * h->NG * 32;
-        A.flag_dlt = A.cnt_gs + (size_t)NGP_RING * 32; A.abort_w = h->d_abort; A.xcc_w = h->d_abort + 16;
-        A.census = (h->dbg_mode == 0) ? h->d_ccnt + h->census_off : nullptr;  // timing modes leave roles out: no census there
-        A.census_tbl = h->d_census_tbl; A.iter_tag = (unsigned)(h->iter + 1);
-        A.census_fail = (h->dbg_census_fail_iter > 0 && !h->exclusive) ? (unsigned)h->dbg_census_fail_iter : 0u;
+        fill_sweep_args(h, tb0, tb1, A);
+        h->last_grid = 1 + h->NG + S;
         if (evs) (void)hipEventRecord(evs[0], h->stream);
-        A.dbg = h->d_dbg;
-        A.fine_ok = ((size_t)2 * (R / 4) * NGP_QS + (size_t)R * 80 + 8320 + 8192 <= h->lds_sweep) ? 1 : 0;  // diagnostic timeline fits in LDS
-        A.variant = h->streamer; A.knob = h->knob;
-        if (h->streamer >= 2) A.fine_ok = (h->lds_rows + 8192 <= h->lds_sweep) ? 1 : 0;
-        A.mean = h->d_mean; A.N = h->N;
-        A.dbg_mode = h->dbg_mode;
         if (h->d_dbg || h->dbg_mode)  // diagnostic instantiation: stamps and timing modes exist only there
             sweep_launch_1((unsigned)(1 + h->NG + S), h->lds_sweep, h->stream, A);
         else
@@ -586,7 +633,7 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
 
 // placement census of the last sweep launch (SweepArgs.census_tbl): who arrived, and where
 std::string census_report(ngp_handle *h) {
-    const size_t grid = (size_t)(1 + h->NG + h->S);
+    const size_t grid = (size_t)(h->last_grid > 0 ? h->last_grid : 1 + h->NG + h->S);
     std::vector<unsigned long long> tb(grid, 0ull);
     if (!h->d_census_tbl || hipMemcpy(tb.data(), h->d_census_tbl, grid * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return "(no census)";
     int per_xcc[16] = {0}, per_se[16][8] = {{0}};
@@ -658,7 +705,7 @@ void launch_variance(ngp_handle *h, int active_set, uint64_t it) {
 
 // resume_mid: the head of this iteration (varE, intercept, fixed-effect sets) has run already -- its sweep ended at the census
 // with nothing changed and is launched again, k_prep first (it redraws the same keyed numbers and clears the hand-off counters)
-int one_iteration(ngp_handle *h, int64_t trace_idx, hipEvent_t *evs, bool resume_mid = false) {
+void iteration_pre(ngp_handle *h, int64_t trace_idx, bool resume_mid) {  // everything in front of the sweep
     const uint64_t it = (uint64_t)(h->iter + 1);
     if (!resume_mid) {
     hipLaunchKernelGGL(k_head, dim3(1), dim3(1024), 0, h->stream, h->d_ycorr, (long long)h->L, (long long)h->N, h->d_scal, h->e_df,
@@ -672,7 +719,10 @@ int one_iteration(ngp_handle *h, int64_t trace_idx, hipEvent_t *evs, bool resume
                        h->d_vbidx, h->d_sets, h->d_scal, h->d_varBeta, h->d_mpm, h->d_lhs0, h->d_rhs0, h->d_beta, h->d_c, h->d_w,
                        h->d_q, h->d_T, h->d_chi, -1, h->seed, (uint64_t)h->chain, it, (long long)h->h_regs.size(), h->d_regs, h->d_regchi, h->d_rcls,
                        h->d_ccnt, (long long)(h->mode == 1 ? h->ccnt_words : 0), h->d_abort, h->d_tup, h->d_tupc, h->d_tupg);
-    launch_sweep(h, 0, h->NBLK, evs);
+}
+
+void iteration_post(ngp_handle *h, int64_t trace_idx) {  // variance / pi draws, traces and posterior sums; advances h->iter
+    const uint64_t it = (uint64_t)(h->iter + 1);
     launch_variance(h, -1, it);
     h->iter += 1;
     const bool do_trace = h->d_trace_loci && trace_idx < h->trace_ext_cap, do_accum = is_kept(h, h->iter);
@@ -690,6 +740,14 @@ int one_iteration(ngp_handle *h, int64_t trace_idx, hipEvent_t *evs, bool resume
             hipLaunchKernelGGL(k_accum_fixed, dim3((unsigned)((h->nfixcol + 255) / 256)), dim3(256), 0, h->stream, (long long)h->nfixcol, h->d_bfix,
                                h->d_sum_bfix, h->d_abort);
     }
+}
+
+// resume_mid: the head of this iteration (varE, intercept, fixed-effect sets) has run already -- its sweep ended at the census
+// with nothing changed and is launched again, k_prep first (it redraws the same keyed numbers and clears the hand-off counters)
+int one_iteration(ngp_handle *h, int64_t trace_idx, hipEvent_t *evs, bool resume_mid = false) {
+    iteration_pre(h, trace_idx, resume_mid);
+    launch_sweep(h, 0, h->NBLK, evs);
+    iteration_post(h, trace_idx);
     return NGP_OK;
 }
 
@@ -790,7 +848,8 @@ int32_t ngp_destroy(ngp_handle *h) {
     if (!h) return NGP_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
-    dfree(h->d_tiles); dfree(h->d_mean); dfree(h->d_gramx); dfree(h->d_cpart); dfree(h->d_cgsum); dfree(h->d_cdlt); dfree(h->d_cdltg); dfree(h->d_rcls); dfree(h->d_seg_set); dfree(h->d_ccnt); dfree(h->d_abort); dfree(h->d_dbg); dfree(h->d_mpm); dfree(h->d_lhs0); dfree(h->d_rhs0); dfree(h->d_beta);
+    release_panel(h);
+     dfree(h->d_cpart); dfree(h->d_cgsum); dfree(h->d_cdlt); dfree(h->d_cdltg); dfree(h->d_rcls); dfree(h->d_seg_set); dfree(h->d_ccnt); dfree(h->d_abort); dfree(h->d_dbg); dfree(h->d_mpm); dfree(h->d_lhs0); dfree(h->d_rhs0); dfree(h->d_beta);
     dfree(h->d_c); dfree(h->d_w); dfree(h->d_q); dfree(h->d_T); dfree(h->d_chi); dfree(h->d_setof); dfree(h->d_loc);
     dfree(h->d_vbidx); dfree(h->d_delta); dfree(h->d_sum_beta); dfree(h->d_sum_beta2); dfree(h->d_sum_delta);
     dfree(h->d_ycorr); dfree(h->d_part); dfree(h->d_dlt); dfree(h->d_sets); dfree(h->d_scal); dfree(h->d_varBeta);
@@ -977,8 +1036,8 @@ int32_t ngp_load_panel_file(ngp_handle *h, const char *path, int32_t centre) {
     (void)hipFree(d_g);
     (void)hipHostFree(h_g);
     dfree(d_mu);
-    if (!why.empty()) { dfree(h->d_tiles); return fail(h, NGP_ERR_ARG, why); }
-    if (e != hipSuccess) { dfree(h->d_tiles); return fail(h, NGP_ERR_HIP, std::string("load_panel_file: ") + hipGetErrorString(e)); }
+    if (!why.empty()) { release_panel(h); return fail(h, NGP_ERR_ARG, why); }
+    if (e != hipSuccess) { release_panel(h); return fail(h, NGP_ERR_HIP, std::string("load_panel_file: ") + hipGetErrorString(e)); }
     return build_gram(h);
     NGP_CATCH(h)
 }
@@ -1232,8 +1291,11 @@ int32_t ngp_set_schedule(ngp_handle *h, int64_t chainLength, int64_t burnIn, int
     NGP_CATCH(h)
 }
 
-int32_t ngp_run(ngp_handle *h, int64_t niter) {
-    NGP_TRY
+}  // extern "C"
+
+namespace {
+// checks and trace buffers in front of a run of niter iterations
+int prepare_run(ngp_handle *h, int64_t niter) {
     int rc;
     if ((rc = enter(h))) return rc;
     if ((rc = ready(h))) return rc;
@@ -1252,6 +1314,80 @@ int32_t ngp_run(ngp_handle *h, int64_t niter) {
         h->trace_cap = niter;
     }
     h->ntrace = niter;
+    return NGP_OK;
+}
+
+// K chains per pass over the panel (k_sweep_multi, ngp_sweep.h): can these handles' chains share ONE sweep launch?  They must
+// share one panel (ngp_share_panel) and run the engine the fused kernel is built for: persistent sweep, fp32 tiles, phase streamer
+// on shards of at most 64 rows, lag 4, 6 or 8, no diagnostics -- and the fused grid must fit the device.
+bool fusable(ngp_handle **hs, int n) {
+    if (n < 2 || n > NGP_MAXC) return false;
+    ngp_handle *h0 = hs[0];
+    if (!h0->pm || h0->mode != 1 || h0->storage != 0 || h0->streamer != 1 || h0->R > 64 || !(h0->D == 4 || h0->D == 6 || h0->D == 8)) return false;
+    for (int i = 0; i < n; i++) {
+        ngp_handle *h = hs[i];
+        if (h->pm != h0->pm || h->device != h0->device || h->dbg_mode != 0 || h->d_dbg || h->dbg_census_fail_iter > 0) return false;
+    }
+    return (int64_t)n * (1 + h0->NG) + h0->S <= h0->cu_count;
+}
+
+// niter iterations of n chains, every iteration ONE fused sweep launch on the first handle's stream; each chain's small kernels
+// (head, coefficients, variance draws, posterior sums) run there too, chain after chain.  Bit for bit what each chain draws alone.
+int run_fused(ngp_handle **hs, int n, int64_t niter) {
+    ngp_handle *h = hs[0];  // errors are reported on the leader (and copied to the others by the caller)
+    int rc;
+    for (int i = 0; i < n; i++)
+        if ((rc = prepare_run(hs[i], niter))) { if (i) h->err = hs[i]->err; return rc; }
+    const int64_t grid = (int64_t)n * (1 + h->NG) + h->S;
+    const size_t lds_sampler = (size_t)(3 * 4096 + 2 * NGP_RING * NGP_BLK + 6 * NGP_BLK) * sizeof(double) + 2 * NGP_BLK * sizeof(int) + 320;
+    const size_t lds = std::max(ngp_multi_lds_bytes((int)h->R, n), lds_sampler);
+    REQUIRE(lds <= 160 * 1024, NGP_ERR_STATE, "fused sweep: LDS of a streamer with this many chains exceeds 160 KiB");
+    HCHK(sweep_multi_set_max_lds((int)lds));
+    // one stream, one abort word: the leader's
+    std::vector<hipStream_t> st((size_t)n);
+    std::vector<unsigned *> ab((size_t)n);
+    for (int i = 0; i < n; i++) { HCHK(hipStreamSynchronize(hs[i]->stream)); st[i] = hs[i]->stream; ab[i] = hs[i]->d_abort; hs[i]->stream = h->stream; hs[i]->d_abort = h->d_abort; }
+    auto restore = [&]() { for (int i = 0; i < n; i++) { hs[i]->stream = st[i]; hs[i]->d_abort = ab[i]; } };
+    CuLease lease(h, grid);
+    hipError_t e = hipEventRecord(h->ev0, h->stream);
+    rc = NGP_OK;
+    for (int64_t it = 0; it < niter && rc == NGP_OK && e == hipSuccess; ++it) {
+        MultiArgs M;
+        M.K = n; M.pad_ = 0;
+        for (int i = 0; i < n; i++) {
+            iteration_pre(hs[i], it, false);
+            fill_sweep_args(hs[i], 0, hs[i]->NBLK, M.a[i]);
+        }
+        for (int i = 1; i < n; i++) { M.a[i].census = nullptr; M.a[i].xcc_w = M.a[0].xcc_w; }
+        sweep_multi_launch((unsigned)grid, lds, h->stream, M);
+        h->sweep_launches += 1; h->last_grid = grid;
+        for (int i = 0; i < n; i++) iteration_post(hs[i], it);
+        if ((it & 15) == 15 || it + 1 == niter) {  // bound the launch queue
+            e = hipStreamSynchronize(h->stream);
+            if (e == hipSuccess) {
+                rc = check_abort(h);  // (no retry: there is one grid, and the lease covers it)
+                if (rc) for (int i = 1; i < n; i++) { hs[i]->poisoned = true; hs[i]->err = h->err; }
+            }
+        }
+    }
+    if (e == hipSuccess) e = hipEventRecord(h->ev1, h->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    restore();
+    if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("fused run: ") + hipGetErrorString(e));
+    if (rc) return rc;
+    float ms = 0.f;
+    HCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
+    for (int i = 0; i < n; i++) { hs[i]->iter_ms += ms; hs[i]->iters_timed += niter; }
+    return NGP_OK;
+}
+}  // namespace
+
+extern "C" {
+
+int32_t ngp_run(ngp_handle *h, int64_t niter) {
+    NGP_TRY
+    int rc;
+    if ((rc = prepare_run(h, niter))) return rc;
     CuLease lease(h);
     HCHK(hipEventRecord(h->ev0, h->stream));
     if ((rc = run_iterations(h, niter, lease, nullptr))) return rc;
@@ -1662,6 +1798,36 @@ int32_t ngp_shards_for_chains(ngp_handle *h, int32_t chains, int32_t *max_shards
     NGP_CATCH(h)
 }
 
+/* K chains per pass, set-up: h takes `owner`'s panel (tiles, Gram window, x'x, column means) by reference -- no copy, no second
+ * 120 GB -- together with its engine, layout and storage; everything that belongs to a chain (effects, residuals, variances, draws,
+ * hand-off rings, posterior sums) is h's own.  The arrays live as long as any handle refers to them. */
+int32_t ngp_share_panel(ngp_handle *h, ngp_handle *owner) {
+    NGP_TRY
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(owner && owner != h && owner->d_tiles != nullptr && owner->pm != nullptr, NGP_ERR_ARG, "ngp_share_panel: the owner has no panel");
+    REQUIRE(owner->device == h->device, NGP_ERR_ARG, "ngp_share_panel: both handles must be on one device");
+    HCHK(hipStreamSynchronize(owner->stream));
+    h->cu_count = owner->cu_count;
+    return alloc_panel(h, owner->N, owner->P, owner);
+    NGP_CATCH(h)
+}
+
+/* The largest max_shards (ngp_set_max_shards, before the panel is set) with which `chains` chains share ONE fused sweep launch:
+ * chains x (1 sampler + ceil(S / 32) reducers) + S streamers <= CUs. */
+int32_t ngp_shards_for_pass(ngp_handle *h, int32_t chains, int32_t *max_shards) {
+    NGP_TRY
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(chains >= 1 && chains <= NGP_MAXC && max_shards, NGP_ERR_ARG, "chains per pass: 1..8");
+    int s = h->cu_count;
+    while (s >= 1 && (int64_t)chains * (1 + (s + NGP_GRP - 1) / NGP_GRP) + s > h->cu_count) --s;
+    REQUIRE(s >= 1, NGP_ERR_ARG, "too many chains for this device");
+    *max_shards = s;
+    return NGP_OK;
+    NGP_CATCH(h)
+}
+
 int32_t ngp_set_storage(ngp_handle *h, int32_t storage) {
     NGP_TRY
     int rc;
@@ -1971,6 +2137,9 @@ int32_t ngp_run_many(ngp_handle **hs, int32_t n, int64_t niter) {
         for (int k = 0; k < i; k++)
             if (hs[k] == hs[i]) return fail(hs[0], NGP_ERR_ARG, "ngp_run_many: the same handle twice");
     }
+    // chains that share one panel (ngp_share_panel) and run the engine the fused kernel serves take ONE sweep launch per iteration:
+    // the panel is streamed once for all of them (K chains per pass)
+    if (fusable(hs, n)) return run_fused(hs, n, niter);
     // one host thread per chain, as a caller would do it (src/samplers.jl:23: one chain per Julia task); the chains of a device run
     // side by side when their grids fit it together (ngp_set_max_shards), in turns otherwise (CuLease)
     std::vector<int32_t> rcs((size_t)n, NGP_OK);
@@ -2348,7 +2517,7 @@ int32_t ngp_get_census(ngp_handle *h, uint64_t *out, int64_t n, int64_t *grid, i
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr && h->mode == 1, NGP_ERR_STATE, "no persistent sweep on this handle");
-    const int64_t g = 1 + h->NG + h->S;
+    const int64_t g = h->last_grid > 0 ? h->last_grid : 1 + h->NG + h->S;
     if (grid) *grid = g;
     if (retries) *retries = h->census_retries;
     if (exclusive) *exclusive = h->exclusive ? 1 : 0;

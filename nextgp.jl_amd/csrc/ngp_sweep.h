@@ -1493,6 +1493,36 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
 #undef NGP_END_OF_BLOCK
 }
 
+// Census: every workgroup of this grid waits for others, so the whole grid must be resident at once.  The host checks that by
+// count (occupancy query, CU lease), but what the dispatcher does with several grids of one process is not ours to know: each
+// workgroup reports in, the last one opens the gate, and if the gate is still shut after 20 ms the launch ends BEFORE any role
+// has touched the chain (abort code NGP_ABORT_CENSUS) -- the host then runs it again with the device to itself.
+__device__ inline bool sweep_census(const SweepArgs &A, const int b, char *smem) {
+    if (!A.census) return true;
+    int *cflag = (int *)smem;
+    if (threadIdx.x == 0) {
+        A.census_tbl[b] = ((unsigned long long)(xcc_id() + 1u) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
+        if (A.census_fail != 0u && A.census_fail == A.iter_tag) atomicCAS(&A.census[1], 0u, 2u);  // test hook
+        const unsigned old = atomicAdd(&A.census[0], 1u);
+        if (old + 1u == gridDim.x) atomicCAS(&A.census[1], 0u, 1u);
+        const unsigned long long t0 = wall_clock64();
+        unsigned verdict;
+        while ((verdict = ld_u32(&A.census[1])) == 0u) {
+            if (wall_clock64() - t0 > NGP_CENSUS_TICKS) atomicCAS(&A.census[1], 0u, 2u);
+            else __builtin_amdgcn_s_sleep(8);
+        }
+        if (verdict != 1u) {
+            st_u32(A.abort_w + 1, A.iter_tag);
+            st_u32(A.abort_w, NGP_ABORT_CENSUS);
+        }
+        *cflag = (verdict == 1u) ? 1 : 0;
+    }
+    __syncthreads();
+    const int cok = *cflag;
+    __syncthreads();  // the roles overwrite this word
+    return cok != 0;
+}
+
 // ------------------------------------------------------------------------------------------
 template <bool DBG>
 __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sweep(SweepArgs A) {
@@ -1501,34 +1531,7 @@ __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
     const int b = blockIdx.x;
     // an earlier launch of this call gave up: nothing runs until the host has looked (the chain stays where that launch found it)
     if (ld_u32(A.abort_w) != 0u) return;
-    // Census: every workgroup of this grid waits for others, so the whole grid must be resident at once.  The host checks that
-    // by count (occupancy query, CU lease), but what the dispatcher does with several grids of one process is not ours to
-    // know: each workgroup reports in, the last one opens the gate, and if the gate is still shut after 20 ms the launch ends
-    // BEFORE any role has touched the chain (abort code NGP_ABORT_CENSUS) -- the host then runs it again with the device to itself.
-    if (A.census) {
-        int *cflag = (int *)smem;
-        if (threadIdx.x == 0) {
-            A.census_tbl[b] = ((unsigned long long)(xcc_id() + 1u) << 32) | (unsigned)__builtin_amdgcn_s_getreg((31 << 11) | 4);
-            if (A.census_fail != 0u && A.census_fail == A.iter_tag) atomicCAS(&A.census[1], 0u, 2u);  // test hook
-            const unsigned old = atomicAdd(&A.census[0], 1u);
-            if (old + 1u == gridDim.x) atomicCAS(&A.census[1], 0u, 1u);
-            const unsigned long long t0 = wall_clock64();
-            unsigned verdict;
-            while ((verdict = ld_u32(&A.census[1])) == 0u) {
-                if (wall_clock64() - t0 > NGP_CENSUS_TICKS) atomicCAS(&A.census[1], 0u, 2u);
-                else __builtin_amdgcn_s_sleep(8);
-            }
-            if (verdict != 1u) {
-                st_u32(A.abort_w + 1, A.iter_tag);
-                st_u32(A.abort_w, NGP_ABORT_CENSUS);
-            }
-            *cflag = (verdict == 1u) ? 1 : 0;
-        }
-        __syncthreads();
-        const int cok = *cflag;
-        __syncthreads();  // the roles overwrite this word
-        if (!cok) return;
-    }
+    if (!sweep_census(A, b, smem)) return;
     if (dbg_mode == 1 && b <= A.NG) return;
     if ((dbg_mode == 2 && b != 0) || ((dbg_mode == 3 || dbg_mode == 4) && b == 0)) return;
     if (b == 0)
@@ -1594,5 +1597,261 @@ __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #undef NGP_DISPATCH_D
     }
 }
+
+
+// ------------------------------------------------------------------------------------------
+// K CHAINS PER PASS OVER THE PANEL (hard part 2).  Independent chains (one handle each, same panel, same
+// layout) share ONE launch: every streamer holds K shards of ycorr and forms X_t'[y_1 .. y_K] from each tile it reads -- the
+// panel is streamed once for K iterations' worth of sampling -- while every chain keeps its own sampler workgroup, reducers and
+// hand-off rings.  Where the sweep is bound by the hand-off latency of its pipeline and not by HBM (short shards: 10k x 100k), the
+// chains' round trips overlap and the aggregate rate grows almost K-fold; each chain stays, bit for bit, the chain it is alone
+// with the same layout (R, S, lag, near lags): per chain nothing about the order of its arithmetic changes.
+//   blocks 0, 8, .., 8 (K-1)   samplers (one XCD under round-robin placement: they read the same Gram blocks -- speed only)
+//   the next K NG blocks       reducers, chain-major
+//   the rest                   S streamers
+// Streamer: the phase streamer of shards of at most 64 rows (role_streamer, one update task per thread, every wave forming the
+// updated shard itself), with the per-chain state in LDS and every per-chain step looped over the chains.
+// ------------------------------------------------------------------------------------------
+template <int DT>
+__device__ inline void role_streamer_multi(const MultiArgs &M, const int s, char *smem) {
+    const SweepArgs &A = M.a[0];
+    const int K = M.K;
+    const int R = A.R, S = A.S, tid = threadIdx.x;
+    const int wv = tid >> 6, j = tid & 63;
+    const size_t TBL = (size_t)(R >> 2) * NGP_QS;
+    char *ring = smem;  // 2 tile slots
+    const size_t CH = ngp_multi_chain_doubles(R);
+    double *cbase = (double *)(smem + 2 * TBL);
+    ChainPtrs *cp = (ChainPtrs *)(cbase + (size_t)K * CH);
+    int *sflag = (int *)(cp + NGP_MAXC);
+    char *scratch = (char *)sflag + 64;  // 3 KiB sink of the L2-warming DMA
+#define NGP_YS(kc) (cbase + (size_t)(kc) * CH)
+#define NGP_RED(kc) (NGP_YS(kc) + 2 * R)
+#define NGP_DL(kc) (NGP_RED(kc) + 512)
+#define NGP_PP(kc) (NGP_DL(kc) + 128)
+    const size_t tile_elems = (size_t)R * NGP_BLK;
+    const int nchunk = R >> 2;
+    const int g = s / NGP_GRP;
+    const int nb = A.t1 - A.t0;
+    auto dma_tile = [&](int ub) {
+        const char *src = (const char *)(A.tiles + ((size_t)(A.t0 + ub) * S + s) * tile_elems);
+        char *dst = ring + (size_t)(ub & 1) * TBL;
+        for (int c = wv - 4; c < nchunk; c += 3) dma16_lds(src + (size_t)c * 1024 + (size_t)j * 16, dst + (size_t)c * NGP_QS);
+    };
+    for (int kc = 0; kc < K; kc++) {  // (kc uniform: the launch arguments are read with scalar loads)
+        if (tid == 0) {
+            ChainPtrs c;
+            c.ycorr = M.a[kc].ycorr; c.part = M.a[kc].part; c.dlt = M.a[kc].dlt; c.cnt_part = M.a[kc].cnt_part; c.flag_dlt = M.a[kc].flag_dlt;
+            cp[kc] = c;
+        }
+        const double *yg = M.a[kc].ycorr + (size_t)s * R;
+        for (int i = tid; i < R; i += NGP_WG) NGP_YS(kc)[i] = yg[i];
+    }
+    if (tid == 0) *sflag = 1;
+    // wave 7: dlt of local block (uu - DT) of every chain into dl[uu & 1]; lanes < K poll their chain's flag
+    auto wait_flags = [&](int target) -> int {  // whole wave; 1 = every chain has finished `target` blocks
+        int ok = 1;
+        if (j < K) ok = wait_ge(cp[j].flag_dlt, (unsigned)target, A.abort_w, 1u) ? 1 : 0;
+        return __ballot(ok == 0) == 0ull ? 1 : 0;
+    };
+    auto poll_dlt = [&](int uu) {
+        const int aa = uu - DT;
+        if (aa < 0 || uu >= nb + DT) return;
+        const int ok = wait_flags(aa + 1);
+        if (!ok && j == 0) *sflag = 0;
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (ok)
+            for (int kc = 0; kc < K; kc++) NGP_DL(kc)[(uu & 1) * 64 + j] = ld_f64(&M.a[kc].dlt[(size_t)(aa % NGP_RING) * NGP_BLK + j]);
+    };
+    // the update task of this thread (fixed for the whole sweep): 8-column chain tcc of row ti0; surplus threads redo the last task
+    const int tq_ = min(tid, 8 * R - 1);
+    const int tcc = tq_ / R, ti0 = tq_ - tcc * R;
+    float keep[DT][8];
+#pragma unroll
+    for (int d = 0; d < DT; d++)
+#pragma unroll
+        for (int jj = 0; jj < 8; jj++) keep[d][jj] = 0.0f;
+    if (wv >= 4 && wv <= 6 && nb > 0) dma_tile(0);
+    const unsigned my_xcc = xcc_id() + 1u;
+    const int nslice = max(1, S / 8);
+    const int slice = (s / 8) % nslice;
+    const size_t gram_bytes = (size_t)DT * NGP_BLK * NGP_BLK * sizeof(double);
+    const size_t slice_bytes = ((gram_bytes / nslice + 1023) / 1024) * 1024;
+    bool same_xcd = false;
+    constexpr bool LAZY = (DT >= NGP_LAZY_LAG);
+    int sig_pending = -1;  // ring slot of the stored, not yet counted partials (all chains)
+    auto try_signal = [&](bool force) {
+        if (!LAZY || wv != 1 || sig_pending < 0) return;
+        if (force) drain_vm();
+        else if ((__builtin_amdgcn_s_getreg((23 << 11) | 7) & 0xC0000Fu) != 0u) return;  // VM_CNT [3:0] and [23:22]
+        if (j < K) atomicAdd(&cp[j].cnt_part[((size_t)sig_pending * A.NG + g) * 32], 1u);
+        sig_pending = -1;
+    };
+    __syncthreads();
+    for (int u0 = 0; u0 < nb + DT; u0 += DT) {
+#pragma unroll
+        for (int d = 0; d < DT; d++) {
+            const int u = u0 + d;
+            if (u >= nb + DT) break;
+            const int a = u - DT;
+            // ---------------- phase A: everything that waits on memory ----------------
+            if (wv >= 4 && wv <= 6) {
+                drain_vm();
+                if (u + 1 < nb) dma_tile(u + 1);
+                if ((u & 7) == 0 && !same_xcd) same_xcd = (ld_u32(A.xcc_w) == my_xcc);
+                if (same_xcd && u + 1 < nb) {
+                    const char *gb = (const char *)(A.gramx + (size_t)(A.t0 + u + 1) * DT * NGP_BLK * NGP_BLK);
+                    const size_t lo = (size_t)slice * slice_bytes, hi = min((size_t)(slice + 1) * slice_bytes, gram_bytes);
+                    for (size_t off = lo + (size_t)(wv - 4) * 1024; off + 1024 <= hi; off += 3 * 1024)
+                        dma16_lds(gb + off + (size_t)j * 16, scratch + (wv - 4) * 1024);
+                }
+            } else if (wv == 7) {
+                if (DT <= 2 || u == 0) poll_dlt(u);
+            }
+            try_signal(false);
+            wg_barrier();
+            if (!*sflag) return;
+            // ---------------- phase B: the 8-column partial sums of ycorr -= X_a dlt_a, every chain ----------------
+            if (a >= 0) {
+                for (int kc = 0; kc < K; kc++) {
+                    const double *dq = NGP_DL(kc) + (u & 1) * 64 + 8 * tcc;
+                    double p = 0.0;
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) p = __builtin_fma((double)keep[d][jj], dq[jj], p);
+                    NGP_PP(kc)[(size_t)tcc * R + ti0] = p;
+                }
+                try_signal(false);
+                wg_barrier();
+                try_signal(false);
+            }
+            // lane i < R of EVERY wave holds the updated y_i of this iteration, chain by chain; wave 0 stores it for the next one
+            double yn[NGP_MAXC];
+#pragma unroll
+            for (int kc = 0; kc < NGP_MAXC; kc++) {
+                yn[kc] = 0.0;
+                if (kc < K && j < R) {
+                    double *ys = NGP_YS(kc);
+                    const double *pp = NGP_PP(kc);
+                    double v = ys[(size_t)(u & 1) * R + j];
+                    if (a >= 0) {
+                        const double T = ((pp[j] + pp[R + j]) + (pp[2 * R + j] + pp[3 * R + j])) +
+                                         ((pp[4 * R + j] + pp[5 * R + j]) + (pp[6 * R + j] + pp[7 * R + j]));
+                        v = v - T;
+                    }
+                    if (wv == 0) ys[(size_t)((u & 1) ^ 1) * R + j] = v;
+                    yn[kc] = v;
+                }
+            }
+            // ---------------- phase C: partial X_u' ycorr of every chain, and tile u into the delay line ----------------
+            if (u < nb) {
+                const int pa = u + 1 - DT;
+                const bool pollw = (wv == 7) && (DT >= 3) && (pa >= 0) && (u + 1 < nb + DT);
+                unsigned fl = 0xFFFFFFFFu;
+                if (pollw && j < K) fl = ld_u32(cp[j].flag_dlt);
+                const float *slotp = (const float *)(ring + (size_t)(u & 1) * TBL);
+                {
+                    const float *tq = slotp + (size_t)(ti0 >> 2) * (NGP_QS / 4) + 32 * tcc + (ti0 & 3);
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) keep[d][jj] = tq[4 * jj];
+                }
+                {   // chain wv: row quads wv, wv+8, ... (lane = column); one read of the tile serves all K chains
+                    const float *col = slotp + 4 * j;
+                    double acc[NGP_MAXC];
+#pragma unroll
+                    for (int kc = 0; kc < NGP_MAXC; kc++) acc[kc] = 0.0;
+                    for (int qd = __builtin_amdgcn_readfirstlane(wv); qd < (R >> 2); qd += 8) {
+                        const float4 x = *(const float4 *)(col + (size_t)qd * (NGP_QS / 4));
+#pragma unroll
+                        for (int kc = 0; kc < NGP_MAXC; kc++)
+                            if (kc < K) {
+                                const double y0 = readlane_d(yn[kc], 4 * qd), y1 = readlane_d(yn[kc], 4 * qd + 1);
+                                const double y2 = readlane_d(yn[kc], 4 * qd + 2), y3 = readlane_d(yn[kc], 4 * qd + 3);
+                                acc[kc] = __builtin_fma((double)x.x, y0, acc[kc]);
+                                acc[kc] = __builtin_fma((double)x.y, y1, acc[kc]);
+                                acc[kc] = __builtin_fma((double)x.z, y2, acc[kc]);
+                                acc[kc] = __builtin_fma((double)x.w, y3, acc[kc]);
+                            }
+                    }
+#pragma unroll
+                    for (int kc = 0; kc < NGP_MAXC; kc++)
+                        if (kc < K) NGP_RED(kc)[wv * 64 + j] = acc[kc];
+                }
+                double dnext[NGP_MAXC];
+                bool have_dnext = false;
+                if (pollw) {
+                    int ok = 1;
+                    if (__ballot(fl < (unsigned)(pa + 1)) != 0ull) {  // some chain's sampler is not that far yet: wait (bounded)
+                        ok = wait_flags(pa + 1);
+                        if (!ok && j == 0) *sflag = 0;
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+                    if (ok) {
+#pragma unroll
+                        for (int kc = 0; kc < NGP_MAXC; kc++)
+                            if (kc < K) dnext[kc] = ld_f64(&M.a[kc].dlt[(size_t)(pa % NGP_RING) * NGP_BLK + j]);
+                        have_dnext = true;
+                    }
+                }
+                try_signal(false);
+                wg_barrier();
+                if (have_dnext) {
+#pragma unroll
+                    for (int kc = 0; kc < NGP_MAXC; kc++)
+                        if (kc < K) NGP_DL(kc)[((u + 1) & 1) * 64 + j] = dnext[kc];
+                }
+                if (wv == 1) {
+                    const int slot = u % NGP_RING;
+                    try_signal(true);  // the previous partials, if their stores were still under way at every boundary
+                    for (int kc = 0; kc < K; kc++) {
+                        const double *red = NGP_RED(kc);
+                        const double p = ((red[j] + red[64 + j]) + (red[128 + j] + red[192 + j])) + ((red[256 + j] + red[320 + j]) + (red[384 + j] + red[448 + j]));
+                        st_f64(&M.a[kc].part[((size_t)slot * S + s) * NGP_BLK + j], p);
+                    }
+                    if (LAZY) {
+                        sig_pending = slot;
+                    } else {
+                        drain_vm();
+                        if (j < K) atomicAdd(&cp[j].cnt_part[((size_t)slot * A.NG + g) * 32], 1u);
+                    }
+                }
+            } else if (wv == 7 && DT >= 3) poll_dlt(u + 1);
+        }
+    }
+    try_signal(true);
+    __syncthreads();
+    for (int kc = 0; kc < K; kc++) {
+        const double *yfin = NGP_YS(kc) + (size_t)((nb + DT) & 1) * R;
+        double *yg = M.a[kc].ycorr + (size_t)s * R;
+        for (int i = tid; i < R; i += NGP_WG) yg[i] = yfin[i];
+    }
+#undef NGP_YS
+#undef NGP_RED
+#undef NGP_DL
+#undef NGP_PP
+}
+
+#if !defined(NGP_INST_DBG) || !NGP_INST_DBG  // one definition: the production translation unit (ngp_sweep_inst.hip, -DNGP_INST_DBG=0)
+__global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sweep_multi(MultiArgs M) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x, K = M.K, NG = M.a[0].NG;
+    if (ld_u32(M.a[0].abort_w) != 0u) return;
+    if (!sweep_census(M.a[0], b, smem)) return;
+    if ((b & 7) == 0 && (b >> 3) < K) {
+        role_sampler<false>(M.a[b >> 3], smem);
+        return;
+    }
+    const int idx = b - min(K, (b + 7) >> 3);  // rank among the blocks that are not samplers
+    if (idx < K * NG) {
+        role_reducer<false>(M.a[idx / NG], idx % NG, smem);
+        return;
+    }
+    const int s = idx - K * NG;
+    switch (M.a[0].D) {  // host: lags 4, 6, 8 (shards of at most 64 rows, fp32 tiles)
+        case 4: role_streamer_multi<4>(M, s, smem); break;
+        case 6: role_streamer_multi<6>(M, s, smem); break;
+        default: role_streamer_multi<8>(M, s, smem); break;
+    }
+}
+#endif
 
 }  // namespace ngp

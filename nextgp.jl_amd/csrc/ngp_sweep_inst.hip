@@ -21,6 +21,13 @@ hipError_t NGP_SFX(sweep_set_max_lds)(int bytes) {
     return hipFuncSetAttribute((const void *)k_sweep<kDbg>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
 }
 #if !NGP_INST_DBG
+// K chains per pass: the production instantiation only
+hipError_t sweep_multi_set_max_lds(int bytes) {
+    return hipFuncSetAttribute((const void *)k_sweep_multi, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+void sweep_multi_launch(unsigned grid, size_t lds_bytes, hipStream_t stream, const MultiArgs &M) {
+    hipLaunchKernelGGL(k_sweep_multi, dim3(grid), dim3(NGP_WG), lds_bytes, stream, M);
+}
 hipError_t sweep_occupancy_0(int *wg_per_cu, size_t lds_bytes) {
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(wg_per_cu, (const void *)k_sweep<false>, NGP_WG, lds_bytes);
 }

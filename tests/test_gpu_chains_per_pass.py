@@ -1,0 +1,82 @@
+"""K chains per pass over the panel (ngp_share_panel + ngp_run_many -> k_sweep_multi): independent chains that share one panel take
+ONE sweep launch per iteration, every streamer forming X_t'[y_1 .. y_K] from each tile it reads.  Each chain must stay, bit for bit,
+the chain it is alone (and so the blocked oracle's chain) -- the reference's loop being replaced is still
+/root/reference/src/functions.jl:124-136, once per chain (src/samplers.jl:23: one chain per task)."""
+import numpy as np
+import pytest
+
+from conftest import add_sets, make_problem
+
+pytestmark = pytest.mark.gpu
+
+
+def build_chains(ngp, X, y, v, spec, K, lag=None, shards=None, seeds=None):
+    chains = []
+    for c in range(K):
+        s = ngp.Sampler(device=0, seed=(seeds or [1001 + i for i in range(K)])[c], chain=c, **({"mode": 1, "lag": lag} if lag else {}))
+        if c == 0:
+            s.set_max_shards(shards if shards else s.shards_for_pass(K))
+            s.set_panel(X)
+        else:
+            s.share_panel(chains[0])
+        add_sets(s, spec, v)
+        s.set_y(y + 0.01 * c)                  # chains need not even share y
+        s.set_residual_prior(4.0, 1.0)
+        s.set_schedule(20, 4, 2)
+        chains.append(s)
+    return chains
+
+
+@pytest.mark.parametrize("K,lag", [(2, None), (3, 6), (4, 4), (6, None), (8, None)])
+def test_fused_chains_equal_the_chains_alone_and_the_oracle(ngp, O, K, lag):
+    N, P = 500, 640
+    X, y, bt, v = make_problem(O, N, P, seed=6)
+    spec = [(0, 300, "PR"), (300, 200, "B"), (500, 140, "R")]
+    fused = build_chains(ngp, X, y, v, spec, K, lag=lag)
+    R, S, _ = fused[0].layout()
+    assert R <= 64 and fused[0].streamer()[0] == 1
+    ngp.Sampler.run_many(fused, 20)
+    assert fused[0].census()["grid"] == K * (1 + (S + 31) // 32) + S          # ONE launch served all chains
+    for c in (0, K - 1):
+        alone = ngp.Sampler(device=0, seed=1001 + c, chain=c, **({"mode": 1, "lag": lag} if lag else {}))
+        alone.set_max_shards(S); alone.set_panel(X)
+        assert alone.layout()[:2] == (R, S)
+        o = O.Oracle(order=1, seed=1001 + c, chain=c)
+        o.set_panel_f32(X, R=R, S=S, D=alone.config()[1], near=alone.near(), nchain=alone.streamer()[1])
+        for m in (alone, o):
+            add_sets(m, spec, v); m.set_y(y + 0.01 * c); m.set_residual_prior(4.0, 1.0); m.set_schedule(20, 4, 2); m.run(20)
+        a, b, f = alone.get_state(), o.get_state(), fused[c].get_state()
+        for key in ("ycorr", "beta", "delta", "varBeta", "piHat"):
+            assert np.array_equal(f[key], a[key]), (c, key)
+            assert np.array_equal(f[key], b[key][:len(f[key])]), (c, key)
+        assert f["varE"] == a["varE"] == b["varE"] and f["iter"] == 20
+        pf, pa = fused[c].get_posterior_sums(), alone.get_posterior_sums()
+        assert pf["nKept"] == pa["nKept"] == 8 and np.array_equal(pf["sum_beta"], pa["sum_beta"]) and pf["sum_varE"] == pa["sum_varE"]
+        assert np.array_equal(fused[c].get_class_state(2)["piHat"], alone.get_class_state(2)["piHat"])
+    # the chains are different chains (own seeds), and a second fused call continues them
+    assert not np.array_equal(fused[0].get_state()["beta"], fused[1].get_state()["beta"])
+    ngp.Sampler.run_many(fused, 5)
+    assert fused[0].get_state()["iter"] == 25
+
+
+def test_shared_panel_lifetime_and_fallback(ngp, O):
+    """The panel arrays live as long as any handle refers to them; handles whose engine the fused kernel does not serve still run
+    through ngp_run_many (side by side, one thread each), with the same results."""
+    N, P = 400, 256
+    X, y, bt, v = make_problem(O, N, P, seed=3)
+    spec = [(0, 256, "PR")]
+    a, b = build_chains(ngp, X, y, v, spec, 2)
+    mp = a.mpm().copy()
+    a.close()                                   # the owner goes first: the sharer keeps the panel alive
+    b.run(5)
+    assert np.array_equal(b.mpm(), mp) and np.isfinite(b.get_state()["beta"]).all()
+    # row-owning streamer (shards of 64+ rows): not fused, still correct
+    c = build_chains(ngp, X, y, v, spec, 2, lag=4, shards=5)
+    assert c[0].streamer()[0] == 2
+    ngp.Sampler.run_many(c, 6)
+    solo = ngp.Sampler(device=0, seed=1002, chain=1, mode=1, lag=4)
+    solo.set_max_shards(5); solo.set_panel(X); add_sets(solo, spec, v); solo.set_y(y + 0.01); solo.set_residual_prior(4.0, 1.0); solo.set_schedule(20, 4, 2)
+    solo.run(6)
+    assert np.array_equal(solo.get_state()["beta"], c[1].get_state()["beta"])
+    with pytest.raises(ngp.NextGPHipError, match="no panel"):
+        ngp.Sampler(device=0).share_panel(ngp.Sampler(device=0))
