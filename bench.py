@@ -61,14 +61,20 @@ def simulate_y(xbeta, N, P):
     return 10.0 + g + e
 
 
-def build_chain(ngp, device, seed, N, P, sets, panel_seed=20250509, storage=None, share=0):
+def build_chain(ngp, device, seed, N, P, sets, panel_seed=20250509, storage=None, share=0, per_pass=0, owner=None, y=None):
     s = ngp.Sampler(device=device, seed=seed, chain=seed - 1001, storage=storage)
     if share > 1:  # this chain is one of `share` that run side by side on the device
         s.set_max_shards(s.shards_for_chains(share))
+    if per_pass > 1 and owner is None:  # the first of `per_pass` chains that share ONE fused sweep launch (and one panel)
+        s.set_max_shards(s.shards_for_pass(per_pass))
     t0 = time.time()
-    s.generate_panel(N, P, 0.05, 0.5, panel_seed)
+    if owner is not None:
+        s.share_panel(owner)  # no second copy of the panel
+    else:
+        s.generate_panel(N, P, 0.05, 0.5, panel_seed)
     setup_s = time.time() - t0
-    y = simulate_y(s.xbeta, N, P)
+    if y is None:
+        y = simulate_y(s.xbeta, N, P)
     v = 0.5 * y.var() / (s.mpm().sum() / N)
     df = 4.0
     for method, col0, ncol in sets:
@@ -180,6 +186,9 @@ def main():
     ap.add_argument("--no-compact", action="store_true", help="skip the extra leg in compact (one byte per genotype) storage")
     ap.add_argument("--chains-per-gpu", type=int, default=0,
                     help="extra leg: that many independent chains side by side on the GPU (aggregate it/s; pays where one chain is not bandwidth-bound)")
+    ap.add_argument("--chains-per-pass", type=int, default=0,
+                    help="extra leg: that many independent chains in ONE fused sweep launch per iteration, the panel streamed once for all of them "
+                         "(aggregate it/s beside the single-chain value; 2..8)")
     ap.add_argument("--storage", default="f32", choices=["f32", "u8"],
                     help="panel storage of the MAIN measurement (default f32 = the headline; u8 = compact storage, for profiling that mode)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on one GPU)")
@@ -238,13 +247,16 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     # effective sample sizes over the K timed iterations (rank 0's chain), Geyer's initial positive sequence
-    tr, trx = s.get_trace(K), s.get_trace_ext(K)
-    ess = {"varE": ess_geyer(tr["varE"]),
-           "varBeta": [ess_geyer(trx["varBeta"][:, i]) for i in range(ntvb)],
-           "beta_min_of_%d" % len(loci): min(ess_geyer(trx["beta"][:, i]) for i in range(len(loci)))}
-    if any(m == "BayesB" for m, _, _ in sets):
-        ess["pi"] = [ess_geyer(trx["pi"][:, i]) for i in range(s.nsets)]
-    ess_min = min([ess["varE"], ess["beta_min_of_%d" % len(loci)]] + ess["varBeta"] + ess.get("pi", []))
+    # (only when at least 200 kept iterations back the estimate: below that the figure is noise)
+    ess, ess_min = None, None
+    if K >= 200:
+        tr, trx = s.get_trace(K), s.get_trace_ext(K)
+        ess = {"varE": ess_geyer(tr["varE"]),
+               "varBeta": [ess_geyer(trx["varBeta"][:, i]) for i in range(ntvb)],
+               "beta_min_of_%d" % len(loci): min(ess_geyer(trx["beta"][:, i]) for i in range(len(loci)))}
+        if any(m == "BayesB" for m, _, _ in sets):
+            ess["pi"] = [ess_geyer(trx["pi"][:, i]) for i in range(s.nsets)]
+        ess_min = min([ess["varE"], ess["beta_min_of_%d" % len(loci)]] + ess["varBeta"] + ess.get("pi", []))
     # dominant-kernel launch duration, HIP events on the library's own stream (five extra iterations, averaged)
     profs = [s.profile_iteration() for _ in range(5)]
     prof = dict(profs[0], avg_ms=float(np.mean([p["avg_ms"] for p in profs])))
@@ -319,9 +331,10 @@ def main():
                 "estimator": "Geyer initial positive sequence over the timed iterations of rank 0's chain (every iteration kept)",
                 "ess": ess,
                 "ess_min": ess_min,
-                "ess_min_per_sec": ess_min / dt,
-                "ess_varE_per_sec": ess["varE"] / dt,
-                "note": "single-chain figures; with n_gpus chains the pooled rate is n_gpus times these",
+                "ess_min_per_sec": None if ess_min is None else ess_min / dt,
+                "ess_varE_per_sec": None if ess is None else ess["varE"] / dt,
+                "note": "single-chain figures; with n_gpus chains the pooled rate is n_gpus times these"
+                        + ("" if ess is not None else "; not estimated: fewer than 200 timed iterations (run with --steps 1000 for an ESS figure)"),
             },
             "device_iter_ms": tm["iter_ms"] / max(tm["iters"], 1),
             "setup_s": setup_s,
@@ -378,6 +391,43 @@ def main():
             out["chains_per_gpu"] = {"chains": kc, "value": kc * K / kdt, "unit": "it/s (aggregate over the chains of this GPU)",
                                      "ms_per_step_of_a_chain": kdt / K * 1e3, "rows_per_shard": cs[0].layout()[0], "shards_per_chain": cs[0].layout()[1],
                                      "speedup_vs_single_chain": (kc * K / kdt) / its}
+            for c in cs:
+                c.close()
+        if world == 1 and args.chains_per_pass > 1 and not compact_main:
+            # K independent chains in ONE fused sweep launch per iteration: every streamer forms X_t'[y_1 .. y_K] from each tile it
+            # reads, so one pass over the panel (4 N P algorithmic bytes) serves K iterations' worth of sampling -- the aggregate
+            # rate BESIDE the single-chain value above, never instead of it; each chain is bit for bit the chain it is alone
+            try:
+                s.close()
+            except Exception:  # noqa: BLE001
+                pass
+            torch.cuda.empty_cache()
+            kp = args.chains_per_pass
+            first, _ = build_chain(ngp, local_rank, 1001, N, P, sets, per_pass=kp)
+            ysh = simulate_y(first.xbeta, N, P)
+            cs = [first] + [build_chain(ngp, local_rank, 1001 + i, N, P, sets, owner=first, y=ysh)[0] for i in range(1, kp)]
+            for c in cs:
+                c.set_schedule(W + K, W, 1)
+            ngp.Sampler.run_many(cs, W)
+            cs[0].get_timing()
+            torch.cuda.synchronize()
+            tk = time.perf_counter()
+            ngp.Sampler.run_many(cs, K)
+            torch.cuda.synchronize()
+            kdt = time.perf_counter() - tk
+            ptm = cs[0].get_timing()
+            cen = cs[0].census()
+            pR, pS, _ = cs[0].layout()
+            out["chains_per_pass"] = {
+                "chains": kp, "value": kp * K / kdt, "unit": "it/s (aggregate over the chains of ONE fused launch per iteration)",
+                "ms_per_pass": kdt / K * 1e3, "device_ms_per_pass": ptm["iter_ms"] / max(ptm["iters"], 1), "sweep_launches": ptm["sweep_launches"],
+                "algorithmic_bytes_per_pass": 4.0 * N * P, "panel_stream_GBps": 4.0 * N * P * (K / kdt) / 1e9,
+                "panel_stream_frac_of_peak": 4.0 * N * P * (K / kdt) / 1e9 / HBM_PEAK_GBS,
+                "grid_workgroups": cen["grid"], "rows_per_shard": pR, "shards": pS, "lag": cs[0].config()[1],
+                "speedup_vs_single_chain": (kp * K / kdt) / its if its else None,
+                "note": "independent chains (own seeds, own draws); every chain bit-identical to the chain it is alone with this layout "
+                        "(tests/test_gpu_chains_per_pass.py)",
+            }
             for c in cs:
                 c.close()
         if world == 1 and not args.no_cpu_baseline:

@@ -1319,11 +1319,11 @@ int prepare_run(ngp_handle *h, int64_t niter) {
 
 // K chains per pass over the panel (k_sweep_multi, ngp_sweep.h): can these handles' chains share ONE sweep launch?  They must
 // share one panel (ngp_share_panel) and run the engine the fused kernel is built for: persistent sweep, fp32 tiles, phase streamer
-// on shards of at most 64 rows, lag 4, 6 or 8, no diagnostics -- and the fused grid must fit the device.
+// on shards of at most 64 rows, lag 6 or 8, no diagnostics -- and the fused grid must fit the device.
 bool fusable(ngp_handle **hs, int n) {
     if (n < 2 || n > NGP_MAXC) return false;
     ngp_handle *h0 = hs[0];
-    if (!h0->pm || h0->mode != 1 || h0->storage != 0 || h0->streamer != 1 || h0->R > 64 || !(h0->D == 4 || h0->D == 6 || h0->D == 8)) return false;
+    if (!h0->pm || h0->mode != 1 || h0->storage != 0 || h0->streamer != 1 || h0->R > 64 || !(h0->D == 6 || h0->D == 8)) return false;
     for (int i = 0; i < n; i++) {
         ngp_handle *h = hs[i];
         if (h->pm != h0->pm || h->device != h0->device || h->dbg_mode != 0 || h->d_dbg || h->dbg_census_fail_iter > 0) return false;
@@ -1372,6 +1372,7 @@ int run_fused(ngp_handle **hs, int n, int64_t niter) {
     }
     if (e == hipSuccess) e = hipEventRecord(h->ev1, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
+    else (void)hipStreamSynchronize(h->stream);
     restore();
     if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("fused run: ") + hipGetErrorString(e));
     if (rc) return rc;

@@ -24,6 +24,7 @@
 // Reference being replaced: the per-SNP loop of /root/reference/src/functions.jl:124-136 and
 // :163-189 (three BLAS-1 passes per SNP over the panel column and its copy).
 #pragma once
+#include <cstddef>
 #include "ngp_sweep_args.h"
 
 #pragma clang fp contract(off)
@@ -180,6 +181,10 @@ __device__ inline void load_rows_pair(const double *blk, int j, double (&out)[NG
 // scalar (SMEM) load that bypasses the scalar cache: lets a wave with LDS-DMA in flight look at a global word
 // without touching vmcnt
 __device__ inline unsigned sld_u32(const unsigned *p) {
+    // (the address is wave-uniform by contract; say so, or a pointer read through a run-time index lands in vector registers)
+    const unsigned long long a = (unsigned long long)p;
+    p = (const unsigned *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a >> 32)) << 32) |
+                           (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a));
     unsigned v;
     asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
     return v;
@@ -965,7 +970,7 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows(const S
 // ------------------------------------------------------------------------------------------
 // reducer g: every wave works on its own blocks (u = wave, wave+8, ...), no workgroup barrier
 template <bool DBG>
-__device__ inline void role_reducer(const SweepArgs &A, const int g, char *smem) {
+__device__ __attribute__((always_inline)) inline void role_reducer(const SweepArgs &A, const int g, char *smem) {
     NGP_DBG_LOCALS
     const int S = A.S, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int s0 = g * NGP_GRP, s1 = min(s0 + NGP_GRP, S), gsize = s1 - s0;
@@ -1052,7 +1057,7 @@ __device__ inline CoefRegs load_coef(const SweepArgs &A, long long k) {
 
 // group sums of local block u -> per-lane total (lane 0 polls, whole wave loads); false on abort
 template <bool DBG>
-__device__ inline bool fetch_group_sums(const SweepArgs &A, int u, int j, double *tot_out) {
+__device__ __attribute__((always_inline)) inline bool fetch_group_sums(const SweepArgs &A, int u, int j, double *tot_out) {
     NGP_DBG_LOCALS
     const int NG = A.NG, slot = u % NGP_RING;
     int ok = 1;
@@ -1074,7 +1079,7 @@ __device__ inline bool fetch_group_sums(const SweepArgs &A, int u, int j, double
 
 // results of a finished block: beta / delta / varBeta (dlt itself left as granules when the chain ended, see role_sampler)
 template <bool DBG>
-__device__ inline void publish_block(const SweepArgs &A, int up, int j, const double *hist, const double *outb, const int *outi,
+__device__ __attribute__((always_inline)) inline void publish_block(const SweepArgs &A, int up, int j, const double *hist, const double *outb, const int *outi,
                                      const int *smeth, const double *ssdf) {
     NGP_DBG_LOCALS
     const int pbuf = up & 1;
@@ -1122,7 +1127,7 @@ __device__ inline void publish_block(const SweepArgs &A, int up, int j, const do
 //   wave 4, 6, 7   lag-2, lag-3 and (near = 4) lag-4 corrections, Gram rows loaded one block ahead into registers
 // LDS: Gd[3][4096] | hist[RING][64] | vacc[RING][64] | r0[4][64] | outb[2][64] | outi[2][64] | flags, per-set constants
 template <bool DBG>
-__device__ inline void role_sampler(const SweepArgs &A, char *smem) {
+__device__ __attribute__((always_inline)) inline void role_sampler(const SweepArgs &A, char *smem) {
     NGP_DBG_LOCALS
     const int D = A.D, tid = threadIdx.x, wv = tid >> 6, j = tid & 63;
     double *Gd = (double *)smem;                // 3 x 4096: diagonal Gram blocks of local blocks u, u+1, u+2
@@ -1497,7 +1502,7 @@ __device__ inline void role_sampler(const SweepArgs &A, char *smem) {
 // count (occupancy query, CU lease), but what the dispatcher does with several grids of one process is not ours to know: each
 // workgroup reports in, the last one opens the gate, and if the gate is still shut after 20 ms the launch ends BEFORE any role
 // has touched the chain (abort code NGP_ABORT_CENSUS) -- the host then runs it again with the device to itself.
-__device__ inline bool sweep_census(const SweepArgs &A, const int b, char *smem) {
+__device__ __attribute__((always_inline)) inline bool sweep_census(const SweepArgs &A, const int b, char *smem) {
     if (!A.census) return true;
     int *cflag = (int *)smem;
     if (threadIdx.x == 0) {
@@ -1612,23 +1617,31 @@ __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 // Streamer: the phase streamer of shards of at most 64 rows (role_streamer, one update task per thread, every wave forming the
 // updated shard itself), with the per-chain state in LDS and every per-chain step looped over the chains.
 // ------------------------------------------------------------------------------------------
-template <int DT>
-__device__ inline void role_streamer_multi(const MultiArgs &M, const int s, char *smem) {
-    const SweepArgs &A = M.a[0];
-    const int K = M.K;
+// KC = chains of the launch, a compile-time constant.  What a chain adds to a block is a handful of short, latency-bound sequences
+// (LDS round trip -> dependent fma chain -> LDS write); looped chain after chain they cost 0.4-0.5 us per chain and block (first
+// version).  Here every phase is written "all loads of all chains, then all arithmetic, then all stores", so the chains' round
+// trips overlap, and the publication of chain c's partial sums is wave c's job (the waves publish side by side).
+// Arithmetic per chain: exactly the one-chain phase streamer's (role_streamer, one update task per thread).
+#ifndef NGP_MULTI_G
+#define NGP_MULTI_G 3  // chains whose loads / arithmetic / stores are interleaved at a time
+#endif
+template <int DT, int KC>
+__device__ __attribute__((always_inline)) inline void role_streamer_multi(const MultiArgs &Mr, const int s, char *smem) {
+    const MultiArgs *Mp = &Mr;     // (the kernel's by-value argument: every index below is a compile-time constant after unrolling)
+    const SweepArgs &A = Mp->a[0];
+    static_assert(KC >= 2 && KC <= 8, "publication: one wave per chain");
     const int R = A.R, S = A.S, tid = threadIdx.x;
-    const int wv = tid >> 6, j = tid & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), j = tid & 63;
     const size_t TBL = (size_t)(R >> 2) * NGP_QS;
     char *ring = smem;  // 2 tile slots
     const size_t CH = ngp_multi_chain_doubles(R);
     double *cbase = (double *)(smem + 2 * TBL);
-    ChainPtrs *cp = (ChainPtrs *)(cbase + (size_t)K * CH);
-    int *sflag = (int *)(cp + NGP_MAXC);
+    int *sflag = (int *)(cbase + (size_t)KC * CH);
     char *scratch = (char *)sflag + 64;  // 3 KiB sink of the L2-warming DMA
-#define NGP_YS(kc) (cbase + (size_t)(kc) * CH)
-#define NGP_RED(kc) (NGP_YS(kc) + 2 * R)
-#define NGP_DL(kc) (NGP_RED(kc) + 512)
-#define NGP_PP(kc) (NGP_DL(kc) + 128)
+#define NGP_YS(kc) (cbase + (size_t)(kc) * CH)   /* 2 x R: the chain's shard of ycorr, by block parity */
+#define NGP_RED(kc) (NGP_YS(kc) + 2 * R)         /* 8 x 64 GEMV chain sums */
+#define NGP_DL(kc) (NGP_RED(kc) + 512)           /* 2 x 64: dlt of the block being applied, by block parity */
+#define NGP_PP(kc) (NGP_DL(kc) + 128)            /* 8 x R: partial sums of the update */
     const size_t tile_elems = (size_t)R * NGP_BLK;
     const int nchunk = R >> 2;
     const int g = s / NGP_GRP;
@@ -1638,20 +1651,30 @@ __device__ inline void role_streamer_multi(const MultiArgs &M, const int s, char
         char *dst = ring + (size_t)(ub & 1) * TBL;
         for (int c = wv - 4; c < nchunk; c += 3) dma16_lds(src + (size_t)c * 1024 + (size_t)j * 16, dst + (size_t)c * NGP_QS);
     };
-    for (int kc = 0; kc < K; kc++) {  // (kc uniform: the launch arguments are read with scalar loads)
-        if (tid == 0) {
-            ChainPtrs c;
-            c.ycorr = M.a[kc].ycorr; c.part = M.a[kc].part; c.dlt = M.a[kc].dlt; c.cnt_part = M.a[kc].cnt_part; c.flag_dlt = M.a[kc].flag_dlt;
-            cp[kc] = c;
-        }
-        const double *yg = M.a[kc].ycorr + (size_t)s * R;
+    // per-chain hand-off words (static indices: registers)
+    const double *dltp[KC];
+    const unsigned *flagp[KC];
+#pragma unroll
+    for (int kc = 0; kc < KC; kc++) { dltp[kc] = Mp->a[kc].dlt; flagp[kc] = Mp->a[kc].flag_dlt; }
+    // wave c < KC publishes chain c
+    const bool pubw = wv < KC;
+    double *my_part = nullptr;
+    unsigned *my_cnt = nullptr;
+#pragma unroll
+    for (int kc = 0; kc < KC; kc++)
+        if (kc == wv) { my_part = Mp->a[kc].part; my_cnt = Mp->a[kc].cnt_part; }
+#pragma unroll
+    for (int kc = 0; kc < KC; kc++) {
+        const double *yg = Mp->a[kc].ycorr + (size_t)s * R;
         for (int i = tid; i < R; i += NGP_WG) NGP_YS(kc)[i] = yg[i];
     }
     if (tid == 0) *sflag = 1;
-    // wave 7: dlt of local block (uu - DT) of every chain into dl[uu & 1]; lanes < K poll their chain's flag
-    auto wait_flags = [&](int target) -> int {  // whole wave; 1 = every chain has finished `target` blocks
+    // wave 7: dlt of local block (uu - DT) of every chain into dl[uu & 1]
+    auto wait_flags = [&](int target) -> int {  // whole wave; lane c < KC waits for chain c; 1 = every chain has finished `target` blocks
         int ok = 1;
-        if (j < K) ok = wait_ge(cp[j].flag_dlt, (unsigned)target, A.abort_w, 1u) ? 1 : 0;
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++)
+            if (j == kc) ok = wait_ge(flagp[kc], (unsigned)target, A.abort_w, 1u) ? 1 : 0;
         return __ballot(ok == 0) == 0ull ? 1 : 0;
     };
     auto poll_dlt = [&](int uu) {
@@ -1660,8 +1683,13 @@ __device__ inline void role_streamer_multi(const MultiArgs &M, const int s, char
         const int ok = wait_flags(aa + 1);
         if (!ok && j == 0) *sflag = 0;
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        if (ok)
-            for (int kc = 0; kc < K; kc++) NGP_DL(kc)[(uu & 1) * 64 + j] = ld_f64(&M.a[kc].dlt[(size_t)(aa % NGP_RING) * NGP_BLK + j]);
+        if (ok) {
+            double v[KC];
+#pragma unroll
+            for (int kc = 0; kc < KC; kc++) v[kc] = ld_f64(&dltp[kc][(size_t)(aa % NGP_RING) * NGP_BLK + j]);
+#pragma unroll
+            for (int kc = 0; kc < KC; kc++) NGP_DL(kc)[(uu & 1) * 64 + j] = v[kc];
+        }
     };
     // the update task of this thread (fixed for the whole sweep): 8-column chain tcc of row ti0; surplus threads redo the last task
     const int tq_ = min(tid, 8 * R - 1);
@@ -1679,12 +1707,12 @@ __device__ inline void role_streamer_multi(const MultiArgs &M, const int s, char
     const size_t slice_bytes = ((gram_bytes / nslice + 1023) / 1024) * 1024;
     bool same_xcd = false;
     constexpr bool LAZY = (DT >= NGP_LAZY_LAG);
-    int sig_pending = -1;  // ring slot of the stored, not yet counted partials (all chains)
+    int sig_pending = -1;  // ring slot of this wave's stored, not yet counted partial
     auto try_signal = [&](bool force) {
-        if (!LAZY || wv != 1 || sig_pending < 0) return;
+        if (!LAZY || !pubw || sig_pending < 0) return;
         if (force) drain_vm();
         else if ((__builtin_amdgcn_s_getreg((23 << 11) | 7) & 0xC0000Fu) != 0u) return;  // VM_CNT [3:0] and [23:22]
-        if (j < K) atomicAdd(&cp[j].cnt_part[((size_t)sig_pending * A.NG + g) * 32], 1u);
+        if (j == 0) atomicAdd(&my_cnt[((size_t)sig_pending * A.NG + g) * 32], 1u);
         sig_pending = -1;
     };
     __syncthreads();
@@ -1705,41 +1733,73 @@ __device__ inline void role_streamer_multi(const MultiArgs &M, const int s, char
                     for (size_t off = lo + (size_t)(wv - 4) * 1024; off + 1024 <= hi; off += 3 * 1024)
                         dma16_lds(gb + off + (size_t)j * 16, scratch + (wv - 4) * 1024);
                 }
-            } else if (wv == 7) {
-                if (DT <= 2 || u == 0) poll_dlt(u);
             }
             try_signal(false);
             wg_barrier();
             if (!*sflag) return;
             // ---------------- phase B: the 8-column partial sums of ycorr -= X_a dlt_a, every chain ----------------
             if (a >= 0) {
-                for (int kc = 0; kc < K; kc++) {
-                    const double *dq = NGP_DL(kc) + (u & 1) * 64 + 8 * tcc;
-                    double p = 0.0;
 #pragma unroll
-                    for (int jj = 0; jj < 8; jj++) p = __builtin_fma((double)keep[d][jj], dq[jj], p);
-                    NGP_PP(kc)[(size_t)tcc * R + ti0] = p;
+                for (int g0 = 0; g0 < KC; g0 += NGP_MULTI_G) {  // groups of chains: their LDS round trips overlap, the register arrays stay small
+                    constexpr int GN = NGP_MULTI_G;
+                    double2 dq2[GN][4];
+                    double p[GN];
+#pragma unroll
+                    for (int q = 0; q < GN; q++)
+                        if (g0 + q < KC) {
+                            const double2 *dq = (const double2 *)(NGP_DL(g0 + q) + (u & 1) * 64 + 8 * tcc);
+#pragma unroll
+                            for (int h = 0; h < 4; h++) dq2[q][h] = dq[h];
+                            p[q] = 0.0;
+                        }
+#pragma unroll
+                    for (int h = 0; h < 4; h++)
+#pragma unroll
+                        for (int q = 0; q < GN; q++)
+                            if (g0 + q < KC) {  // (per chain: the eight fma in column order, as the one-chain streamer)
+                                p[q] = __builtin_fma((double)keep[d][2 * h], dq2[q][h].x, p[q]);
+                                p[q] = __builtin_fma((double)keep[d][2 * h + 1], dq2[q][h].y, p[q]);
+                            }
+#pragma unroll
+                    for (int q = 0; q < GN; q++)
+                        if (g0 + q < KC) NGP_PP(g0 + q)[(size_t)tcc * R + ti0] = p[q];
                 }
                 try_signal(false);
                 wg_barrier();
                 try_signal(false);
             }
             // lane i < R of EVERY wave holds the updated y_i of this iteration, chain by chain; wave 0 stores it for the next one
-            double yn[NGP_MAXC];
+            double yn[KC];
 #pragma unroll
-            for (int kc = 0; kc < NGP_MAXC; kc++) {
-                yn[kc] = 0.0;
-                if (kc < K && j < R) {
-                    double *ys = NGP_YS(kc);
-                    const double *pp = NGP_PP(kc);
-                    double v = ys[(size_t)(u & 1) * R + j];
-                    if (a >= 0) {
-                        const double T = ((pp[j] + pp[R + j]) + (pp[2 * R + j] + pp[3 * R + j])) +
-                                         ((pp[4 * R + j] + pp[5 * R + j]) + (pp[6 * R + j] + pp[7 * R + j]));
-                        v = v - T;
+            for (int g0 = 0; g0 < KC; g0 += NGP_MULTI_G) {
+                constexpr int GN = NGP_MULTI_G;
+                double pv[GN][8];
+#pragma unroll
+                for (int q = 0; q < GN; q++)
+                    if (g0 + q < KC) {
+                        yn[g0 + q] = 0.0;
+                        if (j < R) {
+                            yn[g0 + q] = NGP_YS(g0 + q)[(size_t)(u & 1) * R + j];
+                            if (a >= 0) {
+#pragma unroll
+                                for (int c = 0; c < 8; c++) pv[q][c] = NGP_PP(g0 + q)[(size_t)c * R + j];
+                            }
+                        }
                     }
-                    if (wv == 0) ys[(size_t)((u & 1) ^ 1) * R + j] = v;
-                    yn[kc] = v;
+                if (j < R) {
+                    if (a >= 0) {
+#pragma unroll
+                        for (int q = 0; q < GN; q++)
+                            if (g0 + q < KC) {
+                                const double T = ((pv[q][0] + pv[q][1]) + (pv[q][2] + pv[q][3])) + ((pv[q][4] + pv[q][5]) + (pv[q][6] + pv[q][7]));
+                                yn[g0 + q] = yn[g0 + q] - T;
+                            }
+                    }
+                    if (wv == 0) {
+#pragma unroll
+                        for (int q = 0; q < GN; q++)
+                            if (g0 + q < KC) NGP_YS(g0 + q)[(size_t)((u & 1) ^ 1) * R + j] = yn[g0 + q];
+                    }
                 }
             }
             // ---------------- phase C: partial X_u' ycorr of every chain, and tile u into the delay line ----------------
@@ -1747,36 +1807,48 @@ __device__ inline void role_streamer_multi(const MultiArgs &M, const int s, char
                 const int pa = u + 1 - DT;
                 const bool pollw = (wv == 7) && (DT >= 3) && (pa >= 0) && (u + 1 < nb + DT);
                 unsigned fl = 0xFFFFFFFFu;
-                if (pollw && j < K) fl = ld_u32(cp[j].flag_dlt);
+                if (pollw) {
+#pragma unroll
+                    for (int kc = 0; kc < KC; kc++)
+                        if (j == kc) fl = ld_u32(flagp[kc]);
+                }
                 const float *slotp = (const float *)(ring + (size_t)(u & 1) * TBL);
                 {
                     const float *tq = slotp + (size_t)(ti0 >> 2) * (NGP_QS / 4) + 32 * tcc + (ti0 & 3);
 #pragma unroll
                     for (int jj = 0; jj < 8; jj++) keep[d][jj] = tq[4 * jj];
                 }
-                {   // chain wv: row quads wv, wv+8, ... (lane = column); one read of the tile serves all K chains
+                {   // chain wv: row quads wv, wv+8, ... (lane = column); one read of the tile serves all chains
                     const float *col = slotp + 4 * j;
-                    double acc[NGP_MAXC];
+                    double acc[KC];
 #pragma unroll
-                    for (int kc = 0; kc < NGP_MAXC; kc++) acc[kc] = 0.0;
-                    for (int qd = __builtin_amdgcn_readfirstlane(wv); qd < (R >> 2); qd += 8) {
+                    for (int kc = 0; kc < KC; kc++) acc[kc] = 0.0;
+                    for (int qd = wv; qd < (R >> 2); qd += 8) {
                         const float4 x = *(const float4 *)(col + (size_t)qd * (NGP_QS / 4));
 #pragma unroll
-                        for (int kc = 0; kc < NGP_MAXC; kc++)
-                            if (kc < K) {
-                                const double y0 = readlane_d(yn[kc], 4 * qd), y1 = readlane_d(yn[kc], 4 * qd + 1);
-                                const double y2 = readlane_d(yn[kc], 4 * qd + 2), y3 = readlane_d(yn[kc], 4 * qd + 3);
-                                acc[kc] = __builtin_fma((double)x.x, y0, acc[kc]);
-                                acc[kc] = __builtin_fma((double)x.y, y1, acc[kc]);
-                                acc[kc] = __builtin_fma((double)x.z, y2, acc[kc]);
-                                acc[kc] = __builtin_fma((double)x.w, y3, acc[kc]);
-                            }
+                        for (int g0 = 0; g0 < KC; g0 += NGP_MULTI_G) {
+                            constexpr int GN = NGP_MULTI_G;
+                            double y[GN][4];
+#pragma unroll
+                            for (int q = 0; q < GN; q++)
+                                if (g0 + q < KC) {
+#pragma unroll
+                                    for (int e = 0; e < 4; e++) y[q][e] = readlane_d(yn[g0 + q], 4 * qd + e);
+                                }
+#pragma unroll
+                            for (int q = 0; q < GN; q++) if (g0 + q < KC) acc[g0 + q] = __builtin_fma((double)x.x, y[q][0], acc[g0 + q]);
+#pragma unroll
+                            for (int q = 0; q < GN; q++) if (g0 + q < KC) acc[g0 + q] = __builtin_fma((double)x.y, y[q][1], acc[g0 + q]);
+#pragma unroll
+                            for (int q = 0; q < GN; q++) if (g0 + q < KC) acc[g0 + q] = __builtin_fma((double)x.z, y[q][2], acc[g0 + q]);
+#pragma unroll
+                            for (int q = 0; q < GN; q++) if (g0 + q < KC) acc[g0 + q] = __builtin_fma((double)x.w, y[q][3], acc[g0 + q]);
+                        }
                     }
 #pragma unroll
-                    for (int kc = 0; kc < NGP_MAXC; kc++)
-                        if (kc < K) NGP_RED(kc)[wv * 64 + j] = acc[kc];
+                    for (int kc = 0; kc < KC; kc++) NGP_RED(kc)[wv * 64 + j] = acc[kc];
                 }
-                double dnext[NGP_MAXC];
+                double dnext[KC];
                 bool have_dnext = false;
                 if (pollw) {
                     int ok = 1;
@@ -1787,8 +1859,7 @@ __device__ inline void role_streamer_multi(const MultiArgs &M, const int s, char
                     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
                     if (ok) {
 #pragma unroll
-                        for (int kc = 0; kc < NGP_MAXC; kc++)
-                            if (kc < K) dnext[kc] = ld_f64(&M.a[kc].dlt[(size_t)(pa % NGP_RING) * NGP_BLK + j]);
+                        for (int kc = 0; kc < KC; kc++) dnext[kc] = ld_f64(&dltp[kc][(size_t)(pa % NGP_RING) * NGP_BLK + j]);
                         have_dnext = true;
                     }
                 }
@@ -1796,22 +1867,19 @@ __device__ inline void role_streamer_multi(const MultiArgs &M, const int s, char
                 wg_barrier();
                 if (have_dnext) {
 #pragma unroll
-                    for (int kc = 0; kc < NGP_MAXC; kc++)
-                        if (kc < K) NGP_DL(kc)[((u + 1) & 1) * 64 + j] = dnext[kc];
+                    for (int kc = 0; kc < KC; kc++) NGP_DL(kc)[((u + 1) & 1) * 64 + j] = dnext[kc];
                 }
-                if (wv == 1) {
+                if (pubw) {  // wave c publishes chain c (the waves side by side)
                     const int slot = u % NGP_RING;
-                    try_signal(true);  // the previous partials, if their stores were still under way at every boundary
-                    for (int kc = 0; kc < K; kc++) {
-                        const double *red = NGP_RED(kc);
-                        const double p = ((red[j] + red[64 + j]) + (red[128 + j] + red[192 + j])) + ((red[256 + j] + red[320 + j]) + (red[384 + j] + red[448 + j]));
-                        st_f64(&M.a[kc].part[((size_t)slot * S + s) * NGP_BLK + j], p);
-                    }
+                    const double *red = NGP_RED(wv);
+                    const double p = ((red[j] + red[64 + j]) + (red[128 + j] + red[192 + j])) + ((red[256 + j] + red[320 + j]) + (red[384 + j] + red[448 + j]));
+                    try_signal(true);  // the previous partial, if its store was still under way at every boundary
+                    st_f64(&my_part[((size_t)slot * S + s) * NGP_BLK + j], p);
                     if (LAZY) {
                         sig_pending = slot;
                     } else {
                         drain_vm();
-                        if (j < K) atomicAdd(&cp[j].cnt_part[((size_t)slot * A.NG + g) * 32], 1u);
+                        if (j == 0) atomicAdd(&my_cnt[((size_t)slot * A.NG + g) * 32], 1u);
                     }
                 }
             } else if (wv == 7 && DT >= 3) poll_dlt(u + 1);
@@ -1819,9 +1887,10 @@ __device__ inline void role_streamer_multi(const MultiArgs &M, const int s, char
     }
     try_signal(true);
     __syncthreads();
-    for (int kc = 0; kc < K; kc++) {
+#pragma unroll
+    for (int kc = 0; kc < KC; kc++) {
         const double *yfin = NGP_YS(kc) + (size_t)((nb + DT) & 1) * R;
-        double *yg = M.a[kc].ycorr + (size_t)s * R;
+        double *yg = Mp->a[kc].ycorr + (size_t)s * R;
         for (int i = tid; i < R; i += NGP_WG) yg[i] = yfin[i];
     }
 #undef NGP_YS
@@ -1831,26 +1900,45 @@ __device__ inline void role_streamer_multi(const MultiArgs &M, const int s, char
 }
 
 #if !defined(NGP_INST_DBG) || !NGP_INST_DBG  // one definition: the production translation unit (ngp_sweep_inst.hip, -DNGP_INST_DBG=0)
+// A chain's launch arguments by RUN-TIME chain index: indexing the by-value argument M.a[c] makes the compiler copy all of M to
+// scratch (3 KB per lane) and read every field from there.  The arguments already sit in the kernarg segment -- constant address
+// space, read with scalar loads -- so the entry is addressed there directly (M is the kernel's first argument: offset 0).
+__device__ __attribute__((always_inline)) inline const SweepArgs &multi_chain_args(const int c) {
+    typedef const __attribute__((address_space(4))) char *kptr;
+    kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
+    return *(const SweepArgs *)(ka + offsetof(MultiArgs, a) + (size_t)c * sizeof(SweepArgs));
+}
 __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sweep_multi(MultiArgs M) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     const int b = blockIdx.x, K = M.K, NG = M.a[0].NG;
     if (ld_u32(M.a[0].abort_w) != 0u) return;
     if (!sweep_census(M.a[0], b, smem)) return;
-    if ((b & 7) == 0 && (b >> 3) < K) {
-        role_sampler<false>(M.a[b >> 3], smem);
+#ifndef NGP_MULTI_STRIDE
+#define NGP_MULTI_STRIDE 8  // samplers at blocks 0, 8, 16, ...: one XCD under round-robin placement
+#endif
+    if ((b % NGP_MULTI_STRIDE) == 0 && (b / NGP_MULTI_STRIDE) < K) {
+        role_sampler<false>(multi_chain_args(__builtin_amdgcn_readfirstlane(b / NGP_MULTI_STRIDE)), smem);
         return;
     }
-    const int idx = b - min(K, (b + 7) >> 3);  // rank among the blocks that are not samplers
+    const int idx = b - min(K, (b + NGP_MULTI_STRIDE - 1) / NGP_MULTI_STRIDE);  // rank among the blocks that are not samplers
     if (idx < K * NG) {
-        role_reducer<false>(M.a[idx / NG], idx % NG, smem);
+        role_reducer<false>(multi_chain_args(__builtin_amdgcn_readfirstlane(idx / NG)), idx % NG, smem);
         return;
     }
     const int s = idx - K * NG;
-    switch (M.a[0].D) {  // host: lags 4, 6, 8 (shards of at most 64 rows, fp32 tiles)
-        case 4: role_streamer_multi<4>(M, s, smem); break;
-        case 6: role_streamer_multi<6>(M, s, smem); break;
-        default: role_streamer_multi<8>(M, s, smem); break;
+    // host: lag 6 or 8 (shards of at most 64 rows, fp32 tiles), 2..8 chains
+#define NGP_MULTI_K(DTV)                                              \
+    switch (K) {                                                      \
+        case 2: role_streamer_multi<DTV, 2>(M, s, smem); break;       \
+        case 3: role_streamer_multi<DTV, 3>(M, s, smem); break;       \
+        case 4: role_streamer_multi<DTV, 4>(M, s, smem); break;       \
+        case 5: role_streamer_multi<DTV, 5>(M, s, smem); break;       \
+        case 6: role_streamer_multi<DTV, 6>(M, s, smem); break;       \
+        case 7: role_streamer_multi<DTV, 7>(M, s, smem); break;       \
+        default: role_streamer_multi<DTV, 8>(M, s, smem); break;      \
     }
+    if (M.a[0].D == 6) { NGP_MULTI_K(6) } else { NGP_MULTI_K(8) }
+#undef NGP_MULTI_K
 }
 #endif
 

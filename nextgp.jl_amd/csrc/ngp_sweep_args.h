@@ -92,7 +92,9 @@ __host__ __device__ inline int ngp_u8_tasks(int R) {
 #define NGP_U8_MAX_R 896  // 7 waves x 8 units x 16 rows
 
 // ---- K chains per pass over the panel (k_sweep_multi, ngp_sweep.h) ----
+#ifndef NGP_MAXC
 #define NGP_MAXC 8  // chains per pass (per-chain registers of the streamer: 2 VGPRs each of shard, GEMV sum, dlt)
+#endif
 struct MultiArgs {
     int K, pad_;
     SweepArgs a[NGP_MAXC];  // same tiles / gramx / layout in every entry; a[c].abort_w, census of chain 0 are the launch's
@@ -103,10 +105,10 @@ struct ChainPtrs {  // what a streamer needs of one chain (LDS copy: lanes index
     unsigned *cnt_part;
     const unsigned *flag_dlt;
 };
-// doubles of per-chain LDS state of a multi-chain streamer: shard 2 x R (parity) | 8 x 64 chain partials | 2 x 64 dlt | 8 x R update partials
+// doubles of per-chain LDS state of a multi-chain streamer: shard 2 x R (parity) | 8 x 64 chain sums | 2 x 64 dlt | 8 x R update partials
 __host__ __device__ inline size_t ngp_multi_chain_doubles(int R) { return (size_t)2 * R + 512 + 128 + (size_t)8 * R; }
 __host__ __device__ inline size_t ngp_multi_lds_bytes(int R, int K) {
-    return (size_t)2 * (R >> 2) * NGP_QS + (size_t)K * ngp_multi_chain_doubles(R) * 8 + (size_t)NGP_MAXC * sizeof(ChainPtrs) + 64 + 3072;
+    return (size_t)2 * (R >> 2) * NGP_QS + (size_t)K * ngp_multi_chain_doubles(R) * 8 + 64 + 3072;
 }
 
 hipError_t sweep_multi_set_max_lds(int bytes);

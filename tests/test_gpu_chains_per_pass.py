@@ -27,7 +27,7 @@ def build_chains(ngp, X, y, v, spec, K, lag=None, shards=None, seeds=None):
     return chains
 
 
-@pytest.mark.parametrize("K,lag", [(2, None), (3, 6), (4, 4), (6, None), (8, None)])
+@pytest.mark.parametrize("K,lag", [(2, None), (3, 6), (4, 6), (5, None), (6, None), (7, 6), (8, None)])
 def test_fused_chains_equal_the_chains_alone_and_the_oracle(ngp, O, K, lag):
     N, P = 500, 640
     X, y, bt, v = make_problem(O, N, P, seed=6)
