@@ -110,7 +110,7 @@ int32_t ngp_add_marker_set(ngp_handle *h, int64_t col0, int64_t ncol, int32_t me
                            const int64_t *reg_start, const int64_t *reg_stop, int64_t nreg, const double *varBeta0,
                            double pi0, int32_t estPi, const double *lhs0, const double *rhs0, int32_t *set_id);
 
-/* BayesR marker set (set-up src/mme.jl:374-383): ONE variance for the set (varBeta0, nVarCov = 1), K = 2..4 variance classes with
+/* BayesR marker set (set-up src/mme.jl:374-383): ONE variance for the set (varBeta0, nVarCov = 1), K = 2..8 variance classes with
  * multipliers vClass[v] of that variance (multiplier 0: the effect is exactly 0) and class probabilities pi[v] (sum 1);
  * estPi: pi ~ Dirichlet(nLoci + 1) after every sweep (src/functions.jl:284-288).  delta then holds the CLASS of a locus,
  * counted from 1 as the reference writes it (src/functions.jl:262).  The reference's class search compares cumulative
@@ -220,7 +220,8 @@ int32_t ngp_get_streamer(ngp_handle *h, int32_t *variant, int32_t *gemv_chains);
  * are multiples of 16 rows (up to 896 rows, N up to ~196k on one MI355X); look-ahead lags 3, 4, 6, 8, 12 (4 or 8 for shards
  * taller than 224 rows, 4 above 448 rows; a request is rounded down to the next of these); ngp_get_streamer reports variant 3, 7 GEMV chains.  Input: ngp_set_panel_u8,
  * ngp_load_panel_file, ngp_generate_panel (ngp_set_panel_f64 / _f32 are refused: they carry centred values, not codes).
- * ngp_get_storage: the storage in force and, optionally (compact storage), the P column means. */
+ * ngp_get_storage: the storage in force and, optionally, the P column means the library subtracted (src/prepMatVec.jl:129; zeros where
+ * the caller passed centre = 0): with them a host can rebuild any centred row of the panel from the genotype codes. */
 /* ngp_set_max_shards: the persistent sweep normally splits the rows over every CU but the sampler's and the reducers' (one
  * streamer workgroup per CU, all co-resident).  A smaller number makes the shards taller and leaves CUs free -- for a second
  * chain on the same device (each chain's whole grid must be resident at once), or to exercise tall-shard layouts on small
@@ -284,6 +285,13 @@ int32_t ngp_allreduce_posterior(ngp_handle **hs, int32_t n);
  * turns otherwise.  Every chain is bit for bit what it is alone.  Returns the first non-zero status (message on that handle). */
 int32_t ngp_run_many(ngp_handle **hs, int32_t n, int64_t niter);
 
+/* Kept samples to a binary file without stopping the chain -- the role of the reference's per-iteration text rows (src/samplers.jl:56-104,
+ * src/outFiles.jl:17-21).  From the next ngp_run on, every kept iteration leaves one record (packed on the device, copied on a second
+ * stream, written by a thread of the library); ngp_run returns when its last record is in the file.  NULL closes the file.  Layout:
+ * "NGPSMP01" | int64 P, nvb, nsets, nfix, nclass, record bytes | per set int64 {method, K, col0, ncol, variance entries, tuple k} |
+ * records: int64 iteration | varE | b | b_fixed[nfix] | beta[P] | varBeta[nvb] | piHat[2 nsets] | class probabilities[nclass] |
+ * delta[P] (bytes, padded to 8). */
+int32_t ngp_set_sample_file(ngp_handle *h, const char *path);
 /* Placement census of the last persistent-sweep launch: out[b] = (XCC id + 1) << 32 | HW_REG_HW_ID of workgroup b (0: never resident),
  * n >= *grid entries.  Every launch of the persistent kernel opens with a census of its own grid (all of its workgroups wait for
  * each other, so all must be resident at once); a launch whose grid is not complete within 20 ms ends before any role has touched

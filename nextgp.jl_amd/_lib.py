@@ -15,6 +15,30 @@ LIB_PATH = os.environ.get("NGP_HIP_LIB") or os.path.join(_HERE, "libnextgp_hip.s
 METHOD_BAYESPR, METHOD_BAYESB, METHOD_BAYESC, METHOD_BAYESR, METHOD_TUPLE = 0, 1, 2, 3, 4
 
 
+def read_sample_file(path):
+    """Binary sample file of ngp_set_sample_file -> dict(iter[n], varE[n], b[n], b_fixed[n, nfix], beta[n, P], varBeta[n, nvb], piHat[n, 2 nsets],
+    class_pi[n, nclass], delta[n, P] (uint8), sets=[dict(method, K, col0, ncol, nvb, tk)])."""
+    with open(path, "rb") as f:
+        if f.read(8) != b"NGPSMP01":
+            raise NextGPHipError(f"not a sample file: {path}")
+        P, nvb, nsets, nfix, ncls, rec = np.frombuffer(f.read(48), dtype=np.int64)
+        sets = [dict(zip(("method", "K", "col0", "ncol", "nvb", "tk"), np.frombuffer(f.read(48), dtype=np.int64).tolist())) for _ in range(nsets)]
+        raw = np.frombuffer(f.read(), dtype=np.uint8)
+    n = len(raw) // rec
+    raw = raw[:n * rec].reshape(n, rec)
+    nd = 3 + nfix + P + nvb + 2 * nsets + ncls
+    d = raw[:, :nd * 8].copy().view(np.float64)
+    o = 3
+    out = dict(iter=raw[:, :8].copy().view(np.int64)[:, 0], varE=d[:, 1], b=d[:, 2], sets=sets)
+    out["b_fixed"] = d[:, o:o + nfix]; o += nfix
+    out["beta"] = d[:, o:o + P]; o += P
+    out["varBeta"] = d[:, o:o + nvb]; o += nvb
+    out["piHat"] = d[:, o:o + 2 * nsets]; o += 2 * nsets
+    out["class_pi"] = d[:, o:o + ncls]
+    out["delta"] = raw[:, nd * 8:nd * 8 + P]
+    return out
+
+
 def tuple_columns(col0, nloc, k):
     """Panel columns of a Tuple (correlated BayesPR) set: array [nloc, k], component m of locus l at col0 + 64 (l // Lb) + k (l % Lb) + m
     with Lb = 64 // k loci per 64-column block (include/nextgp_hip.h, ngp_add_marker_set_tuple)."""
@@ -50,7 +74,7 @@ SYMBOLS = [
     "ngp_get_trace", "ngp_get_posterior_sums", "ngp_posterior_len", "ngp_export_posterior_device", "ngp_sweep_set",
     "ngp_get_timing", "ngp_profile_iteration", "ngp_draws_indexed", "ngp_eval_math", "ngp_configure", "ngp_get_config", "ngp_debug_stamps", "ngp_set_near_lags", "ngp_get_near_lags",
     "ngp_set_streamer", "ngp_get_streamer", "ngp_set_storage", "ngp_get_storage", "ngp_set_max_shards", "ngp_shards_for_chains", "ngp_run_many", "ngp_write_panel_file", "ngp_read_panel_header", "ngp_load_panel_file", "ngp_debug_set_mode", "ngp_debug_set_knob", "ngp_set_posterior_sums", "ngp_save_snapshot", "ngp_load_snapshot",
-    "ngp_set_trace_loci", "ngp_get_trace_ext", "ngp_allreduce_posterior", "ngp_add_marker_set_r", "ngp_get_class_state", "ngp_set_class_state", "ngp_add_fixed_set", "ngp_get_fixed", "ngp_set_fixed", "ngp_debug_throw", "ngp_get_census", "ngp_debug_set_virtual_device", "ngp_debug_fail_census", "ngp_add_marker_set_tuple", "ngp_share_panel", "ngp_shards_for_pass",
+    "ngp_set_trace_loci", "ngp_get_trace_ext", "ngp_allreduce_posterior", "ngp_add_marker_set_r", "ngp_get_class_state", "ngp_set_class_state", "ngp_add_fixed_set", "ngp_get_fixed", "ngp_set_fixed", "ngp_debug_throw", "ngp_get_census", "ngp_debug_set_virtual_device", "ngp_debug_fail_census", "ngp_add_marker_set_tuple", "ngp_share_panel", "ngp_shards_for_pass", "ngp_set_sample_file",
 ]
 
 _lib = None
@@ -411,6 +435,10 @@ class Sampler:
         self._chk(self.L.ngp_set_posterior_sums(self.h, _p(a["sum_beta"], C.c_double), _p(a["sum_beta2"], C.c_double),
                                                 _p(a["sum_delta"], C.c_double), _p(a["sum_varBeta"], C.c_double), _p(a["sum_pi"], C.c_double),
                                                 C.c_double(ps["sum_varE"]), C.c_double(ps["sum_b"]), C.c_int64(ps["nKept"])))
+
+    def set_sample_file(self, path):
+        """Every kept iteration of the following runs leaves a binary record in `path` without stopping the chain; None closes the file."""
+        self._chk(self.L.ngp_set_sample_file(self.h, None if path is None else os.fsencode(path)))
 
     def save_snapshot(self, path):
         self._chk(self.L.ngp_save_snapshot(self.h, os.fsencode(path)))

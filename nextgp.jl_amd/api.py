@@ -24,7 +24,7 @@ import numpy as np
 
 from ._lib import METHOD_BAYESB, METHOD_BAYESC, METHOD_BAYESPR, Sampler
 
-__all__ = ["BayesPR", "BayesB", "BayesC", "BayesR", "Random", "SNP", "runLMEM", "summaryMCMC", "read_genotypes", "read_panel_file", "is_panel_file", "prep2RegionData", "parse_formula", "design_columns"]
+__all__ = ["BayesPR", "BayesB", "BayesC", "BayesR", "Random", "SNP", "runLMEM", "summaryMCMC", "read_genotypes", "read_panel_file", "is_panel_file", "prep2RegionData", "parse_formula", "design_columns", "samples_to_out_files"]
 
 
 # ----------------------------------------------------------------------------------------------
@@ -303,6 +303,40 @@ def summaryMCMC(param, outFolder=None):
     return np.loadtxt(os.path.join(outFolder, f"{param}Out"), delimiter="\t", skiprows=1, ndmin=2).mean(axis=0, keepdims=True)
 
 
+def samples_to_out_files(sample_path, outFolder, sets, intercept, has_fixed):
+    """Binary sample stream (ngp_set_sample_file) -> the rows of the reference's *Out text files (src/samplers.jl:56-104), appended
+    behind the header rows: the same text, number for number, as writing them at every kept iteration."""
+    from ._lib import read_sample_file
+    S = read_sample_file(sample_path)
+    files = {}
+
+    def rows(name, lines):
+        files.setdefault(name, []).extend(lines)
+
+    n = len(S["iter"])
+    for i in range(n):
+        rows("b", ["\t".join((_fmt(S["b"][i]) if intercept else []) + (_fmt(S["b_fixed"][i]) if has_fixed else []))])
+        rows("varE", ["\t".join(_fmt(S["varE"][i]))])
+    vb_off, cls_off = 0, 0
+    for k, s in enumerate(sets):
+        sl = slice(s["col0"], s["col0"] + s["P"])
+        K = len(s["prior"].pi) if isinstance(s["prior"], BayesRType) else 0
+        for i in range(n):
+            rows(f"beta{s['name']}", ["\t".join(_fmt(S["beta"][i, sl]))])
+            rows(f"delta{s['name']}", ["\t".join(str(int(v)) for v in S["delta"][i, sl])])
+            if isinstance(s["prior"], (BayesBType, BayesCType)):
+                rows(f"pi{s['name']}", ["\t".join(_fmt(S["piHat"][i, 2 * k:2 * k + 2]))])
+            if K:
+                rows(f"pi{s['name']}", ["\t".join(_fmt(S["class_pi"][i, cls_off:cls_off + K]))])
+            rows(f"var{s['name']}", ["\t".join(_fmt(S["varBeta"][i, vb_off:vb_off + s["nreg"]]))])
+        vb_off += s["nreg"]
+        cls_off += K
+    for name, lines in files.items():
+        with open(os.path.join(outFolder, f"{name}Out"), "a") as f:
+            f.write("\n".join(lines) + ("\n" if lines else ""))
+    return n
+
+
 # ----------------------------------------------------------------------------------------------
 # runLMEM (src/MCMC.jl:31-41)
 # ----------------------------------------------------------------------------------------------
@@ -417,7 +451,7 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
     smp.set_y(y)
     smp.set_schedule(nChain, nBurn, nThin)
     # header rows (src/mme.jl:543-595)
-    if samples == "text":
+    if samples in ("text", "text-sync"):
         _out(outFolder, "b", fixed_names)
         _out(outFolder, "varE", ["e"])
         for s in sets:
@@ -431,7 +465,12 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
             _out(outFolder, f"var{s['name']}", [f"reg_{r + 1}" for r in range(s["nreg"])])
     # the chain (src/samplers.jl:29-105): kept iterations = burnIn+thin : thin : chainLength
     done = 0
-    if samples == "text":
+    if samples not in ("text", "text-sync", "binary", "none"):
+        raise ValueError('samples: "text", "text-sync", "binary" or "none"')
+    smp_path = os.path.join(outFolder, "samples.ngpsmp")
+    if samples in ("text", "binary"):
+        smp.set_sample_file(smp_path)       # kept samples stream out while the chain runs: ONE ngp_run for the whole chain
+    if samples == "text-sync":
         for it in range(nBurn + nThin, nChain + 1, nThin):
             smp.run(it - done)
             done = it
@@ -450,6 +489,11 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
                 _out(outFolder, f"var{s['name']}", _fmt(st["varBeta"][vb_off:vb_off + s["nreg"]]))
                 vb_off += s["nreg"]
     smp.run(nChain - done)
+    if samples in ("text", "binary"):
+        smp.set_sample_file(None)
+    if samples == "text":
+        samples_to_out_files(smp_path, outFolder, sets, intercept, len(fixed_names) > int(intercept))
+        os.remove(smp_path)
     ps = smp.get_posterior_sums()
     n = max(ps["nKept"], 1)
     res = dict(nKept=ps["nKept"], b=ps["sum_b"] / n, varE=ps["sum_varE"] / n, sets={}, fixed_names=fixed_names,

@@ -13,6 +13,7 @@
 #include <cstdlib>
 #include <condition_variable>
 #include <cstring>
+#include <deque>
 #include <mutex>
 #include <string>
 #include <thread>
@@ -34,6 +35,28 @@ struct HFix {  // one fixed-effect set beyond the intercept
 struct PanelMem {  // d_tiles / d_mean / d_gramx / d_mpm of one uploaded panel; handles that share it hold a reference each
     void *tiles = nullptr, *mean = nullptr, *gramx = nullptr, *mpm = nullptr;
     std::atomic<int> refs{1};
+};
+
+// Kept samples streamed to a binary file while the chain runs (ngp_set_sample_file): a ring of NSLOT records on the device, copied to
+// pinned host memory on a second stream, written by a thread of its own.  The chain's stream never waits for the file -- only for a
+// ring slot, when the writer is NSLOT samples behind.
+struct SampleStream {
+    static constexpr int NSLOT = 4;
+    FILE *f = nullptr;
+    std::string path;
+    size_t rec_bytes = 0;
+    bool header_written = false;
+    int device = 0;
+    unsigned char *d_slot[NSLOT] = {nullptr, nullptr, nullptr, nullptr}, *h_slot[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_packed[NSLOT] = {nullptr, nullptr, nullptr, nullptr}, ev_copied[NSLOT] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t copy_stream = nullptr;
+    std::thread writer;
+    std::mutex mu;
+    std::condition_variable cv;
+    std::deque<int> queue;          // slots whose copy has been enqueued, in order
+    bool busy[NSLOT] = {false, false, false, false};
+    bool stop = false, io_error = false;
+    int64_t nenq = 0, nwritten = 0, ndropped = 0;
 };
 
 struct HSet {
@@ -148,6 +171,7 @@ struct ngp_handle {
     int64_t last_grid = 0;       // workgroups of the last sweep launch this handle led (fused launches: K (1 + NG) + S)
     int64_t census_retries = 0;  // launches that ended at the census and were run again with the device to themselves
     int64_t dbg_census_fail_iter = 0;  // ngp_debug_fail_census: the sweep of this iteration ends at its census (once)
+    SampleStream *smp = nullptr;        // ngp_set_sample_file
     struct PanelMem *pm = nullptr;      // the panel's device arrays (tiles, Gram window, x'x, means), shared by reference count: ngp_share_panel
     int vdev = -1;           // ngp_debug_set_virtual_device: the device ngp_allreduce_posterior groups this handle under (-1: the real one)
     unsigned long long *d_census_tbl = nullptr;  // placement of the workgroups of the last sweep launch (inside d_ccnt)
@@ -363,10 +387,11 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P, ngp_handle *owner = nullptr
         h->d_tiles = owner->d_tiles; h->d_mean = owner->d_mean; h->d_gramx = owner->d_gramx; h->d_mpm = owner->d_mpm;
         h->pm = owner->pm; h->pm->refs.fetch_add(1);
     } else {
+    // column means: what the analytic centring of the compact storage uses; kept for the fp32 tiles too (ngp_get_storage: a host
+    // can then rebuild any centred row of the panel from the genotype codes)
+    if ((rc = dalloc(h, &h->d_mean, (size_t)h->Ppad))) return rc;
     if (h->storage == 1) {  // one byte per element (R is a multiple of 16), held behind the same pointer
         if ((rc = dalloc(h, &h->d_tiles, (size_t)h->NBLK * h->S * tile_elems / 4))) return rc;
-        if ((rc = dalloc(h, &h->d_mean, (size_t)h->Ppad))) return rc;
-        HCHK(hipMemsetAsync(h->d_mean, 0, (size_t)h->Ppad * sizeof(double), h->stream));
     } else if ((rc = dalloc(h, &h->d_tiles, (size_t)h->NBLK * h->S * tile_elems))) return rc;
     if ((rc = dalloc(h, &h->d_gramx, (size_t)h->NBLK * h->D * NGP_BLK * NGP_BLK))) return rc;
     if ((rc = dalloc(h, &h->d_mpm, pp))) return rc;
@@ -510,6 +535,7 @@ int set_panel_host(ngp_handle *h, const TIn *M, int64_t N, int64_t P, int64_t ld
     const int64_t R = h->R, S = h->S;
     const size_t blk_elems = (size_t)S * R * NGP_BLK;
     std::vector<float> buf(blk_elems);
+    std::vector<double> means((size_t)h->Ppad, 0.0);
     for (int64_t t = 0; t < h->NBLK; t++) {
         std::fill(buf.begin(), buf.end(), 0.0f);
         for (int jj = 0; jj < NGP_BLK; jj++) {
@@ -521,6 +547,7 @@ int set_panel_host(ngp_handle *h, const TIn *M, int64_t N, int64_t P, int64_t ld
                 double sum = 0.0;
                 for (int64_t i = 0; i < N; i++) sum += (double)col[i];
                 mu = sum / (double)N;
+                means[(size_t)j] = mu;
             }
             for (int64_t i = 0; i < N; i++) {
                 double v = (double)col[i];
@@ -531,6 +558,7 @@ int set_panel_host(ngp_handle *h, const TIn *M, int64_t N, int64_t P, int64_t ld
         }
         HCHK(hipMemcpy(h->d_tiles + (size_t)t * blk_elems, buf.data(), blk_elems * sizeof(float), hipMemcpyHostToDevice));
     }
+    HCHK(hipMemcpy(h->d_mean, means.data(), means.size() * sizeof(double), hipMemcpyHostToDevice));
     return build_gram(h);
 }
 
@@ -705,6 +733,8 @@ void launch_variance(ngp_handle *h, int active_set, uint64_t it) {
 
 // resume_mid: the head of this iteration (varE, intercept, fixed-effect sets) has run already -- its sweep ended at the census
 // with nothing changed and is launched again, k_prep first (it redraws the same keyed numbers and clears the hand-off counters)
+int sample_enqueue(ngp_handle *h);  // (below)
+
 void iteration_pre(ngp_handle *h, int64_t trace_idx, bool resume_mid) {  // everything in front of the sweep
     const uint64_t it = (uint64_t)(h->iter + 1);
     if (!resume_mid) {
@@ -721,7 +751,7 @@ void iteration_pre(ngp_handle *h, int64_t trace_idx, bool resume_mid) {  // ever
                        h->d_ccnt, (long long)(h->mode == 1 ? h->ccnt_words : 0), h->d_abort, h->d_tup, h->d_tupc, h->d_tupg);
 }
 
-void iteration_post(ngp_handle *h, int64_t trace_idx) {  // variance / pi draws, traces and posterior sums; advances h->iter
+int iteration_post(ngp_handle *h, int64_t trace_idx) {  // variance / pi draws, traces and posterior sums; advances h->iter
     const uint64_t it = (uint64_t)(h->iter + 1);
     launch_variance(h, -1, it);
     h->iter += 1;
@@ -739,7 +769,9 @@ void iteration_post(ngp_handle *h, int64_t trace_idx) {  // variance / pi draws,
         if (h->nfixcol > 0)
             hipLaunchKernelGGL(k_accum_fixed, dim3((unsigned)((h->nfixcol + 255) / 256)), dim3(256), 0, h->stream, (long long)h->nfixcol, h->d_bfix,
                                h->d_sum_bfix, h->d_abort);
+        if (h->smp) return sample_enqueue(h);  // the kept sample goes to the file without stopping the chain (src/samplers.jl:56-104)
     }
+    return NGP_OK;
 }
 
 // resume_mid: the head of this iteration (varE, intercept, fixed-effect sets) has run already -- its sweep ended at the census
@@ -747,8 +779,7 @@ void iteration_post(ngp_handle *h, int64_t trace_idx) {  // variance / pi draws,
 int one_iteration(ngp_handle *h, int64_t trace_idx, hipEvent_t *evs, bool resume_mid = false) {
     iteration_pre(h, trace_idx, resume_mid);
     launch_sweep(h, 0, h->NBLK, evs);
-    iteration_post(h, trace_idx);
-    return NGP_OK;
+    return iteration_post(h, trace_idx);
 }
 
 // niter iterations from the handle's current state under `lease`, the launch queue bounded to 16 iterations; a launch that ends at
@@ -801,6 +832,100 @@ int64_t posterior_words(const ngp_handle *h) {
     return 3 * h->P + h->nvb + 2 * (int64_t)h->sets.size() + h->nclass_total + h->nfixcol + 3;
 }
 
+// ---- sample stream (ngp_set_sample_file) ----
+size_t sample_rec_bytes(const ngp_handle *h) {
+    const size_t nd = 3 + (size_t)h->nfixcol + (size_t)h->P + (size_t)h->nvb + 2 * h->sets.size() + (size_t)h->nclass_total;
+    return nd * 8 + (((size_t)h->P + 7) & ~(size_t)7);
+}
+void sample_writer_loop(SampleStream *S) {
+    (void)hipSetDevice(S->device);
+    for (;;) {
+        int slot;
+        {
+            std::unique_lock<std::mutex> lk(S->mu);
+            S->cv.wait(lk, [&] { return S->stop || !S->queue.empty(); });
+            if (S->queue.empty()) return;  // stop, and nothing left
+            slot = S->queue.front();
+        }
+        const bool ok = hipEventSynchronize(S->ev_copied[slot]) == hipSuccess;
+        const long long it = *(const long long *)S->h_slot[slot];
+        bool wrote = false, bad = !ok;
+        if (ok && it >= 0) { wrote = true; bad = std::fwrite(S->h_slot[slot], 1, S->rec_bytes, S->f) != S->rec_bytes; }
+        {
+            std::lock_guard<std::mutex> lk(S->mu);
+            S->queue.pop_front();
+            S->busy[slot] = false;
+            if (bad) S->io_error = true;
+            if (wrote && !bad) S->nwritten++; else if (!wrote) S->ndropped++;
+        }
+        S->cv.notify_all();
+    }
+}
+void sample_close(ngp_handle *h) {
+    SampleStream *S = h->smp;
+    if (!S) return;
+    { std::lock_guard<std::mutex> lk(S->mu); S->stop = true; }
+    S->cv.notify_all();
+    if (S->writer.joinable()) S->writer.join();
+    if (S->f) std::fclose(S->f);
+    for (int i = 0; i < SampleStream::NSLOT; i++) {
+        if (S->d_slot[i]) (void)hipFree(S->d_slot[i]);
+        if (S->h_slot[i]) (void)hipHostFree(S->h_slot[i]);
+        if (S->ev_packed[i]) (void)hipEventDestroy(S->ev_packed[i]);
+        if (S->ev_copied[i]) (void)hipEventDestroy(S->ev_copied[i]);
+    }
+    if (S->copy_stream) (void)hipStreamDestroy(S->copy_stream);
+    delete S;
+    h->smp = nullptr;
+}
+// the kept sample of the iteration just enqueued on h->stream goes into the next ring slot, from there to the host on the copy stream
+int sample_enqueue(ngp_handle *h) {
+    SampleStream *S = h->smp;
+    if (!S->header_written) {  // the model is final now: sizes and the file header
+        S->rec_bytes = sample_rec_bytes(h);
+        for (int i = 0; i < SampleStream::NSLOT; i++) {
+            if (hipMalloc((void **)&S->d_slot[i], S->rec_bytes) != hipSuccess || hipHostMalloc((void **)&S->h_slot[i], S->rec_bytes, hipHostMallocDefault) != hipSuccess)
+                return fail(h, NGP_ERR_NOMEM, "sample ring");
+        }
+        const int64_t hd[6] = {h->P, h->nvb, (int64_t)h->sets.size(), h->nfixcol, h->nclass_total, (int64_t)S->rec_bytes};
+        bool ok = std::fwrite("NGPSMP01", 1, 8, S->f) == 8 && std::fwrite(hd, sizeof(hd), 1, S->f) == 1;
+        for (auto &hs : h->sets) { const int64_t sg[6] = {hs.method, hs.K, hs.col0, hs.ncol, (int64_t)hs.vb0.size(), hs.tk}; ok = ok && std::fwrite(sg, sizeof(sg), 1, S->f) == 1; }
+        if (!ok) return fail(h, NGP_ERR_ARG, "cannot write the sample file header: " + S->path);
+        S->header_written = true;
+    } else if (S->rec_bytes != sample_rec_bytes(h)) {
+        return fail(h, NGP_ERR_STATE, "the model changed while a sample file is open (ngp_set_sample_file again)");
+    }
+    const int slot = (int)(S->nenq % SampleStream::NSLOT);
+    {
+        std::unique_lock<std::mutex> lk(S->mu);
+        S->cv.wait(lk, [&] { return !S->busy[slot]; });  // only when the writer is NSLOT samples behind
+        if (S->io_error) return fail(h, NGP_ERR_ARG, "writing the sample file failed: " + S->path);
+        S->busy[slot] = true;
+    }
+    const long long n = std::max<long long>(std::max<long long>(h->P, h->nvb), std::max<long long>(h->nfixcol, 1));
+    hipLaunchKernelGGL(k_sample_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, S->d_slot[slot], (long long)h->P, (long long)h->nvb,
+                       (int)h->sets.size(), (long long)h->nfixcol, (long long)h->nclass_total, (long long)h->iter, h->d_beta, h->d_delta, h->d_varBeta,
+                       h->d_sets, h->d_scal, h->d_bfix, h->d_abort);
+    HCHK(hipEventRecord(S->ev_packed[slot], h->stream));
+    HCHK(hipStreamWaitEvent(S->copy_stream, S->ev_packed[slot], 0));
+    HCHK(hipMemcpyAsync(S->h_slot[slot], S->d_slot[slot], S->rec_bytes, hipMemcpyDeviceToHost, S->copy_stream));
+    HCHK(hipEventRecord(S->ev_copied[slot], S->copy_stream));
+    { std::lock_guard<std::mutex> lk(S->mu); S->queue.push_back(slot); }
+    S->cv.notify_all();
+    S->nenq++;
+    return NGP_OK;
+}
+// end of a run: every enqueued sample is in the file when the call returns
+int sample_flush(ngp_handle *h) {
+    SampleStream *S = h->smp;
+    if (!S) return NGP_OK;
+    std::unique_lock<std::mutex> lk(S->mu);
+    S->cv.wait(lk, [&] { return S->queue.empty(); });
+    if (S->f) std::fflush(S->f);
+    if (S->io_error) return fail(h, NGP_ERR_ARG, "writing the sample file failed: " + S->path);
+    return NGP_OK;
+}
+
 int ready(ngp_handle *h) {
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
     REQUIRE(h->have_y, NGP_ERR_STATE, "y not set");
@@ -848,6 +973,7 @@ int32_t ngp_destroy(ngp_handle *h) {
     if (!h) return NGP_OK;
     (void)hipSetDevice(h->device);
     if (h->stream) (void)hipStreamSynchronize(h->stream);
+    sample_close(h);
     release_panel(h);
      dfree(h->d_cpart); dfree(h->d_cgsum); dfree(h->d_cdlt); dfree(h->d_cdltg); dfree(h->d_rcls); dfree(h->d_seg_set); dfree(h->d_ccnt); dfree(h->d_abort); dfree(h->d_dbg); dfree(h->d_mpm); dfree(h->d_lhs0); dfree(h->d_rhs0); dfree(h->d_beta);
     dfree(h->d_c); dfree(h->d_w); dfree(h->d_q); dfree(h->d_T); dfree(h->d_chi); dfree(h->d_setof); dfree(h->d_loc);
@@ -893,6 +1019,7 @@ static void ingest_u8_chunk(ngp_handle *h, const uint8_t *d_g, int64_t N, int64_
                            (long long)ld, (long long)ncols, (int)h->R, (int)h->S, (long long)t0);
     } else {
         hipLaunchKernelGGL(k_u8_colmean, dim3((unsigned)ncols), dim3(256), 0, h->stream, d_g, (long long)N, (long long)ld, (int)centre, d_mu);
+        (void)hipMemcpyAsync(h->d_mean + c0, d_mu, (size_t)ncols * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
         hipLaunchKernelGGL(k_u8_fill, dim3((unsigned)h->S, (unsigned)nb), dim3(256), 0, h->stream, h->d_tiles, d_g, (long long)N,
                            (long long)ld, (long long)ncols, (int)h->R, (int)h->S, (long long)t0, d_mu);
     }
@@ -1054,8 +1181,8 @@ int32_t ngp_generate_panel(ngp_handle *h, int64_t N, int64_t P, double maf_lo, d
     if ((rc = dalloc(h, &d_thr, (size_t)P))) { dfree(d_mu); return rc; }
     hipLaunchKernelGGL(k_gen_colmean, dim3((unsigned)P), dim3(256), 0, h->stream, (long long)N, (long long)P, maf_lo, maf_hi, panel_seed,
                        d_mu, d_thr);
+    (void)hipMemcpyAsync(h->d_mean, d_mu, (size_t)P * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
     if (h->storage == 1) {
-        (void)hipMemcpyAsync(h->d_mean, d_mu, (size_t)P * sizeof(double), hipMemcpyDeviceToDevice, h->stream);
         hipLaunchKernelGGL(k_gen_fill8, dim3((unsigned)h->S, (unsigned)h->NBLK), dim3(256), 0, h->stream, (uint8_t *)h->d_tiles, (long long)N,
                            (long long)P, (int)h->R, (int)h->S, panel_seed, d_thr);
     } else
@@ -1361,7 +1488,8 @@ int run_fused(ngp_handle **hs, int n, int64_t niter) {
         for (int i = 1; i < n; i++) { M.a[i].census = nullptr; M.a[i].xcc_w = M.a[0].xcc_w; }
         sweep_multi_launch((unsigned)grid, lds, h->stream, M);
         h->sweep_launches += 1; h->last_grid = grid;
-        for (int i = 0; i < n; i++) iteration_post(hs[i], it);
+        for (int i = 0; i < n && rc == NGP_OK; i++) { rc = iteration_post(hs[i], it); if (rc && i) h->err = hs[i]->err; }
+        if (rc) break;
         if ((it & 15) == 15 || it + 1 == niter) {  // bound the launch queue
             e = hipStreamSynchronize(h->stream);
             if (e == hipSuccess) {
@@ -1379,6 +1507,8 @@ int run_fused(ngp_handle **hs, int n, int64_t niter) {
     float ms = 0.f;
     HCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     for (int i = 0; i < n; i++) { hs[i]->iter_ms += ms; hs[i]->iters_timed += niter; }
+    for (int i = 0; i < n; i++)
+        if ((rc = sample_flush(hs[i]))) { if (i) h->err = hs[i]->err; return rc; }
     return NGP_OK;
 }
 }  // namespace
@@ -1398,6 +1528,7 @@ int32_t ngp_run(ngp_handle *h, int64_t niter) {
     float ms = 0.f;
     HCHK(hipEventElapsedTime(&ms, h->ev0, h->ev1));
     h->iter_ms += ms; h->iters_timed += niter;
+    if ((rc = sample_flush(h))) return rc;
     if (h->dbg_mode != 0) return fail(h, NGP_ERR_DEBUG, "diagnostic timing mode " + std::to_string(h->dbg_mode) + " is active: the chain is invalid (ngp_debug_set_mode(h, 0) ends it)");
     return NGP_OK;
     NGP_CATCH(h)
@@ -1846,7 +1977,7 @@ int32_t ngp_get_storage(ngp_handle *h, int32_t *storage, double *means, int64_t 
     if ((rc = enter(h))) return rc;
     if (storage) *storage = h->storage;
     if (means) {
-        REQUIRE(h->storage == 1 && h->d_tiles != nullptr, NGP_ERR_STATE, "column means exist in compact storage only, after the panel is set");
+        REQUIRE(h->d_tiles != nullptr && h->d_mean != nullptr, NGP_ERR_STATE, "column means exist after the panel is set");
         REQUIRE(P == h->P, NGP_ERR_ARG, "means buffer must hold P entries");
         HCHK(hipStreamSynchronize(h->stream));
         HCHK(hipMemcpy(means, h->d_mean, (size_t)P * sizeof(double), hipMemcpyDeviceToHost));
@@ -2260,7 +2391,7 @@ int32_t ngp_add_marker_set_r(ngp_handle *h, int64_t col0, int64_t ncol, double d
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
-    REQUIRE(vClass && pi && K >= 2 && K <= NGP_RMAX, NGP_ERR_ARG, "BayesR needs 2..4 variance classes with their probabilities");
+    REQUIRE(vClass && pi && K >= 2 && K <= NGP_RMAX, NGP_ERR_ARG, "BayesR needs 2..8 variance classes with their probabilities");
     double ps = 0.0;
     for (int v = 0; v < K; v++) {
         REQUIRE(std::isfinite(vClass[v]) && vClass[v] >= 0.0 && std::isfinite(pi[v]) && pi[v] > 0.0, NGP_ERR_ARG,
@@ -2505,6 +2636,38 @@ int32_t ngp_set_fixed(ngp_handle *h, const double *b, const double *sum_b, int64
     HCHK(hipStreamSynchronize(h->stream));
     if (b) HCHK(hipMemcpy(h->d_bfix, b, (size_t)h->nfixcol * sizeof(double), hipMemcpyHostToDevice));
     if (sum_b) HCHK(hipMemcpy(h->d_sum_bfix, sum_b, (size_t)h->nfixcol * sizeof(double), hipMemcpyHostToDevice));
+    return NGP_OK;
+    NGP_CATCH(h)
+}
+
+/* Kept samples to a binary file WITHOUT stopping the chain (the reference appends text rows at every kept iteration,
+ * src/samplers.jl:56-104, src/outFiles.jl:17-21: 10 MB of text per sample at P = 600,000).  From the next ngp_run on, every kept
+ * iteration (ngp_set_schedule) leaves one record: packed on the device into a ring of four slots, copied to pinned host memory on a
+ * second stream and written by a thread of the library's own; ngp_run returns when its last record is in the file.  path == NULL
+ * closes the file.  File: "NGPSMP01" | int64 P, nvb, nsets, nfix, nclass, record bytes | per set int64 {method, K, col0, ncol,
+ * variance entries, tuple k} | records: int64 iteration | varE | b | b_fixed[nfix] | beta[P] | varBeta[nvb] | piHat[2 nsets] | class
+ * probabilities[nclass] | delta[P] as bytes, padded to 8.  nextgp.jl_amd/api.py (samples_to_out_files) turns it into the
+ * reference's *Out text files. */
+int32_t ngp_set_sample_file(ngp_handle *h, const char *path) {
+    NGP_TRY
+    int rc;
+    if ((rc = enter(h))) return rc;
+    HCHK(hipStreamSynchronize(h->stream));
+    sample_close(h);
+    if (!path) return NGP_OK;
+    REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
+    SampleStream *S = new SampleStream();
+    S->path = path; S->device = h->device;
+    S->f = std::fopen(path, "wb");
+    if (!S->f) { delete S; return fail(h, NGP_ERR_ARG, std::string("cannot open the sample file for writing: ") + path); }
+    hipError_t e = hipStreamCreate(&S->copy_stream);
+    for (int i = 0; i < SampleStream::NSLOT && e == hipSuccess; i++) {
+        e = hipEventCreateWithFlags(&S->ev_packed[i], hipEventDisableTiming);
+        if (e == hipSuccess) e = hipEventCreateWithFlags(&S->ev_copied[i], hipEventDisableTiming);
+    }
+    h->smp = S;
+    if (e != hipSuccess) { sample_close(h); return fail(h, NGP_ERR_HIP, std::string("sample stream: ") + hipGetErrorString(e)); }
+    S->writer = std::thread(sample_writer_loop, S);
     return NGP_OK;
     NGP_CATCH(h)
 }

@@ -11,7 +11,9 @@
 #define NGP_BLK 64
 #define NGP_SEG 256
 #define NGP_GRP 32
-#define NGP_RMAX 4  // variance classes of a BayesR set (the chain keeps their coefficients in registers)
+#define NGP_RMAX 8  // variance classes of a BayesR set (src/functions.jl:241-262 sizes everything by length(vClass))
+#define NGP_RREG 4  // ... of which the block chain keeps the coefficients of the first four in registers; further classes are read
+                    // from the coefficient arrays of k_prep each time a candidate is formed
 #define NGP_KMAX 4  // marker sets of one tuple (correlated BayesPR, src/functions.jl:140-154)
 #define NGP_METHOD_TUPLE_DEV 4
 
@@ -108,16 +110,20 @@ __device__ inline double readlane_d(double v, int lane) {
 //   others   in = |r c| > thr, dlt = in ? r c + w : -beta   (BayesPR: always in)
 // ------------------------------------------------------------------------------------------
 struct RLane {  // class coefficients of one BayesR locus (k_prep): 1/lhs_v, log-weight a_v, sd_v z, uniform u_v; M.rhs
-    double q[NGP_RMAX], a[NGP_RMAX], t[NGP_RMAX], u[NGP_RMAX];
+    double q[NGP_RREG], a[NGP_RREG], t[NGP_RREG], u[NGP_RREG];
     double rhs0;
     int K;
+    const double *ext;  // K > NGP_RREG: rcls + locus (arrays q | a | t | u, NGP_RMAX x Ppad each), else unused
+    long long Ppad;
 };
 __device__ inline RLane load_rlane(const double *__restrict__ rcls, long long Ppad, long long k, int K, const double *__restrict__ rhs0) {
     RLane L;
     L.K = K;
     L.rhs0 = rhs0[k];
+    L.ext = rcls + k;
+    L.Ppad = Ppad;
 #pragma unroll
-    for (int v = 0; v < NGP_RMAX; v++) {
+    for (int v = 0; v < NGP_RREG; v++) {
         const bool on = v < K;
         const size_t o = (size_t)(on ? v : 0) * (size_t)Ppad + (size_t)k;
         L.q[v] = on ? rcls[o] : 0.0;
@@ -127,6 +133,18 @@ __device__ inline RLane load_rlane(const double *__restrict__ rcls, long long Pp
     }
     return L;
 }
+__device__ inline RLane empty_rlane() {
+    RLane L;
+    L.K = 2; L.rhs0 = 0.0; L.ext = nullptr; L.Ppad = 0;
+#pragma unroll
+    for (int v = 0; v < NGP_RREG; v++) { L.q[v] = 0.0; L.a[v] = 0.0; L.t[v] = 0.0; L.u[v] = 0.0; }
+    return L;
+}
+// log-weight of class v given hs = rhs^2 / 2 (src/functions.jl:255 in the stable form): classes >= NGP_RREG come from memory
+__device__ inline double rlane_L(const RLane &L, const int v, const double hs) {
+    const double q = L.ext[(size_t)v * L.Ppad], a = L.ext[((size_t)NGP_RMAX + v) * L.Ppad];
+    return (q == 0.0) ? a : __builtin_fma(hs, q, a);
+}
 __device__ inline void eval_rform(const int meth, const double r, const double bo, const double cc, const double ww, const double st,
                                   const RLane &L, const double iVarE, double &cand, int &cls) {
     if (meth == 3) {
@@ -134,34 +152,45 @@ __device__ inline void eval_rform(const int meth, const double r, const double b
         const double rhs = t + L.rhs0;
         const double s2 = rhs * rhs;
         const double hs = 0.5 * s2;
-        double Lv[NGP_RMAX], e[NGP_RMAX];
+        double Lv[NGP_RREG], e[NGP_RREG];
 #pragma unroll
-        for (int v = 0; v < NGP_RMAX; v++) Lv[v] = (L.q[v] == 0.0) ? L.a[v] : __builtin_fma(hs, L.q[v], L.a[v]);
+        for (int v = 0; v < NGP_RREG; v++) Lv[v] = (L.q[v] == 0.0) ? L.a[v] : __builtin_fma(hs, L.q[v], L.a[v]);
         double m = Lv[0];
 #pragma unroll
-        for (int v = 1; v < NGP_RMAX; v++)
+        for (int v = 1; v < NGP_RREG; v++)
             if (v < L.K && Lv[v] > m) m = Lv[v];
+        for (int v = NGP_RREG; v < L.K; v++) {  // (more than four classes: the same steps, class after class, from memory)
+            const double lv = rlane_L(L, v, hs);
+            if (lv > m) m = lv;
+        }
         double S = 0.0;
 #pragma unroll
-        for (int v = 0; v < NGP_RMAX; v++)
+        for (int v = 0; v < NGP_RREG; v++)
             if (v < L.K) {
                 e[v] = det_exp(Lv[v] - m);
                 S = S + e[v];
             } else e[v] = 0.0;
+        for (int v = NGP_RREG; v < L.K; v++) S = S + det_exp(rlane_L(L, v, hs) - m);
         int c = L.K - 1;
         double cum = 0.0;
         bool found = false;
 #pragma unroll
-        for (int v = 0; v < NGP_RMAX; v++)
+        for (int v = 0; v < NGP_RREG; v++)
             if (v < L.K && !found) {
                 cum = cum + e[v];
                 const double thr = L.u[v] * S;
                 if (cum >= thr) { c = v; found = true; }
             }
+        for (int v = NGP_RREG; v < L.K && !found; v++) {
+            cum = cum + det_exp(rlane_L(L, v, hs) - m);
+            const double thr = L.ext[((size_t)3 * NGP_RMAX + v) * L.Ppad] * S;
+            if (cum >= thr) { c = v; found = true; }
+        }
         double qc = L.q[0], tc = L.t[0];
 #pragma unroll
-        for (int v = 1; v < NGP_RMAX; v++)
+        for (int v = 1; v < NGP_RREG; v++)
             if (c == v) { qc = L.q[v]; tc = L.t[v]; }
+        if (c >= NGP_RREG) { qc = L.ext[(size_t)c * L.Ppad]; tc = L.ext[((size_t)2 * NGP_RMAX + c) * L.Ppad]; }
         if (qc != 0.0) {
             const double d = __builtin_fma(rhs, qc, tc);
             cand = d - bo;

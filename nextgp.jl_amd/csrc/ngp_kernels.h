@@ -444,10 +444,7 @@ __global__ __launch_bounds__(256) void k_recur(const double *__restrict__ part, 
         }
     }
     if (__ballot(meth0 == 3) != 0ull) {  // a BayesR locus in the block: r-form chain (eval_rform)
-        RLane RL;
-        RL.K = 2; RL.rhs0 = 0.0;
-#pragma unroll
-        for (int v = 0; v < NGP_RMAX; v++) { RL.q[v] = 0.0; RL.a[v] = 0.0; RL.t[v] = 0.0; RL.u[v] = 0.0; }
+        RLane RL = empty_rlane();
         if (meth0 == 3) RL = load_rlane(rcls, Ppad, k, sets[si0].K, rhs0);
         const double iVarE = sc->iVarE;
         double rcur = r, dfin = 0.0;
@@ -829,6 +826,36 @@ __global__ __launch_bounds__(256) void k_post(int do_accum, long long P, long lo
         sc->sum_b += sc->b;
         sc->nKept += 1;
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// One kept sample into a slot of the sample ring (ngp_set_sample_file: what the reference appends as text rows of b / varE / beta<set> /
+// delta<set> / pi<set> / var<set>Out at src/samplers.jl:56-104).  Record: int64 iteration (-1: invalid -- an earlier sweep of the
+// call gave up and this iteration will be run again) | varE | b | b_fixed[nfix] | beta[P] | varBeta[nvb] | piHat[2 nsets] |
+// class probabilities [nclass] | delta[P] as bytes.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_sample_pack(unsigned char *__restrict__ rec, long long P, long long nvb, int nsets, long long nfix,
+                                                     long long nclass, long long iter, const double *__restrict__ beta,
+                                                     const uint8_t *__restrict__ delta, const double *__restrict__ varBeta,
+                                                     const DSet *__restrict__ sets, const DScal *__restrict__ sc, const double *__restrict__ bfix,
+                                                     const unsigned *__restrict__ abort_w) {
+    const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
+    long long *hd = (long long *)rec;
+    double *d = (double *)rec + 1;
+    if (abort_w && *abort_w != 0u) { if (k == 0) hd[0] = -1; return; }
+    double *o_fix = d + 2, *o_beta = o_fix + nfix, *o_vb = o_beta + P, *o_pi = o_vb + nvb, *o_cls = o_pi + 2 * nsets;
+    uint8_t *o_delta = (uint8_t *)(o_cls + nclass);
+    if (k == 0) {
+        hd[0] = iter; d[0] = sc->varE; d[1] = sc->b;
+        long long c = 0;
+        for (int s = 0; s < nsets; s++) {
+            o_pi[2 * s] = sets[s].piHat0; o_pi[2 * s + 1] = sets[s].piHat1;
+            for (int v = 0; v < sets[s].K; v++) o_cls[c++] = sets[s].pic[v];
+        }
+    }
+    if (k < nfix) o_fix[k] = bfix[k];
+    if (k < P) { o_beta[k] = beta[k]; o_delta[k] = delta[k]; }
+    if (k < nvb) o_vb[k] = varBeta[k];
 }
 
 // ------------------------------------------------------------------------------------------

@@ -1236,10 +1236,7 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
             } else if (A.rcls && __ballot(meth0 == 3) != 0ull) {
                 // r-form chain (eval_rform, ngp_kernels.h): candidates of all lanes from the current r, the first non-zero one at
                 // or behind the cursor takes its step.  With most loci in the zero class that is a few steps per block.
-                RLane RL;
-                RL.K = 2; RL.rhs0 = 0.0;
-#pragma unroll
-                for (int v = 0; v < NGP_RMAX; v++) { RL.q[v] = 0.0; RL.a[v] = 0.0; RL.t[v] = 0.0; RL.u[v] = 0.0; }
+                RLane RL = empty_rlane();
                 if (meth0 == 3) RL = load_rlane(A.rcls, A.Ppad, (long long)t * NGP_BLK + j, sK[si0], A.rhs0);
                 const double iVarE = A.scal->iVarE;
                 double rcur = r, dfin = 0.0;

@@ -63,7 +63,7 @@
 #define METHOD_B 1
 #define METHOD_C 2 /* BayesC: src/functions.jl:197-235 */
 #define METHOD_R 3 /* BayesR: src/functions.jl:238-289 */
-#define RMAX 4     /* variance classes of a BayesR set (the device keeps them in registers) */
+#define RMAX 8     /* variance classes of a BayesR set (functions.jl:241-262 sizes everything by length(vClass)) */
 #define METHOD_T 4 /* correlated (Tuple) BayesPR: src/functions.jl:140-154, 513-516; set-up src/mme.jl:448-489 */
 #define KMAX 4     /* marker sets of one tuple */
 #define KIND_T_WISHART 11 /* Bartlett factor of a region's inverse-Wishart draw: index (set << 40) | (region << 8) | (i << 4) | j */
@@ -271,6 +271,24 @@ static inline double panel_pj(uint64_t pseed, int64_t j, double lo, double hi) {
 static inline int panel_gij(uint64_t pseed, int64_t i, int64_t j, uint32_t thr) {
     uint64_t h = mix64(mix64(pseed + (uint64_t)j * 0xD1342543DE82EF95ULL) ^ ((uint64_t)i * GOLD + 0x632BE59BD9B4E019ULL));
     return (int)((uint32_t)h < thr) + (int)((uint32_t)(h >> 32) < thr);
+}
+/* genotype codes of chosen ROWS of the synthetic panel (all P columns), row-major [nrows][P], and the column sums over ALL N rows of
+   chosen COLUMNS: a host-side check of a full-size panel regenerates a few rows and audits a few column means without the panel */
+void ora_generate_rows(const int64_t *rows, int64_t nrows, int64_t P, double maf_lo, double maf_hi, uint64_t pseed, uint8_t *G) {
+#pragma omp parallel for schedule(static)
+    for (int64_t j = 0; j < P; j++) {
+        const uint32_t thr = (uint32_t)(panel_pj(pseed, j, maf_lo, maf_hi) * 4294967296.0);
+        for (int64_t r = 0; r < nrows; r++) G[r * P + j] = (uint8_t)panel_gij(pseed, rows[r], j, thr);
+    }
+}
+void ora_column_sums(const int64_t *cols, int64_t ncols, int64_t N, double maf_lo, double maf_hi, uint64_t pseed, int64_t *sums) {
+#pragma omp parallel for schedule(static)
+    for (int64_t c = 0; c < ncols; c++) {
+        const uint32_t thr = (uint32_t)(panel_pj(pseed, cols[c], maf_lo, maf_hi) * 4294967296.0);
+        int64_t sm = 0;
+        for (int64_t i = 0; i < N; i++) sm += panel_gij(pseed, i, cols[c], thr);
+        sums[c] = sm;
+    }
 }
 /* column-major N x P, centred fp32; optionally returns raw genotype sums per column */
 void ora_generate_panel(int64_t N, int64_t P, double maf_lo, double maf_hi, uint64_t pseed, float *X, double *col_mean) {
@@ -1107,7 +1125,7 @@ static void iter_ref(ora_t *h) {
                (locus, comparison).  If no comparison succeeds (cumProbs[end] rounded below a uniform, or NaN probabilities
                after an overflow of exp) the reference fails with an indexing error; here the last class is taken. */
             const int K = S->K;
-            int64_t nLoci[RMAX] = {0, 0, 0, 0};
+            int64_t nLoci[RMAX] = {0};
             int64_t nNonZero = 0;
             double varc[RMAX];
             for (int v = 0; v < K; v++) varc[v] = vb[0] * S->vcls[v];                             /* :244 */
@@ -1639,7 +1657,7 @@ static void iter_blocked(ora_t *h) {
             continue;
         }
         if (Sx->method == METHOD_R) {
-            int64_t nL[RMAX] = {0, 0, 0, 0}, nNonZero = 0;
+            int64_t nL[RMAX] = {0}, nNonZero = 0;
             for (int64_t l = 0; l < Sx->ncol; l++) nL[h->delta[Sx->col0 + l] - 1]++;
             for (int v = 0; v < Sx->K; v++) if (Sx->vcls[v] != 0.0) nNonZero += nL[v];
             double tot = 0.0; int first = 1;

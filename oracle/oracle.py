@@ -83,6 +83,24 @@ def generate_panel(N, P, maf_lo=0.05, maf_hi=0.5, seed=20250509):
     return X, mu
 
 
+def generate_rows(rows, P, maf_lo=0.05, maf_hi=0.5, seed=20250509):
+    """Genotype codes (uint8, [len(rows), P]) of chosen rows of the synthetic panel -- without generating the panel."""
+    rows = np.ascontiguousarray(rows, dtype=np.int64)
+    G = np.empty((len(rows), P), dtype=np.uint8)
+    lib().ora_generate_rows(_p(rows, C.c_int64), C.c_int64(len(rows)), C.c_int64(P), C.c_double(maf_lo), C.c_double(maf_hi), C.c_uint64(seed),
+                            _p(G, C.c_uint8))
+    return G
+
+
+def column_sums(cols, N, maf_lo=0.05, maf_hi=0.5, seed=20250509):
+    """Genotype sums over all N rows of chosen columns of the synthetic panel."""
+    cols = np.ascontiguousarray(cols, dtype=np.int64)
+    out = np.empty(len(cols), dtype=np.int64)
+    lib().ora_column_sums(_p(cols, C.c_int64), C.c_int64(len(cols)), C.c_int64(N), C.c_double(maf_lo), C.c_double(maf_hi), C.c_uint64(seed),
+                          _p(out, C.c_int64))
+    return out
+
+
 class Oracle:
     """Handle-style driver with the same call sequence as the product's C ABI."""
 

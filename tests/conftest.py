@@ -48,7 +48,7 @@ def make_problem(O, N, P, seed=1, ncausal=10, h2=0.5, panel_seed=20250509):
 
 
 def add_sets(m, spec, v):
-    """spec: list of (col0, ncol, 'PR'|'B'|'Bfix'|'C'|'Cfix'|'PR1'|('PRw', width)|'R'|'Rfix'|'R2'); same calls on oracle and product."""
+    """spec: list of (col0, ncol, 'PR'|'B'|'Bfix'|'C'|'Cfix'|'PR1'|('PRw', width)|'R'|'Rfix'|'R2'|'R6'|'R8'); same calls on oracle and product."""
     df = 4.0
     for col0, ncol, kind in spec:
         if kind == "PR":
@@ -73,6 +73,10 @@ def add_sets(m, spec, v):
             m.add_marker_set_r(col0, ncol, df, v * (df - 2) / df, v, [0.0, 0.01, 0.1, 1.0], [0.85, 0.10, 0.04, 0.01], estPi=True)
         elif kind == "Rfix":   # three classes, none of them zero, pi fixed
             m.add_marker_set_r(col0, ncol, df, v * (df - 2) / df, v, [0.001, 0.1, 1.0], [0.6, 0.3, 0.1], estPi=False)
+        elif kind == "R6":     # six variance classes (more than the four the block chain keeps in registers), pi estimated
+            m.add_marker_set_r(col0, ncol, df, v * (df - 2) / df, v, [0.0, 0.0001, 0.001, 0.01, 0.1, 1.0], [0.5, 0.2, 0.12, 0.1, 0.05, 0.03], estPi=True)
+        elif kind == "R8":     # eight classes, no zero class, pi fixed
+            m.add_marker_set_r(col0, ncol, df, v * (df - 2) / df, v, [1e-5, 1e-4, 1e-3, 0.01, 0.05, 0.2, 0.5, 1.0], [0.3, 0.2, 0.15, 0.1, 0.1, 0.06, 0.05, 0.04], estPi=False)
         elif kind == "R2":     # two classes: the zero class first is not required by the reference
             m.add_marker_set_r(col0, ncol, df, v * (df - 2) / df, v, [1.0, 0.0], [0.3, 0.7], estPi=True)
         else:

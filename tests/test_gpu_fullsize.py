@@ -33,11 +33,18 @@ def _chain(ngp, method, niter, engine=(1, 6), seed=1001, P_=P):
 
 
 @pytest.mark.parametrize("method", ["PR", "B", "C", "multi"])
-def test_residual_invariant_and_indicator_consistency(ngp, method):
+def test_residual_invariant_and_indicator_consistency(ngp, O, method):
     s, y = _chain(ngp, method, 12)
     st = s.get_state()
     resid = y - st["b"] - s.xbeta(st["beta"])                       # ycorr recomputed from scratch
     assert np.abs(st["ycorr"] - resid).max() <= 1e-9 * np.abs(y).max()
+    # and on the host, for 64 rows regenerated from the panel generator (no device arithmetic in the check)
+    rr = np.random.default_rng(5)
+    rows, cols = np.sort(rr.choice(N, 64, replace=False)), rr.choice(P, 64, replace=False)
+    means = s.means()
+    assert np.array_equal(means[cols], O.column_sums(cols, N) / float(N))
+    Xr = (O.generate_rows(rows, P).astype(np.float64) - means[None, :]).astype(np.float32).astype(np.float64)
+    assert np.abs(st["ycorr"][rows] - (y[rows] - st["b"] - Xr @ st["beta"])).max() <= 1e-9 * np.abs(y).max()
     assert np.isfinite(st["beta"]).all() and st["varE"] > 0 and st["iter"] == 12
     d = st["delta"]
     assert set(np.unique(d)) <= {0, 1}
@@ -106,7 +113,7 @@ def test_tallest_shards_and_fallback(ngp, N_, P_, mode_):
     assert np.abs(st["ycorr"] - (y - st["b"] - s.xbeta(st["beta"]))).max() < 1e-9
 
 
-def test_north_star_shape_50k_x_600k(ngp):
+def test_north_star_shape_50k_x_600k(ngp, O):
     """BASELINE.json configs[3] at full size (N = 50,000, P = 600,000 as three BayesPR sets; 120 GB of tiles, 64-bit tile
     offsets, 204-row shards, lag 6, the row-owning streamer): the oracle cannot run this, so the size-independent properties
     carry parity -- ycorr == y - 1 b - X beta recomputed from scratch, bitwise reproducibility of two chains with the same
@@ -133,6 +140,19 @@ def test_north_star_shape_50k_x_600k(ngp):
         if len(out) == 0:
             resid = y - st["b"] - s.xbeta(st["beta"])
             assert np.abs(st["ycorr"] - resid).max() <= 1e-9 * np.abs(y).max()
+            # the same invariant on the HOST for 64 random rows, without the device's own X beta: the rows' genotype codes are
+            # regenerated from the counter-based panel generator (oracle), centred with the library's column means (64 of them
+            # audited against the generator's integer column sums), rounded to fp32 as the tiles are, and y_i - b - x_i'beta formed
+            # in numpy
+            rr = np.random.default_rng(17)
+            rows = np.sort(rr.choice(N_, 64, replace=False))
+            means = s.means()
+            cols = rr.choice(P_, 64, replace=False)
+            assert np.array_equal(means[cols], O.column_sums(cols, N_) / float(N_))
+            G = O.generate_rows(rows, P_)
+            Xr = (G.astype(np.float64) - means[None, :]).astype(np.float32).astype(np.float64)
+            host = y[rows] - st["b"] - Xr @ st["beta"]
+            assert np.abs(st["ycorr"][rows] - host).max() <= 1e-9 * np.abs(y).max()
             assert np.isfinite(st["beta"]).all() and st["varE"] > 0 and st["iter"] == 6 and st["delta"].min() == 1 and np.all(st["varBeta"] > 0)
             assert s.get_posterior_sums()["nKept"] == 6
         out.append(st)

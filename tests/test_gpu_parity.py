@@ -100,6 +100,7 @@ CASES = [
     ("tiny", 7, 3, [(0, 3, "PR")]),
     ("r_single", 400, 520, [(0, 520, "R")]),                                     # BayesR (src/functions.jl:238-289)
     ("r_multi", 300, 330, [(0, 100, "Rfix"), (100, 90, "B"), (190, 100, "R2"), (290, 40, "PR")]),   # BayesR lanes beside others in one block
+    ("r_six_eight", 300, 400, [(0, 150, "R6"), (150, 100, "PR"), (250, 150, "R8")]),             # more classes than the chain keeps in registers
 ]
 
 
@@ -725,3 +726,42 @@ def test_allreduce_multi_device_branch_on_one_gpu(ngp, O):
             assert np.array_equal(p[k], tot(lambda i: sums[i][k])), k
         assert p["sum_varE"] == tot(lambda i: sums[i]["sum_varE"])
         assert np.array_equal(s.get_fixed()["sum_b"], tot(lambda i: fx[i]))
+
+
+def test_sample_stream_does_not_stop_the_chain_and_loses_nothing(ngp, O, tmp_path):
+    """ngp_set_sample_file: ONE ngp_run of the whole chain; every kept iteration leaves a binary record (ring of four slots on the device,
+    second stream, writer thread) -- the values the stop-and-copy read-back sees at those iterations, bit for bit.  A launch that
+    ends at its census in the middle (records of the skipped iterations are marked invalid and dropped) is run again: no record is
+    lost or doubled."""
+    ref, X, y, v = _small_model(ngp, O)
+    ref.set_schedule(40, 4, 3)
+    want = {}
+    for it in range(4 + 3, 41, 3):
+        ref.run(it - ref.get_state()["iter"])
+        st = ref.get_state()
+        want[it] = (st["beta"].copy(), st["delta"].copy(), st["varBeta"].copy(), st["piHat"].copy(), st["varE"], st["b"])
+    for fail_at in (0, 17):
+        s, *_ = _small_model(ngp, O)
+        s.set_schedule(40, 4, 3)
+        path = str(tmp_path / f"s{fail_at}.ngpsmp")
+        s.set_sample_file(path)
+        if fail_at:
+            s.debug_fail_census(fail_at)
+        s.run(40)
+        s.set_sample_file(None)
+        S = ngp.read_sample_file(path)
+        assert S["iter"].tolist() == sorted(want), fail_at
+        for i, it in enumerate(S["iter"].tolist()):
+            b, d, vb, pi, vE, bb = want[it]
+            assert np.array_equal(S["beta"][i], b) and np.array_equal(S["delta"][i], d.astype(np.uint8)) and np.array_equal(S["varBeta"][i], vb)
+            assert np.array_equal(S["piHat"][i], pi) and S["varE"][i] == vE and S["b"][i] == bb
+        assert [x["method"] for x in S["sets"]] == [0, 1] and S["sets"][1]["col0"] == 100
+    # many more samples than ring slots, every iteration kept
+    s, *_ = _small_model(ngp, O)
+    s.set_schedule(300, 0, 1)
+    s.set_sample_file(str(tmp_path / "all.ngpsmp"))
+    s.run(300)
+    s.set_sample_file(None)
+    S = ngp.read_sample_file(str(tmp_path / "all.ngpsmp"))
+    assert S["iter"].tolist() == list(range(1, 301)) and np.array_equal(S["beta"][-1], s.get_state()["beta"])
+    assert np.allclose(S["beta"].sum(axis=0), s.get_posterior_sums()["sum_beta"], rtol=1e-12, atol=1e-12)

@@ -93,6 +93,22 @@ def test_runLMEM_end_to_end_matches_oracle(ngp, O, tmp_path):
     assert (out / "betaM2Out").read_text().splitlines()[0].split("\t")[:2] == ["M1", "M2"]
     with pytest.raises(FileExistsError):
         ngp.runLMEM(f'y ~ 1 + SNP(M1,"{g1}")', {"y": y}, 2, 0, 1, outFolder=str(out), VCV=VCV)
+    # The files above came from the sample STREAM (samples="text": the kept samples leave the device while the chain runs, ONE ngp_run
+    # for the whole chain).  The older stop-and-copy path (one ngp_run per kept iteration) writes the same files, byte for byte.
+    out2 = tmp_path / "outSync"
+    res2 = ngp.runLMEM(f'y ~ 1 + SNP(M1,"{g1}") + SNP(M2,"{g2}")', {"y": y}, 20, 6, 2, outFolder=str(out2), VCV=VCV, seed=9, engine=(1, 3),
+                       samples="text-sync")
+    assert sorted(p.name for p in out.iterdir()) == sorted(p.name for p in out2.iterdir())
+    for pth in out.iterdir():
+        assert pth.read_bytes() == (out2 / pth.name).read_bytes(), pth.name
+    assert res2["nKept"] == 7 and np.array_equal(res["sets"]["M1"]["beta"], res2["sets"]["M1"]["beta"])
+    # the binary file itself, and a census-retried launch in the middle of the stream: the dropped records are run again, none is lost
+    out3 = tmp_path / "outBin"
+    ngp.runLMEM(f'y ~ 1 + SNP(M1,"{g1}") + SNP(M2,"{g2}")', {"y": y}, 20, 6, 2, outFolder=str(out3), VCV=VCV, seed=9, engine=(1, 3), samples="binary")
+    S = ngp.read_sample_file(str(out3 / "samples.ngpsmp"))
+    assert S["iter"].tolist() == [8, 10, 12, 14, 16, 18, 20] and S["beta"].shape == (7, P1 + P2) and S["delta"].dtype == np.uint8
+    assert np.array_equal(S["beta"][:, :P1].mean(axis=0), ngp.summaryMCMC("betaM1", outFolder=str(out))[0]) or \
+        np.allclose(S["beta"][:, :P1].mean(axis=0), ngp.summaryMCMC("betaM1", outFolder=str(out))[0], rtol=0, atol=1e-15)
 
 
 @pytest.mark.gpu

@@ -366,6 +366,34 @@ def test_numpy_restatement_bayesr(O):
     assert np.all(a["beta"][20:][cls == 1] == 0.0)                                # :275
 
 
+def test_bayesr_with_more_than_four_classes(O):
+    """The reference sizes BayesR by length(vClass) (functions.jl:241-262); six and eight classes in both oracle orders and in the numpy
+    restatement: identical classes, floats to rounding."""
+    from ref_numpy import RefChain
+    N, P = 90, 120
+    X, y, bt, v = make_problem(O, N, P, seed=16)
+    vc6, pi6 = [0.0, 0.0001, 0.001, 0.01, 0.1, 1.0], [0.5, 0.2, 0.12, 0.1, 0.05, 0.03]
+    vc8, pi8 = [1e-5, 1e-4, 1e-3, 0.01, 0.05, 0.2, 0.5, 1.0], [0.3, 0.2, 0.15, 0.1, 0.1, 0.06, 0.05, 0.04]
+    o0 = O.Oracle(0, seed=19, chain=0); o0.set_panel_f32(X)
+    o1 = O.Oracle(1, seed=19, chain=0); o1.set_panel_f32(X, R=8, S=12, D=4, near=3)
+    ref = RefChain(O, X.astype(np.float64), y, seed=19, chain=0)
+    for m in (o0, o1):
+        m.add_marker_set_r(0, 70, 4.0, v * 0.5, v, vc6, pi6, estPi=True)
+        m.add_marker_set_r(70, 50, 4.0, v * 0.5, v, vc8, pi8, estPi=False)
+        m.set_y(y); m.set_residual_prior(4.0, 0.3 * y.var())
+    ref.add_set_r(0, 70, 4.0, v * 0.5, v, vc6, pi6, estPi=True); ref.add_set_r(70, 50, 4.0, v * 0.5, v, vc8, pi8, estPi=False)
+    ref.E_df, ref.E_scale = 4.0, 0.3 * y.var()
+    for it in range(8):
+        o0.run(1); o1.run(1); ref.run(1)
+        a, b, c = o0.get_state(), o1.get_state(), ref.state()
+        assert np.array_equal(a["delta"], c["delta"]) and np.array_equal(a["delta"], b["delta"]), it
+        for k in ("beta", "ycorr", "varBeta"):
+            assert np.abs(a[k] - c[k]).max() <= 1e-10 * max(1e-6, np.abs(c[k]).max()), (it, k)
+            assert np.abs(a[k] - b[k]).max() <= 1e-10 * max(1e-6, np.abs(a[k]).max()), (it, k)
+    assert a["delta"][:70].max() <= 6 and a["delta"][70:].max() <= 8 and len(np.unique(a["delta"])) > 4
+    assert len(o1.get_class_state(0)["piHat"]) == 6 and abs(o1.get_class_state(0)["piHat"].sum() - 1) < 1e-12
+
+
 def test_det_exp_within_one_ulp(O):
     xs = -np.concatenate([10.0 ** np.random.default_rng(0).uniform(-12, 2.8, 20000), [0.0, 1e-30, 0.3465, 0.3466, 0.35, 707.9]])
     for x in xs:
