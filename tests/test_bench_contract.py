@@ -12,7 +12,8 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def test_bench_line_has_the_contract_fields():
     out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--config", "C4", "--N", "2000", "--P", "6400", "--steps", "8", "--warmup", "1",
-                          "--cpu-cols", "640", "--cpu-seconds", "2", "--chains-per-gpu", "2"], capture_output=True, text=True, timeout=600, cwd=ROOT)
+                          "--cpu-cols", "640", "--cpu-seconds", "2", "--chains-per-gpu", "2", "--chains-per-pass", "3"], capture_output=True, text=True,
+                         timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1
@@ -29,8 +30,10 @@ def test_bench_line_has_the_contract_fields():
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and "sample" in c and c["cpu_model"] and c["one_thread_it_per_s"] > 0
     assert len(d["config"]["sets"]) == 3 and sum(x["ncol"] for x in d["config"]["sets"]) == 6400      # three BayesPR sets, like configs[3]
-    e = d["effective_samples"]
-    assert 0 < e["ess_min"] <= 8 and e["ess_min_per_sec"] > 0 and len(e["ess"]["varBeta"]) == 3 and "beta_min_of_128" in e["ess"]
+    e = d["effective_samples"]   # (an ESS figure needs at least 200 timed iterations behind it: below that the field says so)
+    assert e["ess"] is None and e["ess_min"] is None and e["ess_min_per_sec"] is None and "fewer than 200" in e["note"]
+    kp = d["chains_per_pass"]   # optional leg: three chains in ONE fused sweep launch per iteration, aggregate rate beside the headline
+    assert kp["chains"] == 3 and kp["value"] > 0 and kp["sweep_launches"] == 8 and kp["algorithmic_bytes_per_pass"] == 4.0 * 2000 * 6400
     assert abs(d["value"] - 1e3 / d["ms_per_step"]) < 1e-6 * d["value"]
     kc = d["chains_per_gpu"]    # optional leg: two chains side by side on the GPU, aggregate rate
     assert kc["chains"] == 2 and kc["value"] > 0 and kc["shards_per_chain"] <= 123
