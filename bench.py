@@ -265,8 +265,9 @@ def main():
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the committed rocprofv3
     # summary of the SAME workload (tools/profile_round.sh) is quoted when the configuration matches, else null
     traffic, traffic_src = None, None
-    pmc = os.path.join(ROOT, "profiles", f"r02_pmc_k_sweep_{args.config}{'u8' if compact_main else ''}.json")
-    if os.path.exists(pmc) and not overridden and prof["launches"] == 1:
+    pmc = next((q for q in (os.path.join(ROOT, "profiles", f"{tag}_pmc_k_sweep_{args.config}{'u8' if compact_main else ''}.json") for tag in ("r03", "r02"))
+                if os.path.exists(q)), "")
+    if pmc and not overridden and prof["launches"] == 1:
         pj = json.load(open(pmc))
         traffic, traffic_src = pj["hbm_bytes_per_launch"], f"profiles/{os.path.basename(pmc)} (rocprofv3 --pmc FETCH_SIZE x2 + WRITE_SIZE, separate passes)"
     # posterior means across chains: ONE all-reduce of the packed sums over RCCL / xGMI

@@ -254,7 +254,9 @@ int32_t ngp_get_storage(ngp_handle *h, int32_t *storage, double *means, int64_t 
  * their launches and then return NGP_ERR_DEBUG: the chain they leave behind is invalid.  0 = off. */
 int32_t ngp_debug_set_mode(ngp_handle *h, int32_t mode);
 /* Tuning knob of the row-owning streamer: pacing of its loader wave, 0..4 = s_sleep units (64 clocks) after every four tile
- * requests (default 0), + 16 = count every partial before the block's barrier.  Changes timing only, never results. */
+ * requests (default 0), + 16 = count every partial before the block's barrier, + 1024 (before the panel is set) = build the Gram window
+ * with the fp64 VALU kernel instead of the matrix cores (v_mfma_f64_16x16x4_f64: the same sums in the same order).  Changes timing
+ * only, never results. */
 int32_t ngp_debug_set_knob(ngp_handle *h, int32_t knob);
 
 /* Resume support, second half: overwrite the posterior sums (same shapes as ngp_get_posterior_sums).  With ngp_set_state a

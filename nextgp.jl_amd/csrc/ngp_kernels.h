@@ -915,6 +915,51 @@ __global__ __launch_bounds__(256) void k_gram_part(const float *__restrict__ til
         for (int b = 0; b < 4; b++) out[(4 * tk + a) * NGP_BLK + 4 * tj + b] = acc[a][b];
 }
 
+// The same shard partials on the matrix cores: v_mfma_f64_16x16x4_f64 (the Gram window is the one dense contraction of the path,
+// SURVEY.md section 7.1).  256 threads = 4 waves; wave w owns the 16 columns j = 16 w .. 16 w + 15 of tile t against all 64 columns
+// k of tile t - d: four 16 x 16 accumulators (k = 16 m .. 16 m + 15).  One MFMA contracts FOUR rows (a quad of the quad-major
+// tile): lane l supplies A[k = 16 m + (l & 15)][row l >> 4] and B[row l >> 4][j = 16 w + (l & 15)] -- the 64 lanes of one operand
+// read one contiguous 256-byte piece of the tile, straight from global memory (no LDS staging), converted to f64 once per
+// element.  The matrix core adds the four products to the accumulator one after the other, rows ascending (products of two
+// floats are exact in f64), so every entry is the sequential fma chain over the shard's rows that k_gram_part forms -- bit for
+// bit (tests/test_gpu_parity.py::test_gram_and_mpm compares both with the oracle's chain).  D layout: lane l, register v holds
+// row (l >> 4) + 4 v, column l & 15 (cdna_hip_programming.md, f64 MFMA).
+typedef double ngp_d4 __attribute__((ext_vector_type(4)));
+__global__ __launch_bounds__(256) void k_gram_part_mfma(const float *__restrict__ tiles, double *__restrict__ gpart, int R, int S, int t0, int d) {
+    const int s = blockIdx.x, tb = blockIdx.y, tid = threadIdx.x;
+    const int t = t0 + tb;
+    if (t - d < 0) return;  // block-uniform
+    const int w = tid >> 6, l = tid & 63;
+    const size_t tile_elems = (size_t)R * NGP_BLK;
+    const float *src_t = tiles + ((size_t)t * S + s) * tile_elems;
+    const float *src_a = tiles + ((size_t)(t - d) * S + s) * tile_elems;
+    // element (row 4 q + (l >> 4), column c0 + (l & 15)) of a quad-major tile: q * 256 + (c0 + (l & 15)) * 4 + (l >> 4)
+    const int lo = (l & 15) * 4 + (l >> 4);
+    const float *pb = src_t + 64 * w + lo;
+    const float *pa = src_a + lo;
+    ngp_d4 acc0 = {0.0, 0.0, 0.0, 0.0}, acc1 = acc0, acc2 = acc0, acc3 = acc0;
+    const int nq = R >> 2;
+#pragma unroll 4
+    for (int q = 0; q < nq; q++) {
+        const double b = (double)pb[(size_t)q * 256];
+        const double a0 = (double)pa[(size_t)q * 256], a1 = (double)pa[(size_t)q * 256 + 64], a2 = (double)pa[(size_t)q * 256 + 128],
+                     a3 = (double)pa[(size_t)q * 256 + 192];
+        acc0 = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b, acc0, 0, 0, 0);
+        acc1 = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b, acc1, 0, 0, 0);
+        acc2 = __builtin_amdgcn_mfma_f64_16x16x4f64(a2, b, acc2, 0, 0, 0);
+        acc3 = __builtin_amdgcn_mfma_f64_16x16x4f64(a3, b, acc3, 0, 0, 0);
+    }
+    double *out = gpart + ((size_t)tb * S + s) * (NGP_BLK * NGP_BLK);
+    const int j = 16 * w + (l & 15), kr = l >> 4;
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        out[(size_t)(0 + kr + 4 * v) * NGP_BLK + j] = acc0[v];
+        out[(size_t)(16 + kr + 4 * v) * NGP_BLK + j] = acc1[v];
+        out[(size_t)(32 + kr + 4 * v) * NGP_BLK + j] = acc2[v];
+        out[(size_t)(48 + kr + 4 * v) * NGP_BLK + j] = acc3[v];
+    }
+}
+
 // group sums over shards -> gramx[t][d][k][j]; d == 0 also fills mpm
 __global__ __launch_bounds__(256) void k_gram_reduce(const double *__restrict__ gpart, double *__restrict__ gramx,
                                                      double *__restrict__ mpm, int S, int t0, int nb, int d, int D) {

@@ -74,6 +74,18 @@ def test_gram_and_mpm(ngp, O):
     assert np.allclose(s.mpm(), np.diag(G), rtol=1e-12)
     b = np.random.default_rng(1).normal(size=150)
     assert np.allclose(s.xbeta(b), X.astype(np.float64) @ b, rtol=1e-11, atol=1e-11)
+    # The Gram window is built on the matrix cores (v_mfma_f64_16x16x4_f64); the fp64 VALU kernel it replaced (knob bit 10) forms the
+    # same sequential fma chains over the shard's rows: every plane of the window identical, and so the chains drawn with either
+    v = ngp.Sampler(device=0, seed=3, chain=0, mode=1, lag=6)
+    v.debug_set_knob(1024); v.set_panel(X)
+    m = ngp.Sampler(device=0, seed=3, chain=0, mode=1, lag=6)
+    m.set_panel(X)
+    for t in range(3):
+        assert np.array_equal(v.gram(t), m.gram(t)) and np.array_equal(m.gram(t), o.get_gram(t))
+    assert np.array_equal(v.mpm(), m.mpm())
+    for q in (v, m):
+        add_sets(q, [(0, 150, "PR")], 0.01); q.set_y(y); q.run(8)     # lag 6: the cross planes d = 1..5 enter every block
+    assert np.array_equal(v.get_state()["beta"], m.get_state()["beta"]) and np.array_equal(v.get_state()["ycorr"], m.get_state()["ycorr"])
 
 
 def test_generated_panel_matches_oracle(ngp, O):
