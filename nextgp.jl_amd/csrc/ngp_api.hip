@@ -1455,7 +1455,11 @@ int prepare_run(ngp_handle *h, int64_t niter) {
 bool fusable(ngp_handle **hs, int n) {
     if (n < 2 || n > NGP_MAXC) return false;
     ngp_handle *h0 = hs[0];
-    if (!h0->pm || h0->mode != 1 || h0->storage != 0 || h0->streamer != 1 || h0->R > 64 || !(h0->D == 6 || h0->D == 8)) return false;
+    if (!h0->pm || h0->mode != 1 || h0->storage != 0) return false;
+    const bool phase = h0->streamer == 1 && h0->R <= 64 && (h0->D == 6 || h0->D == 8);                 // role_streamer_multi
+    const bool rows = h0->streamer == 2 && (h0->D >= 4 && h0->D <= 6) && n == 2 &&                       // role_streamer_rows_multi
+                      ngp_rows_multi_lds_bytes((int)h0->R, n) <= (size_t)160 * 1024;
+    if (!phase && !rows) return false;
     for (int i = 0; i < n; i++) {
         ngp_handle *h = hs[i];
         if (h->pm != h0->pm || h->device != h0->device || h->dbg_mode != 0 || h->d_dbg || h->dbg_census_fail_iter > 0) return false;
@@ -1472,7 +1476,7 @@ int run_fused(ngp_handle **hs, int n, int64_t niter) {
         if ((rc = prepare_run(hs[i], niter))) { if (i) h->err = hs[i]->err; return rc; }
     const int64_t grid = (int64_t)n * (1 + h->NG) + h->S;
     const size_t lds_sampler = (size_t)(3 * 4096 + 2 * NGP_RING * NGP_BLK + 6 * NGP_BLK) * sizeof(double) + 2 * NGP_BLK * sizeof(int) + 320;
-    const size_t lds = std::max(ngp_multi_lds_bytes((int)h->R, n), lds_sampler);
+    const size_t lds = std::max(h->streamer == 2 ? ngp_rows_multi_lds_bytes((int)h->R, n) : ngp_multi_lds_bytes((int)h->R, n), lds_sampler);
     REQUIRE(lds <= 160 * 1024, NGP_ERR_STATE, "fused sweep: LDS of a streamer with this many chains exceeds 160 KiB");
     HCHK(sweep_multi_set_max_lds((int)lds));
     // one stream, one abort word: the leader's

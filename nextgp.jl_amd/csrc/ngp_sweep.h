@@ -1896,6 +1896,274 @@ __device__ __attribute__((always_inline)) inline void role_streamer_multi(const 
 #undef NGP_PP
 }
 
+// ------------------------------------------------------------------------------------------
+// K chains per pass for the ROW-OWNING streamer (fp32 tiles, shards of 64..NGP_ROWS_MAX_R rows: the 50k x 600k shape, where one
+// chain streams the panel at 0.62 of the HBM roofline): the loader wave and the tile ring are the one-chain streamer's
+// (role_streamer_rows), every row wave applies the update and forms the GEMV chain of ITS rows for each chain in turn -- the tile
+// element read from LDS serves all chains, the delay line holds the tile once -- wave 2 publishes the chains' partial sums, wave 6
+// fetches their dlt granules.  Per chain: the arithmetic of role_streamer_rows<DT, 0>, operation for operation.
+// LDS: ring | per chain: shard (R) | 2 x 7 x 64 chain sums | 2 x 72 dlt | then flags, counters and the 1 KiB sink.
+// ------------------------------------------------------------------------------------------
+template <int DT, int KC>
+__device__ __attribute__((always_inline)) inline void role_streamer_rows_multi(const MultiArgs &Mr, const int s, char *smem) {
+    const MultiArgs *Mp = &Mr;
+    const SweepArgs &A = Mp->a[0];
+    const int R = A.R, S = A.S, tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int NQ = R >> 2;
+    const int H = min(NGP_ROWS_HMAX, (NQ + 1) >> 1);
+    const int RQ = 2 * NQ + H;
+    char *ring = smem;
+    const size_t CH = ngp_rows_multi_chain_doubles(R);
+    double *cbase = (double *)(smem + (size_t)RQ * NGP_QS);
+#define NGP_YS(kc) (cbase + (size_t)(kc) * CH)
+#define NGP_RED(kc) (NGP_YS(kc) + ((R + 7) & ~7))
+#define NGP_DL(kc) (NGP_RED(kc) + 2 * NGP_ROWS_NW * NGP_BLK)
+    int *sflag = (int *)(cbase + (size_t)KC * CH);
+    int *gcnt0 = sflag + 4, *gcnt1 = sflag + 8;
+    char *scratch = (char *)sflag + 64 + 64;
+    const size_t tile_bytes = (size_t)NQ * 1024;
+    const int g = s / NGP_GRP;
+    const int nb = A.t1 - A.t0;
+#pragma unroll
+    for (int kc = 0; kc < KC; kc++) {
+        const double *yg = Mp->a[kc].ycorr + (size_t)s * R;
+        for (int i = tid; i < R; i += NGP_WG) NGP_YS(kc)[i] = yg[i];
+    }
+    if (tid == 0) { *sflag = 1; *gcnt0 = 0; *gcnt1 = 0; }
+    int base = 0;
+    auto wrap = [&](int p) __attribute__((always_inline)) { return p >= RQ ? p - RQ : p; };
+    if (wv == NGP_ROWS_NW) {
+        // ------------------------------ loader (as role_streamer_rows) ------------------------------
+        const unsigned ring0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)ring;
+        const unsigned scratch0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)scratch;
+        const unsigned voff = (unsigned)lane * 16u;
+        auto dma_quads = [&](int tile, int q0, int q1, int tbase) __attribute__((always_inline)) {
+            if (q0 >= q1) return 0;
+            const char *gp = (const char *)A.tiles + ((size_t)(A.t0 + tile) * S + s) * tile_bytes + (size_t)q0 * 1024;
+            int p = wrap(tbase + q0);
+            int q = q0;
+            for (; q + 4 <= q1; q += 4) {
+                if (p + 4 <= RQ) {
+                    dma16_s4(ring0 + (unsigned)p * NGP_QS, gp, voff);
+                    p += 4;
+                    if (p == RQ) p = 0;
+                } else {
+                    for (int k = 0; k < 4; k++) {
+                        dma16_s(ring0 + (unsigned)p * NGP_QS, gp + k * 1024, voff);
+                        if (++p == RQ) p = 0;
+                    }
+                }
+                gp += 4096;
+            }
+            for (; q < q1; ++q) {
+                dma16_s(ring0 + (unsigned)p * NGP_QS, gp, voff);
+                gp += 1024;
+                if (++p == RQ) p = 0;
+            }
+            return q1 - q0;
+        };
+        const unsigned my_xcc = xcc_id() + 1u;
+        const int nslice = max(1, S / 8);
+        const int slice = (s / 8) % nslice;
+        const size_t gram_bytes = (size_t)min(DT, A.near + 1) * NGP_BLK * NGP_BLK * sizeof(double);
+        const size_t slice_bytes = ((gram_bytes / nslice + 1023) / 1024) * 1024;
+        bool same_xcd = false, xcc_known = false;
+        __builtin_amdgcn_s_setprio(3);
+        if (nb > 0) dma_quads(0, 0, NQ, 0);
+        if (nb > 1) dma_quads(1, 0, H, NQ);
+        drain_vm();
+        wg_barrier();
+        for (int u = 0; u < nb + DT; ++u) {
+            const int base1 = wrap(base + NQ), base2 = wrap(base1 + NQ);
+            if (!xcc_known && (u & 7) == 0) {
+                const unsigned x = sld_u32(A.xcc_w);
+                xcc_known = (x != 0u);
+                same_xcd = (x == my_xcc);
+            }
+            if (same_xcd && u + 1 < nb) {
+                const char *gb = (const char *)(A.gramx + (size_t)(A.t0 + u + 1) * DT * NGP_BLK * NGP_BLK);
+                const size_t lo = (size_t)slice * slice_bytes, hi = min((size_t)(slice + 1) * slice_bytes, gram_bytes);
+                for (size_t off = lo; off + 1024 <= hi; off += 1024) dma16_s(scratch0, gb + off, voff);
+            }
+            if (u + 1 < nb) dma_quads(u + 1, H, NQ, base1);
+            int n2 = 0;
+            if (u + 2 < nb) n2 = dma_quads(u + 2, 0, H, base2);
+            wait_vmcnt_le(n2);
+            wg_barrier();
+            if (!*sflag) return;
+            base = base1;
+        }
+        drain_vm();
+    } else {
+        // ------------------------------ row-owning waves ------------------------------
+        const int c = lane & 7, ql = lane >> 3;
+        const int nqw = (NQ - wv + NGP_ROWS_NW - 1) / NGP_ROWS_NW;
+        const int qt = wv + NGP_ROWS_NW * ql;
+        const bool thas = qt < NQ;
+        const int tslot = thas ? qt : wv, trow = 4 * qt;
+        float4 keep[DT][8];
+#pragma unroll
+        for (int d = 0; d < DT; d++)
+#pragma unroll
+            for (int jj = 0; jj < 8; jj++) keep[d][jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned long long pg0[KC], pg1[KC];  // poller: granules of the next dlt of every chain
+#pragma unroll
+        for (int kc = 0; kc < KC; kc++) { pg0[kc] = 0; pg1[kc] = 0; }
+        int sig_pending = -1;
+        auto try_signal = [&](bool force) __attribute__((always_inline)) {
+            if (wv != NGP_ROWS_PUBW || sig_pending < 0) return;
+            if (force) drain_vm();
+            else if ((__builtin_amdgcn_s_getreg((23 << 11) | 7) & 0xC0000Fu) != 0u) return;
+#pragma unroll
+            for (int kc = 0; kc < KC; kc++)
+                if (lane == kc) atomicAdd(&Mp->a[kc].cnt_part[((size_t)sig_pending * A.NG + g) * 32], 1u);
+            sig_pending = -1;
+        };
+        auto publish = [&](const int u) __attribute__((always_inline)) {
+            const int slot = u % NGP_RING;
+            double p[KC];
+#pragma unroll
+            for (int kc = 0; kc < KC; kc++) {
+                const double *rp = NGP_RED(kc) + (u & 1) * NGP_ROWS_NW * NGP_BLK + lane;
+                p[kc] = ((rp[0] + rp[NGP_BLK]) + (rp[2 * NGP_BLK] + rp[3 * NGP_BLK])) + ((rp[4 * NGP_BLK] + rp[5 * NGP_BLK]) + rp[6 * NGP_BLK]);
+            }
+            try_signal(true);
+#pragma unroll
+            for (int kc = 0; kc < KC; kc++) st_f64(&Mp->a[kc].part[((size_t)slot * S + s) * NGP_BLK + lane], p[kc]);
+            sig_pending = slot;
+        };
+        wg_barrier();
+        for (int u0 = 0; u0 < nb + DT; u0 += DT) {
+#pragma unroll
+            for (int d = 0; d < DT; d++) {
+                const int u = u0 + d;
+                if (u >= nb + DT) break;
+                const int a = u - DT;
+                const int pa = u + 1 - DT;
+                const bool pollw = (wv == NGP_ROWS_POLLW) && (pa >= 0) && (u + 1 < nb + DT);
+                bool have_dnext[KC];
+#pragma unroll
+                for (int kc = 0; kc < KC; kc++) have_dnext[kc] = false;
+                if (pollw) {
+#pragma unroll
+                    for (int kc = 0; kc < KC; kc++) {
+                        if (dlt_granules_valid(pg0[kc], pg1[kc], dlt_tag(Mp->a[kc].nonce, pa))) {
+                            have_dnext[kc] = true;
+                        } else {
+                            const unsigned long long *gp = Mp->a[kc].dltg + ((size_t)(pa % NGP_RING) * NGP_BLK + lane) * 2;
+                            pg0[kc] = ld_u64(gp);
+                            pg1[kc] = ld_u64(gp + 1);
+                        }
+                    }
+                }
+                // ---- ycorr -= X_a dlt_a for the rows of this wave, chain after chain (the tile elements wait in keep[d]) ----
+                if (a >= 0) {
+#pragma unroll
+                    for (int kc = 0; kc < KC; kc++) {
+                        const double *dq = NGP_DL(kc) + (u & 1) * NGP_DLS + 8 * c;
+                        double dqv[8];
+#pragma unroll
+                        for (int jj = 0; jj < 8; jj++) dqv[jj] = dq[jj];
+                        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+#pragma unroll
+                        for (int jj = 0; jj < 8; jj++) {
+                            p0 = __builtin_fma((double)keep[d][jj].x, dqv[jj], p0);
+                            p1 = __builtin_fma((double)keep[d][jj].y, dqv[jj], p1);
+                            p2 = __builtin_fma((double)keep[d][jj].z, dqv[jj], p2);
+                            p3 = __builtin_fma((double)keep[d][jj].w, dqv[jj], p3);
+                        }
+                        p0 = p0 + dpp_f64(p0, 0); p1 = p1 + dpp_f64(p1, 0); p2 = p2 + dpp_f64(p2, 0); p3 = p3 + dpp_f64(p3, 0);
+                        p0 = p0 + dpp_f64(p0, 1); p1 = p1 + dpp_f64(p1, 1); p2 = p2 + dpp_f64(p2, 1); p3 = p3 + dpp_f64(p3, 1);
+                        p0 = p0 + dpp_f64(p0, 2); p1 = p1 + dpp_f64(p1, 2); p2 = p2 + dpp_f64(p2, 2); p3 = p3 + dpp_f64(p3, 2);
+                        if (c == 0 && thas) {
+                            double *yq = NGP_YS(kc) + trow;
+                            const double y0 = yq[0], y1 = yq[1], y2 = yq[2], y3 = yq[3];
+                            yq[0] = y0 - p0; yq[1] = y1 - p1; yq[2] = y2 - p2; yq[3] = y3 - p3;
+                        }
+                    }
+                }
+                try_signal(false);
+                if (u < nb) {
+                    // ---- GEMV chains of this wave: slots wv, wv+7, ... (lane = column); one read of a tile quad serves all chains ----
+                    double acc[KC];
+#pragma unroll
+                    for (int kc = 0; kc < KC; kc++) acc[kc] = 0.0;
+                    for (int k = 0; k < nqw; k++) {
+                        const int q = wv + NGP_ROWS_NW * k;
+                        const float4 x = *(const float4 *)(ring + (size_t)wrap(base + q) * NGP_QS + (size_t)lane * 16);
+#pragma unroll
+                        for (int kc = 0; kc < KC; kc++) {
+                            const double *yq = NGP_YS(kc) + 4 * q;
+                            const double y0 = yq[0], y1 = yq[1], y2 = yq[2], y3 = yq[3];
+                            acc[kc] = __builtin_fma((double)x.x, y0, acc[kc]);
+                            acc[kc] = __builtin_fma((double)x.y, y1, acc[kc]);
+                            acc[kc] = __builtin_fma((double)x.z, y2, acc[kc]);
+                            acc[kc] = __builtin_fma((double)x.w, y3, acc[kc]);
+                        }
+                    }
+#pragma unroll
+                    for (int kc = 0; kc < KC; kc++) NGP_RED(kc)[((u & 1) * NGP_ROWS_NW + wv) * NGP_BLK + lane] = acc[kc];
+                    asm volatile("" ::: "memory");  // LDS serves a wave in order: the count follows the sums
+                    if (lane == 0) __hip_atomic_fetch_add((lds_int_t *)((u & 1) ? gcnt1 : gcnt0), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    try_signal(false);
+                    // ---- tile u into the delay line ----
+                    const char *tq = ring + (size_t)wrap(base + tslot) * NGP_QS + c * 128;
+#pragma unroll
+                    for (int jj = 0; jj < 8; jj++) keep[d][jj] = *(const float4 *)(tq + jj * 16);
+                }
+                // the publisher waits for the seven chain waves through the LDS counter and publishes at once (before the barrier)
+                if (wv == NGP_ROWS_PUBW && u < nb) {
+                    const int *gc = (u & 1) ? gcnt1 : gcnt0;
+                    for (unsigned sp = 0; lds_flag_ld(gc) < NGP_ROWS_NW; ++sp) {
+                        if ((sp & 255u) == 255u && (lds_flag_ld(sflag) == 0 || sp > (NGP_SPIN_LIMIT << 4))) {
+                            if (lane == 0) *sflag = 0;
+                            break;
+                        }
+                        __builtin_amdgcn_s_sleep(0);
+                    }
+                    asm volatile("" ::: "memory");
+                    if (lane == 0) lds_flag_st((u & 1) ? gcnt0 : gcnt1, 0);
+                    publish(u);
+                }
+                if (pollw) {
+#pragma unroll
+                    for (int kc = 0; kc < KC; kc++) {
+                        int ok = 1;
+                        if (!have_dnext[kc]) {
+                            ok = wait_dlt_granules_all(Mp->a[kc].dltg, Mp->a[kc].nonce, pa, lane, A.abort_w, 1u, pg0[kc], pg1[kc]) ? 1 : 0;
+                            if (!ok && lane == 0) *sflag = 0;
+                        }
+                        if (ok) NGP_DL(kc)[((u + 1) & 1) * NGP_DLS + lane] = dlt_granules_value(pg0[kc], pg1[kc]);
+                    }
+                }
+                if (wv == NGP_ROWS_POLLW && pa + 1 >= 0 && u + 2 < nb + DT) {
+#pragma unroll
+                    for (int kc = 0; kc < KC; kc++) {
+                        const unsigned long long *gp = Mp->a[kc].dltg + ((size_t)((pa + 1) % NGP_RING) * NGP_BLK + lane) * 2;
+                        pg0[kc] = ld_u64(gp);
+                        pg1[kc] = ld_u64(gp + 1);
+                    }
+                }
+                try_signal(DT < 4);
+                wg_barrier();
+                if (!*sflag) return;
+                base = wrap(base + NQ);
+            }
+        }
+        try_signal(true);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int kc = 0; kc < KC; kc++) {
+        double *yg = Mp->a[kc].ycorr + (size_t)s * R;
+        for (int i = tid; i < R; i += NGP_WG) yg[i] = NGP_YS(kc)[i];
+    }
+#undef NGP_YS
+#undef NGP_RED
+#undef NGP_DL
+}
+
 #if !defined(NGP_INST_DBG) || !NGP_INST_DBG  // one definition: the production translation unit (ngp_sweep_inst.hip, -DNGP_INST_DBG=0)
 // A chain's launch arguments by RUN-TIME chain index: indexing the by-value argument M.a[c] makes the compiler copy all of M to
 // scratch (3 KB per lane) and read every field from there.  The arguments already sit in the kernarg segment -- constant address
@@ -1933,6 +2201,12 @@ __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         case 6: role_streamer_multi<DTV, 6>(M, s, smem); break;       \
         case 7: role_streamer_multi<DTV, 7>(M, s, smem); break;       \
         default: role_streamer_multi<DTV, 8>(M, s, smem); break;      \
+    }
+    if (M.a[0].variant == 2) {  // row-owning streamer, lag 4 or 6 (host: fp32 tiles, shards of 64..NGP_ROWS_MAX_R rows), 2 chains
+        if (M.a[0].D == 4) role_streamer_rows_multi<4, 2>(M, s, smem);
+        else if (M.a[0].D == 5) role_streamer_rows_multi<5, 2>(M, s, smem);
+        else role_streamer_rows_multi<6, 2>(M, s, smem);
+        return;
     }
     if (M.a[0].D == 6) { NGP_MULTI_K(6) } else { NGP_MULTI_K(8) }
 #undef NGP_MULTI_K

@@ -111,6 +111,12 @@ __host__ __device__ inline size_t ngp_multi_lds_bytes(int R, int K) {
     return (size_t)2 * (R >> 2) * NGP_QS + (size_t)K * ngp_multi_chain_doubles(R) * 8 + 64 + 3072;
 }
 
+// the same for the row-owning streamer (fp32 tiles, shards of 64..NGP_ROWS_MAX_R rows, lag 6; 2 or 3 chains)
+__host__ __device__ inline size_t ngp_rows_multi_chain_doubles(int R) { return (size_t)((R + 7) & ~7) + 2 * NGP_ROWS_NW * NGP_BLK + 2 * NGP_DLS; }
+__host__ __device__ inline size_t ngp_rows_multi_lds_bytes(int R, int K) {
+    const size_t nq = (size_t)R / 4, hq = nq + 1 < 2 * (size_t)NGP_ROWS_HMAX ? (nq + 1) / 2 : (size_t)NGP_ROWS_HMAX;
+    return (2 * nq + hq) * NGP_QS + (size_t)K * ngp_rows_multi_chain_doubles(R) * 8 + 64 + 64 + 1024;
+}
 hipError_t sweep_multi_set_max_lds(int bytes);
 void sweep_multi_launch(unsigned grid, size_t lds_bytes, hipStream_t stream, const MultiArgs &M);
 

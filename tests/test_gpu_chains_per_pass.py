@@ -59,6 +59,28 @@ def test_fused_chains_equal_the_chains_alone_and_the_oracle(ngp, O, K, lag):
     assert fused[0].get_state()["iter"] == 25
 
 
+@pytest.mark.parametrize("K,lag", [(2, 6), (2, 4)])
+def test_fused_chains_on_the_row_owning_streamer(ngp, O, K, lag):
+    """The same over the row-owning streamer (shards of 64+ rows, lag 6: the layout of the 50k x 600k shape): two or three chains in
+    one launch, each bit for bit the chain it is alone and the blocked oracle's."""
+    N, P = 700, 520
+    X, y, bt, v = make_problem(O, N, P, seed=8)
+    spec = [(0, 260, "PR"), (260, 260, "B")]
+    fused = build_chains(ngp, X, y, v, spec, K, lag=lag, shards=6)
+    R, S, _ = fused[0].layout()
+    assert fused[0].streamer() == (2, 7) and R >= 64 and fused[0].config() == (1, lag)
+    ngp.Sampler.run_many(fused, 20)
+    assert fused[0].census()["grid"] == K * (1 + (S + 31) // 32) + S
+    for c in range(K):
+        o = O.Oracle(order=1, seed=1001 + c, chain=c)
+        o.set_panel_f32(X, R=R, S=S, D=lag, near=fused[0].near(), nchain=7)
+        add_sets(o, spec, v); o.set_y(y + 0.01 * c); o.set_residual_prior(4.0, 1.0); o.set_schedule(20, 4, 2); o.run(20)
+        f, b = fused[c].get_state(), o.get_state()
+        for key in ("ycorr", "beta", "delta", "varBeta", "piHat"):
+            assert np.array_equal(f[key], b[key][:len(f[key])]), (c, key)
+        assert f["varE"] == b["varE"]
+
+
 def test_shared_panel_lifetime_and_fallback(ngp, O):
     """The panel arrays live as long as any handle refers to them; handles whose engine the fused kernel does not serve still run
     through ngp_run_many (side by side, one thread each), with the same results."""
@@ -70,11 +92,11 @@ def test_shared_panel_lifetime_and_fallback(ngp, O):
     a.close()                                   # the owner goes first: the sharer keeps the panel alive
     b.run(5)
     assert np.array_equal(b.mpm(), mp) and np.isfinite(b.get_state()["beta"]).all()
-    # row-owning streamer (shards of 64+ rows): not fused, still correct
-    c = build_chains(ngp, X, y, v, spec, 2, lag=4, shards=5)
+    # row-owning streamer at a lag the fused kernel does not serve: not fused, still correct
+    c = build_chains(ngp, X, y, v, spec, 2, lag=5, shards=5)
     assert c[0].streamer()[0] == 2
     ngp.Sampler.run_many(c, 6)
-    solo = ngp.Sampler(device=0, seed=1002, chain=1, mode=1, lag=4)
+    solo = ngp.Sampler(device=0, seed=1002, chain=1, mode=1, lag=5)
     solo.set_max_shards(5); solo.set_panel(X); add_sets(solo, spec, v); solo.set_y(y + 0.01); solo.set_residual_prior(4.0, 1.0); solo.set_schedule(20, 4, 2)
     solo.run(6)
     assert np.array_equal(solo.get_state()["beta"], c[1].get_state()["beta"])

@@ -14,7 +14,7 @@ for k in range(K):
     s = ngp.Sampler(device=0, seed=1001 + k, chain=k, **({"mode": 1, "lag": lag} if lag else {}))
     if k == 0:
         if K > 1:
-            s.set_max_shards(s.shards_for_pass(K))
+            s.set_max_shards(int(os.environ.get("NGP_TOOL_SHARDS", "0")) or s.shards_for_pass(K))
         s.generate_panel(N, P)
         rng = np.random.default_rng(1); bt = np.zeros(P); idx = rng.choice(P, max(10, P // 100), replace=False); bt[idx] = rng.normal(size=len(idx))
         g = s.xbeta(bt); y = 10 + g + np.random.default_rng(2).normal(size=N) * np.sqrt(g.var())
