@@ -22,7 +22,7 @@ from typing import Optional
 
 import numpy as np
 
-from ._lib import METHOD_BAYESB, METHOD_BAYESC, METHOD_BAYESPR, Sampler
+from ._lib import METHOD_BAYESB, METHOD_BAYESC, METHOD_BAYESPR, Sampler, tuple_columns, tuple_panel, tuple_span
 
 __all__ = ["BayesPR", "BayesB", "BayesC", "BayesR", "Random", "SNP", "runLMEM", "summaryMCMC", "read_genotypes", "read_panel_file", "is_panel_file", "prep2RegionData", "parse_formula", "design_columns", "samples_to_out_files"]
 
@@ -33,7 +33,7 @@ __all__ = ["BayesPR", "BayesB", "BayesC", "BayesR", "Random", "SNP", "runLMEM", 
 @dataclass
 class BayesPRType:  # src/runTime.jl:30-45
     r: int
-    v: float
+    v: object       # a variance, or -- for correlated marker sets, VCV key (:M1, :M2) -- their k x k covariance matrix (src/mme.jl:493-516)
     name: str = "BayesPR"
 
 
@@ -77,7 +77,7 @@ class GenomicTerm:  # src/runTime.jl:13-28
 
 
 def BayesPR(r, v, name="BayesPR"):
-    return BayesPRType(int(r), float(v), name)
+    return BayesPRType(int(r), float(v) if np.ndim(v) == 0 else np.asarray(v, dtype=np.float64), name)
 
 
 def BayesB(pi, v, name="BayesB", estimatePi=False):
@@ -293,6 +293,13 @@ def _out(folder, name, row):
         f.write("\t".join(row) + "\n")
 
 
+def _var_names(s):
+    """Header of var<set>Out: reg_r (src/mme.jl:593-595); for correlated sets one column per entry of the region's k x k matrix."""
+    if s["k"] > 1:
+        return [f"reg_{r + 1}_{a + 1}{b + 1}" for r in range(s["nreg"]) for a in range(s["k"]) for b in range(s["k"])]
+    return [f"reg_{r + 1}" for r in range(s["nvb"])]
+
+
 def _fmt(x):
     return [repr(float(v)) for v in np.atleast_1d(x)]
 
@@ -319,17 +326,17 @@ def samples_to_out_files(sample_path, outFolder, sets, intercept, has_fixed):
         rows("varE", ["\t".join(_fmt(S["varE"][i]))])
     vb_off, cls_off = 0, 0
     for k, s in enumerate(sets):
-        sl = slice(s["col0"], s["col0"] + s["P"])
         K = len(s["prior"].pi) if isinstance(s["prior"], BayesRType) else 0
         for i in range(n):
-            rows(f"beta{s['name']}", ["\t".join(_fmt(S["beta"][i, sl]))])
-            rows(f"delta{s['name']}", ["\t".join(str(int(v)) for v in S["delta"][i, sl])])
+            for m, nm in enumerate(s["members"]):
+                rows(f"beta{nm}", ["\t".join(_fmt(S["beta"][i, s["cols"][:, m]]))])
+                rows(f"delta{nm}", ["\t".join(str(int(v)) for v in S["delta"][i, s["cols"][:, m]])])
             if isinstance(s["prior"], (BayesBType, BayesCType)):
                 rows(f"pi{s['name']}", ["\t".join(_fmt(S["piHat"][i, 2 * k:2 * k + 2]))])
             if K:
                 rows(f"pi{s['name']}", ["\t".join(_fmt(S["class_pi"][i, cls_off:cls_off + K]))])
-            rows(f"var{s['name']}", ["\t".join(_fmt(S["varBeta"][i, vb_off:vb_off + s["nreg"]]))])
-        vb_off += s["nreg"]
+            rows(f"var{s['name']}", ["\t".join(_fmt(S["varBeta"][i, vb_off:vb_off + s["nvb"]]))])
+        vb_off += s["nvb"]
         cls_off += K
     for name, lines in files.items():
         with open(os.path.join(outFolder, f"{name}Out"), "a") as f:
@@ -383,7 +390,45 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
         mats = conv
     if not all(M.dtype == np.uint8 for M in mats):  # one byte per genotype only when every set comes that way
         mats = [np.asarray(M, dtype=np.float64) for M in mats]
-    panel = np.asfortranarray(np.concatenate(mats, axis=1))
+    # Correlated marker sets: a VCV key that is a TUPLE of set names (src/mme.jl:448-489) joins those sets into one unit whose loci
+    # draw their k effects together (src/functions.jl:140-154).  On the device the k columns of a locus sit side by side, from a
+    # 64-column boundary on (ngp_add_marker_set_tuple): the panel is assembled accordingly, everything else in formula order.
+    by_name = {t.name: i for i, t in enumerate(snps)}
+    tuples = [key for key in VCV if isinstance(key, tuple)]
+    in_tuple = {}
+    for key in tuples:
+        if not all(nm in by_name for nm in key):
+            raise ValueError(f"correlated marker sets {key}: every member needs its SNP(...) term")
+        if len({mats[by_name[nm]].shape[1] for nm in key}) != 1:
+            raise ValueError("correlated marker sets must have the same loci (src/mme.jl:453)")
+        if len({snps[by_name[nm]].map for nm in key}) != 1:
+            raise ValueError("correlated marker sets must have the same map file!")          # src/mme.jl:453
+        if any(nm in summaryStat for nm in key):
+            raise ValueError("Not available to use summary statistics in correlated effects")  # src/mme.jl:469
+        for nm in key:
+            in_tuple[nm] = key
+    units, pieces, ncols = [], [], 0          # units: ("set", name) | ("tuple", key), in formula order of their first member
+    done_t = set()
+    for t in snps:
+        if t.name in in_tuple:
+            key = in_tuple[t.name]
+            if key in done_t:
+                continue
+            done_t.add(key)
+            pad = (-ncols) % 64
+            if pad:
+                pieces.append(np.zeros((len(y), pad), dtype=mats[0].dtype)); ncols += pad
+            blk = tuple_panel([np.asfortranarray(mats[by_name[nm]]) for nm in key])
+            nloc = mats[by_name[key[0]]].shape[1]
+            units.append(("tuple", key, ncols, nloc))
+            pieces.append(blk); ncols += blk.shape[1]
+            pad = (-ncols) % 64                  # the set owns its blocks to the end of the last one
+            if pad:
+                pieces.append(np.zeros((len(y), pad), dtype=mats[0].dtype)); ncols += pad
+        else:
+            units.append(("set", t.name, ncols, mats[by_name[t.name]].shape[1]))
+            pieces.append(mats[by_name[t.name]]); ncols += mats[by_name[t.name]].shape[1]
+    panel = np.asfortranarray(np.concatenate(pieces, axis=1))
     smp = Sampler(device=device, seed=seed, chain=chain, storage=storage, **(dict(mode=engine[0], lag=engine[1]) if engine else {}))
     smp.set_panel(panel, centre=True)  # centring: src/prepMatVec.jl:129
     # residual prior (src/mme.jl:63-94)
@@ -419,10 +464,26 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
         else:
             smp.add_fixed_set(Xc)
         fixed_names += names
-    # marker sets (src/mme.jl:287-347, 492-520)
-    sets, col0 = [], 0
-    for t, M in zip(snps, mats):
-        P = M.shape[1]
+    # marker sets (src/mme.jl:287-347, 492-520; correlated sets :448-489)
+    sets = []
+    for unit in units:
+        if unit[0] == "tuple":
+            _, key, col0, nloc = unit
+            prior = VCV[key]
+            k = len(key)
+            if not isinstance(prior, BayesPRType) or np.shape(prior.v) != (k, k):
+                raise NotImplementedError(f"correlated marker sets {key}: BayesPR(r, v) with v the {k} x {k} covariance matrix (src/mme.jl:448-489)")
+            df = 3.0 + k                                                   # src/mme.jl:493
+            vm = np.asarray(prior.v, dtype=np.float64)
+            scale = vm * (df - k - 1.0) if k > 1 else vm * (df - 2.0) / df  # src/mme.jl:501
+            t0 = snps[by_name[key[0]]]
+            regions = _regions_for(prior, nloc, t0.map, outFolder, "_".join(key))
+            sid = smp.add_marker_set_tuple(col0, nloc, k, df, scale, regions, vm)
+            cols = tuple_columns(col0, nloc, k)
+            sets.append(dict(id=sid, name="_".join(key), members=list(key), cols=cols, P=nloc, prior=prior, nreg=len(regions), nvb=len(regions) * k * k, k=k))
+            continue
+        _, name, col0, P = unit
+        t = snps[by_name[name]]
         prior = VCV.get(t.name)
         if prior is None:  # src/mme.jl:324-329, 504, 518
             prior = BayesPR(9999, 0.05)
@@ -446,8 +507,8 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
             sid = smp.add_marker_set_r(col0, P, df, scale, prior.v, prior.class_, prior.pi, estPi=prior.estimatePi, lhs0=lhs0, rhs0=rhs0)
         else:
             sid = smp.add_marker_set(col0, P, METHOD_BAYESPR, df, scale, regions, [prior.v] * len(regions), lhs0=lhs0, rhs0=rhs0)
-        sets.append(dict(id=sid, name=t.name, col0=col0, P=P, prior=prior, nreg=len(regions)))
-        col0 += P
+        sets.append(dict(id=sid, name=t.name, members=[t.name], cols=np.arange(col0, col0 + P)[:, None], P=P, prior=prior, nreg=len(regions),
+                         nvb=P if isinstance(prior, BayesBType) else len(regions), k=1))
     smp.set_y(y)
     smp.set_schedule(nChain, nBurn, nThin)
     # header rows (src/mme.jl:543-595)
@@ -456,13 +517,14 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
         _out(outFolder, "varE", ["e"])
         for s in sets:
             names = [f"M{i + 1}" for i in range(s["P"])]  # src/prepMatVec.jl:131
-            _out(outFolder, f"beta{s['name']}", names)
-            _out(outFolder, f"delta{s['name']}", names)
+            for nm in s["members"]:
+                _out(outFolder, f"beta{nm}", names)
+                _out(outFolder, f"delta{nm}", names)
             if isinstance(s["prior"], (BayesBType, BayesCType)):  # src/samplers.jl:80-82
                 _out(outFolder, f"pi{s['name']}", ["pi1", "pi2"])
             if isinstance(s["prior"], BayesRType):               # one column per class (src/mme.jl:589-591)
                 _out(outFolder, f"pi{s['name']}", [f"pi{v + 1}" for v in range(len(s["prior"].pi))])
-            _out(outFolder, f"var{s['name']}", [f"reg_{r + 1}" for r in range(s["nreg"])])
+            _out(outFolder, f"var{s['name']}", _var_names(s))
     # the chain (src/samplers.jl:29-105): kept iterations = burnIn+thin : thin : chainLength
     done = 0
     if samples not in ("text", "text-sync", "binary", "none"):
@@ -479,15 +541,15 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
             _out(outFolder, "varE", _fmt(st["varE"]))
             vb_off = 0
             for k, s in enumerate(sets):
-                sl = slice(s["col0"], s["col0"] + s["P"])
-                _out(outFolder, f"beta{s['name']}", _fmt(st["beta"][sl]))
-                _out(outFolder, f"delta{s['name']}", [str(int(v)) for v in st["delta"][sl]])
+                for m, nm in enumerate(s["members"]):
+                    _out(outFolder, f"beta{nm}", _fmt(st["beta"][s["cols"][:, m]]))
+                    _out(outFolder, f"delta{nm}", [str(int(v)) for v in st["delta"][s["cols"][:, m]]])
                 if isinstance(s["prior"], (BayesBType, BayesCType)):
                     _out(outFolder, f"pi{s['name']}", _fmt(st["piHat"][2 * k:2 * k + 2]))
                 if isinstance(s["prior"], BayesRType):
                     _out(outFolder, f"pi{s['name']}", _fmt(smp.get_class_state(s["id"])["piHat"]))
-                _out(outFolder, f"var{s['name']}", _fmt(st["varBeta"][vb_off:vb_off + s["nreg"]]))
-                vb_off += s["nreg"]
+                _out(outFolder, f"var{s['name']}", _fmt(st["varBeta"][vb_off:vb_off + s["nvb"]]))
+                vb_off += s["nvb"]
     smp.run(nChain - done)
     if samples in ("text", "binary"):
         smp.set_sample_file(None)
@@ -500,11 +562,14 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
                fixed=smp.get_fixed()["sum_b"] / n if len(fixed_names) > int(intercept) else np.zeros(0))
     vb_off = 0
     for k, s in enumerate(sets):
-        sl = slice(s["col0"], s["col0"] + s["P"])
-        res["sets"][s["name"]] = dict(beta=ps["sum_beta"][sl] / n, delta=ps["sum_delta"][sl] / n,
-                                      var=ps["sum_varBeta"][vb_off:vb_off + s["nreg"]] / n, pi=ps["sum_pi"][2 * k:2 * k + 2] / n)
+        for m, nm in enumerate(s["members"]):
+            cm = s["cols"][:, m]
+            res["sets"][nm] = dict(beta=ps["sum_beta"][cm] / n, delta=ps["sum_delta"][cm] / n,
+                                   var=ps["sum_varBeta"][vb_off:vb_off + s["nvb"]] / n, pi=ps["sum_pi"][2 * k:2 * k + 2] / n)
+            if s["k"] > 1:   # correlated sets: the posterior mean of every region's k x k covariance matrix
+                res["sets"][nm]["var"] = (ps["sum_varBeta"][vb_off:vb_off + s["nvb"]] / n).reshape(s["nreg"], s["k"], s["k"])
         if isinstance(s["prior"], BayesRType):
             res["sets"][s["name"]]["pi"] = smp.get_class_state(s["id"])["sum_pi"] / n
-        vb_off += s["nreg"]
+        vb_off += s["nvb"]
     res["sampler"] = smp
     return res

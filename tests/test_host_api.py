@@ -244,3 +244,43 @@ def test_runLMEM_compact_storage(ngp, O, tmp_path):
     np.savetxt(frac, G + 0.25, fmt="%.2f", delimiter=" ")
     with pytest.raises(ValueError, match="integer genotype codes"):
         ngp.runLMEM(f'y ~ 1 + SNP(M,"{frac}")', {"y": y}, 4, 1, 1, outFolder=str(tmp_path / "bad"), VCV=VCV, storage="u8")
+
+
+@pytest.mark.gpu
+def test_runLMEM_correlated_marker_sets(ngp, O, tmp_path):
+    """A VCV key that is a tuple of set names = correlated marker sets (src/mme.jl:448-489): sampleBayesPR!(::Tuple), src/functions.jl:140-154.
+    The mirror interleaves the members' columns for the device and writes beta / delta files per member, one var file for the tuple."""
+    N, nloc = 150, 70
+    X1 = O.generate_panel(N, 2 * nloc + 40, seed=5)[0]
+    G = np.rint(X1.astype(np.float64) - X1.astype(np.float64).min(axis=0))          # raw 0/1/2 genotypes
+    rng = np.random.default_rng(4)
+    y = 2.0 + (G[:, 3] - G[:, 3].mean()) * 0.7 - (G[:, nloc + 3] - G[:, nloc + 3].mean()) * 0.4 + rng.normal(size=N)
+    files = []
+    for i, sl in enumerate((slice(0, nloc), slice(nloc, 2 * nloc), slice(2 * nloc, 2 * nloc + 40))):
+        f = tmp_path / f"g{i}.txt"; np.savetxt(f, G[:, sl], fmt="%d", delimiter=" "); files.append(f)
+    vm = np.array([[0.02, 0.008], [0.008, 0.03]])
+    VCV = {("A", "B"): ngp.BayesPR(9999, vm), "C": ngp.BayesPR(9999, 0.01), "e": ngp.Random("I", 0.5 * y.var())}
+    out = tmp_path / "out"
+    res = ngp.runLMEM(f'y ~ 1 + SNP(A,"{files[0]}") + SNP(B,"{files[1]}") + SNP(C,"{files[2]}")', {"y": y}, 16, 4, 2, outFolder=str(out), VCV=VCV, seed=6)
+    assert res["nKept"] == 6 and res["sets"]["A"]["var"].shape == (1, 2, 2)
+    # the same model on the reference-order oracle: members interleaved from column 0, the plain set behind the tuple's last block
+    Gc = G - G.mean(axis=0)
+    Xt = ngp.tuple_panel([np.asfortranarray(Gc[:, :nloc]), np.asfortranarray(Gc[:, nloc:2 * nloc])])
+    off = -(-Xt.shape[1] // 64) * 64
+    Xp = np.asfortranarray(np.hstack([Xt, np.zeros((N, off - Xt.shape[1])), Gc[:, 2 * nloc:]]).astype(np.float32))
+    o = O.Oracle(0, seed=6, chain=0)
+    o.set_panel_f32(Xp)
+    o.add_marker_set_tuple(0, nloc, 2, 5.0, vm * 2.0, [(0, nloc)], vm)
+    o.add_marker_set(off, 40, 0, 4.0, 0.01 * 0.5, [(0, 40)], [0.01])
+    o.set_y(y); o.set_residual_prior(4.0, 0.5 * y.var() * 0.5); o.set_schedule(16, 4, 2); o.run(16)
+    ps = o.get_posterior_sums()
+    cols = ngp.tuple_columns(0, nloc, 2)
+    for m, nm in enumerate(("A", "B")):
+        assert np.abs(res["sets"][nm]["beta"] - ps["sum_beta"][cols[:, m]] / 6).max() < 1e-9
+    assert np.abs(res["sets"]["C"]["beta"] - ps["sum_beta"][off:off + 40] / 6).max() < 1e-9
+    assert np.allclose(res["sets"]["A"]["var"].ravel(), ps["sum_varBeta"][:4] / 6, rtol=1e-8)
+    for name, ncol in (("betaA", nloc), ("betaB", nloc), ("deltaA", nloc), ("betaC", 40), ("varA_B", 4), ("varC", 1)):
+        lines = (out / f"{name}Out").read_text().splitlines()
+        assert len(lines) == 7 and len(lines[0].split("\t")) == ncol, name
+    assert (out / "varA_BOut").read_text().splitlines()[0].split("\t") == ["reg_1_11", "reg_1_12", "reg_1_21", "reg_1_22"]
+    assert np.allclose(ngp.summaryMCMC("betaB", outFolder=str(out))[0], res["sets"]["B"]["beta"], rtol=0, atol=1e-12)
