@@ -94,6 +94,72 @@ function add_marker_set_r!(h::Handle, col0::Integer, ncol::Integer, df::Float64,
     return id[]
 end
 
+# Correlated marker sets -- sampleBayesPR!(::Tuple), src/functions.jl:140-154, set-up src/mme.jl:448-489.  M[pSet].data is a Vector of
+# N x k matrices X_l (src/mme.jl:456-457); on the device the k columns of a locus sit side by side, floor(64 / k) loci per 64-column
+# block from a block boundary on (include/nextgp_hip.h, ngp_add_marker_set_tuple).  tuple_panel builds that block of the panel,
+# tuple_columns says where component m of locus l went (1-based panel columns), add_marker_set_tuple! declares the set:
+# df = M[pSet].df (3 + k), scale = M[pSet].scale (k x k), regionArray in loci, v = varBeta[pSet][1] (k x k).
+function tuple_columns(col0::Integer, nloc::Integer, k::Integer)      # col0: 0-based first panel column of the set (a multiple of 64)
+    Lb = 64 ÷ k
+    return [col0 + 64 * ((l - 1) ÷ Lb) + k * ((l - 1) % Lb) + m for l in 1:nloc, m in 1:k]   # 1-based panel column of (locus l, component m)
+end
+function tuple_panel(data::Vector{Matrix{Float64}})                   # data[l] = X_l, N x k
+    nloc, (N, k) = length(data), size(data[1])
+    Lb = 64 ÷ k; nblk = cld(nloc, Lb)
+    out = zeros(Float64, N, 64 * nblk)                                # the set owns its blocks to the end of the last one
+    cols = tuple_columns(0, nloc, k)
+    for l in 1:nloc, m in 1:k
+        out[:, cols[l, m]] .= data[l][:, m]
+    end
+    return out
+end
+function add_marker_set_tuple!(h::Handle, col0::Integer, nloc::Integer, k::Integer, df::Float64, scale::Matrix{Float64}, regionArray,
+                               v::Matrix{Float64})
+    rs = Int64[first(r) - 1 for r in regionArray]
+    re = Int64[last(r) for r in regionArray]
+    id = Ref{Int32}(0)
+    sc = Matrix{Float64}(permutedims(scale)); vb = Matrix{Float64}(permutedims(v))   # row-major for the C side (both are symmetric)
+    check(h, ccall((:ngp_add_marker_set_tuple, LIB), Int32,
+                   (Ptr{Cvoid}, Int64, Int64, Int32, Float64, Ptr{Float64}, Ptr{Int64}, Ptr{Int64}, Int64, Ptr{Float64}, Ref{Int32}),
+                   h.ptr, col0, nloc, k, df, sc, rs, re, length(rs), vb, id))
+    return id[]
+end
+
+# K chains per pass over the panel: h takes owner's panel by reference (no copy); run_many! then gives all of them ONE sweep
+# launch per iteration.  shards_for_pass: the max_shards the first handle needs (before its panel is set) so that K chains fit.
+share_panel!(h::Handle, owner::Handle) = check(h, ccall((:ngp_share_panel, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}), h.ptr, owner.ptr))
+function shards_for_pass(h::Handle, chains::Integer)
+    v = Ref{Int32}(0)
+    check(h, ccall((:ngp_shards_for_pass, LIB), Int32, (Ptr{Cvoid}, Int32, Ref{Int32}), h.ptr, chains, v))
+    return Int(v[])
+end
+
+# Kept samples to a binary file while the chain runs (instead of a text row per kept iteration, src/samplers.jl:56-104): call before
+# run!, close with `nothing`; nextgp.jl_amd/api.py (samples_to_out_files) or the reader below turn the file into the *Out tables.
+set_sample_file!(h::Handle, path::Union{AbstractString,Nothing}) =
+    check(h, path === nothing ? ccall((:ngp_set_sample_file, LIB), Int32, (Ptr{Cvoid}, Ptr{UInt8}), h.ptr, C_NULL) :
+                                ccall((:ngp_set_sample_file, LIB), Int32, (Ptr{Cvoid}, Cstring), h.ptr, path))
+function read_sample_file(path::AbstractString)
+    open(path, "r") do io
+        String(read(io, 8)) == "NGPSMP01" || error("not a sample file: $path")
+        P, nvb, nsets, nfix, ncls, rec = ntuple(_ -> read(io, Int64), 6)
+        sets = [ntuple(_ -> read(io, Int64), 6) for _ in 1:nsets]     # (method, K, col0, ncol, variance entries, tuple k)
+        nd = 3 + nfix + P + nvb + 2 * nsets + ncls
+        samples = NamedTuple[]
+        while !eof(io)
+            raw = read(io, rec)
+            length(raw) == rec || break
+            d = reinterpret(Float64, raw[1:8 * nd])
+            o = 3
+            push!(samples, (iter = reinterpret(Int64, raw[1:8])[1], varE = d[2], b = d[3], b_fixed = d[o + 1:o + nfix],
+                            beta = d[o + nfix + 1:o + nfix + P], varBeta = d[o + nfix + P + 1:o + nfix + P + nvb],
+                            piHat = d[o + nfix + P + nvb + 1:o + nfix + P + nvb + 2 * nsets],
+                            class_pi = d[o + nfix + P + nvb + 2 * nsets + 1:nd], delta = raw[8 * nd + 1:8 * nd + P]))
+        end
+        return (sets = sets, samples = samples)
+    end
+end
+
 function class_state(h::Handle, set_id::Integer)
     pi = zeros(8); sp = zeros(8); K = Ref{Int64}(0)
     check(h, ccall((:ngp_get_class_state, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Ref{Int64}), h.ptr, set_id, pi, sp, K))
