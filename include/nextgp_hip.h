@@ -255,7 +255,7 @@ int32_t ngp_get_storage(ngp_handle *h, int32_t *storage, double *means, int64_t 
 int32_t ngp_debug_set_mode(ngp_handle *h, int32_t mode);
 /* Tuning knob of the row-owning streamer: pacing of its loader wave, 0..4 = s_sleep units (64 clocks) after every four tile
  * requests (default 0), + 16 = count every partial before the block's barrier, + 1024 (before the panel is set) = build the Gram window
- * with the fp64 VALU kernel instead of the matrix cores (v_mfma_f64_16x16x4_f64: the same sums in the same order).  Changes timing
+ * on the matrix cores (v_mfma_f64_16x16x4_f64) instead of the fp64 VALU kernel: the same sums in the same order, bit for bit.  Changes timing
  * only, never results. */
 int32_t ngp_debug_set_knob(ngp_handle *h, int32_t knob);
 

@@ -164,7 +164,7 @@ struct ngp_handle {
     int64_t sweep_launches = 0;
     // diagnostics (ngp_debug_set_mode): != 0 makes every chain invalid, ngp_run / ngp_sweep_set then return NGP_ERR_DEBUG
     int dbg_mode = 0;
-    int gram_engine = 0;  // 0: Gram window on the matrix cores (k_gram_part_mfma), 1: fp64 VALU (k_gram_part); set through the knob's bit 10
+    int gram_engine = 0;  // 0: Gram window by the fp64 VALU kernel (k_gram_part), 1: on the matrix cores (k_gram_part_mfma, bit-identical); the knob's bit 10
     int knob = 0;  // pacing of the loader wave of the row-owning streamer: s_sleep units after every four requests (ngp_debug_set_knob)
     bool adding_r = false;  // ngp_add_marker_set is being called by ngp_add_marker_set_r
     bool poisoned = false;  // a sweep gave up half-way (abort word): the chain state is unusable until ngp_set_y / ngp_set_state
@@ -511,10 +511,10 @@ int build_gram(ngp_handle *h) {
     for (int d = 0; d < h->D; d++)
         for (int64_t t0 = 0; t0 < h->NBLK; t0 += nb_max) {
             int nb = (int)std::min<int64_t>(nb_max, h->NBLK - t0);
-            if (h->gram_engine == 1)  // fp64 VALU contraction (diagnostic: ngp_debug_set_knob bit 10 before the panel is set)
+            if (h->gram_engine == 0)  // fp64 VALU contraction: the default (1.63 ms per launch at 50k x 600k against 1.84 on the matrix cores)
                 hipLaunchKernelGGL(k_gram_part, dim3((unsigned)h->S, (unsigned)nb), dim3(256), 0, h->stream, h->d_tiles, d_gpart, (int)h->R,
                                    (int)h->S, (int)t0, d);
-            else                      // matrix cores: v_mfma_f64_16x16x4_f64, the same sums in the same order
+            else                      // matrix cores (ngp_debug_set_knob bit 10 before the panel is set): v_mfma_f64_16x16x4_f64, the same sums in the same order
                 hipLaunchKernelGGL(k_gram_part_mfma, dim3((unsigned)h->S, (unsigned)nb), dim3(256), 0, h->stream, h->d_tiles, d_gpart, (int)h->R,
                                    (int)h->S, (int)t0, d);
             long long ne = (long long)nb * NGP_BLK * NGP_BLK;
@@ -1898,7 +1898,7 @@ int32_t ngp_debug_set_knob(ngp_handle *h, int32_t knob) {
     int rc;
     if ((rc = enter(h))) return rc;
     h->knob = knob;
-    h->gram_engine = (knob & 1024) ? 1 : 0;  // bit 10: build the Gram window with the fp64 VALU kernel instead of the matrix cores (same bits)
+    h->gram_engine = (knob & 1024) ? 1 : 0;  // bit 10: build the Gram window on the matrix cores instead of the fp64 VALU kernel (same bits)
     return NGP_OK;
     NGP_CATCH(h)
 }

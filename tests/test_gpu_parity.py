@@ -74,8 +74,9 @@ def test_gram_and_mpm(ngp, O):
     assert np.allclose(s.mpm(), np.diag(G), rtol=1e-12)
     b = np.random.default_rng(1).normal(size=150)
     assert np.allclose(s.xbeta(b), X.astype(np.float64) @ b, rtol=1e-11, atol=1e-11)
-    # The Gram window is built on the matrix cores (v_mfma_f64_16x16x4_f64); the fp64 VALU kernel it replaced (knob bit 10) forms the
-    # same sequential fma chains over the shard's rows: every plane of the window identical, and so the chains drawn with either
+    # The Gram window can be built on the matrix cores (v_mfma_f64_16x16x4_f64, knob bit 10): the matrix core adds the four products of
+    # a quad in row order, i.e. forms the same sequential fma chains over the shard's rows as the fp64 VALU kernel -- every plane of the
+    # window identical, and so the chains drawn with either
     v = ngp.Sampler(device=0, seed=3, chain=0, mode=1, lag=6)
     v.debug_set_knob(1024); v.set_panel(X)
     m = ngp.Sampler(device=0, seed=3, chain=0, mode=1, lag=6)

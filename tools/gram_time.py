@@ -1,4 +1,4 @@
-"""Set-up time of a generated panel with the Gram window on the matrix cores (default) and on the fp64 VALU kernel (knob bit 10):
+"""Set-up time of a generated panel with the Gram window by the fp64 VALU kernel (default) and on the matrix cores (knob bit 10):
 python tools/gram_time.py N P"""
 import os, sys, time
 import numpy as np
@@ -7,7 +7,7 @@ from ngp_pkg import load_pkg
 ngp = load_pkg()
 N, P = int(sys.argv[1]), int(sys.argv[2])
 ref = None
-for name, knob in (("mfma", 0), ("valu", 1024), ("mfma", 0)):
+for name, knob in (("valu", 0), ("mfma", 1024), ("valu", 0), ("mfma", 1024)):
     s = ngp.Sampler(device=0, seed=1, chain=0)
     s.debug_set_knob(knob)
     t0 = time.perf_counter(); s.generate_panel(N, P); dt = time.perf_counter() - t0
