@@ -1635,8 +1635,8 @@ __device__ __attribute__((always_inline)) inline void role_streamer_multi(const 
     double *cbase = (double *)(smem + 2 * TBL);
     int *sflag = (int *)(cbase + (size_t)KC * CH);
     char *scratch = (char *)sflag + 64;  // 3 KiB sink of the L2-warming DMA
-#define NGP_YS(kc) (cbase + (size_t)(kc) * CH)   /* 2 x R: the chain's shard of ycorr, by block parity */
-#define NGP_RED(kc) (NGP_YS(kc) + 2 * R)         /* 8 x 64 GEMV chain sums */
+#define NGP_YS(kc) (cbase + (size_t)(kc) * CH)   /* R: the chain's shard of ycorr */
+#define NGP_RED(kc) (NGP_YS(kc) + R)             /* 8 x 64 GEMV chain sums */
 #define NGP_DL(kc) (NGP_RED(kc) + 512)           /* 2 x 64: dlt of the block being applied, by block parity */
 #define NGP_PP(kc) (NGP_DL(kc) + 128)            /* 8 x R: partial sums of the update */
     const size_t tile_elems = (size_t)R * NGP_BLK;
@@ -1765,39 +1765,18 @@ __device__ __attribute__((always_inline)) inline void role_streamer_multi(const 
                 wg_barrier();
                 try_signal(false);
             }
-            // lane i < R of EVERY wave holds the updated y_i of this iteration, chain by chain; wave 0 stores it for the next one
-            double yn[KC];
-#pragma unroll
-            for (int g0 = 0; g0 < KC; g0 += NGP_MULTI_G) {
-                constexpr int GN = NGP_MULTI_G;
-                double pv[GN][8];
-#pragma unroll
-                for (int q = 0; q < GN; q++)
-                    if (g0 + q < KC) {
-                        yn[g0 + q] = 0.0;
-                        if (j < R) {
-                            yn[g0 + q] = NGP_YS(g0 + q)[(size_t)(u & 1) * R + j];
-                            if (a >= 0) {
-#pragma unroll
-                                for (int c = 0; c < 8; c++) pv[q][c] = NGP_PP(g0 + q)[(size_t)c * R + j];
-                            }
-                        }
-                    }
-                if (j < R) {
-                    if (a >= 0) {
-#pragma unroll
-                        for (int q = 0; q < GN; q++)
-                            if (g0 + q < KC) {
-                                const double T = ((pv[q][0] + pv[q][1]) + (pv[q][2] + pv[q][3])) + ((pv[q][4] + pv[q][5]) + (pv[q][6] + pv[q][7]));
-                                yn[g0 + q] = yn[g0 + q] - T;
-                            }
-                    }
-                    if (wv == 0) {
-#pragma unroll
-                        for (int q = 0; q < GN; q++)
-                            if (g0 + q < KC) NGP_YS(g0 + q)[(size_t)((u & 1) ^ 1) * R + j] = yn[g0 + q];
-                    }
+            // the updated shard of chain c is formed ONCE, by wave c (lane = row: tree of the 8 partial sums), and read by every wave's
+            // GEMV from LDS behind a barrier -- formed by every wave for itself (what the one-chain streamer does to save this
+            // barrier) it cost 30 KB of LDS reads per chain and block, and its v_readlane-fed GEMV 32 readlanes per quad and chain
+            if (a >= 0) {
+                if (wv < KC && j < R) {
+                    double *ys = NGP_YS(wv);
+                    const double *pp = NGP_PP(wv);
+                    const double T = ((pp[j] + pp[R + j]) + (pp[2 * R + j] + pp[3 * R + j])) +
+                                     ((pp[4 * R + j] + pp[5 * R + j]) + (pp[6 * R + j] + pp[7 * R + j]));
+                    ys[j] = ys[j] - T;
                 }
+                wg_barrier();
             }
             // ---------------- phase C: partial X_u' ycorr of every chain, and tile u into the delay line ----------------
             if (u < nb) {
@@ -1829,8 +1808,9 @@ __device__ __attribute__((always_inline)) inline void role_streamer_multi(const 
 #pragma unroll
                             for (int q = 0; q < GN; q++)
                                 if (g0 + q < KC) {
+                                    const double *yq = NGP_YS(g0 + q) + 4 * qd;  // (one address for the whole wave: a broadcast read)
 #pragma unroll
-                                    for (int e = 0; e < 4; e++) y[q][e] = readlane_d(yn[g0 + q], 4 * qd + e);
+                                    for (int e = 0; e < 4; e++) y[q][e] = yq[e];
                                 }
 #pragma unroll
                             for (int q = 0; q < GN; q++) if (g0 + q < KC) acc[g0 + q] = __builtin_fma((double)x.x, y[q][0], acc[g0 + q]);
@@ -1886,7 +1866,7 @@ __device__ __attribute__((always_inline)) inline void role_streamer_multi(const 
     __syncthreads();
 #pragma unroll
     for (int kc = 0; kc < KC; kc++) {
-        const double *yfin = NGP_YS(kc) + (size_t)((nb + DT) & 1) * R;
+        const double *yfin = NGP_YS(kc);
         double *yg = Mp->a[kc].ycorr + (size_t)s * R;
         for (int i = tid; i < R; i += NGP_WG) yg[i] = yfin[i];
     }

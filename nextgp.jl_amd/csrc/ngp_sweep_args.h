@@ -105,8 +105,8 @@ struct ChainPtrs {  // what a streamer needs of one chain (LDS copy: lanes index
     unsigned *cnt_part;
     const unsigned *flag_dlt;
 };
-// doubles of per-chain LDS state of a multi-chain streamer: shard 2 x R (parity) | 8 x 64 chain sums | 2 x 64 dlt | 8 x R update partials
-__host__ __device__ inline size_t ngp_multi_chain_doubles(int R) { return (size_t)2 * R + 512 + 128 + (size_t)8 * R; }
+// doubles of per-chain LDS state of a multi-chain streamer: shard R | 8 x 64 chain sums | 2 x 64 dlt | 8 x R update partials
+__host__ __device__ inline size_t ngp_multi_chain_doubles(int R) { return (size_t)R + 512 + 128 + (size_t)8 * R; }
 __host__ __device__ inline size_t ngp_multi_lds_bytes(int R, int K) {
     return (size_t)2 * (R >> 2) * NGP_QS + (size_t)K * ngp_multi_chain_doubles(R) * 8 + 64 + 3072;
 }
