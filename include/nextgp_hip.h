@@ -206,7 +206,12 @@ int32_t ngp_eval_math(ngp_handle *h, int32_t which, const double *in, int64_t n,
  * 0 = automatic, 1 = phase streamer (every shard height), 2 = row-owning waves + loader wave (shards of at most 224 rows,
  * lags 3..6; the default for shards of 64 to 224 rows).  Both replace the loop of src/functions.jl:124-136; they differ in
  * the summation order of the shard partial of X_t'ycorr only: ngp_get_streamer reports the variant in force and the number of
- * GEMV chains per partial (8 or 7), which the blocked oracle needs like R, S, lag and near lags. */
+ * GEMV chains per partial (8 or 7), which the blocked oracle needs like R, S, lag and near lags.
+ * 4 / 6 = variant 2 with TWO / THREE shards per streamer workgroup (lag 3 / lag 2): what fp32 panels of more than 63,232 rows (one
+ * resident wave of 256-row shards) run in automatically -- two up to 107,520 rows, three up to 156,576 on 256 CUs; the layout (R, S)
+ * and every result are those of variant 2 with that layout and lag, only the grid is S / 2 or S / 3 streamers (ngp_get_streamer
+ * reports 2).  Taller fp32 panels fall back to the per-block engine (mode 0) -- or take the compact storage, whose shards reach
+ * 896 rows. */
 int32_t ngp_set_streamer(ngp_handle *h, int32_t variant);
 int32_t ngp_get_streamer(ngp_handle *h, int32_t *variant, int32_t *gemv_chains);
 

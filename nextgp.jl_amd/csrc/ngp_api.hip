@@ -94,7 +94,9 @@ struct ngp_handle {
     int max_shards_req = 0;  // streamer workgroups the persistent sweep may use (0 = all CUs but the sampler's and the reducers')
     int storage = 0;       // 0: centred fp32 tiles; 1: compact -- byte tiles + Float64 column means (ngp_set_storage)
     double *d_mean = nullptr;  // compact storage: column means, Ppad
-    int streamer_req = 0;  // streamer variant requested: 0 automatic, 1 phase streamer, 2 row-owning waves + loader wave
+    int streamer_req = 0;  // streamer variant requested: 0 automatic, 1 phase streamer, 2 row-owning waves + loader wave, 4 / 6 = 2 with
+                           // two / three shards per workgroup at any N (automatic only above one resident wave of 256-row shards)
+    int V = 1;             // shards per streamer workgroup (role_streamer_rows_tall: 2, 3); the sweep's grid has S / V streamers
     int streamer = 1;      // variant in force (persistent sweep only)
     int nchain = 8;        // GEMV chains per shard partial: 8 (phase streamer, per-block engine) or 7 (row-owning waves)
     int D = 1;         // Gram planes stored per block (= lag in mode 1, 1 in mode 0)
@@ -244,7 +246,7 @@ struct CuLease {
         if (h->mode != 1) return;
         // workgroups are handed to the 8 XCDs in turn, so a grid occupies ceil(grid / 8) CUs of EVERY XCD: the unit of the lease
         // (three grids of 85 workgroups -- 255 of 256 CUs -- do not fit: 3 x 11 > 32 per XCD; measured, they wait for each other)
-        dev = h->device & 63; want = (int)(((grid_override > 0 ? grid_override : 1 + h->NG + h->S) + 7) / 8);
+        dev = h->device & 63; want = (int)(((grid_override > 0 ? grid_override : 1 + h->NG + h->S / h->V) + 7) / 8);
         cap = std::max(1, h->cu_count / 8);
         acquire(h->exclusive);
     }
@@ -326,9 +328,11 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P, ngp_handle *owner = nullptr
         h->mode = owner->mode; h->lag = owner->lag; h->lag_auto = owner->lag_auto; h->near_req = owner->near_req; h->near = owner->near;
         h->max_shards_req = owner->max_shards_req; h->storage = owner->storage; h->streamer_req = owner->streamer_req;
         h->streamer = owner->streamer; h->nchain = owner->nchain; h->D = owner->D; h->NG = owner->NG; h->R = owner->R; h->S = owner->S;
+        h->V = owner->V;
     } else {
     // persistent mode: sampler + reducers + S streamers must all be resident, one workgroup per CU
     int64_t max_shards = 256;
+    h->V = 1;
     if (h->storage == 1) {
         // compact storage: byte tiles, units of 16 rows, the row-owning roles only (persistent sweep)
         REQUIRE(h->mode == 1, NGP_ERR_ARG, "compact storage runs in the persistent sweep (ngp_configure mode 1) only");
@@ -354,7 +358,23 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P, ngp_handle *owner = nullptr
     if (h->mode == 1) {
         max_shards = h->cu_count - 1 - (h->cu_count + NGP_GRP - 1) / NGP_GRP;
         if (h->max_shards_req > 0) max_shards = std::min<int64_t>(max_shards, h->max_shards_req);
-        if (N > max_shards * 256) h->mode = 0;  // too many rows for one resident wave of streamers (2 LDS tile slots + partials)
+        // Taller than one resident wave of 256-row shards: every streamer workgroup owns V = 2 (lag 3) or 3 (lag 2) shards of at
+        // most 224 rows (role_streamer_rows_tall) -- S = V W shards, W workgroups, 1 + ceil(V W / 32) + W <= CUs.
+        int tallV = 0;
+        int64_t w_max = 0;
+        for (int v = 2; v <= 3 && !tallV; v++) {
+            if (h->streamer_req != 0 && h->streamer_req != 2 * v) continue;
+            if (h->streamer_req == 0 && N <= max_shards * 256) continue;
+            int64_t w = h->cu_count - 1;
+            while (w > 1 && 1 + (v * w + NGP_GRP - 1) / NGP_GRP + w > h->cu_count) w--;
+            if (h->max_shards_req > 0) w = std::max<int64_t>(1, std::min<int64_t>(w, h->max_shards_req / v));
+            if (N <= v * w * NGP_ROWS_MAX_R && h->lag >= 3) { tallV = v; w_max = w; }
+        }
+        if (tallV) {
+            choose_layout(N, tallV * w_max, NGP_ROWS_MAX_R, &h->R, &h->S);
+            h->S = (h->S + tallV - 1) / tallV * tallV;  // (all-padding shards at the end if need be: zero tiles, zero rows of ycorr)
+            h->V = tallV;
+        } else if (N > max_shards * 256) h->mode = 0;  // too many rows for one resident wave of streamers (2 LDS tile slots + partials)
         else choose_layout(N, max_shards, 256, &h->R, &h->S);  // 8 R / 4 update tasks <= 512 threads, two 1040 R / 4 byte LDS slots
     }
     if (h->mode == 0) choose_layout(N, 256, 508, &h->R, &h->S);  // LDS bound of k_step: R*264 + 4096 <= 160 KiB
@@ -366,9 +386,11 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P, ngp_handle *owner = nullptr
     // (from 64-row shards on since the publisher stopped waiting for the block's barrier: 20k x 100k 3.66 -> 3.26 ms, 28k x 100k
     // 3.97 -> 3.45, 16k x 100k 3.38 -> 3.16, equal at 52-60 rows, the phase streamer ahead at 44 rows: 1.86 against 1.99 us per block)
     if (h->mode == 1 && h->R <= NGP_ROWS_MAX_R && h->lag >= 3 && (h->streamer_req == 2 || (h->streamer_req == 0 && h->R >= 64))) h->streamer = 2;
+    if (h->V > 1) h->streamer = 2;
     h->nchain = (h->streamer == 2) ? NGP_ROWS_NW : 8;
     if (h->streamer == 2) {
         if (h->D > 6) h->D = 6;  // register delay line: 32 VGPRs per lag
+        if (h->V > 1) h->D = (h->V == 2) ? 3 : 2;  // ... and per shard of the workgroup
     } else if (h->mode == 1 && h->R > 128 && h->D > 5) h->D = 5;  // tall shards: the register delay line holds 5 tiles at most
     // a fourth near lag overloads the sampler CU at short shards (+17 % time at 10k x 100k); the phase streamer of tall shards,
     // where with lag 5 nothing is left for the reducers then, saves 8 % with it; with the row-owning streamer (lag 6) the sampler
@@ -377,6 +399,8 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P, ngp_handle *owner = nullptr
     h->near = h->near_req ? h->near_req : ((h->mode == 1 && h->streamer == 2 && h->R >= 64) ? 2 : ((h->mode == 1 && h->R > 128) ? 4 : 3));
     }
     }
+    // the sampler adds more than 8 group sums only where it fetches them one block ahead (lags 2-3: fetch_group_sums)
+    if (h->mode == 1 && !owner) REQUIRE(h->NG <= 8 || h->D <= 3, NGP_ERR_STATE, "internal: more shard groups than the sampler adds");
     h->NBLK = (P + NGP_BLK - 1) / NGP_BLK;
     h->Ppad = h->NBLK * NGP_BLK;
     h->L = h->R * h->S;
@@ -445,7 +469,7 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P, ngp_handle *owner = nullptr
         if (2 * TB + misc + 8192 <= lds_max) h->lds_sweep = std::max(h->lds_sweep, 2 * TB + misc + 8192);  // room for the diagnostic timeline
         if (h->streamer >= 2) {  // ring of 2 NQ + H slots | shard | 2 x 7 x 64 chain partials | 2 x 72 dlt | 2 x 8 row sums | flags | 1 KiB sink
             const size_t nq = (h->streamer == 3) ? (size_t)h->R / 16 : (size_t)h->R / 4, hq = std::min<size_t>(NGP_ROWS_HMAX, (nq + 1) / 2);
-            const size_t need = (2 * nq + hq) * NGP_QS + (size_t)((h->R + 7) & ~7) * 8 + 2 * NGP_ROWS_NW * NGP_BLK * 8 + 2 * NGP_DLS * 8 + 16 * 8 + 64 + 1024;
+            const size_t need = (2 * nq + hq) * NGP_QS + (size_t)h->V * ((h->R + 7) & ~7) * 8 + 2 * NGP_ROWS_NW * NGP_BLK * 8 + 2 * NGP_DLS * 8 + 16 * 8 + 64 + 1024;
             h->lds_rows = need;
             h->lds_sweep = std::max(need, lds_sampler);
             if (need + 8192 <= lds_max) h->lds_sweep = std::max(h->lds_sweep, need + 8192);
@@ -457,8 +481,8 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P, ngp_handle *owner = nullptr
         // per CU.  Checked here, not assumed (a grid that does not fit would only show up as a spin timeout).
         int wg_per_cu = 0;
         HCHK(sweep_occupancy_0(&wg_per_cu, h->lds_sweep));
-        if (wg_per_cu < 1 || 1 + h->NG + h->S > (int64_t)wg_per_cu * h->cu_count)
-            return fail(h, NGP_ERR_STATE, "persistent sweep: grid of " + std::to_string(1 + h->NG + h->S) + " workgroups cannot be co-resident (" +
+        if (wg_per_cu < 1 || 1 + h->NG + h->S / h->V > (int64_t)wg_per_cu * h->cu_count)
+            return fail(h, NGP_ERR_STATE, "persistent sweep: grid of " + std::to_string(1 + h->NG + h->S / h->V) + " workgroups cannot be co-resident (" +
                                               std::to_string(wg_per_cu) + " per CU x " + std::to_string(h->cu_count) + " CUs); use ngp_configure(mode 0)");
         if ((rc = dalloc(h, &h->d_cpart, (size_t)NGP_RING * h->S * NGP_BLK))) return rc;
         if ((rc = dalloc(h, &h->d_cgsum, (size_t)NGP_RING * h->NG * NGP_BLK))) return rc;
@@ -611,7 +635,7 @@ bool is_kept(const ngp_handle *h, int64_t it) {  // src/samplers.jl:26
 void fill_sweep_args(ngp_handle *h, int64_t tb0, int64_t tb1, SweepArgs &A) {
     const int R = (int)h->R, S = (int)h->S;
     A.tiles = h->d_tiles; A.ycorr = h->d_ycorr; A.gramx = h->d_gramx;
-    A.D = h->D; A.R = R; A.S = S; A.NG = h->NG; A.near = h->near; A.fine_ok = 0; A.t0 = (int)tb0; A.t1 = (int)tb1;
+    A.V = h->V; A.D = h->D; A.R = R; A.S = S; A.NG = h->NG; A.near = h->near; A.fine_ok = 0; A.t0 = (int)tb0; A.t1 = (int)tb1;
     A.beta = h->d_beta; A.delta = h->d_delta; A.c = h->d_c; A.w = h->d_w; A.q = h->d_q; A.mpm = h->d_mpm; A.chi = h->d_chi;
     A.setof = h->d_setof; A.vbidx = h->d_vbidx; A.sets = h->d_sets; A.varBeta = h->d_varBeta;
     A.rcls = h->d_rcls; A.rhs0 = h->d_rhs0; A.scal = h->d_scal; A.Ppad = h->Ppad;
@@ -639,12 +663,12 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
         // (the hand-off counters were zeroed by k_prep, which precedes every sweep in the stream)
         SweepArgs A;
         fill_sweep_args(h, tb0, tb1, A);
-        h->last_grid = 1 + h->NG + S;
+        h->last_grid = 1 + h->NG + S / h->V;
         if (evs) (void)hipEventRecord(evs[0], h->stream);
-        if (h->d_dbg || h->dbg_mode)  // diagnostic instantiation: stamps and timing modes exist only there
-            sweep_launch_1((unsigned)(1 + h->NG + S), h->lds_sweep, h->stream, A);
+        if ((h->d_dbg || h->dbg_mode) && h->V == 1)  // diagnostic instantiation: stamps and timing modes exist only there
+            sweep_launch_1((unsigned)h->last_grid, h->lds_sweep, h->stream, A);
         else
-            sweep_launch_0((unsigned)(1 + h->NG + S), h->lds_sweep, h->stream, A);
+            sweep_launch_0((unsigned)h->last_grid, h->lds_sweep, h->stream, A);
         if (evs) (void)hipEventRecord(evs[1], h->stream);
         h->sweep_launches += 1;
         return;
@@ -666,7 +690,7 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
 
 // placement census of the last sweep launch (SweepArgs.census_tbl): who arrived, and where
 std::string census_report(ngp_handle *h) {
-    const size_t grid = (size_t)(h->last_grid > 0 ? h->last_grid : 1 + h->NG + h->S);
+    const size_t grid = (size_t)(h->last_grid > 0 ? h->last_grid : 1 + h->NG + h->S / h->V);
     std::vector<unsigned long long> tb(grid, 0ull);
     if (!h->d_census_tbl || hipMemcpy(tb.data(), h->d_census_tbl, grid * sizeof(unsigned long long), hipMemcpyDeviceToHost) != hipSuccess) return "(no census)";
     int per_xcc[16] = {0}, per_se[16][8] = {{0}};
@@ -1455,7 +1479,7 @@ int prepare_run(ngp_handle *h, int64_t niter) {
 bool fusable(ngp_handle **hs, int n) {
     if (n < 2 || n > NGP_MAXC) return false;
     ngp_handle *h0 = hs[0];
-    if (!h0->pm || h0->mode != 1 || h0->storage != 0) return false;
+    if (!h0->pm || h0->mode != 1 || h0->storage != 0 || h0->V != 1) return false;
     const bool phase = h0->streamer == 1 && h0->R <= 64 && (h0->D == 6 || h0->D == 8);                 // role_streamer_multi
     const bool rows = h0->streamer == 2 && (h0->D >= 4 && h0->D <= 6) && n == 2 &&                       // role_streamer_rows_multi
                       ngp_rows_multi_lds_bytes((int)h0->R, n) <= (size_t)160 * 1024;
@@ -1908,7 +1932,8 @@ int32_t ngp_set_streamer(ngp_handle *h, int32_t variant) {
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles == nullptr, NGP_ERR_STATE, "ngp_set_streamer must precede the panel upload");
-    REQUIRE(variant >= 0 && variant <= 2, NGP_ERR_ARG, "streamer variant: 0 (automatic), 1 (phase streamer) or 2 (row-owning waves)");
+    REQUIRE((variant >= 0 && variant <= 2) || variant == 4 || variant == 6, NGP_ERR_ARG,
+            "streamer variant: 0 (automatic), 1 (phase streamer), 2 (row-owning waves) or 4 / 6 (row-owning waves, two / three shards per workgroup)");
     h->streamer_req = variant;
     return NGP_OK;
     NGP_CATCH(h)
@@ -2691,7 +2716,7 @@ int32_t ngp_get_census(ngp_handle *h, uint64_t *out, int64_t n, int64_t *grid, i
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr && h->mode == 1, NGP_ERR_STATE, "no persistent sweep on this handle");
-    const int64_t g = h->last_grid > 0 ? h->last_grid : 1 + h->NG + h->S;
+    const int64_t g = h->last_grid > 0 ? h->last_grid : 1 + h->NG + h->S / h->V;
     if (grid) *grid = g;
     if (retries) *retries = h->census_retries;
     if (exclusive) *exclusive = h->exclusive ? 1 : 0;

@@ -968,6 +968,256 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows(const S
 }
 
 // ------------------------------------------------------------------------------------------
+// Row-owning streamer with V shards per workgroup (fp32 tiles of panels too tall for one resident wave of 224-row shards:
+// N above 63k).  The layout stays what it is everywhere else -- S shards of R <= 224 rows, one partial per shard and block, the
+// reducers' groups of 32 shards -- so the chain is, bit for bit, the chain of that layout; only the assignment changes: workgroup
+// s owns shards V s .. V s + V - 1 (the host makes S a multiple of V) and takes a block in V sub-steps, one tile each.  The LDS
+// ring (2 tiles + H quads), the loader wave, the one barrier per tile, the publisher and the poller are those of
+// role_streamer_rows; the delay line holds V tiles per lag (32 V VGPRs), so V = 2 runs at lag 3 and V = 3 at lag 2 -- enough
+// there: a block takes V times as long on the stream side, and the hand-off loop's latency is hidden by (lag - 1) block periods.
+template <int DT, int V>
+__device__ __attribute__((always_inline)) inline void role_streamer_rows_tall(const SweepArgs &A, const int s, char *smem) {
+    const int R = A.R, S = A.S, tid = threadIdx.x;
+    const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int NQ = R >> 2;
+    const int H = min(NGP_ROWS_HMAX, (NQ + 1) >> 1);
+    const int RQ = 2 * NQ + H;
+    const int RP = (R + 7) & ~7;
+    char *ring = smem;
+    double *ys = (double *)(smem + (size_t)RQ * NGP_QS);     // the V shards of ycorr, resident for the whole sweep
+    double *red = ys + V * RP;                               // 2 (sub-step parity) x 7 chains x 64 columns
+    double *dl = red + 2 * NGP_ROWS_NW * NGP_BLK;            // 2 (block parity) x 72: dlt of the block being applied
+    double *rsy = dl + 2 * NGP_DLS;                          // (only the chain counters live here)
+    int *sflag = (int *)(rsy + 16);
+    char *scratch = (char *)(rsy + 16) + 64;                 // 1 KiB sink of the L2-warming DMA
+    const size_t tile_bytes = (size_t)NQ * 1024;
+    const int sh0 = V * s;                                   // first shard of this workgroup
+    double *yg = A.ycorr + (size_t)sh0 * R;
+    const int nb = A.t1 - A.t0;
+    const int nv = (nb + DT) * V;                            // sub-steps of the sweep
+    for (int i = tid; i < V * R; i += NGP_WG) ys[(i / R) * RP + (i % R)] = yg[i];
+    int *gcnt0 = (int *)(rsy + 7), *gcnt1 = (int *)(rsy + 15);
+    if (tid == 0) { *sflag = 1; *gcnt0 = 0; *gcnt1 = 0; }
+    int base = 0;  // ring slot of quad 0 of the tile of this sub-step
+    auto wrap = [&](int p) __attribute__((always_inline)) { return p >= RQ ? p - RQ : p; };
+    if (wv == NGP_ROWS_NW) {
+        // ------------------------------ loader ------------------------------
+        const unsigned ring0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)ring;
+        const unsigned scratch0 = (unsigned)(size_t)(__attribute__((address_space(3))) const char *)scratch;
+        const unsigned voff = (unsigned)lane * 16u;
+        const int pace = A.knob & 7;
+        // quads [q0, q1) of the tile of sub-step w = (block w / V, shard sh0 + w % V) into ring slots tbase + q
+        auto dma_quads = [&](int w, int q0, int q1, int tbase) __attribute__((always_inline)) {
+            const int u = w / V, hh = w % V;
+            if (u >= nb || q0 >= q1) return 0;
+            const char *g = (const char *)A.tiles + ((size_t)(A.t0 + u) * S + sh0 + hh) * tile_bytes + (size_t)q0 * 1024;
+            int p = wrap(tbase + q0);
+            int q = q0;
+            for (; q + 4 <= q1; q += 4) {
+                if (p + 4 <= RQ) {
+                    dma16_s4(ring0 + (unsigned)p * NGP_QS, g, voff);
+                    p += 4;
+                    if (p == RQ) p = 0;
+                    switch (pace) {
+                        case 1: __builtin_amdgcn_s_sleep(1); break;
+                        case 2: __builtin_amdgcn_s_sleep(2); break;
+                        case 3: __builtin_amdgcn_s_sleep(3); break;
+                        case 4: __builtin_amdgcn_s_sleep(4); break;
+                        default: break;
+                    }
+                } else {
+                    for (int k = 0; k < 4; k++) {
+                        dma16_s(ring0 + (unsigned)p * NGP_QS, g + k * 1024, voff);
+                        if (++p == RQ) p = 0;
+                    }
+                }
+                g += 4096;
+            }
+            for (; q < q1; ++q) {
+                dma16_s(ring0 + (unsigned)p * NGP_QS, g, voff);
+                g += 1024;
+                if (++p == RQ) p = 0;
+            }
+            return q1 - q0;
+        };
+        const unsigned my_xcc = xcc_id() + 1u;
+        const int W = S / V;
+        const int nslice = max(1, W / 8);
+        const int slice = (s / 8) % nslice;
+        const size_t gram_bytes = (size_t)min(DT, A.near + 1) * NGP_BLK * NGP_BLK * sizeof(double);
+        const size_t slice_bytes = ((gram_bytes / nslice + 1023) / 1024) * 1024;
+        bool same_xcd = false, xcc_known = false;
+        __builtin_amdgcn_s_setprio(3);
+        dma_quads(0, 0, NQ, 0);
+        dma_quads(1, 0, H, NQ);
+        drain_vm();  // the first tile has landed
+        wg_barrier();
+        for (int w = 0; w < nv; ++w) {
+            const int base1 = wrap(base + NQ), base2 = wrap(base1 + NQ);
+            if (w % V == 0) {  // speed only: Gram blocks of the next block into the sampler's L2 (see role_streamer_rows)
+                const int u = w / V;
+                if (!xcc_known && (u & 7) == 0) {
+                    const unsigned x = sld_u32(A.xcc_w);
+                    xcc_known = (x != 0u);
+                    same_xcd = (x == my_xcc);
+                }
+                if (same_xcd && u + 1 < nb) {
+                    const char *gb = (const char *)(A.gramx + (size_t)(A.t0 + u + 1) * DT * NGP_BLK * NGP_BLK);
+                    const size_t lo = (size_t)slice * slice_bytes, hi = min((size_t)(slice + 1) * slice_bytes, gram_bytes);
+                    for (size_t off = lo; off + 1024 <= hi; off += 1024) dma16_s(scratch0, gb + off, voff);
+                }
+            }
+            dma_quads(w + 1, H, NQ, base1);
+            const int n2 = dma_quads(w + 2, 0, H, base2);
+            wait_vmcnt_le(n2);  // everything up to the last quad of the next tile has landed
+            wg_barrier();
+            if (!*sflag) return;
+            base = base1;
+        }
+        drain_vm();
+    } else {
+        // ------------------------------ row-owning waves ------------------------------
+        const int c = lane & 7, ql = lane >> 3;
+        const int nqw = (NQ - wv + NGP_ROWS_NW - 1) / NGP_ROWS_NW;
+        const int qt = wv + NGP_ROWS_NW * ql;      // the quad of this lane's update task
+        const bool thas = qt < NQ;
+        const int tslot = thas ? qt : wv, trow = 4 * qt;
+        float4 keep[DT][V][8];
+#pragma unroll
+        for (int d = 0; d < DT; d++)
+#pragma unroll
+            for (int hh = 0; hh < V; hh++)
+#pragma unroll
+                for (int jj = 0; jj < 8; jj++) keep[d][hh][jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+        unsigned long long pg0 = 0, pg1 = 0;
+        int sig_pending = -1;  // counter (slot x NG + group) of the stored, not yet counted partial
+        auto try_signal = [&](bool force) __attribute__((always_inline)) {
+            if (wv != NGP_ROWS_PUBW || sig_pending < 0) return;
+            if (force) drain_vm();
+            else if ((__builtin_amdgcn_s_getreg((23 << 11) | 7) & 0xC0000Fu) != 0u) return;
+            if (lane == 0) atomicAdd(&A.cnt_part[(size_t)sig_pending * 32], 1u);
+            sig_pending = -1;
+        };
+        auto publish = [&](const int u, const int hh, const int par) __attribute__((always_inline)) {
+            const int slot = u % NGP_RING;
+            const double *rp = red + par * NGP_ROWS_NW * NGP_BLK + lane;
+            const double p = ((rp[0] + rp[NGP_BLK]) + (rp[2 * NGP_BLK] + rp[3 * NGP_BLK])) + ((rp[4 * NGP_BLK] + rp[5 * NGP_BLK]) + rp[6 * NGP_BLK]);
+            try_signal(true);
+            st_f64(&A.part[((size_t)slot * S + sh0 + hh) * NGP_BLK + lane], p);
+            sig_pending = slot * A.NG + (sh0 + hh) / NGP_GRP;
+        };
+        wg_barrier();
+        for (int u0 = 0; u0 < nb + DT; u0 += DT) {
+#pragma unroll
+            for (int d = 0; d < DT; d++) {
+                const int u = u0 + d;
+                if (u >= nb + DT) break;
+                const int a = u - DT;  // block whose update is applied now (its tiles wait in keep[d])
+                const int pa = u + 1 - DT;
+#pragma unroll
+                for (int hh = 0; hh < V; hh++) {
+                    const int par = (V & 1) ? ((u * V + hh) & 1) : (hh & 1);
+                    double *ysh = ys + hh * RP;
+                    // poller (last sub-step of the block): dlt of the block applied in the next one
+                    const bool pollw = (wv == NGP_ROWS_POLLW) && (hh == V - 1) && (pa >= 0) && (u + 1 < nb + DT);
+                    bool have_dnext = false;
+                    if (pollw) {
+                        if (dlt_granules_valid(pg0, pg1, dlt_tag(A.nonce, pa))) {
+                            have_dnext = true;
+                        } else {
+                            const unsigned long long *gp = A.dltg + ((size_t)(pa % NGP_RING) * NGP_BLK + lane) * 2;
+                            pg0 = ld_u64(gp);
+                            pg1 = ld_u64(gp + 1);
+                        }
+                    }
+                    // ---- ycorr -= X_a dlt_a for the rows of this wave in shard hh ----
+                    if (a >= 0) {
+                        const double *dq = dl + (u & 1) * NGP_DLS + 8 * c;
+                        double dqv[8];
+#pragma unroll
+                        for (int jj = 0; jj < 8; jj++) dqv[jj] = dq[jj];
+                        double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+#pragma unroll
+                        for (int jj = 0; jj < 8; jj++) {
+                            p0 = __builtin_fma((double)keep[d][hh][jj].x, dqv[jj], p0);
+                            p1 = __builtin_fma((double)keep[d][hh][jj].y, dqv[jj], p1);
+                            p2 = __builtin_fma((double)keep[d][hh][jj].z, dqv[jj], p2);
+                            p3 = __builtin_fma((double)keep[d][hh][jj].w, dqv[jj], p3);
+                        }
+                        p0 = p0 + dpp_f64(p0, 0); p1 = p1 + dpp_f64(p1, 0); p2 = p2 + dpp_f64(p2, 0); p3 = p3 + dpp_f64(p3, 0);
+                        p0 = p0 + dpp_f64(p0, 1); p1 = p1 + dpp_f64(p1, 1); p2 = p2 + dpp_f64(p2, 1); p3 = p3 + dpp_f64(p3, 1);
+                        p0 = p0 + dpp_f64(p0, 2); p1 = p1 + dpp_f64(p1, 2); p2 = p2 + dpp_f64(p2, 2); p3 = p3 + dpp_f64(p3, 2);
+                        if (c == 0 && thas) {
+                            double *yq = ysh + trow;
+                            const double y0 = yq[0], y1 = yq[1], y2 = yq[2], y3 = yq[3];
+                            yq[0] = y0 - p0; yq[1] = y1 - p1; yq[2] = y2 - p2; yq[3] = y3 - p3;
+                        }
+                    }
+                    try_signal(false);
+                    if (u < nb) {
+                        // ---- GEMV chain of this wave over the tile of (block u, shard hh) ----
+                        double acc = 0.0;
+                        for (int k = 0; k < nqw; k++) {
+                            const int q = wv + NGP_ROWS_NW * k;
+                            const float4 x = *(const float4 *)(ring + (size_t)wrap(base + q) * NGP_QS + (size_t)lane * 16);
+                            const double *yq = ysh + 4 * q;
+                            const double y0 = yq[0], y1 = yq[1], y2 = yq[2], y3 = yq[3];
+                            acc = __builtin_fma((double)x.x, y0, acc);
+                            acc = __builtin_fma((double)x.y, y1, acc);
+                            acc = __builtin_fma((double)x.z, y2, acc);
+                            acc = __builtin_fma((double)x.w, y3, acc);
+                        }
+                        red[(par * NGP_ROWS_NW + wv) * NGP_BLK + lane] = acc;
+                        asm volatile("" ::: "memory");  // LDS serves a wave in order: the count follows the sum
+                        if (lane == 0) __hip_atomic_fetch_add((lds_int_t *)(par ? gcnt1 : gcnt0), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        try_signal(false);
+                        // ---- the tile into the delay line ----
+                        const char *tq = ring + (size_t)wrap(base + tslot) * NGP_QS + c * 128;
+#pragma unroll
+                        for (int jj = 0; jj < 8; jj++) keep[d][hh][jj] = *(const float4 *)(tq + jj * 16);
+                    }
+                    // publisher: waits for the seven chains through the counter in LDS, not for the barrier (see role_streamer_rows)
+                    if (wv == NGP_ROWS_PUBW && u < nb) {
+                        const int *gc = par ? gcnt1 : gcnt0;
+                        for (unsigned sp = 0; lds_flag_ld(gc) < NGP_ROWS_NW; ++sp) {
+                            if ((sp & 255u) == 255u && (lds_flag_ld(sflag) == 0 || sp > (NGP_SPIN_LIMIT << 4))) {
+                                if (lane == 0) *sflag = 0;
+                                break;
+                            }
+                            __builtin_amdgcn_s_sleep(0);
+                        }
+                        asm volatile("" ::: "memory");
+                        if (lane == 0) lds_flag_st(par ? gcnt0 : gcnt1, 0);  // the other parity: counted in the next sub-step, behind the barrier
+                        publish(u, hh, par);
+                    }
+                    if (pollw) {
+                        int ok = 1;
+                        if (!have_dnext) {
+                            ok = wait_dlt_granules_all(A.dltg, A.nonce, pa, lane, A.abort_w, 1u, pg0, pg1) ? 1 : 0;
+                            if (!ok && lane == 0) *sflag = 0;
+                        }
+                        if (ok) dl[((u + 1) & 1) * NGP_DLS + lane] = dlt_granules_value(pg0, pg1);
+                    }
+                    if (wv == NGP_ROWS_POLLW && hh == V - 1 && pa + 1 >= 0 && u + 2 < nb + DT) {
+                        const unsigned long long *gp = A.dltg + ((size_t)((pa + 1) % NGP_RING) * NGP_BLK + lane) * 2;
+                        pg0 = ld_u64(gp);
+                        pg1 = ld_u64(gp + 1);
+                    }
+                    // the count of a stored partial must not slip behind the barrier at lag 3 (see role_streamer_rows)
+                    try_signal(DT < 4 || (A.knob & 16));
+                    wg_barrier();
+                    if (!*sflag) return;
+                    base = wrap(base + NQ);
+                }
+            }
+        }
+        try_signal(true);
+    }
+    __syncthreads();
+    for (int i = tid; i < V * R; i += NGP_WG) yg[i] = ys[(i / R) * RP + (i % R)];
+}
+
+// ------------------------------------------------------------------------------------------
 // reducer g: every wave works on its own blocks (u = wave, wave+8, ...), no workgroup barrier
 template <bool DBG>
 __device__ __attribute__((always_inline)) inline void role_reducer(const SweepArgs &A, const int g, char *smem) {
@@ -1073,6 +1323,13 @@ __device__ __attribute__((always_inline)) inline bool fetch_group_sums(const Swe
 #pragma unroll
     for (int g = 1; g < 8; g++)
         if (g < NG) tot = tot + gv[g];
+    for (int g0 = 8; g0 < NG; g0 += 8) {  // several shards per streamer workgroup (lags 2-3): up to 699 shards = 22 groups, same order
+#pragma unroll
+        for (int g = 0; g < 8; g++) gv[g] = ld_f64(gp + (size_t)min(g0 + g, NG - 1) * NGP_BLK);
+#pragma unroll
+        for (int g = 0; g < 8; g++)
+            if (g0 + g < NG) tot = tot + gv[g];
+    }
     *tot_out = tot;
     return true;
 }
@@ -1542,6 +1799,13 @@ __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         role_reducer<DBG>(A, b - 1, smem);
     else {
         const int s = b - 1 - A.NG;
+        if (A.variant == 2 && A.V > 1) {  // V shards per workgroup (host: fp32 tiles, S a multiple of V; V = 2 at lag 3, V = 3 at lag 2)
+            if constexpr (!DBG) {
+                if (A.V == 2) role_streamer_rows_tall<3, 2>(A, s, smem);
+                else role_streamer_rows_tall<2, 3>(A, s, smem);
+            }
+            return;
+        }
         if (A.variant == 2) {  // row-owning waves + loader wave (host: R <= NGP_ROWS_MAX_R, lag 3..6)
             switch (A.D) {
                 case 3: role_streamer_rows<DBG, 3, 0>(A, s, smem); break;

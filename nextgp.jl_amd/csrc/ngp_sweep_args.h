@@ -29,6 +29,7 @@ struct SweepArgs {
                           // row pairs interleaved (gram_pair_index)
     int knob;     // tuning knob of the streamers (ngp_debug_set_knob), see role_streamer_rows
     int variant;  // streamer variant: 1 = phase streamer (role_streamer), 2 = row-owning waves + loader wave (role_streamer_rows)
+    int V;        // shards per streamer workgroup (1; 2: role_streamer_rows_tall, the grid then has S / V streamers)
     int D, R, S, NG, near, fine_ok, t0, t1;  // near: look-ahead lags 1..near are corrected by the sampler, farther ones by the reducers
      // fine_ok: the streamers' LDS has room for the diagnostic timeline
     double *beta;

@@ -92,25 +92,45 @@ def test_xbeta_is_linear(ngp):
     assert np.abs(lhs - rhs).max() <= 1e-10 * np.abs(lhs).max()
 
 
-@pytest.mark.parametrize("N_,P_,mode_", [(63000, 700, 1), (63232, 400, 1), (63300, 300, 0)], ids=["R256", "R256_full", "fallback"])
-def test_tallest_shards_and_fallback(ngp, N_, P_, mode_):
-    """The persistent sweep holds shards of at most 256 rows (247 streamers -> N <= 63232); beyond that the per-block engine
-    takes over.  (A layout rule that preferred 4*odd rows once produced 260-row shards here and dropped update tasks.)"""
-    s = ngp.Sampler(device=0, seed=5, chain=0)
-    s.generate_panel(N_, P_)
+@pytest.mark.parametrize("N_,P_,mode_,V_", [(63000, 700, 1, 1), (63232, 400, 1, 1), (63300, 300, 1, 2), (100000, 1000, 1, 2), (107520, 200, 1, 2),
+                                            (107600, 200, 1, 3), (156576, 300, 1, 3), (156600, 200, 0, 1)],
+                         ids=["R256", "R256_full", "two_shards", "100k", "two_shards_full", "three_shards", "three_shards_full", "fallback"])
+def test_tallest_shards_and_fallback(ngp, N_, P_, mode_, V_):
+    """The persistent sweep holds shards of at most 256 rows, one per streamer workgroup (247 streamers -> N <= 63232); above
+    that a workgroup owns two shards of at most 224 rows (240 workgroups -> N <= 107520, lag 3), then three (233 workgroups ->
+    N <= 156576, lag 2); beyond that the per-block engine takes over.  (A layout rule that preferred 4*odd rows once produced 260-row shards here and dropped update tasks.)"""
+    def chain(**kw):
+        s = ngp.Sampler(device=0, seed=5, chain=0, **kw)
+        s.generate_panel(N_, P_)
+        rng = np.random.default_rng(1)
+        bt = np.zeros(P_); bt[rng.choice(P_, 10, replace=False)] = rng.normal(size=10)
+        g = s.xbeta(bt)
+        y = 3.0 + g + np.random.default_rng(2).normal(size=N_) * np.sqrt(g.var())
+        v = 0.5 * y.var() / (s.mpm().sum() / N_)
+        h = P_ // 2
+        s.add_marker_set(0, h, 0, 4.0, v * 0.5, [(0, h)], [v])
+        s.add_marker_set(h, P_ - h, 1, 4.0, v * 0.5, [(j, j + 1) for j in range(P_ - h)], np.full(P_ - h, v), pi0=0.1, estPi=True)
+        s.set_y(y); s.set_residual_prior(4.0, 0.25 * y.var())
+        return s, y
+    s, y = chain()
     R, S, nblk = s.layout()
     assert s.config()[0] == mode_ and (R <= 256 if mode_ == 1 else True) and R * S >= N_
-    rng = np.random.default_rng(1)
-    bt = np.zeros(P_); bt[rng.choice(P_, 10, replace=False)] = rng.normal(size=10)
-    g = s.xbeta(bt)
-    y = 3.0 + g + np.random.default_rng(2).normal(size=N_) * np.sqrt(g.var())
-    v = 0.5 * y.var() / (s.mpm().sum() / N_)
-    h = P_ // 2
-    s.add_marker_set(0, h, 0, 4.0, v * 0.5, [(0, h)], [v])
-    s.add_marker_set(h, P_ - h, 1, 4.0, v * 0.5, [(j, j + 1) for j in range(P_ - h)], np.full(P_ - h, v), pi0=0.1, estPi=True)
-    s.set_y(y); s.set_residual_prior(4.0, 0.25 * y.var()); s.run(6)
+    if V_ > 1:
+        assert R <= 224 and S % V_ == 0 and s.config() == (1, 5 - V_) and s.streamer() == (2, 7)
+    s.run(6)
     st = s.get_state()
     assert np.abs(st["ycorr"] - (y - st["b"] - s.xbeta(st["beta"]))).max() < 1e-9
+    if V_ > 1:
+        assert s.census()["grid"] == 1 + (S + 31) // 32 + S // V_
+        # the same chain in the per-block engine (another layout, another summation order): indicators identical, floats to 1e-9
+        # (the residual invariant alone once passed with the sampler adding only 8 of these layouts' 15 group sums)
+        r, _ = chain(mode=0, lag=1)
+        assert r.config()[0] == 0
+        r.run(6)
+        sr = r.get_state()
+        assert np.array_equal(st["delta"], sr["delta"])
+        assert np.abs(st["beta"] - sr["beta"]).max() <= 1e-9 * max(1e-3, np.abs(sr["beta"]).max())
+        assert abs(st["varE"] - sr["varE"]) <= 1e-9 * sr["varE"] and np.abs(st["varBeta"] - sr["varBeta"]).max() <= 1e-9 * np.abs(sr["varBeta"]).max()
 
 
 def test_north_star_shape_50k_x_600k(ngp, O):

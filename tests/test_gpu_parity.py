@@ -152,6 +152,58 @@ def test_chain_bit_exact_vs_blocked_oracle(ngp, O, name, N, P, spec, engine):
     assert np.abs(a["ycorr"] - resid).max() <= 1e-10 * max(1.0, np.abs(y).max())
 
 
+TALL = [  # (N, P, sets, max shards, V): streamer variants 4 / 6 = V = 2 / 3 shards per streamer workgroup (what fp32 panels above 63k rows run in)
+    ("r4_default", 500, 1000, [(0, 1000, "PR")], None, 2),                                     # 4-row shards: one quad per tile
+    ("r220_w4", 1700, 300, [(0, 300, "PR")], 8, 2),                                            # the tallest tiles the ring holds twice
+    ("r188_multi", 1500, 450, [(0, 150, "PR"), (150, 170, "B"), (320, 130, "R")], 8, 2),
+    ("odd_S_padded", 50, 200, [(0, 200, ("PRw", 37))], 6, 2),                                  # 5 shards -> a sixth, all padding
+    ("r76_ragged", 601, 130, [(0, 130, "C")], 8, 2),
+    ("ng15", 1900, 200, [(0, 120, "PR"), (120, 80, "B")], None, 2),                            # 476 shards: 15 reducer groups (> 8: further batches of group sums)
+    ("v3_r220", 2600, 300, [(0, 300, "PR")], 12, 3),                                           # three shards per workgroup, lag 2
+    ("v3_multi", 1000, 450, [(0, 150, "PR"), (150, 170, "B"), (320, 130, "R")], 9, 3),
+    ("v3_padded", 50, 200, [(0, 200, ("PRw", 37))], 6, 3),                                     # 5 shards -> 6
+    ("v3_ng22", 2790, 200, [(0, 120, "PR"), (120, 80, "B")], None, 3),                         # 699 shards: 22 reducer groups
+]
+
+
+@pytest.mark.parametrize("name,N,P,spec,shards,V", TALL, ids=[c[0] for c in TALL])
+def test_several_shards_per_workgroup_bit_exact(ngp, O, name, N, P, spec, shards, V):
+    """role_streamer_rows_tall: the layout (R, S), the partial of every shard and the reducers' groups are those of the row-owning
+    streamer, a workgroup merely owns V shards -- so the chain must equal the blocked oracle's for that layout (7 GEMV chains,
+    lag 3 with two shards, lag 2 with three), bit for bit."""
+    X, y, bt, v = make_problem(O, N, P, seed=5)
+    s = ngp.Sampler(device=0, seed=1001, chain=0, mode=1, lag=6, streamer=2 * V)
+    if shards:
+        s.set_max_shards(shards)
+    s.set_panel(X)
+    R, S, nblk = s.layout()
+    D = 5 - V
+    assert s.config() == (1, D) and s.streamer() == (2, 7) and S % V == 0 and R <= 224 and R * S >= N
+    if name == "ng15":
+        assert (R, S) == (4, 476)
+    if name == "v3_ng22":
+        assert (R, S) == (4, 699)
+    if "padded" in name:
+        assert R * (S - 1) >= N                 # the last shard holds no row of the panel
+    o = O.Oracle(order=1, seed=1001, chain=0)
+    o.set_panel_f32(X, R=R, S=S, D=D, near=s.near(), nchain=7)
+    niter = 12
+    for m in (s, o):
+        add_sets(m, spec, v)
+        m.set_y(y); m.set_residual_prior(4.0, 0.25 * y.var()); m.set_schedule(niter, 4, 2); m.run(niter)
+    a, b = s.get_state(), o.get_state()
+    assert np.array_equal(a["delta"], b["delta"])
+    for k in ("ycorr", "beta", "varBeta", "piHat"):
+        assert np.array_equal(a[k], b[k]), k
+    assert a["varE"] == b["varE"] and a["b"] == b["b"] and a["iter"] == niter
+    pa, pb = s.get_posterior_sums(), o.get_posterior_sums()
+    for k in ("sum_beta", "sum_beta2", "sum_delta", "sum_varBeta", "sum_pi"):
+        assert np.array_equal(pa[k], pb[k]), k
+    assert s.census()["grid"] == 1 + (S + 31) // 32 + S // V    # S / V streamers
+    resid = y - a["b"] - s.xbeta(a["beta"])
+    assert np.abs(a["ycorr"] - resid).max() <= 1e-10 * max(1.0, np.abs(y).max())
+
+
 @pytest.mark.parametrize("engine", [(0, 1), (1, 6)], ids=["blocklaunch", "persist_lag6"])
 @pytest.mark.parametrize("kind", ["PR", "B", "C", "R"])
 def test_chain_vs_reference_order_oracle(ngp, O, kind, engine):
