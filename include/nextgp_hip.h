@@ -71,6 +71,16 @@ int32_t ngp_debug_stamps(ngp_handle *h, int32_t enable, uint64_t *out, int64_t n
  * centre != 0: subtract the column mean first (src/prepMatVec.jl:129).  Stored as fp32, re-tiled. */
 int32_t ngp_set_panel_f64(ngp_handle *h, const double *M, int64_t N, int64_t P, int64_t ld, int32_t centre);
 int32_t ngp_set_panel_f32(ngp_handle *h, const float *M, int64_t N, int64_t P, int64_t ld, int32_t centre);
+/* The same panel in column ranges: the reference keeps ONE Float64 matrix per marker set (M[set].data, src/mme.jl:296-311) and the
+ * sweep wants ONE panel with the sets side by side -- so the sets are handed over one after another, no concatenated copy on the
+ * host.  ngp_begin_panel fixes N x P (layout, allocation; a new model like every ngp_set_panel_*), ngp_panel_columns_* writes
+ * columns [col0, col0 + ncol) from a column-major matrix (any order, any boundaries; columns never written stay zero columns),
+ * ngp_end_panel builds mpm and the Gram window.  Conversion, centring and tiling run on the device from 256 MiB staging chunks
+ * (ngp_set_panel_f64 / _f32 are these three calls).  Nothing else may be called on the handle between begin and end. */
+int32_t ngp_begin_panel(ngp_handle *h, int64_t N, int64_t P);
+int32_t ngp_panel_columns_f64(ngp_handle *h, int64_t col0, const double *M, int64_t ncol, int64_t ld, int32_t centre);
+int32_t ngp_panel_columns_f32(ngp_handle *h, int64_t col0, const float *M, int64_t ncol, int64_t ld, int32_t centre);
+int32_t ngp_end_panel(ngp_handle *h);
 /* Same panel from one byte per genotype (0/1/2 allele counts, or any value 0..255): a quarter of the fp32 host footprint and
  * of the PCIe transfer; centring and the fp32 conversion happen on the device and give bit for bit the tiles of
  * ngp_set_panel_f64 on the same values (integer column sum / N). */

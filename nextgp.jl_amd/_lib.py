@@ -69,6 +69,7 @@ def tuple_panel(sets):
 # every symbol include/nextgp_hip.h declares
 SYMBOLS = [
     "ngp_abi_version", "ngp_create", "ngp_destroy", "ngp_last_error", "ngp_set_panel_f64", "ngp_set_panel_f32", "ngp_set_panel_u8",
+    "ngp_begin_panel", "ngp_panel_columns_f64", "ngp_panel_columns_f32", "ngp_end_panel",
     "ngp_generate_panel", "ngp_get_layout", "ngp_get_mpm", "ngp_get_gram", "ngp_xbeta", "ngp_add_marker_set", "ngp_set_y",
     "ngp_set_residual_prior", "ngp_set_intercept", "ngp_set_schedule", "ngp_run", "ngp_get_state", "ngp_set_state",
     "ngp_get_trace", "ngp_get_posterior_sums", "ngp_posterior_len", "ngp_export_posterior_device", "ngp_sweep_set",
@@ -249,6 +250,25 @@ class Sampler:
             f, t = self.L.ngp_set_panel_f64, C.c_double
         self.N, self.P = M.shape
         self._chk(f(self.h, _p(M, t), C.c_int64(self.N), C.c_int64(self.P), C.c_int64(self.N), C.c_int32(int(centre))))
+
+    def begin_panel(self, N, P):
+        """A panel handed over in column ranges (one marker set after another, no concatenated host copy): begin_panel,
+        panel_columns(col0, M) for every range, end_panel."""
+        self._chk(self.L.ngp_begin_panel(self.h, C.c_int64(N), C.c_int64(P)))
+        self.N, self.P = N, P
+
+    def panel_columns(self, col0, M, centre=False):
+        M = np.asarray(M)
+        if M.dtype == np.float32:
+            M = np.asfortranarray(M)
+            f, t = self.L.ngp_panel_columns_f32, C.c_float
+        else:
+            M = np.asfortranarray(M, dtype=np.float64)
+            f, t = self.L.ngp_panel_columns_f64, C.c_double
+        self._chk(f(self.h, C.c_int64(col0), _p(M, t), C.c_int64(M.shape[1]), C.c_int64(M.shape[0]), C.c_int32(int(centre))))
+
+    def end_panel(self):
+        self._chk(self.L.ngp_end_panel(self.h))
 
     def generate_panel(self, N, P, maf_lo=0.05, maf_hi=0.5, seed=20250509):
         self._chk(self.L.ngp_generate_panel(self.h, C.c_int64(N), C.c_int64(P), C.c_double(maf_lo), C.c_double(maf_hi),

@@ -428,9 +428,18 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
         else:
             units.append(("set", t.name, ncols, mats[by_name[t.name]].shape[1]))
             pieces.append(mats[by_name[t.name]]); ncols += mats[by_name[t.name]].shape[1]
-    panel = np.asfortranarray(np.concatenate(pieces, axis=1))
     smp = Sampler(device=device, seed=seed, chain=chain, storage=storage, **(dict(mode=engine[0], lag=engine[1]) if engine else {}))
-    smp.set_panel(panel, centre=True)  # centring: src/prepMatVec.jl:129
+    if storage is None and all(np.asarray(pc).dtype != np.uint8 for pc in pieces):
+        # the sets go to the device one after another (ngp_begin_panel / ngp_panel_columns_* / ngp_end_panel): no concatenated host copy
+        smp.begin_panel(len(y), ncols)
+        c0 = 0
+        for pc in pieces:
+            if pc.shape[1] and np.any(pc):       # (padding columns stay the zero columns they are born as)
+                smp.panel_columns(c0, pc, centre=True)  # centring: src/prepMatVec.jl:129
+            c0 += pc.shape[1]
+        smp.end_panel()
+    else:
+        smp.set_panel(np.asfortranarray(np.concatenate(pieces, axis=1)), centre=True)  # centring: src/prepMatVec.jl:129
     # residual prior (src/mme.jl:63-94)
     e_prior = VCV.get("e", Random("I", 100.0))
     if not (e_prior.str in ("I", "", None) or (isinstance(e_prior.str, (list, tuple)) and len(e_prior.str) == 0)):

@@ -96,6 +96,7 @@ struct ngp_handle {
     double *d_mean = nullptr;  // compact storage: column means, Ppad
     int streamer_req = 0;  // streamer variant requested: 0 automatic, 1 phase streamer, 2 row-owning waves + loader wave, 4 / 6 = 2 with
                            // two / three shards per workgroup at any N (automatic only above one resident wave of 256-row shards)
+    bool panel_open = false;  // between ngp_begin_panel and ngp_end_panel: columns may still arrive, the Gram window does not exist yet
     int V = 1;             // shards per streamer workgroup (role_streamer_rows_tall: 2, 3); the sweep's grid has S / V streamers
     int streamer = 1;      // variant in force (persistent sweep only)
     int nchain = 8;        // GEMV chains per shard partial: 8 (phase streamer, per-block engine) or 7 (row-owning waves)
@@ -458,7 +459,7 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P, ngp_handle *owner = nullptr
     h->fix.clear(); h->nfixcol = 0; dfree(h->d_bfix); dfree(h->d_sum_bfix);
     dfree(h->d_trace_loci); dfree(h->d_tr_beta); dfree(h->d_tr_vb); dfree(h->d_tr_pi);
     h->ntl = 0; h->ntvb = 0; h->trace_ext_cap = 0;
-    h->have_y = false; h->iter = 0; h->poisoned = false;
+    h->have_y = false; h->iter = 0; h->poisoned = false; h->panel_open = false;
     if (h->storage == 0) HCHK(hipFuncSetAttribute((const void *)k_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_step));
     if (h->mode == 1) {
         const size_t lds_sampler = (size_t)(3 * 4096 + 2 * NGP_RING * NGP_BLK + 6 * NGP_BLK) * sizeof(double) + 2 * NGP_BLK * sizeof(int) + 320;
@@ -553,42 +554,70 @@ int build_gram(ngp_handle *h) {
     return NGP_OK;
 }
 
+// ---- host panels in Float64 / Float32, whole or in column ranges (ngp_begin_panel / ngp_panel_columns_* / ngp_end_panel) ----
+int begin_panel(ngp_handle *h, int64_t N, int64_t P) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(h->storage == 0, NGP_ERR_ARG, "compact storage takes genotype codes: ngp_set_panel_u8, ngp_load_panel_file or ngp_generate_panel");
+    if ((rc = alloc_panel(h, N, P))) return rc;  // (tiles and means are born zero: columns never uploaded stay zero columns)
+    h->panel_open = true;
+    return NGP_OK;
+}
+
+// columns [col0, col0 + ncol) from a column-major host matrix: staged through the device in chunks of whole columns (256 MiB)
+template <typename TIn>
+int panel_columns(ngp_handle *h, int64_t col0, const TIn *M, int64_t ncol, int64_t ld, int centre) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(h->panel_open && h->d_tiles != nullptr, NGP_ERR_STATE, "ngp_panel_columns_* needs an open panel (ngp_begin_panel)");
+    REQUIRE(M != nullptr, NGP_ERR_ARG, "null panel pointer");
+    REQUIRE(ld >= h->N, NGP_ERR_ARG, "leading dimension smaller than N");
+    REQUIRE(col0 >= 0 && ncol > 0 && col0 + ncol <= h->P, NGP_ERR_ARG, "column range outside the panel");
+    const int64_t N = h->N;
+    const int64_t cchunk = std::max<int64_t>(1, std::min<int64_t>(ncol, ((int64_t)256 << 20) / (int64_t)(ld * sizeof(TIn))));
+    TIn *d_g = nullptr;
+    unsigned *d_bad = nullptr;
+    if (hipMalloc((void **)&d_g, (size_t)cchunk * ld * sizeof(TIn)) != hipSuccess) return fail(h, NGP_ERR_NOMEM, "staging buffer");
+    if ((rc = dalloc(h, &d_bad, 1))) { (void)hipFree(d_g); return rc; }
+    hipError_t e = hipSuccess;
+    for (int64_t c0 = 0; c0 < ncol && e == hipSuccess; c0 += cchunk) {
+        const int64_t nc = std::min<int64_t>(cchunk, ncol - c0);
+        // the last column may be shorter than ld in the caller's buffer: nc - 1 full columns + N elements
+        e = hipMemcpyAsync(d_g, M + (size_t)c0 * ld, ((size_t)(nc - 1) * ld + (size_t)N) * sizeof(TIn), hipMemcpyHostToDevice, h->stream);
+        if (e != hipSuccess) break;
+        double *d_mu = h->d_mean + col0 + c0;
+        hipLaunchKernelGGL(k_cols_mean<TIn>, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, h->stream, (const TIn *)d_g, (long long)N, (long long)ld,
+                           (long long)nc, centre, d_mu, d_bad);
+        hipLaunchKernelGGL(k_cols_fill<TIn>, dim3((unsigned)((h->L / 4 + 255) / 256), (unsigned)nc), dim3(256), 0, h->stream, h->d_tiles, (const TIn *)d_g,
+                           (long long)N, (long long)ld, (long long)(col0 + c0), (int)h->R, (int)h->S, (const double *)d_mu);
+        e = hipStreamSynchronize(h->stream);  // the staging buffer is reused by the next chunk
+    }
+    unsigned bad = 0;
+    if (e == hipSuccess) e = hipMemcpy(&bad, d_bad, sizeof(unsigned), hipMemcpyDeviceToHost);
+    (void)hipFree(d_g);
+    dfree(d_bad);
+    if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("panel columns: ") + hipGetErrorString(e));
+    REQUIRE(bad == 0u, NGP_ERR_ARG, "non-finite genotype value in panel");
+    return NGP_OK;
+}
+
+int end_panel(ngp_handle *h) {
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(h->panel_open && h->d_tiles != nullptr, NGP_ERR_STATE, "no open panel (ngp_begin_panel)");
+    h->panel_open = false;
+    return build_gram(h);
+}
+
 template <typename TIn>
 int set_panel_host(ngp_handle *h, const TIn *M, int64_t N, int64_t P, int64_t ld, int centre) {
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(M != nullptr, NGP_ERR_ARG, "null panel pointer");
     REQUIRE(ld >= N, NGP_ERR_ARG, "leading dimension smaller than N");
-    REQUIRE(h->storage == 0, NGP_ERR_ARG, "compact storage takes genotype codes: ngp_set_panel_u8, ngp_load_panel_file or ngp_generate_panel");
-    if ((rc = alloc_panel(h, N, P))) return rc;
-    const int64_t R = h->R, S = h->S;
-    const size_t blk_elems = (size_t)S * R * NGP_BLK;
-    std::vector<float> buf(blk_elems);
-    std::vector<double> means((size_t)h->Ppad, 0.0);
-    for (int64_t t = 0; t < h->NBLK; t++) {
-        std::fill(buf.begin(), buf.end(), 0.0f);
-        for (int jj = 0; jj < NGP_BLK; jj++) {
-            int64_t j = t * NGP_BLK + jj;
-            if (j >= P) break;
-            const TIn *col = M + (size_t)j * ld;
-            double mu = 0.0;
-            if (centre) {  // src/prepMatVec.jl:129
-                double sum = 0.0;
-                for (int64_t i = 0; i < N; i++) sum += (double)col[i];
-                mu = sum / (double)N;
-                means[(size_t)j] = mu;
-            }
-            for (int64_t i = 0; i < N; i++) {
-                double v = (double)col[i];
-                if (!std::isfinite(v)) return fail(h, NGP_ERR_ARG, "non-finite genotype value in panel");
-                int64_t s = i / R, ii = i - s * R;
-                buf[(size_t)s * NGP_BLK * R + tile_off((int)ii, jj)] = (float)(v - mu);
-            }
-        }
-        HCHK(hipMemcpy(h->d_tiles + (size_t)t * blk_elems, buf.data(), blk_elems * sizeof(float), hipMemcpyHostToDevice));
-    }
-    HCHK(hipMemcpy(h->d_mean, means.data(), means.size() * sizeof(double), hipMemcpyHostToDevice));
-    return build_gram(h);
+    if ((rc = begin_panel(h, N, P))) return rc;
+    if ((rc = panel_columns<TIn>(h, 0, M, P, ld, centre))) return rc;
+    return end_panel(h);
 }
 
 int sync_tables(ngp_handle *h) {
@@ -957,6 +986,7 @@ int sample_flush(ngp_handle *h) {
 
 int ready(ngp_handle *h) {
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
+    REQUIRE(!h->panel_open, NGP_ERR_STATE, "the panel is still open: ngp_end_panel builds the Gram window the sweep needs");
     REQUIRE(h->have_y, NGP_ERR_STATE, "y not set");
     REQUIRE(!h->sets.empty(), NGP_ERR_STATE, "no marker set added");
     return sync_tables(h);
@@ -1031,6 +1061,26 @@ int32_t ngp_set_panel_f64(ngp_handle *h, const double *M, int64_t N, int64_t P, 
 int32_t ngp_set_panel_f32(ngp_handle *h, const float *M, int64_t N, int64_t P, int64_t ld, int32_t centre) {
     NGP_TRY
     return set_panel_host<float>(h, M, N, P, ld, centre);
+    NGP_CATCH(h)
+}
+int32_t ngp_begin_panel(ngp_handle *h, int64_t N, int64_t P) {
+    NGP_TRY
+    return begin_panel(h, N, P);
+    NGP_CATCH(h)
+}
+int32_t ngp_panel_columns_f64(ngp_handle *h, int64_t col0, const double *M, int64_t ncol, int64_t ld, int32_t centre) {
+    NGP_TRY
+    return panel_columns<double>(h, col0, M, ncol, ld, centre);
+    NGP_CATCH(h)
+}
+int32_t ngp_panel_columns_f32(ngp_handle *h, int64_t col0, const float *M, int64_t ncol, int64_t ld, int32_t centre) {
+    NGP_TRY
+    return panel_columns<float>(h, col0, M, ncol, ld, centre);
+    NGP_CATCH(h)
+}
+int32_t ngp_end_panel(ngp_handle *h) {
+    NGP_TRY
+    return end_panel(h);
     NGP_CATCH(h)
 }
 
@@ -1974,6 +2024,7 @@ int32_t ngp_share_panel(ngp_handle *h, ngp_handle *owner) {
     if ((rc = enter(h))) return rc;
     REQUIRE(owner && owner != h && owner->d_tiles != nullptr && owner->pm != nullptr, NGP_ERR_ARG, "ngp_share_panel: the owner has no panel");
     REQUIRE(owner->device == h->device, NGP_ERR_ARG, "ngp_share_panel: both handles must be on one device");
+    REQUIRE(!owner->panel_open, NGP_ERR_STATE, "ngp_share_panel: the owner's panel is still open (ngp_end_panel)");
     HCHK(hipStreamSynchronize(owner->stream));
     h->cu_count = owner->cu_count;
     return alloc_panel(h, owner->N, owner->P, owner);

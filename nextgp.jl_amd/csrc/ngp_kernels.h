@@ -1023,6 +1023,39 @@ __global__ __launch_bounds__(256) void k_gen_fill(float *__restrict__ tiles, lon
     }
 }
 
+// Host panels in Float64 / Float32 (src/prepMatVec.jl:116-131 hands the sampler a centred Float64 matrix per marker set): a staged
+// chunk of whole columns (column-major, leading dimension ld) -> column means and centred fp32 quad-major tiles, on the device.
+// The mean is the sequential sum over the rows divided by N (one thread per column: the order of the host loop this replaces,
+// so panels uploaded before and after that change are bit-identical); a non-finite sum flags the chunk.
+template <typename TIn>
+__global__ __launch_bounds__(64) void k_cols_mean(const TIn *__restrict__ g, long long N, long long ld, long long nc, int centre,
+                                                  double *__restrict__ mu, unsigned *__restrict__ bad) {
+    const long long c = (long long)blockIdx.x * 64 + threadIdx.x;
+    if (c >= nc) return;
+    const TIn *col = g + (size_t)c * ld;
+    double sum = 0.0;
+    for (long long i = 0; i < N; i++) sum += (double)col[i];
+    if (!(sum - sum == 0.0)) atomicOr(bad, 1u);  // inf or nan somewhere in the column
+    mu[c] = centre ? sum / (double)N : 0.0;
+}
+// thread = (column c of the chunk, quad Q of the padded panel): rows 4 Q .. 4 Q + 3 live in one shard (R is a multiple of 4)
+template <typename TIn>
+__global__ __launch_bounds__(256) void k_cols_fill(float *__restrict__ tiles, const TIn *__restrict__ g, long long N, long long ld,
+                                                   long long col0, int R, int S, const double *__restrict__ mu) {
+    const long long Q = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long i0 = 4 * Q;
+    if (i0 >= (long long)R * S) return;
+    const long long c = blockIdx.y, j = col0 + c;
+    const int s = (int)(i0 / R), ii = (int)(i0 - (long long)s * R), jj = (int)(j & (NGP_BLK - 1));
+    const TIn *col = g + (size_t)c * ld;
+    const double m = mu[c];
+    float v[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) v[r] = (i0 + r < N) ? (float)((double)col[i0 + r] - m) : 0.0f;
+    float *tp = tiles + ((size_t)(j >> 6) * S + s) * ((size_t)R * NGP_BLK) + tile_off(ii, jj);
+    *(float4 *)tp = make_float4(v[0], v[1], v[2], v[3]);
+}
+
 // compact genotype input (one byte per genotype, column-major staging chunk of ncols columns, leading dimension ld):
 // integer column sums -> mean = sum / N exactly as the host path computes it, then centred fp32 quad-major tiles
 __global__ __launch_bounds__(256) void k_u8_colmean(const uint8_t *__restrict__ G, long long N, long long ld, int centre,

@@ -43,6 +43,17 @@ set_panel!(h::Handle, data::Matrix{Float64}; centre::Bool=false) =
     check(h, ccall((:ngp_set_panel_f64, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Int64, Int64, Int64, Int32),
                    h.ptr, data, size(data, 1), size(data, 2), stride(data, 2), centre))
 
+# The same panel one marker set after another (M[s].data are separate matrices, src/mme.jl:296-311): no concatenated host copy.
+# begin_panel!(h, N, Ptot); panel_columns!(h, col0, M[s].data) for every set (col0 0-based); end_panel!(h) builds mpm and the Gram window.
+begin_panel!(h::Handle, N::Integer, P::Integer) = check(h, ccall((:ngp_begin_panel, LIB), Int32, (Ptr{Cvoid}, Int64, Int64), h.ptr, N, P))
+panel_columns!(h::Handle, col0::Integer, data::Matrix{Float64}; centre::Bool=false) =
+    check(h, ccall((:ngp_panel_columns_f64, LIB), Int32, (Ptr{Cvoid}, Int64, Ptr{Float64}, Int64, Int64, Int32),
+                   h.ptr, col0, data, size(data, 2), stride(data, 2), centre))
+panel_columns!(h::Handle, col0::Integer, data::Matrix{Float32}; centre::Bool=false) =
+    check(h, ccall((:ngp_panel_columns_f32, LIB), Int32, (Ptr{Cvoid}, Int64, Ptr{Float32}, Int64, Int64, Int32),
+                   h.ptr, col0, data, size(data, 2), stride(data, 2), centre))
+end_panel!(h::Handle) = check(h, ccall((:ngp_end_panel, LIB), Int32, (Ptr{Cvoid},), h.ptr))
+
 # one byte per genotype (raw allele counts, e.g. read from a binary file instead of src/prepMatVec.jl:116): centred on the device
 set_panel!(h::Handle, data::Matrix{UInt8}; centre::Bool=true) =
     check(h, ccall((:ngp_set_panel_u8, LIB), Int32, (Ptr{Cvoid}, Ptr{UInt8}, Int64, Int64, Int64, Int32),
@@ -139,25 +150,31 @@ end
 set_sample_file!(h::Handle, path::Union{AbstractString,Nothing}) =
     check(h, path === nothing ? ccall((:ngp_set_sample_file, LIB), Int32, (Ptr{Cvoid}, Ptr{UInt8}), h.ptr, C_NULL) :
                                 ccall((:ngp_set_sample_file, LIB), Int32, (Ptr{Cvoid}, Cstring), h.ptr, path))
-function read_sample_file(path::AbstractString)
+# f(sets, sample) for every record of the file, one record in memory at a time (a record is 9 bytes per locus)
+function foreach_sample(f, path::AbstractString)
     open(path, "r") do io
         String(read(io, 8)) == "NGPSMP01" || error("not a sample file: $path")
         P, nvb, nsets, nfix, ncls, rec = ntuple(_ -> read(io, Int64), 6)
         sets = [ntuple(_ -> read(io, Int64), 6) for _ in 1:nsets]     # (method, K, col0, ncol, variance entries, tuple k)
         nd = 3 + nfix + P + nvb + 2 * nsets + ncls
-        samples = NamedTuple[]
+        raw = Vector{UInt8}(undef, rec)
         while !eof(io)
-            raw = read(io, rec)
-            length(raw) == rec || break
-            d = reinterpret(Float64, raw[1:8 * nd])
+            readbytes!(io, raw, rec) == rec || break
+            d = reinterpret(Float64, view(raw, 1:8 * nd))
             o = 3
-            push!(samples, (iter = reinterpret(Int64, raw[1:8])[1], varE = d[2], b = d[3], b_fixed = d[o + 1:o + nfix],
-                            beta = d[o + nfix + 1:o + nfix + P], varBeta = d[o + nfix + P + 1:o + nfix + P + nvb],
-                            piHat = d[o + nfix + P + nvb + 1:o + nfix + P + nvb + 2 * nsets],
-                            class_pi = d[o + nfix + P + nvb + 2 * nsets + 1:nd], delta = raw[8 * nd + 1:8 * nd + P]))
+            f(sets, (iter = reinterpret(Int64, view(raw, 1:8))[1], varE = d[2], b = d[3], b_fixed = d[o + 1:o + nfix],
+                     beta = d[o + nfix + 1:o + nfix + P], varBeta = d[o + nfix + P + 1:o + nfix + P + nvb],
+                     piHat = d[o + nfix + P + nvb + 1:o + nfix + P + nvb + 2 * nsets],
+                     class_pi = d[o + nfix + P + nvb + 2 * nsets + 1:nd], delta = raw[8 * nd + 1:8 * nd + P]))
         end
-        return (sets = sets, samples = samples)
     end
+end
+function read_sample_file(path::AbstractString)
+    samples = NamedTuple[]; sets = nothing
+    foreach_sample(path) do st, smp
+        sets = st; push!(samples, smp)
+    end
+    return (sets = sets, samples = samples)
 end
 
 function class_state(h::Handle, set_id::Integer)
@@ -229,8 +246,14 @@ function runSampler!(ycorr, nData, E, X, b, Z, u, varU, M, beta, varBeta, delta,
     E.str == "I" || error("weighted residuals: use the reference sampler")
     h = Handle(device=device, seed=seed)
     sets = collect(keys(M))                       # Dict order, as src/samplers.jl:50
-    panel = hcat((M[s].data for s in sets)...)    # consecutive column ranges of ONE panel
-    set_panel!(h, panel)
+    # consecutive column ranges of ONE panel on the device, handed over set by set (no hcat of the M[s].data on the host)
+    begin_panel!(h, size(M[sets[1]].data, 1), sum(M[s].dims[2] for s in sets))
+    col0 = 0
+    for s in sets
+        panel_columns!(h, col0, M[s].data)       # already centred (src/prepMatVec.jl:129)
+        col0 += M[s].dims[2]
+    end
+    end_panel!(h)
     col0 = 0
     ids = Dict{Any,Int32}()
     for s in sets
@@ -257,38 +280,54 @@ function runSampler!(ycorr, nData, E, X, b, Z, u, varU, M, beta, varBeta, delta,
                        h.ptr, Xd, size(Xd, 1), size(Xd, 2), size(Xd, 1), Float64.(X[x].lhs), Float64.(X[x].rhs), Ref{Int32}(0)))
     end
     nfix = isempty(xsets) ? 0 : sum(X[x].nCol for x in xsets)
-    bfix = Vector{Float64}(undef, max(nfix, 1)); sbfix = similar(bfix); nfx = Ref{Int64}(0)
     set_y!(h, Vector{Float64}(ycorr))            # ycorr == y at this point (src/mme.jl:57)
     set_residual_prior!(h, E.df, E.scale)
     check(h, ccall((:ngp_set_intercept, LIB), Int32, (Ptr{Cvoid}, Int32), h.ptr, 0))
     set_schedule!(h, chainLength, burnIn, outputFreq)
+    # ONE call for the whole chain: the kept samples (these2Keep, src/samplers.jl:26) go to a binary file through a copy stream and
+    # a writer thread of the library while the chain runs -- the device never stops for a sample
+    smpfile = joinpath(outPut, "samples.ngp")
+    set_sample_file!(h, smpfile)
+    run!(h, chainLength)
+    set_sample_file!(h, nothing)                 # flushes and closes
+    # ... and become the rows of the reference's *Out files afterwards, one record in memory at a time
+    foreach_sample(smpfile) do sinfo, smp
+        open(io -> writedlm(io, smp.b_fixed'), outPut * "/bOut", "a")       # src/samplers.jl:57
+        open(io -> writedlm(io, smp.varE), outPut * "/varEOut", "a")        # src/samplers.jl:58
+        c0 = 0; v0 = 0; k0 = 0
+        for (k, s) in enumerate(sets)
+            P = M[s].dims[2]
+            open(io -> writedlm(io, smp.beta[c0+1:c0+P]'), outPut * "/beta$(s)Out", "a")          # :80
+            open(io -> writedlm(io, Int.(smp.delta[c0+1:c0+P])'), outPut * "/delta$(s)Out", "a")  # :81
+            M[s].method in ("BayesB", "BayesC") && open(io -> writedlm(io, smp.piHat[2k-1:2k]'), outPut * "/pi$(s)Out", "a")   # :80-82
+            if M[s].method == "BayesR"                                                              # one column per class
+                K = Int(sinfo[k][2])
+                open(io -> writedlm(io, smp.class_pi[k0+1:k0+K]'), outPut * "/pi$(s)Out", "a")
+                k0 += K
+            end
+            nr = length(varBeta[s])
+            open(io -> writedlm(io, smp.varBeta[v0+1:v0+nr]'), outPut * "/var$(s)Out", "a")       # :101-103
+            c0 += P; v0 += nr
+        end
+    end
+    # the caller's arrays as the reference's sampler leaves them: the state after the last iteration
     Ptot = col0
     bet = Vector{Float64}(undef, Ptot); del = Vector{Int64}(undef, Ptot)
     nvb = sum(length(varBeta[s]) for s in sets); vb = Vector{Float64}(undef, nvb); pih = Vector{Float64}(undef, 2 * length(sets))
     ve = Ref{Float64}(0.0); bb = Ref{Float64}(0.0); it = Ref{Int64}(0)
-    done = 0
-    for keep in (burnIn + outputFreq):outputFreq:chainLength      # these2Keep, src/samplers.jl:26
-        run!(h, keep - done); done = keep
-        check(h, ccall((:ngp_get_state, LIB), Int32,
-                       (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}, Ref{Float64}, Ref{Int64}),
-                       h.ptr, ycorr, bet, del, vb, pih, ve, bb, it))
-        check(h, ccall((:ngp_get_fixed, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ref{Int64}), h.ptr, bfix, sbfix, nfx))
-        b[1:nfix] .= bfix[1:nfix]                                          # positions follow keys(X), like X[xSet].pos (src/mme.jl:112-117)
-        open(io -> writedlm(io, bfix[1:nfix]'), outPut * "/bOut", "a")     # src/samplers.jl:57
-        open(io -> writedlm(io, ve[]), outPut * "/varEOut", "a")          # src/samplers.jl:58
-        c0 = 0; v0 = 0
-        for (k, s) in enumerate(sets)
-            P = M[s].dims[2]
-            open(io -> writedlm(io, bet[c0+1:c0+P]'), outPut * "/beta$(s)Out", "a")    # :80
-            open(io -> writedlm(io, del[c0+1:c0+P]'), outPut * "/delta$(s)Out", "a")   # :81
-            M[s].method in ("BayesB", "BayesC") && open(io -> writedlm(io, pih[2k-1:2k]'), outPut * "/pi$(s)Out", "a")   # :80-82
-            M[s].method == "BayesR" && open(io -> writedlm(io, class_state(h, ids[s])[1]'), outPut * "/pi$(s)Out", "a")  # one column per class
-            nr = length(varBeta[s])
-            open(io -> writedlm(io, vb[v0+1:v0+nr]'), outPut * "/var$(s)Out", "a")     # :101-103
-            c0 += P; v0 += nr
-        end
+    bfix = Vector{Float64}(undef, max(nfix, 1)); sbfix = similar(bfix); nfx = Ref{Int64}(0)
+    check(h, ccall((:ngp_get_state, LIB), Int32,
+                   (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ptr{Int64}, Ptr{Float64}, Ptr{Float64}, Ref{Float64}, Ref{Float64}, Ref{Int64}),
+                   h.ptr, ycorr, bet, del, vb, pih, ve, bb, it))
+    check(h, ccall((:ngp_get_fixed, LIB), Int32, (Ptr{Cvoid}, Ptr{Float64}, Ptr{Float64}, Ref{Int64}), h.ptr, bfix, sbfix, nfx))
+    b[1:nfix] .= bfix[1:nfix]                    # positions follow keys(X), like X[xSet].pos (src/mme.jl:112-117)
+    c0 = 0; v0 = 0
+    for s in sets
+        P = M[s].dims[2]; nr = length(varBeta[s])
+        vec(beta[M[s].pos]) .= bet[c0+1:c0+P]; vec(delta[M[s].pos]) .= del[c0+1:c0+P]
+        varBeta[s] isa Vector{Float64} && (varBeta[s] .= vb[v0+1:v0+nr])
+        c0 += P; v0 += nr
     end
-    run!(h, chainLength - done)
     return h
 end
 

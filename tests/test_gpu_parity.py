@@ -89,6 +89,50 @@ def test_gram_and_mpm(ngp, O):
     assert np.array_equal(v.get_state()["beta"], m.get_state()["beta"]) and np.array_equal(v.get_state()["ycorr"], m.get_state()["ycorr"])
 
 
+def test_panel_in_column_ranges_equals_whole_panel(ngp, O):
+    """ngp_begin_panel / ngp_panel_columns_* / ngp_end_panel (one marker set after another, as M[set].data of src/mme.jl:296-311 come,
+    without a concatenated host copy) build bit for bit the panel of ngp_set_panel_f64: means (sequential sum / N), tiles, mpm, Gram."""
+    rng = np.random.default_rng(3)
+    N, P = 333, 300
+    G = rng.integers(0, 3, size=(N, P)).astype(np.float64) + rng.normal(size=(N, P)) * 0.01
+    whole = ngp.Sampler(device=0, seed=1, chain=0)
+    whole.set_panel(G, centre=True)
+    parts = ngp.Sampler(device=0, seed=1, chain=0)
+    parts.begin_panel(N, P)
+    with pytest.raises(ngp.NextGPHipError, match="still open"):
+        parts.add_marker_set(0, P, 0, 4.0, 1.0, [(0, P)], [1.0]); parts.set_y(np.zeros(N)); parts.run(1)
+    parts = ngp.Sampler(device=0, seed=1, chain=0)
+    parts.begin_panel(N, P)
+    for a, b in ((130, 300), (0, 57), (57, 130)):       # any order, boundaries inside 64-column blocks
+        parts.panel_columns(a, G[:, a:b], centre=True)
+    with pytest.raises(ngp.NextGPHipError, match="outside the panel"):
+        parts.panel_columns(250, G[:, :100], centre=True)
+    parts.end_panel()
+    mw, mp = whole.means(), parts.means()
+    assert np.array_equal(mw, mp) and np.array_equal(mw, np.cumsum(G, axis=0)[-1] / N)   # the sequential sum of the host loop it replaces
+    assert np.array_equal(whole.mpm(), parts.mpm())
+    for t in range((P + 63) // 64):
+        assert np.array_equal(whole.gram(t), parts.gram(t))
+    for j in (0, 56, 57, 129, 130, 299):                 # X e_j recovers column j of the tiles exactly
+        e = np.zeros(P); e[j] = 1.0
+        col = (G[:, j] - mw[j]).astype(np.float32).astype(np.float64)
+        assert np.array_equal(whole.xbeta(e), col) and np.array_equal(parts.xbeta(e), col)
+    # Float32 input, not centred; a column range never written stays a zero column
+    F = G.astype(np.float32)
+    f = ngp.Sampler(device=0, seed=1, chain=0)
+    f.begin_panel(N, P); f.panel_columns(64, F[:, 64:200]); f.end_panel()
+    e = np.zeros(P); e[70] = 1.0
+    assert np.array_equal(f.xbeta(e), F[:, 70].astype(np.float64)) and not f.means().any()
+    e = np.zeros(P); e[10] = 1.0
+    assert not f.xbeta(e).any() and f.mpm()[10] == 0.0
+    bad = G.copy(); bad[5, 7] = np.inf
+    b = ngp.Sampler(device=0, seed=1, chain=0)
+    with pytest.raises(ngp.NextGPHipError, match="non-finite"):
+        b.set_panel(bad, centre=True)
+    with pytest.raises(ngp.NextGPHipError, match="open panel"):
+        ngp.Sampler(device=0, seed=1, chain=0).end_panel()
+
+
 def test_generated_panel_matches_oracle(ngp, O):
     N, P = 517, 130
     X, mu = O.generate_panel(N, P, seed=99)
