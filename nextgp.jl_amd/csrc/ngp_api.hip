@@ -290,13 +290,15 @@ void dfree(T *&p) {
     if (p) { (void)hipFree(p); p = nullptr; }
 }
 
-// rows per shard R: a multiple of 4, 4*odd where that fits under the cap (the layouts of the first versions, kept so that
-// results stay comparable; with quad-major tiles any multiple of 4 reads conflict-free), S = ceil(N/R)
-void choose_layout(int64_t N, int64_t max_shards, int64_t r_cap, int64_t *R, int64_t *S) {
+// rows per shard R: a multiple of 4 -- 4*odd where that fits under the cap when the shard count is left to the library (the layouts
+// of the first versions, kept so that results stay comparable; with quad-major tiles any multiple of 4 reads conflict-free), the
+// smallest multiple of 4 that serves an explicit ngp_set_max_shards (there every workgroup counts: 10k rows on 209 shards are 48 rows
+// each, 52 would leave 16 CUs idle); S = ceil(N/R)
+void choose_layout(int64_t N, int64_t max_shards, int64_t r_cap, int64_t *R, int64_t *S, bool prefer_odd = true) {
     int64_t r0 = (N + max_shards - 1) / max_shards;
     int64_t m = (r0 + 3) / 4;
     if (m < 1) m = 1;
-    if ((m & 1) == 0 && 4 * (m + 1) <= r_cap) m += 1;
+    if (prefer_odd && (m & 1) == 0 && 4 * (m + 1) <= r_cap) m += 1;
     int64_t r = 4 * m;
     if (r > r_cap) r = r_cap;
     *R = r;
@@ -372,11 +374,11 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P, ngp_handle *owner = nullptr
             if (N <= v * w * NGP_ROWS_MAX_R && h->lag >= 3) { tallV = v; w_max = w; }
         }
         if (tallV) {
-            choose_layout(N, tallV * w_max, NGP_ROWS_MAX_R, &h->R, &h->S);
+            choose_layout(N, tallV * w_max, NGP_ROWS_MAX_R, &h->R, &h->S, h->max_shards_req <= 0);
             h->S = (h->S + tallV - 1) / tallV * tallV;  // (all-padding shards at the end if need be: zero tiles, zero rows of ycorr)
             h->V = tallV;
         } else if (N > max_shards * 256) h->mode = 0;  // too many rows for one resident wave of streamers (2 LDS tile slots + partials)
-        else choose_layout(N, max_shards, 256, &h->R, &h->S);  // 8 R / 4 update tasks <= 512 threads, two 1040 R / 4 byte LDS slots
+        else choose_layout(N, max_shards, 256, &h->R, &h->S, h->max_shards_req <= 0);  // 8 R / 4 update tasks <= 512 threads, two 1040 R / 4 byte LDS slots
     }
     if (h->mode == 0) choose_layout(N, 256, 508, &h->R, &h->S);  // LDS bound of k_step: R*264 + 4096 <= 160 KiB
     h->NG = (int)((h->S + NGP_GRP - 1) / NGP_GRP);
@@ -478,10 +480,12 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P, ngp_handle *owner = nullptr
         if (h->lds_sweep > lds_max) return fail(h, NGP_ERR_ARG, "panel too tall for the persistent sweep (LDS)");
         HCHK(sweep_set_max_lds_0((int)h->lds_sweep));
         HCHK(sweep_set_max_lds_1((int)h->lds_sweep));
+        if (h->V > 1) HCHK(sweep_tall_set_max_lds((int)h->lds_sweep));
         // every workgroup of the persistent kernel waits for others: the whole grid must be resident at once, one workgroup
         // per CU.  Checked here, not assumed (a grid that does not fit would only show up as a spin timeout).
         int wg_per_cu = 0;
-        HCHK(sweep_occupancy_0(&wg_per_cu, h->lds_sweep));
+        if (h->V > 1) HCHK(sweep_tall_occupancy(&wg_per_cu, h->lds_sweep));
+        else HCHK(sweep_occupancy_0(&wg_per_cu, h->lds_sweep));
         if (wg_per_cu < 1 || 1 + h->NG + h->S / h->V > (int64_t)wg_per_cu * h->cu_count)
             return fail(h, NGP_ERR_STATE, "persistent sweep: grid of " + std::to_string(1 + h->NG + h->S / h->V) + " workgroups cannot be co-resident (" +
                                               std::to_string(wg_per_cu) + " per CU x " + std::to_string(h->cu_count) + " CUs); use ngp_configure(mode 0)");
@@ -694,7 +698,9 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
         fill_sweep_args(h, tb0, tb1, A);
         h->last_grid = 1 + h->NG + S / h->V;
         if (evs) (void)hipEventRecord(evs[0], h->stream);
-        if ((h->d_dbg || h->dbg_mode) && h->V == 1)  // diagnostic instantiation: stamps and timing modes exist only there
+        if (h->V > 1)  // several shards per streamer workgroup: a kernel of its own (no diagnostics there)
+            sweep_tall_launch((unsigned)h->last_grid, h->lds_sweep, h->stream, A);
+        else if (h->d_dbg || h->dbg_mode)  // diagnostic instantiation: stamps and timing modes exist only there
             sweep_launch_1((unsigned)h->last_grid, h->lds_sweep, h->stream, A);
         else
             sweep_launch_0((unsigned)h->last_grid, h->lds_sweep, h->stream, A);
@@ -1526,6 +1532,15 @@ int prepare_run(ngp_handle *h, int64_t niter) {
 // K chains per pass over the panel (k_sweep_multi, ngp_sweep.h): can these handles' chains share ONE sweep launch?  They must
 // share one panel (ngp_share_panel) and run the engine the fused kernel is built for: persistent sweep, fp32 tiles, phase streamer
 // on shards of at most 64 rows, lag 6 or 8, no diagnostics -- and the fused grid must fit the device.
+// reducer workgroups of a fused launch serve two chains each from NGP_PAIR_FROM chains on (phase streamer only; knob bits 11 / 12
+// force it on / off for timing)
+int fused_pair(const ngp_handle *h0, int n) {
+    if (h0->streamer != 1 || n < 2) return 0;
+    if (h0->knob & 2048) return 1;
+    if (h0->knob & 4096) return 0;
+    return n >= NGP_PAIR_FROM ? 1 : 0;
+}
+
 bool fusable(ngp_handle **hs, int n) {
     if (n < 2 || n > NGP_MAXC) return false;
     ngp_handle *h0 = hs[0];
@@ -1538,7 +1553,7 @@ bool fusable(ngp_handle **hs, int n) {
         ngp_handle *h = hs[i];
         if (h->pm != h0->pm || h->device != h0->device || h->dbg_mode != 0 || h->d_dbg || h->dbg_census_fail_iter > 0) return false;
     }
-    return (int64_t)n * (1 + h0->NG) + h0->S <= h0->cu_count;
+    return (int64_t)n + ngp_multi_reducers(n, h0->NG, fused_pair(h0, n)) + h0->S <= h0->cu_count;
 }
 
 // niter iterations of n chains, every iteration ONE fused sweep launch on the first handle's stream; each chain's small kernels
@@ -1548,7 +1563,8 @@ int run_fused(ngp_handle **hs, int n, int64_t niter) {
     int rc;
     for (int i = 0; i < n; i++)
         if ((rc = prepare_run(hs[i], niter))) { if (i) h->err = hs[i]->err; return rc; }
-    const int64_t grid = (int64_t)n * (1 + h->NG) + h->S;
+    const int pair = fused_pair(h, n);
+    const int64_t grid = (int64_t)n + ngp_multi_reducers(n, h->NG, pair) + h->S;
     const size_t lds_sampler = (size_t)(3 * 4096 + 2 * NGP_RING * NGP_BLK + 6 * NGP_BLK) * sizeof(double) + 2 * NGP_BLK * sizeof(int) + 320;
     const size_t lds = std::max(h->streamer == 2 ? ngp_rows_multi_lds_bytes((int)h->R, n) : ngp_multi_lds_bytes((int)h->R, n), lds_sampler);
     REQUIRE(lds <= 160 * 1024, NGP_ERR_STATE, "fused sweep: LDS of a streamer with this many chains exceeds 160 KiB");
@@ -1563,7 +1579,7 @@ int run_fused(ngp_handle **hs, int n, int64_t niter) {
     rc = NGP_OK;
     for (int64_t it = 0; it < niter && rc == NGP_OK && e == hipSuccess; ++it) {
         MultiArgs M;
-        M.K = n; M.pad_ = 0;
+        M.K = n; M.pair = pair;
         for (int i = 0; i < n; i++) {
             iteration_pre(hs[i], it, false);
             fill_sweep_args(hs[i], 0, hs[i]->NBLK, M.a[i]);
@@ -2039,7 +2055,8 @@ int32_t ngp_shards_for_pass(ngp_handle *h, int32_t chains, int32_t *max_shards) 
     if ((rc = enter(h))) return rc;
     REQUIRE(chains >= 1 && chains <= NGP_MAXC && max_shards, NGP_ERR_ARG, "chains per pass: 1..8");
     int s = h->cu_count;
-    while (s >= 1 && (int64_t)chains * (1 + (s + NGP_GRP - 1) / NGP_GRP) + s > h->cu_count) --s;
+    const int pair = (chains >= NGP_PAIR_FROM && !(h->knob & 4096)) || (h->knob & 2048) ? 1 : 0;  // (fused_pair, for the phase streamer this serves)
+    while (s >= 1 && (int64_t)chains + ngp_multi_reducers(chains, (s + NGP_GRP - 1) / NGP_GRP, pair) + s > h->cu_count) --s;
     REQUIRE(s >= 1, NGP_ERR_ARG, "too many chains for this device");
     *max_shards = s;
     return NGP_OK;

@@ -25,6 +25,7 @@
 // :163-189 (three BLAS-1 passes per SNP over the panel column and its copy).
 #pragma once
 #include <cstddef>
+#include <type_traits>
 #include "ngp_sweep_args.h"
 
 #pragma clang fp contract(off)
@@ -1219,13 +1220,15 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows_tall(co
 
 // ------------------------------------------------------------------------------------------
 // reducer g: every wave works on its own blocks (u = wave, wave+8, ...), no workgroup barrier
+// (waves wv0 .. wv0 + nwv - 1 of the workgroup serve this chain's group: all eight, or four when the workgroup serves two chains)
 template <bool DBG>
-__device__ __attribute__((always_inline)) inline void role_reducer(const SweepArgs &A, const int g, char *smem) {
+__device__ __attribute__((always_inline)) inline void role_reducer(const SweepArgs &A, const int g, char *smem, const int wv0 = 0,
+                                                                   const int nwv = NGP_WG / 64) {
     NGP_DBG_LOCALS
     const int S = A.S, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int s0 = g * NGP_GRP, s1 = min(s0 + NGP_GRP, S), gsize = s1 - s0;
     const int nb = A.t1 - A.t0;
-    for (int u = wv; u < nb; u += NGP_WG / 64) {
+    for (int u = wv - wv0; u < nb; u += nwv) {
         const int slot = u % NGP_RING, round = u / NGP_RING;
         int ok = 1;
         if (lane == 0) ok = wait_ge(&A.cnt_part[((size_t)slot * A.NG + g) * 32], (unsigned)((round + 1) * gsize), A.abort_w, 2u) ? 1 : 0;
@@ -1306,7 +1309,7 @@ __device__ inline CoefRegs load_coef(const SweepArgs &A, long long k) {
 // workgroup barrier that drains LDS traffic only: global loads issued before it stay in flight
 
 // group sums of local block u -> per-lane total (lane 0 polls, whole wave loads); false on abort
-template <bool DBG>
+template <bool DBG, bool NGBIG = false>
 __device__ __attribute__((always_inline)) inline bool fetch_group_sums(const SweepArgs &A, int u, int j, double *tot_out) {
     NGP_DBG_LOCALS
     const int NG = A.NG, slot = u % NGP_RING;
@@ -1323,6 +1326,7 @@ __device__ __attribute__((always_inline)) inline bool fetch_group_sums(const Swe
 #pragma unroll
     for (int g = 1; g < 8; g++)
         if (g < NG) tot = tot + gv[g];
+    if constexpr (NGBIG)
     for (int g0 = 8; g0 < NG; g0 += 8) {  // several shards per streamer workgroup (lags 2-3): up to 699 shards = 22 groups, same order
 #pragma unroll
         for (int g = 0; g < 8; g++) gv[g] = ld_f64(gp + (size_t)min(g0 + g, NG - 1) * NGP_BLK);
@@ -1383,7 +1387,8 @@ __device__ __attribute__((always_inline)) inline void publish_block(const SweepA
 //   wave 5   lag-1 correction (cross block in registers, loaded one block ahead), final total, LDS flag for wave 0
 //   wave 4, 6, 7   lag-2, lag-3 and (near = 4) lag-4 corrections, Gram rows loaded one block ahead into registers
 // LDS: Gd[3][4096] | hist[RING][64] | vacc[RING][64] | r0[4][64] | outb[2][64] | outi[2][64] | flags, per-set constants
-template <bool DBG>
+// NGBIG: more than 8 groups of shards may exist (k_sweep_tall: several shards per streamer workgroup, lags 2-3)
+template <bool DBG, bool NGBIG = false>
 __device__ __attribute__((always_inline)) inline void role_sampler(const SweepArgs &A, char *smem) {
     NGP_DBG_LOCALS
     const int D = A.D, tid = threadIdx.x, wv = tid >> 6, j = tid & 63;
@@ -1423,7 +1428,7 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
     __syncthreads();
     if (wv == 2) {
         double tot;
-        if (fetch_group_sums<DBG>(A, 0, j, &tot)) r0[j] = tot;
+        if (fetch_group_sums<DBG, NGBIG>(A, 0, j, &tot)) r0[j] = tot;
         else if (j == 0) *sabort = 1;
     }
     __syncthreads();
@@ -1446,7 +1451,7 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
             if (D == 1) {  // lag 1: nothing can be fetched or corrected ahead
                 tot = r0[rs * NGP_BLK + j];
                 bool okc = true;
-                if (u >= 1) okc = fetch_group_sums<DBG>(A, u, j, &tot);
+                if (u >= 1) okc = fetch_group_sums<DBG, NGBIG>(A, u, j, &tot);
                 if (!okc && j == 0) *sabort = 1;
             } else {       // wave 5 applies the look-ahead corrections and leaves the final total in r0[buf]
                 // bounded like every other spin: an abort raised by another wave of this workgroup ends the wait
@@ -1645,7 +1650,7 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
             for (int u = 0; u < nb; ++u) {
                 if (u + 1 < nb && D >= 2) {
                     double tot;
-                    if (fetch_group_sums<DBG>(A, u + 1, j, &tot)) r0[((u + 1) & 3) * NGP_BLK + j] = tot;
+                    if (fetch_group_sums<DBG, NGBIG>(A, u + 1, j, &tot)) r0[((u + 1) & 3) * NGP_BLK + j] = tot;
                     else if (j == 0) *sabort = 1;
                 }
                 NGP_END_OF_BLOCK();
@@ -1799,13 +1804,6 @@ __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         role_reducer<DBG>(A, b - 1, smem);
     else {
         const int s = b - 1 - A.NG;
-        if (A.variant == 2 && A.V > 1) {  // V shards per workgroup (host: fp32 tiles, S a multiple of V; V = 2 at lag 3, V = 3 at lag 2)
-            if constexpr (!DBG) {
-                if (A.V == 2) role_streamer_rows_tall<3, 2>(A, s, smem);
-                else role_streamer_rows_tall<2, 3>(A, s, smem);
-            }
-            return;
-        }
         if (A.variant == 2) {  // row-owning waves + loader wave (host: R <= NGP_ROWS_MAX_R, lag 3..6)
             switch (A.D) {
                 case 3: role_streamer_rows<DBG, 3, 0>(A, s, smem); break;
@@ -1865,6 +1863,26 @@ __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 }
 
 
+#if defined(NGP_INST_DBG) && NGP_INST_DBG  // one definition: the second translation unit (it is the shorter one to compile)
+// The persistent sweep of fp32 panels too tall for one shard per workgroup (role_streamer_rows_tall; host: V = 2 at lag 3, V = 3 at
+// lag 2, S a multiple of V, grid 1 + NG + S / V).  A kernel of its own so that k_sweep stays what it is: the sampler here adds up to
+// 22 group sums (NGBIG), and the extra code of both cost k_sweep 7 % at 10k x 100k when they were branches of it (SGPR pressure).
+__global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sweep_tall(SweepArgs A) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int b = blockIdx.x;
+    if (ld_u32(A.abort_w) != 0u) return;
+    if (!sweep_census(A, b, smem)) return;
+    if (b == 0)
+        role_sampler<false, true>(A, smem);
+    else if (b <= A.NG)
+        role_reducer<false>(A, b - 1, smem);
+    else if (A.V == 2)
+        role_streamer_rows_tall<3, 2>(A, b - 1 - A.NG, smem);
+    else
+        role_streamer_rows_tall<2, 3>(A, b - 1 - A.NG, smem);
+}
+#endif
+
 // ------------------------------------------------------------------------------------------
 // K CHAINS PER PASS OVER THE PANEL (hard part 2).  Independent chains (one handle each, same panel, same
 // layout) share ONE launch: every streamer holds K shards of ycorr and forms X_t'[y_1 .. y_K] from each tile it reads -- the
@@ -1884,13 +1902,75 @@ __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 // trips overlap, and the publication of chain c's partial sums is wave c's job (the waves publish side by side).
 // Arithmetic per chain: exactly the one-chain phase streamer's (role_streamer, one update task per thread).
 #ifndef NGP_MULTI_G
-#define NGP_MULTI_G 3  // chains whose loads / arithmetic / stores are interleaved at a time
+#define NGP_MULTI_G 4  // chains whose loads / arithmetic / stores are interleaved at a time
 #endif
+// Wave-uniform operands without the LDS broadcast.  Every lane of a wave multiplies its own tile element by the SAME dlt_j (update)
+// or y_i (GEMV); read as broadcast LDS reads that is 16 bytes per lane and operand pair -- 256 KB of LDS reads per block with eight
+// chains, 2,000 of a block's 8,000 clocks on the LDS pipe alone, each.  Instead the 8 (4) values are read ONCE per wave, lane l
+// holding value l mod 8 (l mod 4), and v_fmac_f64 takes its first factor through the DPP modifier row_newbcast:N -- lane N of the
+// lane's row of 16, the DGEMM broadcast of the VALU -- fused exactly like __builtin_fma (tools/microbench/dpp_bcast.hip).
+// One asm statement carries a whole group of chains, step by step, so that the chains' dependent fmac interleave; the leading
+// s_nop covers the two wait states a DPP read needs after a VALU write of its source (the compiler does not see DPP in asm).
+#define NGP_FB(P, D, X, N) "v_fmac_f64_dpp " P ", " D ", " X " row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n\t"
+template <int GN>
+__device__ __attribute__((always_inline)) inline void fmac8_bcast(double (&p)[GN], const double (&dv)[GN], const double (&x)[8]) {
+    static_assert(GN >= 1 && GN <= 4, "group of 1..4 chains");
+#define NGP_X8 "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7])
+    if constexpr (GN == 1) {
+#define NGP_ST(N, XO) NGP_FB("%0", "%1", XO, N)
+        asm("s_nop 1\n\t" NGP_ST(0, "%2") NGP_ST(1, "%3") NGP_ST(2, "%4") NGP_ST(3, "%5") NGP_ST(4, "%6") NGP_ST(5, "%7") NGP_ST(6, "%8") NGP_ST(7, "%9")
+            : "+v"(p[0]) : "v"(dv[0]), NGP_X8);
+#undef NGP_ST
+    } else if constexpr (GN == 2) {
+#define NGP_ST(N, XO) NGP_FB("%0", "%2", XO, N) NGP_FB("%1", "%3", XO, N)
+        asm("s_nop 1\n\t" NGP_ST(0, "%4") NGP_ST(1, "%5") NGP_ST(2, "%6") NGP_ST(3, "%7") NGP_ST(4, "%8") NGP_ST(5, "%9") NGP_ST(6, "%10") NGP_ST(7, "%11")
+            : "+v"(p[0]), "+v"(p[1]) : "v"(dv[0]), "v"(dv[1]), NGP_X8);
+#undef NGP_ST
+    } else if constexpr (GN == 3) {
+#define NGP_ST(N, XO) NGP_FB("%0", "%3", XO, N) NGP_FB("%1", "%4", XO, N) NGP_FB("%2", "%5", XO, N)
+        asm("s_nop 1\n\t" NGP_ST(0, "%6") NGP_ST(1, "%7") NGP_ST(2, "%8") NGP_ST(3, "%9") NGP_ST(4, "%10") NGP_ST(5, "%11") NGP_ST(6, "%12") NGP_ST(7, "%13")
+            : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]) : "v"(dv[0]), "v"(dv[1]), "v"(dv[2]), NGP_X8);
+#undef NGP_ST
+    } else {
+#define NGP_ST(N, XO) NGP_FB("%0", "%4", XO, N) NGP_FB("%1", "%5", XO, N) NGP_FB("%2", "%6", XO, N) NGP_FB("%3", "%7", XO, N)
+        asm("s_nop 1\n\t" NGP_ST(0, "%8") NGP_ST(1, "%9") NGP_ST(2, "%10") NGP_ST(3, "%11") NGP_ST(4, "%12") NGP_ST(5, "%13") NGP_ST(6, "%14") NGP_ST(7, "%15")
+            : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) : "v"(dv[0]), "v"(dv[1]), "v"(dv[2]), "v"(dv[3]), NGP_X8);
+#undef NGP_ST
+    }
+#undef NGP_X8
+}
+// the same for a quad of rows: acc_c += x_e * y_c[e], e = 0..3 in order (yv: lane l holds y_c[l mod 4])
+template <int GN>
+__device__ __attribute__((always_inline)) inline void fmac4_bcast(double (&a)[GN], const double (&yv)[GN], const double (&x)[4]) {
+    static_assert(GN >= 1 && GN <= 4, "group of 1..4 chains");
+#define NGP_X4 "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3])
+    if constexpr (GN == 1) {
+#define NGP_ST(N, XO) NGP_FB("%0", "%1", XO, N)
+        asm("s_nop 1\n\t" NGP_ST(0, "%2") NGP_ST(1, "%3") NGP_ST(2, "%4") NGP_ST(3, "%5") : "+v"(a[0]) : "v"(yv[0]), NGP_X4);
+#undef NGP_ST
+    } else if constexpr (GN == 2) {
+#define NGP_ST(N, XO) NGP_FB("%0", "%2", XO, N) NGP_FB("%1", "%3", XO, N)
+        asm("s_nop 1\n\t" NGP_ST(0, "%4") NGP_ST(1, "%5") NGP_ST(2, "%6") NGP_ST(3, "%7") : "+v"(a[0]), "+v"(a[1]) : "v"(yv[0]), "v"(yv[1]), NGP_X4);
+#undef NGP_ST
+    } else if constexpr (GN == 3) {
+#define NGP_ST(N, XO) NGP_FB("%0", "%3", XO, N) NGP_FB("%1", "%4", XO, N) NGP_FB("%2", "%5", XO, N)
+        asm("s_nop 1\n\t" NGP_ST(0, "%6") NGP_ST(1, "%7") NGP_ST(2, "%8") NGP_ST(3, "%9")
+            : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]) : "v"(yv[0]), "v"(yv[1]), "v"(yv[2]), NGP_X4);
+#undef NGP_ST
+    } else {
+#define NGP_ST(N, XO) NGP_FB("%0", "%4", XO, N) NGP_FB("%1", "%5", XO, N) NGP_FB("%2", "%6", XO, N) NGP_FB("%3", "%7", XO, N)
+        asm("s_nop 1\n\t" NGP_ST(0, "%8") NGP_ST(1, "%9") NGP_ST(2, "%10") NGP_ST(3, "%11")
+            : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "v"(yv[0]), "v"(yv[1]), "v"(yv[2]), "v"(yv[3]), NGP_X4);
+#undef NGP_ST
+    }
+#undef NGP_X4
+}
+
 template <int DT, int KC>
 __device__ __attribute__((always_inline)) inline void role_streamer_multi(const MultiArgs &Mr, const int s, char *smem) {
     const MultiArgs *Mp = &Mr;     // (the kernel's by-value argument: every index below is a compile-time constant after unrolling)
     const SweepArgs &A = Mp->a[0];
-    static_assert(KC >= 2 && KC <= 8, "publication: one wave per chain");
+    static_assert(KC >= 2 && KC <= 8, "publication: waves 0-3, two chains each at most");
     const int R = A.R, S = A.S, tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), j = tid & 63;
     const size_t TBL = (size_t)(R >> 2) * NGP_QS;
@@ -1917,13 +1997,18 @@ __device__ __attribute__((always_inline)) inline void role_streamer_multi(const 
     const unsigned *flagp[KC];
 #pragma unroll
     for (int kc = 0; kc < KC; kc++) { dltp[kc] = Mp->a[kc].dlt; flagp[kc] = Mp->a[kc].flag_dlt; }
-    // wave c < KC publishes chain c
-    const bool pubw = wv < KC;
-    double *my_part = nullptr;
-    unsigned *my_cnt = nullptr;
+    // waves 0-3 publish: wave w the partial sums of chain w and of chain w + 4.  Not waves 4-6 -- they issue the tile DMA, and a
+    // wave that waits for its DMA (s_waitcnt vmcnt) waits for the acknowledgement of its last store with it: with one publishing
+    // wave per chain, the fifth chain put that microsecond into phase A of every block (10k x 100k: 2.06 -> 2.85 us per block).
+    const bool pubw = wv < 4 && wv < KC;
+    const bool pub2 = pubw && (wv + 4 < KC);
+    double *my_part = nullptr, *my_part2 = nullptr;
+    unsigned *my_cnt = nullptr, *my_cnt2 = nullptr;
 #pragma unroll
-    for (int kc = 0; kc < KC; kc++)
+    for (int kc = 0; kc < KC; kc++) {
         if (kc == wv) { my_part = Mp->a[kc].part; my_cnt = Mp->a[kc].cnt_part; }
+        if (kc == wv + 4) { my_part2 = Mp->a[kc].part; my_cnt2 = Mp->a[kc].cnt_part; }
+    }
 #pragma unroll
     for (int kc = 0; kc < KC; kc++) {
         const double *yg = Mp->a[kc].ycorr + (size_t)s * R;
@@ -1952,9 +2037,9 @@ __device__ __attribute__((always_inline)) inline void role_streamer_multi(const 
             for (int kc = 0; kc < KC; kc++) NGP_DL(kc)[(uu & 1) * 64 + j] = v[kc];
         }
     };
-    // the update task of this thread (fixed for the whole sweep): 8-column chain tcc of row ti0; surplus threads redo the last task
-    const int tq_ = min(tid, 8 * R - 1);
-    const int tcc = tq_ / R, ti0 = tq_ - tcc * R;
+    // the update task of this thread (fixed for the whole sweep): 8-column chain tcc = its wave, row ti0 = its lane -- so the eight
+    // dlt of a task are wave-uniform (fmac8_bcast); lanes beyond the shard redo the last row (R <= 64: host)
+    const int tcc = wv, ti0 = min(j, R - 1);
     float keep[DT][8];
 #pragma unroll
     for (int d = 0; d < DT; d++)
@@ -1974,6 +2059,7 @@ __device__ __attribute__((always_inline)) inline void role_streamer_multi(const 
         if (force) drain_vm();
         else if ((__builtin_amdgcn_s_getreg((23 << 11) | 7) & 0xC0000Fu) != 0u) return;  // VM_CNT [3:0] and [23:22]
         if (j == 0) atomicAdd(&my_cnt[((size_t)sig_pending * A.NG + g) * 32], 1u);
+        if (pub2 && j == 1) atomicAdd(&my_cnt2[((size_t)sig_pending * A.NG + g) * 32], 1u);
         sig_pending = -1;
     };
     __syncthreads();
@@ -2000,31 +2086,22 @@ __device__ __attribute__((always_inline)) inline void role_streamer_multi(const 
             if (!*sflag) return;
             // ---------------- phase B: the 8-column partial sums of ycorr -= X_a dlt_a, every chain ----------------
             if (a >= 0) {
+                double xk[8];
 #pragma unroll
-                for (int g0 = 0; g0 < KC; g0 += NGP_MULTI_G) {  // groups of chains: their LDS round trips overlap, the register arrays stay small
-                    constexpr int GN = NGP_MULTI_G;
-                    double2 dq2[GN][4];
-                    double p[GN];
+                for (int h = 0; h < 8; h++) xk[h] = (double)keep[d][h];
+                // (per chain: the eight fma in column order, as the one-chain streamer; the chains of a group interleaved)
+                auto upd_group = [&](auto gn, const int g0) __attribute__((always_inline)) {
+                    constexpr int GN = decltype(gn)::value;
+                    double dv[GN], p[GN];
 #pragma unroll
-                    for (int q = 0; q < GN; q++)
-                        if (g0 + q < KC) {
-                            const double2 *dq = (const double2 *)(NGP_DL(g0 + q) + (u & 1) * 64 + 8 * tcc);
+                    for (int q = 0; q < GN; q++) { dv[q] = NGP_DL(g0 + q)[(u & 1) * 64 + 8 * tcc + (j & 7)]; p[q] = 0.0; }
+                    fmac8_bcast<GN>(p, dv, xk);
 #pragma unroll
-                            for (int h = 0; h < 4; h++) dq2[q][h] = dq[h];
-                            p[q] = 0.0;
-                        }
+                    for (int q = 0; q < GN; q++) NGP_PP(g0 + q)[(size_t)tcc * R + ti0] = p[q];
+                };
 #pragma unroll
-                    for (int h = 0; h < 4; h++)
-#pragma unroll
-                        for (int q = 0; q < GN; q++)
-                            if (g0 + q < KC) {  // (per chain: the eight fma in column order, as the one-chain streamer)
-                                p[q] = __builtin_fma((double)keep[d][2 * h], dq2[q][h].x, p[q]);
-                                p[q] = __builtin_fma((double)keep[d][2 * h + 1], dq2[q][h].y, p[q]);
-                            }
-#pragma unroll
-                    for (int q = 0; q < GN; q++)
-                        if (g0 + q < KC) NGP_PP(g0 + q)[(size_t)tcc * R + ti0] = p[q];
-                }
+                for (int g0 = 0; g0 + NGP_MULTI_G <= KC; g0 += NGP_MULTI_G) upd_group(std::integral_constant<int, NGP_MULTI_G>{}, g0);
+                if constexpr (KC % NGP_MULTI_G != 0) upd_group(std::integral_constant<int, KC % NGP_MULTI_G>{}, KC - KC % NGP_MULTI_G);
                 try_signal(false);
                 wg_barrier();
                 try_signal(false);
@@ -2065,26 +2142,20 @@ __device__ __attribute__((always_inline)) inline void role_streamer_multi(const 
                     for (int kc = 0; kc < KC; kc++) acc[kc] = 0.0;
                     for (int qd = wv; qd < (R >> 2); qd += 8) {
                         const float4 x = *(const float4 *)(col + (size_t)qd * (NGP_QS / 4));
+                        const double xd[4] = {(double)x.x, (double)x.y, (double)x.z, (double)x.w};
+                        // (the quad's four y of a chain: one 8-byte read per lane, lane l holding y[4 qd + l mod 4]; fmac4_bcast)
+                        auto gemv_group = [&](auto gn, const int g0) __attribute__((always_inline)) {
+                            constexpr int GN = decltype(gn)::value;
+                            double yv[GN], ac[GN];
 #pragma unroll
-                        for (int g0 = 0; g0 < KC; g0 += NGP_MULTI_G) {
-                            constexpr int GN = NGP_MULTI_G;
-                            double y[GN][4];
+                            for (int q = 0; q < GN; q++) { yv[q] = NGP_YS(g0 + q)[4 * qd + (j & 3)]; ac[q] = acc[g0 + q]; }
+                            fmac4_bcast<GN>(ac, yv, xd);
 #pragma unroll
-                            for (int q = 0; q < GN; q++)
-                                if (g0 + q < KC) {
-                                    const double *yq = NGP_YS(g0 + q) + 4 * qd;  // (one address for the whole wave: a broadcast read)
+                            for (int q = 0; q < GN; q++) acc[g0 + q] = ac[q];
+                        };
 #pragma unroll
-                                    for (int e = 0; e < 4; e++) y[q][e] = yq[e];
-                                }
-#pragma unroll
-                            for (int q = 0; q < GN; q++) if (g0 + q < KC) acc[g0 + q] = __builtin_fma((double)x.x, y[q][0], acc[g0 + q]);
-#pragma unroll
-                            for (int q = 0; q < GN; q++) if (g0 + q < KC) acc[g0 + q] = __builtin_fma((double)x.y, y[q][1], acc[g0 + q]);
-#pragma unroll
-                            for (int q = 0; q < GN; q++) if (g0 + q < KC) acc[g0 + q] = __builtin_fma((double)x.z, y[q][2], acc[g0 + q]);
-#pragma unroll
-                            for (int q = 0; q < GN; q++) if (g0 + q < KC) acc[g0 + q] = __builtin_fma((double)x.w, y[q][3], acc[g0 + q]);
-                        }
+                        for (int g0 = 0; g0 + NGP_MULTI_G <= KC; g0 += NGP_MULTI_G) gemv_group(std::integral_constant<int, NGP_MULTI_G>{}, g0);
+                        if constexpr (KC % NGP_MULTI_G != 0) gemv_group(std::integral_constant<int, KC % NGP_MULTI_G>{}, KC - KC % NGP_MULTI_G);
                     }
 #pragma unroll
                     for (int kc = 0; kc < KC; kc++) NGP_RED(kc)[wv * 64 + j] = acc[kc];
@@ -2110,17 +2181,24 @@ __device__ __attribute__((always_inline)) inline void role_streamer_multi(const 
 #pragma unroll
                     for (int kc = 0; kc < KC; kc++) NGP_DL(kc)[((u + 1) & 1) * 64 + j] = dnext[kc];
                 }
-                if (pubw) {  // wave c publishes chain c (the waves side by side)
+                if (pubw) {  // waves 0-3 publish side by side, chains w and w + 4
                     const int slot = u % NGP_RING;
                     const double *red = NGP_RED(wv);
                     const double p = ((red[j] + red[64 + j]) + (red[128 + j] + red[192 + j])) + ((red[256 + j] + red[320 + j]) + (red[384 + j] + red[448 + j]));
-                    try_signal(true);  // the previous partial, if its store was still under way at every boundary
+                    double p2 = 0.0;
+                    if (pub2) {
+                        const double *red2 = NGP_RED(wv + 4);
+                        p2 = ((red2[j] + red2[64 + j]) + (red2[128 + j] + red2[192 + j])) + ((red2[256 + j] + red2[320 + j]) + (red2[384 + j] + red2[448 + j]));
+                    }
+                    try_signal(true);  // the previous partials, if their stores were still under way at every boundary
                     st_f64(&my_part[((size_t)slot * S + s) * NGP_BLK + j], p);
+                    if (pub2) st_f64(&my_part2[((size_t)slot * S + s) * NGP_BLK + j], p2);
                     if (LAZY) {
                         sig_pending = slot;
                     } else {
                         drain_vm();
                         if (j == 0) atomicAdd(&my_cnt[((size_t)slot * A.NG + g) * 32], 1u);
+                        if (pub2 && j == 1) atomicAdd(&my_cnt2[((size_t)slot * A.NG + g) * 32], 1u);
                     }
                 }
             } else if (wv == 7 && DT >= 3) poll_dlt(u + 1);
@@ -2430,12 +2508,23 @@ __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         return;
     }
     const int idx = b - min(K, (b + NGP_MULTI_STRIDE - 1) / NGP_MULTI_STRIDE);  // rank among the blocks that are not samplers
-    if (idx < K * NG) {
-        role_reducer<false>(multi_chain_args(__builtin_amdgcn_readfirstlane(idx / NG)), idx % NG, smem);
+    const int NR = ngp_multi_reducers(K, NG, M.pair);
+    if (idx < NR) {
+        if (M.pair) {  // workgroup (p, g): chain 2 p in waves 0-3, chain 2 p + 1 in waves 4-7 (an unpaired last chain keeps all eight)
+            const int pr = idx / NG, wq = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
+            if (2 * pr + 1 >= K) role_reducer<false>(multi_chain_args(__builtin_amdgcn_readfirstlane(2 * pr)), idx % NG, smem);
+            else role_reducer<false>(multi_chain_args(__builtin_amdgcn_readfirstlane(2 * pr + wq)), idx % NG, smem, 4 * wq, 4);
+        } else {
+            role_reducer<false>(multi_chain_args(__builtin_amdgcn_readfirstlane(idx / NG)), idx % NG, smem);
+        }
         return;
     }
-    const int s = idx - K * NG;
+    const int s = idx - NR;
     // host: lag 6 or 8 (shards of at most 64 rows, fp32 tiles), 2..8 chains
+#ifdef NGP_MULTI_ONLY  /* resource-usage experiments: one instantiation (hipcc -DNGP_MULTI_ONLY=8 -Rpass-analysis=kernel-resource-usage) */
+    role_streamer_multi<8, NGP_MULTI_ONLY>(M, s, smem);
+    return;
+#endif
 #define NGP_MULTI_K(DTV)                                              \
     switch (K) {                                                      \
         case 2: role_streamer_multi<DTV, 2>(M, s, smem); break;       \

@@ -96,8 +96,13 @@ __host__ __device__ inline int ngp_u8_tasks(int R) {
 #ifndef NGP_MAXC
 #define NGP_MAXC 8  // chains per pass (per-chain registers of the streamer: 2 VGPRs each of shard, GEMV sum, dlt)
 #endif
+#ifndef NGP_PAIR_FROM
+#define NGP_PAIR_FROM 4  // from this many chains on a reducer workgroup serves TWO chains (four waves each): K NG / 2 CUs go back to the streamers
+#endif
+// reducer workgroups of a fused launch
+__host__ __device__ inline int ngp_multi_reducers(int K, int NG, int pair) { return pair ? ((K + 1) / 2) * NG : K * NG; }
 struct MultiArgs {
-    int K, pad_;
+    int K, pair;  // pair != 0: reducer workgroup (p, g) serves chains 2 p (waves 0-3) and 2 p + 1 (waves 4-7) of group g
     SweepArgs a[NGP_MAXC];  // same tiles / gramx / layout in every entry; a[c].abort_w, census of chain 0 are the launch's
 };
 struct ChainPtrs {  // what a streamer needs of one chain (LDS copy: lanes index it by chain)
@@ -128,6 +133,10 @@ hipError_t sweep_set_max_lds_0(int bytes);
 hipError_t sweep_set_max_lds_1(int bytes);
 hipError_t sweep_occupancy_0(int *wg_per_cu, size_t lds_bytes);
 void sweep_launch_0(unsigned grid, size_t lds_bytes, hipStream_t stream, const SweepArgs &A);
+// k_sweep_tall (several shards per streamer workgroup; lives in the second translation unit)
+hipError_t sweep_tall_set_max_lds(int bytes);
+hipError_t sweep_tall_occupancy(int *wg_per_cu, size_t lds_bytes);
+void sweep_tall_launch(unsigned grid, size_t lds_bytes, hipStream_t stream, const SweepArgs &A);
 void sweep_launch_1(unsigned grid, size_t lds_bytes, hipStream_t stream, const SweepArgs &A);
 
 }  // namespace ngp

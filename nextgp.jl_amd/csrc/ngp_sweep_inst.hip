@@ -32,6 +32,18 @@ hipError_t sweep_occupancy_0(int *wg_per_cu, size_t lds_bytes) {
     return hipOccupancyMaxActiveBlocksPerMultiprocessor(wg_per_cu, (const void *)k_sweep<false>, NGP_WG, lds_bytes);
 }
 #endif
+#if NGP_INST_DBG
+// several shards per streamer workgroup (tall fp32 panels): defined in this translation unit, the shorter one
+hipError_t sweep_tall_set_max_lds(int bytes) {
+    return hipFuncSetAttribute((const void *)k_sweep_tall, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+hipError_t sweep_tall_occupancy(int *wg_per_cu, size_t lds_bytes) {
+    return hipOccupancyMaxActiveBlocksPerMultiprocessor(wg_per_cu, (const void *)k_sweep_tall, NGP_WG, lds_bytes);
+}
+void sweep_tall_launch(unsigned grid, size_t lds_bytes, hipStream_t stream, const SweepArgs &A) {
+    hipLaunchKernelGGL(k_sweep_tall, dim3(grid), dim3(NGP_WG), lds_bytes, stream, A);
+}
+#endif
 void NGP_SFX(sweep_launch)(unsigned grid, size_t lds_bytes, hipStream_t stream, const SweepArgs &A) {
     hipLaunchKernelGGL(k_sweep<kDbg>, dim3(grid), dim3(NGP_WG), lds_bytes, stream, A);
 }

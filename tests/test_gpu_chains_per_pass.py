@@ -36,7 +36,9 @@ def test_fused_chains_equal_the_chains_alone_and_the_oracle(ngp, O, K, lag):
     R, S, _ = fused[0].layout()
     assert R <= 64 and fused[0].streamer()[0] == 1
     ngp.Sampler.run_many(fused, 20)
-    assert fused[0].census()["grid"] == K * (1 + (S + 31) // 32) + S          # ONE launch served all chains
+    # ONE launch served all chains: K samplers, S streamers, and reducers per group of 32 shards -- one workgroup per chain, or
+    # (from four chains on) one per pair of chains
+    assert fused[0].census()["grid"] == K + (((K + 1) // 2) if K >= 4 else K) * ((S + 31) // 32) + S
     for c in (0, K - 1):
         alone = ngp.Sampler(device=0, seed=1001 + c, chain=c, **({"mode": 1, "lag": lag} if lag else {}))
         alone.set_max_shards(S); alone.set_panel(X)

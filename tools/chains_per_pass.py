@@ -12,6 +12,7 @@ method = os.environ.get("NGP_TOOL_METHOD", "PR")
 chains = []
 for k in range(K):
     s = ngp.Sampler(device=0, seed=1001 + k, chain=k, **({"mode": 1, "lag": lag} if lag else {}))
+    if "NGP_TOOL_KNOB" in os.environ: s.debug_set_knob(int(os.environ["NGP_TOOL_KNOB"]))  # 2048 / 4096: reducers serve two chains each / one
     if k == 0:
         if K > 1:
             s.set_max_shards(int(os.environ.get("NGP_TOOL_SHARDS", "0")) or s.shards_for_pass(K))
