@@ -28,6 +28,10 @@
 #include <type_traits>
 #include "ngp_sweep_args.h"
 
+#ifndef NGP_ROWS_DPP
+#define NGP_ROWS_DPP 1  // row-owning streamer: y of a quad by DPP broadcast (see fmac4_bcast)
+#endif
+
 #pragma clang fp contract(off)
 
 namespace ngp {
@@ -500,6 +504,69 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
 }
 
 
+// Wave-uniform operands without the LDS broadcast.  Every lane of a wave multiplies its own tile element by the SAME dlt_j (update)
+// or y_i (GEMV); read as broadcast LDS reads that is 16 bytes per lane and operand pair -- 256 KB of LDS reads per block with eight
+// chains, 2,000 of a block's 8,000 clocks on the LDS pipe alone, each.  Instead the 8 (4) values are read ONCE per wave, lane l
+// holding value l mod 8 (l mod 4), and v_fmac_f64 takes its first factor through the DPP modifier row_newbcast:N -- lane N of the
+// lane's row of 16, the DGEMM broadcast of the VALU -- fused exactly like __builtin_fma (tools/microbench/dpp_bcast.hip).
+// One asm statement carries a whole group of chains, step by step, so that the chains' dependent fmac interleave; the leading
+// s_nop covers the two wait states a DPP read needs after a VALU write of its source (the compiler does not see DPP in asm).
+#define NGP_FB(P, D, X, N) "v_fmac_f64_dpp " P ", " D ", " X " row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n\t"
+template <int GN>
+__device__ __attribute__((always_inline)) inline void fmac8_bcast(double (&p)[GN], const double (&dv)[GN], const double (&x)[8]) {
+    static_assert(GN >= 1 && GN <= 4, "group of 1..4 chains");
+#define NGP_X8 "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7])
+    if constexpr (GN == 1) {
+#define NGP_ST(N, XO) NGP_FB("%0", "%1", XO, N)
+        asm("s_nop 1\n\t" NGP_ST(0, "%2") NGP_ST(1, "%3") NGP_ST(2, "%4") NGP_ST(3, "%5") NGP_ST(4, "%6") NGP_ST(5, "%7") NGP_ST(6, "%8") NGP_ST(7, "%9")
+            : "+v"(p[0]) : "v"(dv[0]), NGP_X8);
+#undef NGP_ST
+    } else if constexpr (GN == 2) {
+#define NGP_ST(N, XO) NGP_FB("%0", "%2", XO, N) NGP_FB("%1", "%3", XO, N)
+        asm("s_nop 1\n\t" NGP_ST(0, "%4") NGP_ST(1, "%5") NGP_ST(2, "%6") NGP_ST(3, "%7") NGP_ST(4, "%8") NGP_ST(5, "%9") NGP_ST(6, "%10") NGP_ST(7, "%11")
+            : "+v"(p[0]), "+v"(p[1]) : "v"(dv[0]), "v"(dv[1]), NGP_X8);
+#undef NGP_ST
+    } else if constexpr (GN == 3) {
+#define NGP_ST(N, XO) NGP_FB("%0", "%3", XO, N) NGP_FB("%1", "%4", XO, N) NGP_FB("%2", "%5", XO, N)
+        asm("s_nop 1\n\t" NGP_ST(0, "%6") NGP_ST(1, "%7") NGP_ST(2, "%8") NGP_ST(3, "%9") NGP_ST(4, "%10") NGP_ST(5, "%11") NGP_ST(6, "%12") NGP_ST(7, "%13")
+            : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]) : "v"(dv[0]), "v"(dv[1]), "v"(dv[2]), NGP_X8);
+#undef NGP_ST
+    } else {
+#define NGP_ST(N, XO) NGP_FB("%0", "%4", XO, N) NGP_FB("%1", "%5", XO, N) NGP_FB("%2", "%6", XO, N) NGP_FB("%3", "%7", XO, N)
+        asm("s_nop 1\n\t" NGP_ST(0, "%8") NGP_ST(1, "%9") NGP_ST(2, "%10") NGP_ST(3, "%11") NGP_ST(4, "%12") NGP_ST(5, "%13") NGP_ST(6, "%14") NGP_ST(7, "%15")
+            : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) : "v"(dv[0]), "v"(dv[1]), "v"(dv[2]), "v"(dv[3]), NGP_X8);
+#undef NGP_ST
+    }
+#undef NGP_X8
+}
+// the same for a quad of rows: acc_c += x_e * y_c[e], e = 0..3 in order (yv: lane l holds y_c[l mod 4])
+template <int GN>
+__device__ __attribute__((always_inline)) inline void fmac4_bcast(double (&a)[GN], const double (&yv)[GN], const double (&x)[4]) {
+    static_assert(GN >= 1 && GN <= 4, "group of 1..4 chains");
+#define NGP_X4 "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3])
+    if constexpr (GN == 1) {
+#define NGP_ST(N, XO) NGP_FB("%0", "%1", XO, N)
+        asm("s_nop 1\n\t" NGP_ST(0, "%2") NGP_ST(1, "%3") NGP_ST(2, "%4") NGP_ST(3, "%5") : "+v"(a[0]) : "v"(yv[0]), NGP_X4);
+#undef NGP_ST
+    } else if constexpr (GN == 2) {
+#define NGP_ST(N, XO) NGP_FB("%0", "%2", XO, N) NGP_FB("%1", "%3", XO, N)
+        asm("s_nop 1\n\t" NGP_ST(0, "%4") NGP_ST(1, "%5") NGP_ST(2, "%6") NGP_ST(3, "%7") : "+v"(a[0]), "+v"(a[1]) : "v"(yv[0]), "v"(yv[1]), NGP_X4);
+#undef NGP_ST
+    } else if constexpr (GN == 3) {
+#define NGP_ST(N, XO) NGP_FB("%0", "%3", XO, N) NGP_FB("%1", "%4", XO, N) NGP_FB("%2", "%5", XO, N)
+        asm("s_nop 1\n\t" NGP_ST(0, "%6") NGP_ST(1, "%7") NGP_ST(2, "%8") NGP_ST(3, "%9")
+            : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]) : "v"(yv[0]), "v"(yv[1]), "v"(yv[2]), NGP_X4);
+#undef NGP_ST
+    } else {
+#define NGP_ST(N, XO) NGP_FB("%0", "%4", XO, N) NGP_FB("%1", "%5", XO, N) NGP_FB("%2", "%6", XO, N) NGP_FB("%3", "%7", XO, N)
+        asm("s_nop 1\n\t" NGP_ST(0, "%8") NGP_ST(1, "%9") NGP_ST(2, "%10") NGP_ST(3, "%11")
+            : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "v"(yv[0]), "v"(yv[1]), "v"(yv[2]), "v"(yv[3]), NGP_X4);
+#undef NGP_ST
+    }
+#undef NGP_X4
+}
+
+
 // ------------------------------------------------------------------------------------------
 // Streamer, variant 2 ("row-owning waves"), shards of up to NGP_ROWS_MAX_R rows, lags 3..6.
 //
@@ -545,15 +612,21 @@ __device__ inline double dpp_f64(double v, const int ctrl_sel) {
     return __hiloint2double(hi, lo);
 }
 
-// s_waitcnt vmcnt(n) for a wave-uniform run-time n in 0..NGP_ROWS_HMAX (the instruction takes an immediate)
+// s_waitcnt vmcnt(n) for a wave-uniform run-time n in 0..63 (the instruction takes an immediate; the counter has 6 bits)
 __device__ inline void wait_vmcnt_le(int n) {
 #define NGP_VMC(i) case i: asm volatile("s_waitcnt vmcnt(" #i ")" ::: "memory"); break;
+#define NGP_VMC8(b) NGP_VMC(b) NGP_VMC(b + 1) NGP_VMC(b + 2) NGP_VMC(b + 3) NGP_VMC(b + 4) NGP_VMC(b + 5) NGP_VMC(b + 6) NGP_VMC(b + 7)
     switch (n) {
         NGP_VMC(1) NGP_VMC(2) NGP_VMC(3) NGP_VMC(4) NGP_VMC(5) NGP_VMC(6) NGP_VMC(7) NGP_VMC(8) NGP_VMC(9) NGP_VMC(10) NGP_VMC(11)
         NGP_VMC(12) NGP_VMC(13) NGP_VMC(14) NGP_VMC(15) NGP_VMC(16) NGP_VMC(17) NGP_VMC(18) NGP_VMC(19) NGP_VMC(20) NGP_VMC(21)
-        NGP_VMC(22) NGP_VMC(23) NGP_VMC(24) NGP_VMC(25) NGP_VMC(26) NGP_VMC(27) NGP_VMC(28) NGP_VMC(29) NGP_VMC(30) NGP_VMC(31) NGP_VMC(32) NGP_VMC(36) NGP_VMC(40) NGP_VMC(44) NGP_VMC(48) NGP_VMC(56)
+        NGP_VMC(22) NGP_VMC(23) NGP_VMC(24) NGP_VMC(25) NGP_VMC(26) NGP_VMC(27) NGP_VMC(28) NGP_VMC(29) NGP_VMC(30) NGP_VMC(31)
+        NGP_VMC(32) NGP_VMC(33) NGP_VMC(34) NGP_VMC(35) NGP_VMC(36) NGP_VMC(37) NGP_VMC(38) NGP_VMC(39) NGP_VMC(40) NGP_VMC(41)
+        NGP_VMC(42) NGP_VMC(43) NGP_VMC(44) NGP_VMC(45) NGP_VMC(46) NGP_VMC(47) NGP_VMC(48) NGP_VMC(49) NGP_VMC(50) NGP_VMC(51)
+        NGP_VMC(52) NGP_VMC(53) NGP_VMC(54) NGP_VMC(55) NGP_VMC(56) NGP_VMC(57) NGP_VMC(58) NGP_VMC(59) NGP_VMC(60) NGP_VMC(61)
+        NGP_VMC(62) NGP_VMC(63)
         default: asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); break;
     }
+#undef NGP_VMC8
 #undef NGP_VMC
 }
 
@@ -672,6 +745,10 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows(const S
                 const size_t lo = (size_t)slice * slice_bytes, hi = min((size_t)(slice + 1) * slice_bytes, gram_bytes);
                 for (size_t off = lo; off + 1024 <= hi; off += 1024) dma16_s(scratch0, gb + off, voff);
             }
+            // (Requesting more of tile u+2 here -- into the slots of tile u, which the row waves have left 1.7 us into the block,
+            // so that more than H requests are in flight while the loader sits at the barrier -- was built and measured: 50k x 600k
+            // 24.1 -> 25.1 ms per iteration.  The stream itself gains, but the partial sums going out and dlt coming in queue behind
+            // the deeper request queue, and the hand-off loop is what bounds the sweep.)
             if (u + 1 < nb) dma_quads(u + 1, H, NQ, base1);
             int n2 = 0;
             if (u + 2 < nb) n2 = dma_quads(u + 2, 0, H, base2);
@@ -871,12 +948,21 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows(const S
                             }
                         } else {
                             const float4 x = *(const float4 *)(ring + (size_t)wrap(base + q) * NGP_QS + (size_t)lane * 16);
+#if NGP_ROWS_DPP
+                            // the quad's four y: ONE 8-byte read per lane (lane l: y[4 q + l mod 4]) and the DPP broadcast, instead of
+                            // 32 bytes per lane of broadcast reads -- a quarter of this loop's LDS read cycles beside the tile DMA
+                            const double xd[4] = {(double)x.x, (double)x.y, (double)x.z, (double)x.w};
+                            double yv[1] = {ys[4 * q + (lane & 3)]}, ac[1] = {acc};
+                            fmac4_bcast<1>(ac, yv, xd);
+                            acc = ac[0];
+#else
                             const double *yq = ys + 4 * q;
                             const double y0 = yq[0], y1 = yq[1], y2 = yq[2], y3 = yq[3];
                             acc = __builtin_fma((double)x.x, y0, acc);
                             acc = __builtin_fma((double)x.y, y1, acc);
                             acc = __builtin_fma((double)x.z, y2, acc);
                             acc = __builtin_fma((double)x.w, y3, acc);
+#endif
                         }
                     }
                     red[((u & 1) * NGP_ROWS_NW + wv) * NGP_BLK + lane] = acc;
@@ -1904,68 +1990,6 @@ __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #ifndef NGP_MULTI_G
 #define NGP_MULTI_G 4  // chains whose loads / arithmetic / stores are interleaved at a time
 #endif
-// Wave-uniform operands without the LDS broadcast.  Every lane of a wave multiplies its own tile element by the SAME dlt_j (update)
-// or y_i (GEMV); read as broadcast LDS reads that is 16 bytes per lane and operand pair -- 256 KB of LDS reads per block with eight
-// chains, 2,000 of a block's 8,000 clocks on the LDS pipe alone, each.  Instead the 8 (4) values are read ONCE per wave, lane l
-// holding value l mod 8 (l mod 4), and v_fmac_f64 takes its first factor through the DPP modifier row_newbcast:N -- lane N of the
-// lane's row of 16, the DGEMM broadcast of the VALU -- fused exactly like __builtin_fma (tools/microbench/dpp_bcast.hip).
-// One asm statement carries a whole group of chains, step by step, so that the chains' dependent fmac interleave; the leading
-// s_nop covers the two wait states a DPP read needs after a VALU write of its source (the compiler does not see DPP in asm).
-#define NGP_FB(P, D, X, N) "v_fmac_f64_dpp " P ", " D ", " X " row_newbcast:" #N " row_mask:0xf bank_mask:0xf\n\t"
-template <int GN>
-__device__ __attribute__((always_inline)) inline void fmac8_bcast(double (&p)[GN], const double (&dv)[GN], const double (&x)[8]) {
-    static_assert(GN >= 1 && GN <= 4, "group of 1..4 chains");
-#define NGP_X8 "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3]), "v"(x[4]), "v"(x[5]), "v"(x[6]), "v"(x[7])
-    if constexpr (GN == 1) {
-#define NGP_ST(N, XO) NGP_FB("%0", "%1", XO, N)
-        asm("s_nop 1\n\t" NGP_ST(0, "%2") NGP_ST(1, "%3") NGP_ST(2, "%4") NGP_ST(3, "%5") NGP_ST(4, "%6") NGP_ST(5, "%7") NGP_ST(6, "%8") NGP_ST(7, "%9")
-            : "+v"(p[0]) : "v"(dv[0]), NGP_X8);
-#undef NGP_ST
-    } else if constexpr (GN == 2) {
-#define NGP_ST(N, XO) NGP_FB("%0", "%2", XO, N) NGP_FB("%1", "%3", XO, N)
-        asm("s_nop 1\n\t" NGP_ST(0, "%4") NGP_ST(1, "%5") NGP_ST(2, "%6") NGP_ST(3, "%7") NGP_ST(4, "%8") NGP_ST(5, "%9") NGP_ST(6, "%10") NGP_ST(7, "%11")
-            : "+v"(p[0]), "+v"(p[1]) : "v"(dv[0]), "v"(dv[1]), NGP_X8);
-#undef NGP_ST
-    } else if constexpr (GN == 3) {
-#define NGP_ST(N, XO) NGP_FB("%0", "%3", XO, N) NGP_FB("%1", "%4", XO, N) NGP_FB("%2", "%5", XO, N)
-        asm("s_nop 1\n\t" NGP_ST(0, "%6") NGP_ST(1, "%7") NGP_ST(2, "%8") NGP_ST(3, "%9") NGP_ST(4, "%10") NGP_ST(5, "%11") NGP_ST(6, "%12") NGP_ST(7, "%13")
-            : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]) : "v"(dv[0]), "v"(dv[1]), "v"(dv[2]), NGP_X8);
-#undef NGP_ST
-    } else {
-#define NGP_ST(N, XO) NGP_FB("%0", "%4", XO, N) NGP_FB("%1", "%5", XO, N) NGP_FB("%2", "%6", XO, N) NGP_FB("%3", "%7", XO, N)
-        asm("s_nop 1\n\t" NGP_ST(0, "%8") NGP_ST(1, "%9") NGP_ST(2, "%10") NGP_ST(3, "%11") NGP_ST(4, "%12") NGP_ST(5, "%13") NGP_ST(6, "%14") NGP_ST(7, "%15")
-            : "+v"(p[0]), "+v"(p[1]), "+v"(p[2]), "+v"(p[3]) : "v"(dv[0]), "v"(dv[1]), "v"(dv[2]), "v"(dv[3]), NGP_X8);
-#undef NGP_ST
-    }
-#undef NGP_X8
-}
-// the same for a quad of rows: acc_c += x_e * y_c[e], e = 0..3 in order (yv: lane l holds y_c[l mod 4])
-template <int GN>
-__device__ __attribute__((always_inline)) inline void fmac4_bcast(double (&a)[GN], const double (&yv)[GN], const double (&x)[4]) {
-    static_assert(GN >= 1 && GN <= 4, "group of 1..4 chains");
-#define NGP_X4 "v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3])
-    if constexpr (GN == 1) {
-#define NGP_ST(N, XO) NGP_FB("%0", "%1", XO, N)
-        asm("s_nop 1\n\t" NGP_ST(0, "%2") NGP_ST(1, "%3") NGP_ST(2, "%4") NGP_ST(3, "%5") : "+v"(a[0]) : "v"(yv[0]), NGP_X4);
-#undef NGP_ST
-    } else if constexpr (GN == 2) {
-#define NGP_ST(N, XO) NGP_FB("%0", "%2", XO, N) NGP_FB("%1", "%3", XO, N)
-        asm("s_nop 1\n\t" NGP_ST(0, "%4") NGP_ST(1, "%5") NGP_ST(2, "%6") NGP_ST(3, "%7") : "+v"(a[0]), "+v"(a[1]) : "v"(yv[0]), "v"(yv[1]), NGP_X4);
-#undef NGP_ST
-    } else if constexpr (GN == 3) {
-#define NGP_ST(N, XO) NGP_FB("%0", "%3", XO, N) NGP_FB("%1", "%4", XO, N) NGP_FB("%2", "%5", XO, N)
-        asm("s_nop 1\n\t" NGP_ST(0, "%6") NGP_ST(1, "%7") NGP_ST(2, "%8") NGP_ST(3, "%9")
-            : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]) : "v"(yv[0]), "v"(yv[1]), "v"(yv[2]), NGP_X4);
-#undef NGP_ST
-    } else {
-#define NGP_ST(N, XO) NGP_FB("%0", "%4", XO, N) NGP_FB("%1", "%5", XO, N) NGP_FB("%2", "%6", XO, N) NGP_FB("%3", "%7", XO, N)
-        asm("s_nop 1\n\t" NGP_ST(0, "%8") NGP_ST(1, "%9") NGP_ST(2, "%10") NGP_ST(3, "%11")
-            : "+v"(a[0]), "+v"(a[1]), "+v"(a[2]), "+v"(a[3]) : "v"(yv[0]), "v"(yv[1]), "v"(yv[2]), "v"(yv[3]), NGP_X4);
-#undef NGP_ST
-    }
-#undef NGP_X4
-}
-
 template <int DT, int KC>
 __device__ __attribute__((always_inline)) inline void role_streamer_multi(const MultiArgs &Mr, const int s, char *smem) {
     const MultiArgs *Mp = &Mr;     // (the kernel's by-value argument: every index below is a compile-time constant after unrolling)
