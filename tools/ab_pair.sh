@@ -1,5 +1,4 @@
-# chains per pass at 10k x 100k, K = 2..8 (one line each) -> gpurun_out/r03x/pass_table.txt
 mkdir -p gpurun_out/r03x
-for K in 2 3 4 5 6 7 8; do timeout -k 10 120 python tools/chains_per_pass.py 10000 100000 $K 100 8; done > gpurun_out/r03x/pass_table.txt 2>&1
-NGP_TOOL_METHOD=B timeout -k 10 120 python tools/chains_per_pass.py 10000 100000 8 100 8 >> gpurun_out/r03x/pass_table.txt 2>&1
-cut -c1-220 gpurun_out/r03x/pass_table.txt
+timeout -k 10 300 python -m pytest tests/test_gpu_chains_per_pass.py -m gpu -x -q > gpurun_out/r03x/t.txt 2>&1; tail -3 gpurun_out/r03x/t.txt
+for cfg in "8 0" "8 8192" "8 0" "8 8192" "4 0" "4 8192" "2 0" "2 8192"; do set -- $cfg; NGP_TOOL_KNOB=$2 timeout -k 10 120 python tools/chains_per_pass.py 10000 100000 $1 100 8 | sed "s/^/knob=$2 /" ; done > gpurun_out/r03x/streams.txt 2>&1
+cut -c1-175 gpurun_out/r03x/streams.txt
