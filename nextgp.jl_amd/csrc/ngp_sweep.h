@@ -2011,6 +2011,9 @@ __device__ __attribute__((always_inline)) inline void role_streamer_multi(const 
     const int nchunk = R >> 2;
     const int g = s / NGP_GRP;
     const int nb = A.t1 - A.t0;
+    // (the lean scalar-base requests of the row-owning loader -- dma16_s4, runs of four quads per wave -- were tried here: three
+    // chains unchanged, eight chains 1890 -> 1760 it/s: the requests of a block then leave in one burst, and the partial sums and
+    // dlt of eight chains queue behind it)
     auto dma_tile = [&](int ub) {
         const char *src = (const char *)(A.tiles + ((size_t)(A.t0 + ub) * S + s) * tile_elems);
         char *dst = ring + (size_t)(ub & 1) * TBL;
