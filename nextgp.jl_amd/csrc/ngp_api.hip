@@ -464,7 +464,7 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P, ngp_handle *owner = nullptr
     h->have_y = false; h->iter = 0; h->poisoned = false; h->panel_open = false;
     if (h->storage == 0) HCHK(hipFuncSetAttribute((const void *)k_step, hipFuncAttributeMaxDynamicSharedMemorySize, (int)h->lds_step));
     if (h->mode == 1) {
-        const size_t lds_sampler = (size_t)(3 * 4096 + 2 * NGP_RING * NGP_BLK + 6 * NGP_BLK) * sizeof(double) + 2 * NGP_BLK * sizeof(int) + 320;
+        const size_t lds_sampler = (size_t)(3 * 4096 + 2 * NGP_RING * NGP_BLK + 6 * NGP_BLK) * sizeof(double) + 2 * NGP_BLK * sizeof(int) + 320 + NGP_SAMPLER_TUPLE_LDS;
         const size_t lds_max = 160 * 1024;
         const size_t misc = (size_t)h->R * 16 + 4096 + 2 * 512 + 128 + 3072 + (size_t)h->R * 64;
         const size_t TB = (size_t)(h->R / 4) * NGP_QS;  // LDS footprint of one tile (quads NGP_QS bytes apart)
@@ -480,6 +480,7 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P, ngp_handle *owner = nullptr
         if (h->lds_sweep > lds_max) return fail(h, NGP_ERR_ARG, "panel too tall for the persistent sweep (LDS)");
         HCHK(sweep_set_max_lds_0((int)h->lds_sweep));
         HCHK(sweep_set_max_lds_1((int)h->lds_sweep));
+        HCHK(sweep_tup_set_max_lds((int)h->lds_sweep));
         if (h->V > 1) HCHK(sweep_tall_set_max_lds((int)h->lds_sweep));
         // every workgroup of the persistent kernel waits for others: the whole grid must be resident at once, one workgroup
         // per CU.  Checked here, not assumed (a grid that does not fit would only show up as a spin timeout).
@@ -702,6 +703,14 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
             sweep_tall_launch((unsigned)h->last_grid, h->lds_sweep, h->stream, A);
         else if (h->d_dbg || h->dbg_mode)  // diagnostic instantiation: stamps and timing modes exist only there
             sweep_launch_1((unsigned)h->last_grid, h->lds_sweep, h->stream, A);
+        // Models with a Tuple set run the kernel that carries that chain (k_sweep<false> does not).  The two kernels are otherwise the
+        // same program, and which one is faster for a model without a Tuple set is a matter of code layout: measured on one box,
+        // interleaved (tools/ab3.sh), 50k x 600k (204-row shards) 24.45 ms per iteration in k_sweep<false> against 24.20 in k_sweep_tup
+        // (the previous library: 24.15), 10k x 100k 2.80 against 2.94, 20k x 100k (84-row shards) 3.15 against 3.23.  So tall fp32
+        // shards of the row-owning streamer take k_sweep_tup as well; knob bit 14 forces it, bit 15 forbids it.
+        else if (h->ntuple > 0 || (h->knob & 16384) ||
+                 (!(h->knob & 32768) && h->streamer == 2 && h->storage == 0 && h->R >= 160))
+            sweep_tup_launch((unsigned)h->last_grid, h->lds_sweep, h->stream, A);
         else
             sweep_launch_0((unsigned)h->last_grid, h->lds_sweep, h->stream, A);
         if (evs) (void)hipEventRecord(evs[1], h->stream);
@@ -1552,6 +1561,7 @@ bool fusable(ngp_handle **hs, int n) {
     for (int i = 0; i < n; i++) {
         ngp_handle *h = hs[i];
         if (h->pm != h0->pm || h->device != h0->device || h->dbg_mode != 0 || h->d_dbg || h->dbg_census_fail_iter > 0) return false;
+        if (h->ntuple > 0) return false;  // the fused kernel's samplers are compiled without the Tuple chain (role_sampler<.., TUP = false>)
     }
     return (int64_t)n + ngp_multi_reducers(n, h0->NG, fused_pair(h0, n)) + h0->S <= h0->cu_count;
 }
@@ -1565,7 +1575,7 @@ int run_fused(ngp_handle **hs, int n, int64_t niter) {
         if ((rc = prepare_run(hs[i], niter))) { if (i) h->err = hs[i]->err; return rc; }
     const int pair = fused_pair(h, n);
     const int64_t grid = (int64_t)n + ngp_multi_reducers(n, h->NG, pair) + h->S;
-    const size_t lds_sampler = (size_t)(3 * 4096 + 2 * NGP_RING * NGP_BLK + 6 * NGP_BLK) * sizeof(double) + 2 * NGP_BLK * sizeof(int) + 320;
+    const size_t lds_sampler = (size_t)(3 * 4096 + 2 * NGP_RING * NGP_BLK + 6 * NGP_BLK) * sizeof(double) + 2 * NGP_BLK * sizeof(int) + 320 + NGP_SAMPLER_TUPLE_LDS;
     const size_t lds = std::max(h->streamer == 2 ? ngp_rows_multi_lds_bytes((int)h->R, n) : ngp_multi_lds_bytes((int)h->R, n), lds_sampler);
     REQUIRE(lds <= 160 * 1024, NGP_ERR_STATE, "fused sweep: LDS of a streamer with this many chains exceeds 160 KiB");
     HCHK(sweep_multi_set_max_lds((int)lds));

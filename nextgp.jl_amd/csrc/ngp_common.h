@@ -227,43 +227,77 @@ __device__ inline TupLane load_tuplane(const double *__restrict__ tupc, const do
     T.ww = w[kcol];
     return T;
 }
-template <typename GAt>
-__device__ inline double tuple_chain(const int k, const long long nloc, const long long first_locus, const int j, const double tot,
-                                     const double bo, const TupLane &T, GAt G) {
-    const int Lb = NGP_BLK / k;
+// loci per 64-column block and first column of lane j's locus, without a run-time division (k = 1..NGP_KMAX)
+__device__ inline int tuple_loci_per_block(const int k) { return k == 1 ? 64 : (k == 2 ? 32 : (k == 3 ? 21 : 16)); }
+__device__ inline int tuple_gbase(const int k, const int j) { return k == 1 ? j : (k == 2 ? (j & ~1) : (k == 3 ? (j / 3) * 3 : (j & ~3))); }
+// used lanes of the block that begins at locus first_locus (wave-uniform)
+__device__ inline int tuple_nvalid(const int k, const long long nloc, const long long first_locus) {
+    const int Lb = tuple_loci_per_block(k);
     const long long left = nloc - first_locus;
-    const int nvalid = (int)(left < Lb ? left : Lb) * k;  // used lanes of this block (uniform)
-    const int gbase = (j / k) * k;
+    return (int)(left < Lb ? left : Lb) * k;
+}
+// K = k as a compile-time constant: with a run-time k every "component b exists" test is a branch, every load sits in a basic block
+// of its own behind a full wait (64 LDS round trips in a row per sixteen steps: 7 us per block); here the loads of sixteen steps
+// leave together
+template <int K, typename GAt>
+__device__ __attribute__((always_inline)) inline double tuple_chain_k(const int nvalid, const int j, const double tot, const double bo, const TupLane &T, GAt G) {
+    const int gbase = tuple_gbase(K, j);
     const bool valid = j < nvalid;
     // x_m'(ycorr + X_l beta_l): the add-back of all k effects of the locus, components in order
     double rfull = tot;
+    double bm[K];
 #pragma unroll
-    for (int b = 0; b < NGP_KMAX; b++)
-        if (b < k) {
-            const double bm = __shfl(bo, gbase + b);
-            if (valid) rfull = __builtin_fma(T.grow[b], bm, rfull);
-        }
+    for (int b = 0; b < K; b++) bm[b] = __shfl(bo, gbase + b);
+#pragma unroll
+    for (int b = 0; b < K; b++)
+        if (valid) rfull = __builtin_fma(T.grow[b], bm[b], rfull);
     // scaled form, as the Symbol path's chain: e = W + sum_b C[b] r_b is this lane's candidate dlt
     double e = T.ww;
+    double rb[K];
 #pragma unroll
-    for (int b = 0; b < NGP_KMAX; b++)
-        if (b < k) {
-            const double rb = __shfl(rfull, gbase + b);
-            e = __builtin_fma(rb, T.crow[b], e);
-        }
+    for (int b = 0; b < K; b++) rb[b] = __shfl(rfull, gbase + b);
+#pragma unroll
+    for (int b = 0; b < K; b++) e = __builtin_fma(rb[b], T.crow[b], e);
     if (!valid) e = 0.0;
     // a finished column s changes e by H(s) dlt_s, H(s) = -(sum_b C[b] G[s][column b of this lane's locus]), for the columns of
-    // LATER loci only (the k effects of a locus are drawn together)
-    for (int sl = 0; sl < nvalid; ++sl) {
-        const double dk = readlane_d(e, sl);
-        double t = T.crow[0] * G(sl, gbase);
+    // LATER loci only (the k effects of a locus are drawn together).  The H of sixteen steps are formed first -- independent loads
+    // and fma, in flight together -- so that the serial part of a step is what it is on the Symbol path: one readlane, one fma.
+    // Steps beyond the block's used lanes have H = 0 and dlt = 0.
+    for (int s0 = 0; s0 < nvalid; s0 += 16) {
+        double g[16][K];
 #pragma unroll
-        for (int b = 1; b < NGP_KMAX; b++)
-            if (b < k) t = __builtin_fma(T.crow[b], G(sl, gbase + b), t);
-        const double Hs = (valid && sl < gbase) ? -t : 0.0;
-        e = __builtin_fma(Hs, dk, e);
+        for (int i = 0; i < 16; i++)
+#pragma unroll
+            for (int b = 0; b < K; b++) g[i][b] = G(s0 + i, gbase + b);
+        double H[16];
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            double t = T.crow[0] * g[i][0];
+#pragma unroll
+            for (int b = 1; b < K; b++) t = __builtin_fma(T.crow[b], g[i][b], t);
+            H[i] = (valid && s0 + i < gbase) ? -t : 0.0;
+        }
+#pragma unroll
+        for (int i = 0; i < 16; i++) {
+            const double dk = readlane_d(e, s0 + i);
+            e = __builtin_fma(H[i], dk, e);
+        }
     }
     return e;
+}
+template <typename GAt>
+__device__ __attribute__((always_inline)) inline double tuple_chain_nv(const int k, const int nvalid, const int j, const double tot, const double bo, const TupLane &T, GAt G) {
+    switch (k) {
+        case 1: return tuple_chain_k<1>(nvalid, j, tot, bo, T, G);
+        case 2: return tuple_chain_k<2>(nvalid, j, tot, bo, T, G);
+        case 3: return tuple_chain_k<3>(nvalid, j, tot, bo, T, G);
+        default: return tuple_chain_k<4>(nvalid, j, tot, bo, T, G);
+    }
+}
+template <typename GAt>
+__device__ __attribute__((always_inline)) inline double tuple_chain(const int k, const long long nloc, const long long first_locus, const int j, const double tot,
+                                     const double bo, const TupLane &T, GAt G) {
+    return tuple_chain_nv(k, tuple_nvalid(k, nloc, first_locus), j, tot, bo, T, G);
 }
 
 // Tile (t, s) = R rows x 64 columns of fp32, stored QUAD-MAJOR: element (row i, column j) sits at (i >> 2) * 256 + j * 4 + (i & 3).

@@ -1474,7 +1474,11 @@ __device__ __attribute__((always_inline)) inline void publish_block(const SweepA
 //   wave 4, 6, 7   lag-2, lag-3 and (near = 4) lag-4 corrections, Gram rows loaded one block ahead into registers
 // LDS: Gd[3][4096] | hist[RING][64] | vacc[RING][64] | r0[4][64] | outb[2][64] | outi[2][64] | flags, per-set constants
 // NGBIG: more than 8 groups of shards may exist (k_sweep_tall: several shards per streamer workgroup, lags 2-3)
-template <bool DBG, bool NGBIG = false>
+// TUP: the model may hold Tuple (correlated BayesPR) sets.  The production kernel of every other model is compiled WITHOUT that code
+// (k_sweep<false>; models with a tuple set run k_sweep_tup): the four unrolled chains of the tuple path in the critical wave's loop
+// cost the Symbol methods 3-7 % at 10k x 100k although none of it executes there (code layout / register allocation of a
+// 240-VGPR kernel; measured against the previous library on the same box).
+template <bool DBG, bool NGBIG = false, bool TUP = true>
 __device__ __attribute__((always_inline)) inline void role_sampler(const SweepArgs &A, char *smem) {
     NGP_DBG_LOCALS
     const int D = A.D, tid = threadIdx.x, wv = tid >> 6, j = tid & 63;
@@ -1491,6 +1495,33 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
     const int nb = A.t1 - A.t0;
     const size_t bsz = NGP_BLK * NGP_BLK;
     int *sK = sabort + 52;  // classes of each set (BayesR), behind ssdf
+    // Tuple sets: lane coefficients of the block (rows of C and of X_l'X_l, W: 9 x 64) and (k, used lanes), two parities -- wave 1
+    // fetches them one block ahead, like the critical wave does its own Symbol coefficients (fetched inside the block, behind the
+    // set lookup and the set's constants, they were three dependent round trips of the chain: 9.6 us per block)
+    double *tl = (double *)(sabort + 80);        // 2 x 9 x 64
+    int *tmeta = (int *)(tl + 2 * 9 * NGP_BLK);  // 2 x 4: k (0: not a tuple block), used lanes
+    auto tuple_prefetch = [&](const int ub) __attribute__((always_inline)) {  // wave 1; ub: local block
+        if (!TUP || !A.tup || ub >= nb) return;
+        const long long tblk = (long long)(A.t0 + ub);
+        const long long kcol = tblk * NGP_BLK + j;
+        const int si = A.setof[kcol];
+        const unsigned long long mask = __ballot(si >= 0 && smeth[si < 0 ? 0 : si] == NGP_METHOD_TUPLE_DEV);
+        int *meta = tmeta + (ub & 1) * 4;
+        if (mask == 0ull) {
+            if (j == 0) meta[0] = 0;
+            return;
+        }
+        const int sit = __builtin_amdgcn_readfirstlane(__shfl(si, __builtin_ctzll(mask)));
+        const TupLane TL = load_tuplane(A.tupc, A.tupg, A.w, A.Ppad, kcol);
+        const int k = A.tup[sit].k;
+        const long long first_locus = (tblk - (A.tup[sit].col0 >> 6)) * tuple_loci_per_block(k);
+        const int nvalid = tuple_nvalid(k, A.tup[sit].nloc, first_locus);
+        double *dst = tl + (size_t)(ub & 1) * (9 * NGP_BLK) + j;
+#pragma unroll
+        for (int b = 0; b < NGP_KMAX; b++) { dst[b * NGP_BLK] = TL.crow[b]; dst[(NGP_KMAX + b) * NGP_BLK] = TL.grow[b]; }
+        dst[2 * NGP_KMAX * NGP_BLK] = TL.ww;
+        if (j == 0) { meta[0] = k; meta[1] = nvalid; }
+    };
     if (tid < 16) {
         smeth[tid] = A.sets[tid].method;
         ssdf[tid] = A.sets[tid].sdf;
@@ -1517,6 +1548,7 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
         if (fetch_group_sums<DBG, NGBIG>(A, 0, j, &tot)) r0[j] = tot;
         else if (j == 0) *sabort = 1;
     }
+    if (wv == 1) tuple_prefetch(0);
     __syncthreads();
     if (*sabort) return;
 #define NGP_END_OF_BLOCK()                                                                       \
@@ -1567,19 +1599,24 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
             int isave = 1;
             // BayesR: the lane's set and method (one byte per lane, read only when the model has a BayesR set at all)
             int meth0 = -1, si0 = -1;
-            if (A.rcls || A.tup) {
+            if (A.rcls) {
                 si0 = A.setof[(long long)t * NGP_BLK + j];
                 meth0 = (si0 >= 0) ? smeth[si0] : -1;
             }
-            unsigned long long tmask = 0ull;
-            if (A.tup) tmask = __ballot(meth0 == NGP_METHOD_TUPLE_DEV);
-            if (tmask != 0ull) {
-                // a block of a Tuple set: one step per locus, its k effects drawn together (tuple_chain, ngp_common.h)
-                const int sit = __builtin_amdgcn_readfirstlane(__shfl(si0, __builtin_ctzll(tmask)));
-                const DTup Tp = A.tup[sit];
-                const TupLane TL = load_tuplane(A.tupc, A.tupg, A.w, A.Ppad, (long long)t * NGP_BLK + j);
-                const long long first_locus = ((long long)t - Tp.col0 / NGP_BLK) * (NGP_BLK / Tp.k);
-                dsave = tuple_chain(Tp.k, Tp.nloc, first_locus, j, tot, bo, TL, [&](int sl, int cc2) { return Gd[(u % 3) * 4096 + sl * NGP_BLK + cc2]; });
+            int tk = 0;
+            if constexpr (TUP) {
+                if (A.tup) tk = __builtin_amdgcn_readfirstlane(tmeta[buf * 4]);
+            }
+            if (TUP && tk != 0) {
+                // a block of a Tuple set: one step per locus, its k effects drawn together (tuple_chain, ngp_common.h); the lane
+                // coefficients wait in LDS (wave 1, one block ahead)
+                const int nvalid = __builtin_amdgcn_readfirstlane(tmeta[buf * 4 + 1]);
+                const double *tsrc = tl + (size_t)buf * (9 * NGP_BLK) + j;
+                TupLane TL;
+#pragma unroll
+                for (int b = 0; b < NGP_KMAX; b++) { TL.crow[b] = tsrc[b * NGP_BLK]; TL.grow[b] = tsrc[(NGP_KMAX + b) * NGP_BLK]; }
+                TL.ww = tsrc[2 * NGP_KMAX * NGP_BLK];
+                dsave = tuple_chain_nv(tk, nvalid, j, tot, bo, TL, [&](int sl, int cc2) { return Gd[(u % 3) * 4096 + sl * NGP_BLK + cc2]; });
                 isave = 1;
             } else if (A.rcls && __ballot(meth0 == 3) != 0ull) {
                 // r-form chain (eval_rform, ngp_kernels.h): candidates of all lanes from the current r, the first non-zero one at
@@ -1674,6 +1711,7 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
         }
     } else if (wv == 1) {
         for (int u = 0; u < nb; ++u) {
+            tuple_prefetch(u + 1);
             if (u >= 1) publish_block<DBG>(A, u - 1, j, hist, outb, outi, smeth, ssdf);
             NGP_END_OF_BLOCK();
         }
@@ -1874,82 +1912,21 @@ __device__ __attribute__((always_inline)) inline bool sweep_census(const SweepAr
 }
 
 // ------------------------------------------------------------------------------------------
+// k_sweep<false>: the production kernel of models without a Tuple set; k_sweep<true>: the diagnostic kernel (time stamps, timing
+// modes; every method); k_sweep_tup: the production kernel of models with a Tuple set (third translation unit)
 template <bool DBG>
 __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sweep(SweepArgs A) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    NGP_DBG_LOCALS
-    const int b = blockIdx.x;
-    // an earlier launch of this call gave up: nothing runs until the host has looked (the chain stays where that launch found it)
-    if (ld_u32(A.abort_w) != 0u) return;
-    if (!sweep_census(A, b, smem)) return;
-    if (dbg_mode == 1 && b <= A.NG) return;
-    if ((dbg_mode == 2 && b != 0) || ((dbg_mode == 3 || dbg_mode == 4) && b == 0)) return;
-    if (b == 0)
-        role_sampler<DBG>(A, smem);
-    else if (b <= A.NG)
-        role_reducer<DBG>(A, b - 1, smem);
-    else {
-        const int s = b - 1 - A.NG;
-        if (A.variant == 2) {  // row-owning waves + loader wave (host: R <= NGP_ROWS_MAX_R, lag 3..6)
-            switch (A.D) {
-                case 3: role_streamer_rows<DBG, 3, 0>(A, s, smem); break;
-                case 4: role_streamer_rows<DBG, 4, 0>(A, s, smem); break;
-                case 5: role_streamer_rows<DBG, 5, 0>(A, s, smem); break;
-                default: role_streamer_rows<DBG, 6, 0>(A, s, smem); break;  // (lag 7 was built: 58 VGPRs of the delay line spill, 2.58 -> 3.08 us per block)
-            }
-            return;
-        }
-        if (A.variant == 3) {  // compact storage: the same roles over byte tiles (host: R a multiple of 16, lag from the lists below)
-            const int nt = ngp_u8_tasks(A.R);
-            if (nt == 1) {
-                switch (A.D) {
-                    case 3: role_streamer_rows<DBG, 3, 1>(A, s, smem); break;
-                    case 4: role_streamer_rows<DBG, 4, 1>(A, s, smem); break;
-                    case 6: role_streamer_rows<DBG, 6, 1>(A, s, smem); break;
-                    case 8: role_streamer_rows<DBG, 8, 1>(A, s, smem); break;
-                    default: role_streamer_rows<DBG, 12, 1>(A, s, smem); break;
-                }
-            } else if (nt == 2) {
-                if (A.D == 4) role_streamer_rows<DBG, 4, 2>(A, s, smem);
-                else role_streamer_rows<DBG, 8, 2>(A, s, smem);
-            } else {
-                role_streamer_rows<DBG, 4, 4>(A, s, smem);  // (192 VGPRs of delay line at lag 6 spill)
-            }
-            return;
-        }
-        const int tpt = (8 * A.R + NGP_WG - 1) / NGP_WG;  // 1..4
-#define NGP_DISPATCH_D(T)                                      \
-    switch (A.D) {                                             \
-        case 1: role_streamer<DBG, 1, T>(A, s, smem); break;        \
-        case 2: role_streamer<DBG, 2, T>(A, s, smem); break;        \
-        case 3: role_streamer<DBG, 3, T>(A, s, smem); break;        \
-        default: role_streamer<DBG, 4, T>(A, s, smem); break;       \
-    }
-#define NGP_DISPATCH_D8(T)                                     \
-    switch (A.D) {                                             \
-        case 5: role_streamer<DBG, 5, T>(A, s, smem); break;        \
-        case 6: role_streamer<DBG, 6, T>(A, s, smem); break;        \
-        case 7: role_streamer<DBG, 7, T>(A, s, smem); break;        \
-        case 8: role_streamer<DBG, 8, T>(A, s, smem); break;        \
-        default: NGP_DISPATCH_D(T)                             \
-    }
-        if (tpt == 1) {
-            NGP_DISPATCH_D8(1)
-        } else if (tpt == 2) {
-            NGP_DISPATCH_D8(2)
-        } else {
-            switch (A.D) {  // host clamps the lag to 5 for tall shards (register budget of the delay line: 32 VGPRs per lag)
-                case 5: role_streamer<DBG, 5, 4>(A, s, smem); break;
-                default: NGP_DISPATCH_D(4)
-            }
-        }
-#undef NGP_DISPATCH_D8
-#undef NGP_DISPATCH_D
-    }
+    constexpr bool TUP = DBG;
+#include "ngp_sweep_body.inc"
 }
+#if defined(NGP_INST_DBG) && NGP_INST_DBG == 2
+__global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sweep_tup(SweepArgs A) {
+    constexpr bool DBG = false, TUP = true;
+#include "ngp_sweep_body.inc"
+}
+#endif
 
-
-#if defined(NGP_INST_DBG) && NGP_INST_DBG  // one definition: the second translation unit (it is the shorter one to compile)
+#if defined(NGP_INST_DBG) && NGP_INST_DBG == 1  // one definition: the second translation unit (it is the shorter one to compile)
 // The persistent sweep of fp32 panels too tall for one shard per workgroup (role_streamer_rows_tall; host: V = 2 at lag 3, V = 3 at
 // lag 2, S a multiple of V, grid 1 + NG + S / V).  A kernel of its own so that k_sweep stays what it is: the sampler here adds up to
 // 22 group sums (NGBIG), and the extra code of both cost k_sweep 7 % at 10k x 100k when they were branches of it (SGPR pressure).
@@ -2531,7 +2508,8 @@ __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #define NGP_MULTI_STRIDE 8  // samplers at blocks 0, 8, 16, ...: one XCD under round-robin placement
 #endif
     if ((b % NGP_MULTI_STRIDE) == 0 && (b / NGP_MULTI_STRIDE) < K) {
-        role_sampler<false>(multi_chain_args(__builtin_amdgcn_readfirstlane(b / NGP_MULTI_STRIDE)), smem);
+        // (without the Tuple chain, like k_sweep<false>: chains with a Tuple set are not fused -- fusable(), ngp_api.hip)
+        role_sampler<false, false, false>(multi_chain_args(__builtin_amdgcn_readfirstlane(b / NGP_MULTI_STRIDE)), smem);
         return;
     }
     const int idx = b - min(K, (b + NGP_MULTI_STRIDE - 1) / NGP_MULTI_STRIDE);  // rank among the blocks that are not samplers

@@ -16,6 +16,7 @@
 #define NGP_LAZY_LAG 7  // streamers count their partials lazily from this lag on
 #endif
 #define NGP_QS 1040
+#define NGP_SAMPLER_TUPLE_LDS (2 * 9 * 64 * 8 + 64)  // sampler workgroup: lane coefficients of a Tuple block, two parities, + (k, used lanes)
 #define NGP_ABORT_CENSUS 9u        // abort code: the grid was not co-resident within NGP_CENSUS_TICKS (no state was modified)
 #define NGP_CENSUS_TICKS 2000000ull  // 20 ms of the 100 MHz wall clock
 #define NGP_DBG_STREAM (1u << 20)  // offset of streamer 0's stamps in the debug buffer
@@ -133,6 +134,9 @@ hipError_t sweep_set_max_lds_0(int bytes);
 hipError_t sweep_set_max_lds_1(int bytes);
 hipError_t sweep_occupancy_0(int *wg_per_cu, size_t lds_bytes);
 void sweep_launch_0(unsigned grid, size_t lds_bytes, hipStream_t stream, const SweepArgs &A);
+// k_sweep_tup (models with a Tuple set; third translation unit, -DNGP_INST_DBG=2)
+hipError_t sweep_tup_set_max_lds(int bytes);
+void sweep_tup_launch(unsigned grid, size_t lds_bytes, hipStream_t stream, const SweepArgs &A);
 // k_sweep_tall (several shards per streamer workgroup; lives in the second translation unit)
 hipError_t sweep_tall_set_max_lds(int bytes);
 hipError_t sweep_tall_occupancy(int *wg_per_cu, size_t lds_bytes);

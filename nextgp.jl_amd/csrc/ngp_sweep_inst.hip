@@ -1,15 +1,25 @@
 // ngp_sweep_inst.hip -- one instantiation of the persistent sweep kernel (ngp_sweep.h) and its host-side launch stubs.
-// Compiled twice: -DNGP_INST_DBG=0 (production kernel) and -DNGP_INST_DBG=1 (diagnostic kernel: time stamps, timing modes).
+// Compiled three times: -DNGP_INST_DBG=0 (production kernel, K chains per pass), =1 (diagnostic kernel: time stamps, timing modes;
+// tall fp32 panels), =2 (production kernel of models with a Tuple set).
 #include <hip/hip_runtime.h>
 
 #include "ngp_sweep.h"
 
 #ifndef NGP_INST_DBG
-#error "compile with -DNGP_INST_DBG=0 or -DNGP_INST_DBG=1"
+#error "compile with -DNGP_INST_DBG=0, 1 or 2"
 #endif
 
 namespace ngp {
 
+#if NGP_INST_DBG == 2
+// the production kernel of models with a Tuple (correlated BayesPR) set: a translation unit of its own (the units compile in parallel)
+hipError_t sweep_tup_set_max_lds(int bytes) {
+    return hipFuncSetAttribute((const void *)k_sweep_tup, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+void sweep_tup_launch(unsigned grid, size_t lds_bytes, hipStream_t stream, const SweepArgs &A) {
+    hipLaunchKernelGGL(k_sweep_tup, dim3(grid), dim3(NGP_WG), lds_bytes, stream, A);
+}
+#else
 #if NGP_INST_DBG
 #define NGP_SFX(name) name##_1
 #else
@@ -47,5 +57,6 @@ void sweep_tall_launch(unsigned grid, size_t lds_bytes, hipStream_t stream, cons
 void NGP_SFX(sweep_launch)(unsigned grid, size_t lds_bytes, hipStream_t stream, const SweepArgs &A) {
     hipLaunchKernelGGL(k_sweep<kDbg>, dim3(grid), dim3(NGP_WG), lds_bytes, stream, A);
 }
+#endif
 
 }  // namespace ngp

@@ -14,7 +14,13 @@ s.generate_panel(N,P)
 rng=np.random.default_rng(1); bt=np.zeros(P); idx=rng.choice(P,P//100,replace=False); bt[idx]=rng.normal(size=P//100)
 g=s.xbeta(bt); y=10+g+np.random.default_rng(2).normal(size=N)*np.sqrt(g.var())
 v=0.5*y.var()/(s.mpm().sum()/N)
-s.add_marker_set(0,P,0,4.0,v*0.5,[(0,P)],[v]); s.set_y(y); s.set_residual_prior(4.0,0.25*y.var())
+tk = int(os.environ.get("NGP_TOOL_TUPLE", "0"))  # k: the panel as ONE correlated (Tuple BayesPR) set of k components per locus
+if tk:
+    nloc = (P // 64) * (64 // tk); V = v * (0.7 * np.eye(tk) + 0.3)
+    s.add_marker_set_tuple(0, nloc, tk, 3.0 + tk, V * 0.5, [(0, nloc)], V)
+else:
+    s.add_marker_set(0,P,0,4.0,v*0.5,[(0,P)],[v])
+s.set_y(y); s.set_residual_prior(4.0,0.25*y.var())
 s.run(3)
 t=time.perf_counter(); s.run(10); dt=(time.perf_counter()-t)/10
 print(f"lag {lag}: {dt*1e3:.2f} ms/iter  layout {s.layout()}")
