@@ -318,7 +318,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "ngp::k_sweep (persistent sweep: one launch streams the whole N x P panel once)" if prof["launches"] == 1 else "ngp::k_step (one 64-SNP column block per launch)",
+                "kernel": "ngp::k_sweep / k_sweep_tup (the persistent sweep kernel: one launch streams the whole N x P panel once; models with a Tuple set and tall fp32 shards run the k_sweep_tup instantiation)" if prof["launches"] == 1 else "ngp::k_step (one 64-SNP column block per launch)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -10,7 +10,10 @@ base_cfg = sys.argv[3] if len(sys.argv) > 3 else cfg
 storage = sys.argv[4] if len(sys.argv) > 4 else "f32"
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 out = os.path.join(root, "gpurun_out")
-KERNELS = ("ngp::k_sweep(ngp::SweepArgs)", "void ngp::k_sweep<false>(ngp::SweepArgs)", "void ngp::k_sweep<true>(ngp::SweepArgs)")
+# the persistent sweep kernel in its instantiations (k_sweep_tup: Tuple sets and tall fp32 shards of the row-owning streamer;
+# k_sweep_tall: fp32 panels with several shards per streamer workgroup)
+KERNELS = ("ngp::k_sweep(ngp::SweepArgs)", "void ngp::k_sweep<false>(ngp::SweepArgs)", "void ngp::k_sweep<true>(ngp::SweepArgs)",
+           "ngp::k_sweep_tup(ngp::SweepArgs)", "ngp::k_sweep_tall(ngp::SweepArgs)")
 
 
 def counter(kind, name):
@@ -24,11 +27,13 @@ def counter(kind, name):
 
 
 fetch, write = counter("fetch", "FETCH_SIZE"), counter("write", "WRITE_SIZE")
+found = sorted({row["Kernel_Name"] for f in glob.glob(os.path.join(out, f"{tag}_{cfg}_fetch", "**", "*counter_collection.csv"), recursive=True)
+                for row in csv.DictReader(open(f)) if row["Kernel_Name"] in KERNELS})
 bench = json.loads(open(os.path.join(out, f"{tag}_{cfg}_bench.json")).read().strip().splitlines()[-1])
 summary = {
     "command": f"rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --config {base_cfg} --storage {storage} --steps 10 --warmup 2 --no-cpu-baseline --no-compact (two separate passes)",
     "workload": bench["config"]["workload"],
-    "kernel": "ngp::k_sweep",
+    "kernel": ", ".join(found) if found else "ngp::k_sweep",
     "FETCH_SIZE_KB_per_launch_raw": sum(fetch) / max(len(fetch), 1),
     "FETCH_SIZE_launches": len(fetch),
     "WRITE_SIZE_KB_per_launch_raw": sum(write) / max(len(write), 1),
