@@ -1474,11 +1474,12 @@ __device__ __attribute__((always_inline)) inline void publish_block(const SweepA
 //   wave 4, 6, 7   lag-2, lag-3 and (near = 4) lag-4 corrections, Gram rows loaded one block ahead into registers
 // LDS: Gd[3][4096] | hist[RING][64] | vacc[RING][64] | r0[4][64] | outb[2][64] | outi[2][64] | flags, per-set constants
 // NGBIG: more than 8 groups of shards may exist (k_sweep_tall: several shards per streamer workgroup, lags 2-3)
-// TUP: the model may hold Tuple (correlated BayesPR) sets.  The production kernel of every other model is compiled WITHOUT that code
-// (k_sweep<false>; models with a tuple set run k_sweep_tup): the four unrolled chains of the tuple path in the critical wave's loop
-// cost the Symbol methods 3-7 % at 10k x 100k although none of it executes there (code layout / register allocation of a
-// 240-VGPR kernel; measured against the previous library on the same box).
-template <bool DBG, bool NGBIG = false, bool TUP = true>
+// TUP / RCLS: the model may hold Tuple (correlated BayesPR) / BayesR sets.  The production kernel of every other model -- BayesPR, BayesB,
+// BayesC: the methods of the benchmark configurations -- is compiled WITHOUT their chains (k_sweep<false>; models with such a set run
+// k_sweep_tup, the full kernel): the four unrolled chains of the tuple path in the critical wave's loop cost the Symbol methods
+// 3-7 % at 10k x 100k although none of it executes there (code layout / register allocation of a 240-VGPR kernel; measured against
+// the previous library on the same box).
+template <bool DBG, bool NGBIG = false, bool TUP = true, bool RCLS = true>
 __device__ __attribute__((always_inline)) inline void role_sampler(const SweepArgs &A, char *smem) {
     NGP_DBG_LOCALS
     const int D = A.D, tid = threadIdx.x, wv = tid >> 6, j = tid & 63;
@@ -1599,7 +1600,7 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
             int isave = 1;
             // BayesR: the lane's set and method (one byte per lane, read only when the model has a BayesR set at all)
             int meth0 = -1, si0 = -1;
-            if (A.rcls) {
+            if (RCLS && A.rcls) {
                 si0 = A.setof[(long long)t * NGP_BLK + j];
                 meth0 = (si0 >= 0) ? smeth[si0] : -1;
             }
@@ -1618,7 +1619,7 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
                 TL.ww = tsrc[2 * NGP_KMAX * NGP_BLK];
                 dsave = tuple_chain_nv(tk, nvalid, j, tot, bo, TL, [&](int sl, int cc2) { return Gd[(u % 3) * 4096 + sl * NGP_BLK + cc2]; });
                 isave = 1;
-            } else if (A.rcls && __ballot(meth0 == 3) != 0ull) {
+            } else if (RCLS && A.rcls && __ballot(meth0 == 3) != 0ull) {
                 // r-form chain (eval_rform, ngp_kernels.h): candidates of all lanes from the current r, the first non-zero one at
                 // or behind the cursor takes its step.  With most loci in the zero class that is a few steps per block.
                 RLane RL = empty_rlane();
@@ -2509,7 +2510,7 @@ __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #endif
     if ((b % NGP_MULTI_STRIDE) == 0 && (b / NGP_MULTI_STRIDE) < K) {
         // (without the Tuple chain, like k_sweep<false>: chains with a Tuple set are not fused -- fusable(), ngp_api.hip)
-        role_sampler<false, false, false>(multi_chain_args(__builtin_amdgcn_readfirstlane(b / NGP_MULTI_STRIDE)), smem);
+        role_sampler<false, false, false, true>(multi_chain_args(__builtin_amdgcn_readfirstlane(b / NGP_MULTI_STRIDE)), smem);
         return;
     }
     const int idx = b - min(K, (b + NGP_MULTI_STRIDE - 1) / NGP_MULTI_STRIDE);  // rank among the blocks that are not samplers
