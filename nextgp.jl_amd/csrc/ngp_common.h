@@ -159,10 +159,13 @@ __device__ inline void eval_rform(const int meth, const double r, const double b
 #pragma unroll
         for (int v = 1; v < NGP_RREG; v++)
             if (v < L.K && Lv[v] > m) m = Lv[v];
-        for (int v = NGP_RREG; v < L.K; v++) {  // (more than four classes: the same steps, class after class, from memory)
-            const double lv = rlane_L(L, v, hs);
-            if (lv > m) m = lv;
-        }
+        // (more than four classes: the same steps, class after class; their log-weights come from memory ONCE per evaluation)
+        double Lx[NGP_RMAX - NGP_RREG];
+#pragma unroll
+        for (int v = NGP_RREG; v < NGP_RMAX; v++) Lx[v - NGP_RREG] = (v < L.K) ? rlane_L(L, v, hs) : 0.0;
+#pragma unroll
+        for (int v = NGP_RREG; v < NGP_RMAX; v++)
+            if (v < L.K && Lx[v - NGP_RREG] > m) m = Lx[v - NGP_RREG];
         double S = 0.0;
 #pragma unroll
         for (int v = 0; v < NGP_RREG; v++)
@@ -170,7 +173,13 @@ __device__ inline void eval_rform(const int meth, const double r, const double b
                 e[v] = det_exp(Lv[v] - m);
                 S = S + e[v];
             } else e[v] = 0.0;
-        for (int v = NGP_RREG; v < L.K; v++) S = S + det_exp(rlane_L(L, v, hs) - m);
+        double ex[NGP_RMAX - NGP_RREG];
+#pragma unroll
+        for (int v = NGP_RREG; v < NGP_RMAX; v++)
+            if (v < L.K) {
+                ex[v - NGP_RREG] = det_exp(Lx[v - NGP_RREG] - m);
+                S = S + ex[v - NGP_RREG];
+            } else ex[v - NGP_RREG] = 0.0;
         int c = L.K - 1;
         double cum = 0.0;
         bool found = false;
@@ -181,11 +190,13 @@ __device__ inline void eval_rform(const int meth, const double r, const double b
                 const double thr = L.u[v] * S;
                 if (cum >= thr) { c = v; found = true; }
             }
-        for (int v = NGP_RREG; v < L.K && !found; v++) {
-            cum = cum + det_exp(rlane_L(L, v, hs) - m);
-            const double thr = L.ext[((size_t)3 * NGP_RMAX + v) * L.Ppad] * S;
-            if (cum >= thr) { c = v; found = true; }
-        }
+#pragma unroll
+        for (int v = NGP_RREG; v < NGP_RMAX; v++)
+            if (v < L.K && !found) {
+                cum = cum + ex[v - NGP_RREG];
+                const double thr = L.ext[((size_t)3 * NGP_RMAX + v) * L.Ppad] * S;
+                if (cum >= thr) { c = v; found = true; }
+            }
         double qc = L.q[0], tc = L.t[0];
 #pragma unroll
         for (int v = 1; v < NGP_RREG; v++)
