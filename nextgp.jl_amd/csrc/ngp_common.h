@@ -155,48 +155,61 @@ __device__ inline void eval_rform(const int meth, const double r, const double b
         double Lv[NGP_RREG], e[NGP_RREG];
 #pragma unroll
         for (int v = 0; v < NGP_RREG; v++) Lv[v] = (L.q[v] == 0.0) ? L.a[v] : __builtin_fma(hs, L.q[v], L.a[v]);
+        // The four register classes are handled without a branch (selects): their four det_exp -- forty dependent fp64 operations
+        // each -- then run interleaved instead of one after the other behind "does this class exist" tests; the values are the same.
+        const bool more = L.K > NGP_RREG;
         double m = Lv[0];
 #pragma unroll
-        for (int v = 1; v < NGP_RREG; v++)
-            if (v < L.K && Lv[v] > m) m = Lv[v];
+        for (int v = 1; v < NGP_RREG; v++) m = (v < L.K && Lv[v] > m) ? Lv[v] : m;
         // (more than four classes: the same steps, class after class; their log-weights come from memory ONCE per evaluation)
-        double Lx[NGP_RMAX - NGP_RREG];
+        double Lx[NGP_RMAX - NGP_RREG], ex[NGP_RMAX - NGP_RREG];
 #pragma unroll
-        for (int v = NGP_RREG; v < NGP_RMAX; v++) Lx[v - NGP_RREG] = (v < L.K) ? rlane_L(L, v, hs) : 0.0;
+        for (int v = NGP_RREG; v < NGP_RMAX; v++) { Lx[v - NGP_RREG] = 0.0; ex[v - NGP_RREG] = 0.0; }
+        if (more) {
 #pragma unroll
-        for (int v = NGP_RREG; v < NGP_RMAX; v++)
-            if (v < L.K && Lx[v - NGP_RREG] > m) m = Lx[v - NGP_RREG];
+            for (int v = NGP_RREG; v < NGP_RMAX; v++) Lx[v - NGP_RREG] = (v < L.K) ? rlane_L(L, v, hs) : 0.0;
+#pragma unroll
+            for (int v = NGP_RREG; v < NGP_RMAX; v++)
+                if (v < L.K && Lx[v - NGP_RREG] > m) m = Lx[v - NGP_RREG];
+        }
         double S = 0.0;
 #pragma unroll
-        for (int v = 0; v < NGP_RREG; v++)
-            if (v < L.K) {
-                e[v] = det_exp(Lv[v] - m);
-                S = S + e[v];
-            } else e[v] = 0.0;
-        double ex[NGP_RMAX - NGP_RREG];
+        for (int v = 0; v < NGP_RREG; v++) {
+            const double ev = det_exp(Lv[v] - m);
+            e[v] = (v < L.K) ? ev : 0.0;
+        }
 #pragma unroll
-        for (int v = NGP_RREG; v < NGP_RMAX; v++)
-            if (v < L.K) {
-                ex[v - NGP_RREG] = det_exp(Lx[v - NGP_RREG] - m);
-                S = S + ex[v - NGP_RREG];
-            } else ex[v - NGP_RREG] = 0.0;
+        for (int v = 0; v < NGP_RREG; v++) S = (v < L.K) ? S + e[v] : S;
+        if (more) {
+#pragma unroll
+            for (int v = NGP_RREG; v < NGP_RMAX; v++)
+                if (v < L.K) {
+                    ex[v - NGP_RREG] = det_exp(Lx[v - NGP_RREG] - m);
+                    S = S + ex[v - NGP_RREG];
+                }
+        }
         int c = L.K - 1;
         double cum = 0.0;
         bool found = false;
 #pragma unroll
-        for (int v = 0; v < NGP_RREG; v++)
-            if (v < L.K && !found) {
-                cum = cum + e[v];
-                const double thr = L.u[v] * S;
-                if (cum >= thr) { c = v; found = true; }
-            }
+        for (int v = 0; v < NGP_RREG; v++) {
+            const bool take = (v < L.K) && !found;
+            const double cn = cum + e[v];
+            const double thr = L.u[v] * S;
+            const bool hit = take && (cn >= thr);
+            cum = take ? cn : cum;
+            c = hit ? v : c;
+            found = found || hit;
+        }
+        if (more) {
 #pragma unroll
-        for (int v = NGP_RREG; v < NGP_RMAX; v++)
-            if (v < L.K && !found) {
-                cum = cum + ex[v - NGP_RREG];
-                const double thr = L.ext[((size_t)3 * NGP_RMAX + v) * L.Ppad] * S;
-                if (cum >= thr) { c = v; found = true; }
-            }
+            for (int v = NGP_RREG; v < NGP_RMAX; v++)
+                if (v < L.K && !found) {
+                    cum = cum + ex[v - NGP_RREG];
+                    const double thr = L.ext[((size_t)3 * NGP_RMAX + v) * L.Ppad] * S;
+                    if (cum >= thr) { c = v; found = true; }
+                }
+        }
         double qc = L.q[0], tc = L.t[0];
 #pragma unroll
         for (int v = 1; v < NGP_RREG; v++)
