@@ -15,7 +15,9 @@ rng=np.random.default_rng(1); bt=np.zeros(P); idx=rng.choice(P,P//100,replace=Fa
 g=s.xbeta(bt); y=10+g+np.random.default_rng(2).normal(size=N)*np.sqrt(g.var())
 v=0.5*y.var()/(s.mpm().sum()/N)
 tk = int(os.environ.get("NGP_TOOL_TUPLE", "0"))  # k: the panel as ONE correlated (Tuple BayesPR) set of k components per locus
-if tk:
+if os.environ.get("NGP_TOOL_METHOD") == "R":
+    s.add_marker_set_r(0, P, 4.0, v * 0.5, v, [0.0, 0.01, 0.1, 1.0], [0.95, 0.03, 0.015, 0.005], estPi=True)
+elif tk:
     nloc = (P // 64) * (64 // tk); V = v * (0.7 * np.eye(tk) + 0.3)
     s.add_marker_set_tuple(0, nloc, tk, 3.0 + tk, V * 0.5, [(0, nloc)], V)
 else:
