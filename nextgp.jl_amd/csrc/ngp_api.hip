@@ -86,6 +86,7 @@ struct ngp_handle {
     hipStream_t stream = nullptr;
     int64_t N = 0, P = 0, R = 0, S = 0, NBLK = 0, Ppad = 0, L = 0;
     size_t lds_step = 0, lds_sweep = 0, lds_rows = 0;
+    size_t lds_sweep_lean = 0;  // the same without the sampler's staging area of BayesR / Tuple coefficients: what k_sweep<false> is launched with
     int mode = 1;      // 1: persistent sweep kernel, 0: one streaming + one recursion launch per block
     int lag = 8;       // look-ahead D of the persistent sweep (blocks); shards taller than 128 rows are capped at 5
     bool lag_auto = true;  // lag not chosen by the caller (ngp_configure): tall shards then take the measured best
@@ -330,6 +331,7 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P, ngp_handle *owner = nullptr
     if (owner) {  // the owner's layout, engine and storage, as they are
         h->mode = owner->mode; h->lag = owner->lag; h->lag_auto = owner->lag_auto; h->near_req = owner->near_req; h->near = owner->near;
         h->max_shards_req = owner->max_shards_req; h->storage = owner->storage; h->streamer_req = owner->streamer_req;
+        h->lds_rows = owner->lds_rows;
         h->streamer = owner->streamer; h->nchain = owner->nchain; h->D = owner->D; h->NG = owner->NG; h->R = owner->R; h->S = owner->S;
         h->V = owner->V;
     } else {
@@ -476,6 +478,12 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P, ngp_handle *owner = nullptr
             h->lds_rows = need;
             h->lds_sweep = std::max(need, lds_sampler);
             if (need + 8192 <= lds_max) h->lds_sweep = std::max(h->lds_sweep, need + 8192);
+        }
+        {   // the lean kernel (models of BayesPR / BayesB / BayesC sets) has no use for the sampler's BayesR / Tuple staging area
+            const size_t lean_sampler = lds_sampler - NGP_SAMPLER_TUPLE_LDS;
+            const size_t streamer_need = (h->streamer >= 2) ? h->lds_rows : 2 * TB + misc;
+            h->lds_sweep_lean = std::max(streamer_need, lean_sampler);
+            if (streamer_need + 8192 <= lds_max) h->lds_sweep_lean = std::max(h->lds_sweep_lean, streamer_need + 8192);
         }
         if (h->lds_sweep > lds_max) return fail(h, NGP_ERR_ARG, "panel too tall for the persistent sweep (LDS)");
         HCHK(sweep_set_max_lds_0((int)h->lds_sweep));
@@ -710,7 +718,7 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
         else if (h->ntuple > 0 || h->nclass_total > 0 || (h->knob & 16384))
             sweep_tup_launch((unsigned)h->last_grid, h->lds_sweep, h->stream, A);
         else
-            sweep_launch_0((unsigned)h->last_grid, h->lds_sweep, h->stream, A);
+            sweep_launch_0((unsigned)h->last_grid, h->lds_sweep_lean, h->stream, A);
         if (evs) (void)hipEventRecord(evs[1], h->stream);
         h->sweep_launches += 1;
         return;

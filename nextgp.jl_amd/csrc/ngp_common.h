@@ -113,8 +113,10 @@ struct RLane {  // class coefficients of one BayesR locus (k_prep): 1/lhs_v, log
     double q[NGP_RREG], a[NGP_RREG], t[NGP_RREG], u[NGP_RREG];
     double rhs0;
     int K;
-    const double *ext;  // K > NGP_RREG: rcls + locus (arrays q | a | t | u, NGP_RMAX x Ppad each), else unused
-    long long Ppad;
+    // K > NGP_RREG: the classes from the fifth on, array arr (q, a, t, u) of class v at ext[v * Ppad + arr * astride] -- in memory
+    // rcls + locus with astride = NGP_RMAX * Ppad, or the sampler's LDS copy (Ppad = 64, astride = 4 x 64, base moved back by 4 classes)
+    const double *ext;
+    long long Ppad, astride;
 };
 __device__ inline RLane load_rlane(const double *__restrict__ rcls, long long Ppad, long long k, int K, const double *__restrict__ rhs0) {
     RLane L;
@@ -122,6 +124,7 @@ __device__ inline RLane load_rlane(const double *__restrict__ rcls, long long Pp
     L.rhs0 = rhs0[k];
     L.ext = rcls + k;
     L.Ppad = Ppad;
+    L.astride = (long long)NGP_RMAX * Ppad;
 #pragma unroll
     for (int v = 0; v < NGP_RREG; v++) {
         const bool on = v < K;
@@ -135,14 +138,14 @@ __device__ inline RLane load_rlane(const double *__restrict__ rcls, long long Pp
 }
 __device__ inline RLane empty_rlane() {
     RLane L;
-    L.K = 2; L.rhs0 = 0.0; L.ext = nullptr; L.Ppad = 0;
+    L.K = 2; L.rhs0 = 0.0; L.ext = nullptr; L.Ppad = 0; L.astride = 0;
 #pragma unroll
     for (int v = 0; v < NGP_RREG; v++) { L.q[v] = 0.0; L.a[v] = 0.0; L.t[v] = 0.0; L.u[v] = 0.0; }
     return L;
 }
 // log-weight of class v given hs = rhs^2 / 2 (src/functions.jl:255 in the stable form): classes >= NGP_RREG come from memory
 __device__ inline double rlane_L(const RLane &L, const int v, const double hs) {
-    const double q = L.ext[(size_t)v * L.Ppad], a = L.ext[((size_t)NGP_RMAX + v) * L.Ppad];
+    const double q = L.ext[(size_t)v * L.Ppad], a = L.ext[(size_t)v * L.Ppad + (size_t)L.astride];
     return (q == 0.0) ? a : __builtin_fma(hs, q, a);
 }
 __device__ inline void eval_rform(const int meth, const double r, const double bo, const double cc, const double ww, const double st,
@@ -206,7 +209,7 @@ __device__ inline void eval_rform(const int meth, const double r, const double b
             for (int v = NGP_RREG; v < NGP_RMAX; v++)
                 if (v < L.K && !found) {
                     cum = cum + ex[v - NGP_RREG];
-                    const double thr = L.ext[((size_t)3 * NGP_RMAX + v) * L.Ppad] * S;
+                    const double thr = L.ext[(size_t)v * L.Ppad + (size_t)3 * L.astride] * S;
                     if (cum >= thr) { c = v; found = true; }
                 }
         }
@@ -214,7 +217,7 @@ __device__ inline void eval_rform(const int meth, const double r, const double b
 #pragma unroll
         for (int v = 1; v < NGP_RREG; v++)
             if (c == v) { qc = L.q[v]; tc = L.t[v]; }
-        if (c >= NGP_RREG) { qc = L.ext[(size_t)c * L.Ppad]; tc = L.ext[((size_t)2 * NGP_RMAX + c) * L.Ppad]; }
+        if (c >= NGP_RREG) { qc = L.ext[(size_t)c * L.Ppad]; tc = L.ext[(size_t)c * L.Ppad + (size_t)2 * L.astride]; }
         if (qc != 0.0) {
             const double d = __builtin_fma(rhs, qc, tc);
             cand = d - bo;

@@ -1529,6 +1529,7 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
     double *rl = (double *)(tmeta + 16);               // 2 x 17 x 64
     int *rlm = (int *)(rl + 2 * 17 * NGP_BLK);         // 2 x (64 methods | 64 class counts)
     int *rmeta = rlm + 2 * 128;                        // 2 x 4: the block holds a BayesR locus
+    double *rlx = (double *)(rmeta + 16);              // 2 x (4 arrays x 4 classes x 64): classes 5..8 of the lanes that have them
     auto rcls_prefetch = [&](const int ub) __attribute__((always_inline)) {  // wave 1; ub: local block
         if (!RCLS || !A.rcls || ub >= nb) return;
         const long long kcol = (long long)(A.t0 + ub) * NGP_BLK + j;
@@ -1548,6 +1549,16 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
         dst[16 * NGP_BLK] = RL.rhs0;
         rlm[(ub & 1) * 128 + j] = meth;
         rlm[(ub & 1) * 128 + 64 + j] = Kc;
+        if (__ballot(meth == 3 && Kc > NGP_RREG) != 0ull) {  // classes 5..8: array arr of class v at rlx[(arr * 4 + v - 4) * 64 + lane]
+            double *dx = rlx + (size_t)(ub & 1) * (16 * NGP_BLK) + j;
+#pragma unroll
+            for (int arr = 0; arr < 4; arr++)
+#pragma unroll
+                for (int v = NGP_RREG; v < NGP_RMAX; v++) {
+                    const bool on = (meth == 3) && v < Kc;
+                    dx[(arr * 4 + v - NGP_RREG) * NGP_BLK] = on ? A.rcls[((size_t)arr * NGP_RMAX + v) * (size_t)A.Ppad + (size_t)kcol] : 0.0;
+                }
+        }
     };
     if (tid < 16) {
         smeth[tid] = A.sets[tid].method;
@@ -1662,8 +1673,10 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
                     }
                     RL.rhs0 = src[16 * NGP_BLK];
                     RL.K = rlm[buf * 128 + 64 + j];
-                    RL.ext = A.rcls + ((long long)t * NGP_BLK + j);
-                    RL.Ppad = A.Ppad;
+                    // (classes 5..8 from the LDS copy: class stride 64, array stride 4 x 64, base moved back by the four register classes)
+                    RL.ext = rlx + (size_t)buf * (16 * NGP_BLK) + j - NGP_RREG * NGP_BLK;
+                    RL.Ppad = NGP_BLK;
+                    RL.astride = 4 * NGP_BLK;
                 }
                 const double iVarE = iVarE_sweep;
                 double rcur = r, dfin = 0.0;
