@@ -10,7 +10,7 @@ from conftest import add_sets
 ngp = load_pkg()
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-KINDS = ["PR", "B", "Bfix", "C", "Cfix", "PR1", "R", "Rfix", "R2", ("PRw", 37)]
+KINDS = ["PR", "B", "Bfix", "C", "Cfix", "PR1", "R", "Rfix", "R2", "R6", "R8", ("PRw", 37)]
 bad = 0
 for case in range(ncases):
     N = int(rng.choice([7, 33, 100, 257, 500, 900, 1500, 2600, 4000]))
@@ -18,7 +18,7 @@ for case in range(ncases):
     storage = rng.choice(["f32", "u8"])
     lag = int(rng.choice([1, 2, 3, 4, 5, 6, 8] if storage == "f32" else [3, 4, 6, 8, 12]))
     near = int(rng.choice([0, 1, 2, 3, 4]))
-    streamer = int(rng.choice([0, 1, 2])) if storage == "f32" else 0
+    streamer = int(rng.choice([0, 1, 2, 4, 6])) if storage == "f32" else 0   # 4 / 6: two / three shards per streamer workgroup (lag 3 / 2)
     shards = int(rng.choice([0, 0, 3, 17, 60]))
     X, mu = O.generate_panel(N, P, seed=int(rng.integers(1, 1 << 30)))
     G = np.rint(X.astype(np.float64) + mu[None, :]).astype(np.uint8)
