@@ -1523,43 +1523,6 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
         dst[2 * NGP_KMAX * NGP_BLK] = TL.ww;
         if (j == 0) { meta[0] = k; meta[1] = nvalid; }
     };
-    // BayesR sets: the lane's method and class count, its class coefficients of the first four classes and M.rhs (17 x 64), two
-    // parities -- the same one-block-ahead fetch by wave 1 (inside the block they were three dependent round trips: set lookup ->
-    // class count -> coefficients; 10.5 us per block with three steps of the chain to take)
-    double *rl = (double *)(tmeta + 16);               // 2 x 17 x 64
-    int *rlm = (int *)(rl + 2 * 17 * NGP_BLK);         // 2 x (64 methods | 64 class counts)
-    int *rmeta = rlm + 2 * 128;                        // 2 x 4: the block holds a BayesR locus
-    double *rlx = (double *)(rmeta + 16);              // 2 x (4 arrays x 4 classes x 64): classes 5..8 of the lanes that have them
-    auto rcls_prefetch = [&](const int ub) __attribute__((always_inline)) {  // wave 1; ub: local block
-        if (!RCLS || !A.rcls || ub >= nb) return;
-        const long long kcol = (long long)(A.t0 + ub) * NGP_BLK + j;
-        const int si = A.setof[kcol];
-        const int meth = (si >= 0) ? smeth[si] : -1;
-        const int Kc = (si >= 0) ? sK[si] : 2;
-        const unsigned long long mask = __ballot(meth == 3);
-        if (j == 0) rmeta[(ub & 1) * 4] = (mask != 0ull) ? 1 : 0;
-        if (mask == 0ull) return;
-        RLane RL = empty_rlane();
-        if (meth == 3) RL = load_rlane(A.rcls, A.Ppad, kcol, Kc, A.rhs0);
-        double *dst = rl + (size_t)(ub & 1) * (17 * NGP_BLK) + j;
-#pragma unroll
-        for (int v = 0; v < NGP_RREG; v++) {
-            dst[v * NGP_BLK] = RL.q[v]; dst[(4 + v) * NGP_BLK] = RL.a[v]; dst[(8 + v) * NGP_BLK] = RL.t[v]; dst[(12 + v) * NGP_BLK] = RL.u[v];
-        }
-        dst[16 * NGP_BLK] = RL.rhs0;
-        rlm[(ub & 1) * 128 + j] = meth;
-        rlm[(ub & 1) * 128 + 64 + j] = Kc;
-        if (__ballot(meth == 3 && Kc > NGP_RREG) != 0ull) {  // classes 5..8: array arr of class v at rlx[(arr * 4 + v - 4) * 64 + lane]
-            double *dx = rlx + (size_t)(ub & 1) * (16 * NGP_BLK) + j;
-#pragma unroll
-            for (int arr = 0; arr < 4; arr++)
-#pragma unroll
-                for (int v = NGP_RREG; v < NGP_RMAX; v++) {
-                    const bool on = (meth == 3) && v < Kc;
-                    dx[(arr * 4 + v - NGP_RREG) * NGP_BLK] = on ? A.rcls[((size_t)arr * NGP_RMAX + v) * (size_t)A.Ppad + (size_t)kcol] : 0.0;
-                }
-        }
-    };
     if (tid < 16) {
         smeth[tid] = A.sets[tid].method;
         ssdf[tid] = A.sets[tid].sdf;
@@ -1586,7 +1549,7 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
         if (fetch_group_sums<DBG, NGBIG>(A, 0, j, &tot)) r0[j] = tot;
         else if (j == 0) *sabort = 1;
     }
-    if (wv == 1) { tuple_prefetch(0); rcls_prefetch(0); }
+    if (wv == 1) tuple_prefetch(0);
     __syncthreads();
     if (*sabort) return;
 #define NGP_END_OF_BLOCK()                                                                       \
@@ -1599,10 +1562,6 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
     if (wv == 0) {
         // ---------------- critical wave: LDS + ALU only ----------------
         CoefRegs cur = load_coef(A, (long long)A.t0 * NGP_BLK + j), nxt = cur;
-        double iVarE_sweep = 0.0;  // (BayesR: 1 / varE of this iteration, constant during the sweep)
-        if constexpr (RCLS) {
-            if (A.rcls) iVarE_sweep = A.scal->iVarE;
-        }
         for (int u = 0; u < nb; ++u) {
             const int t = A.t0 + u, buf = u & 1, slot = u % NGP_RING, rs = u & 3;
             if (u + 1 < nb) nxt = load_coef(A, (long long)(t + 1) * NGP_BLK + j);
@@ -1640,9 +1599,10 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
             double dsave;
             int isave = 1;
             // BayesR: the lane's set and method (one byte per lane, read only when the model has a BayesR set at all)
-            int rblk = 0;
-            if constexpr (RCLS) {
-                if (A.rcls) rblk = __builtin_amdgcn_readfirstlane(rmeta[buf * 4]);
+            int meth0 = -1, si0 = -1;
+            if (RCLS && A.rcls) {
+                si0 = A.setof[(long long)t * NGP_BLK + j];
+                meth0 = (si0 >= 0) ? smeth[si0] : -1;
             }
             int tk = 0;
             if constexpr (TUP) {
@@ -1659,26 +1619,12 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
                 TL.ww = tsrc[2 * NGP_KMAX * NGP_BLK];
                 dsave = tuple_chain_nv(tk, nvalid, j, tot, bo, TL, [&](int sl, int cc2) { return Gd[(u % 3) * 4096 + sl * NGP_BLK + cc2]; });
                 isave = 1;
-            } else if (RCLS && rblk != 0) {
+            } else if (RCLS && A.rcls && __ballot(meth0 == 3) != 0ull) {
                 // r-form chain (eval_rform, ngp_kernels.h): candidates of all lanes from the current r, the first non-zero one at
-                // or behind the cursor takes its step.  With most loci in the zero class that is a few steps per block.  The lane's
-                // method, class count and coefficients wait in LDS (wave 1, one block ahead); classes beyond the fourth stay in memory.
-                const int meth0 = rlm[buf * 128 + j];
-                RLane RL;
-                {
-                    const double *src = rl + (size_t)buf * (17 * NGP_BLK) + j;
-#pragma unroll
-                    for (int v = 0; v < NGP_RREG; v++) {
-                        RL.q[v] = src[v * NGP_BLK]; RL.a[v] = src[(4 + v) * NGP_BLK]; RL.t[v] = src[(8 + v) * NGP_BLK]; RL.u[v] = src[(12 + v) * NGP_BLK];
-                    }
-                    RL.rhs0 = src[16 * NGP_BLK];
-                    RL.K = rlm[buf * 128 + 64 + j];
-                    // (classes 5..8 from the LDS copy: class stride 64, array stride 4 x 64, base moved back by the four register classes)
-                    RL.ext = rlx + (size_t)buf * (16 * NGP_BLK) + j - NGP_RREG * NGP_BLK;
-                    RL.Ppad = NGP_BLK;
-                    RL.astride = 4 * NGP_BLK;
-                }
-                const double iVarE = iVarE_sweep;
+                // or behind the cursor takes its step.  With most loci in the zero class that is a few steps per block.
+                RLane RL = empty_rlane();
+                if (meth0 == 3) RL = load_rlane(A.rcls, A.Ppad, (long long)t * NGP_BLK + j, sK[si0], A.rhs0);
+                const double iVarE = A.scal->iVarE;
                 double rcur = r, dfin = 0.0;
                 int cfin = 1, kstart = 0;
                 for (int guard = 0; guard < NGP_BLK + 1; ++guard) {
@@ -1767,7 +1713,6 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
     } else if (wv == 1) {
         for (int u = 0; u < nb; ++u) {
             tuple_prefetch(u + 1);
-            rcls_prefetch(u + 1);
             if (u >= 1) publish_block<DBG>(A, u - 1, j, hist, outb, outi, smeth, ssdf);
             NGP_END_OF_BLOCK();
         }

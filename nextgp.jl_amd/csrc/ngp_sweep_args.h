@@ -16,9 +16,7 @@
 #define NGP_LAZY_LAG 7  // streamers count their partials lazily from this lag on
 #endif
 #define NGP_QS 1040
-// sampler workgroup, behind its flags: lane coefficients of a Tuple block (9 x 64 doubles, two parities) + (k, used lanes), then lane
-// coefficients of a BayesR block (17 x 64 doubles, two parities) + (method, classes) per lane + flags -- fetched one block ahead by wave 1
-#define NGP_SAMPLER_TUPLE_LDS (2 * 9 * 64 * 8 + 64 + 2 * 17 * 64 * 8 + 2 * 128 * 4 + 64 + 2 * 16 * 64 * 8)  // (+ classes 5..8 of a BayesR block)
+#define NGP_SAMPLER_TUPLE_LDS (2 * 9 * 64 * 8 + 64)  // sampler workgroup: lane coefficients of a Tuple block, two parities, + (k, used lanes)
 #define NGP_ABORT_CENSUS 9u        // abort code: the grid was not co-resident within NGP_CENSUS_TICKS (no state was modified)
 #define NGP_CENSUS_TICKS 2000000ull  // 20 ms of the 100 MHz wall clock
 #define NGP_DBG_STREAM (1u << 20)  // offset of streamer 0's stamps in the debug buffer
