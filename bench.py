@@ -189,9 +189,9 @@ def main():
     ap.add_argument("--no-compact", action="store_true", help="skip the extra leg in compact (one byte per genotype) storage")
     ap.add_argument("--chains-per-gpu", type=int, default=0,
                     help="extra leg: that many independent chains side by side on the GPU (aggregate it/s; pays where one chain is not bandwidth-bound)")
-    ap.add_argument("--chains-per-pass", type=int, default=0,
+    ap.add_argument("--chains-per-pass", type=int, default=-1,
                     help="extra leg: that many independent chains in ONE fused sweep launch per iteration, the panel streamed once for all of them "
-                         "(aggregate it/s beside the single-chain value; 2..8)")
+                         "(aggregate it/s beside the single-chain value; 2..8; default: 8 on shards of at most 64 rows, 2 on taller ones; 0 or 1: skip)")
     ap.add_argument("--storage", default="f32", choices=["f32", "u8"],
                     help="panel storage of the MAIN measurement (default f32 = the headline; u8 = compact storage, for profiling that mode)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend (nccl = RCCL; gloo only to rehearse N > 1 on one GPU)")
@@ -397,6 +397,8 @@ def main():
                                      "speedup_vs_single_chain": (kc * K / kdt) / its}
             for c in cs:
                 c.close()
+        if args.chains_per_pass < 0:  # default: what the fused kernel serves at this shape (phase streamer: 8 chains, row-owning streamer: 2)
+            args.chains_per_pass = (2 if N >= 64 * 247 else 8) if (world == 1 and not compact_main and N <= 224 * 240) else 0
         if world == 1 and args.chains_per_pass > 1 and not compact_main:
             # K independent chains in ONE fused sweep launch per iteration: every streamer forms X_t'[y_1 .. y_K] from each tile it
             # reads, so one pass over the panel (4 N P algorithmic bytes) serves K iterations' worth of sampling -- the aggregate

@@ -31,7 +31,7 @@ found = sorted({row["Kernel_Name"] for f in glob.glob(os.path.join(out, f"{tag}_
                 for row in csv.DictReader(open(f)) if row["Kernel_Name"] in KERNELS})
 bench = json.loads(open(os.path.join(out, f"{tag}_{cfg}_bench.json")).read().strip().splitlines()[-1])
 summary = {
-    "command": f"rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --config {base_cfg} --storage {storage} --steps 10 --warmup 2 --no-cpu-baseline --no-compact (two separate passes)",
+    "command": f"rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --output-format csv -- python3 bench.py --config {base_cfg} --storage {storage} --steps 10 --warmup 2 --no-cpu-baseline --no-compact --chains-per-pass 0 (two separate passes)",
     "workload": bench["config"]["workload"],
     "kernel": ", ".join(found) if found else "ngp::k_sweep",
     "FETCH_SIZE_KB_per_launch_raw": sum(fetch) / max(len(fetch), 1),

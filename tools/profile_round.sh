@@ -14,7 +14,7 @@ export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 python3 bench.py --config $CFG --storage $STO > $OUT/${TAG}_${CFG}${SFX}_bench.json 2> $OUT/${TAG}_${CFG}${SFX}_bench.err
-ARGS="bench.py --config $CFG --storage $STO --steps 10 --warmup 2 --no-cpu-baseline --no-compact"
+ARGS="bench.py --config $CFG --storage $STO --steps 10 --warmup 2 --no-cpu-baseline --no-compact --chains-per-pass 0"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_${CFG}${SFX}_stats -o run -- python3 $ARGS > $OUT/${TAG}_${CFG}${SFX}_stats.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/${TAG}_${CFG}${SFX}_fetch -o run -- python3 $ARGS > $OUT/${TAG}_${CFG}${SFX}_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/${TAG}_${CFG}${SFX}_write -o run -- python3 $ARGS > $OUT/${TAG}_${CFG}${SFX}_write.log 2>&1
