@@ -2542,9 +2542,13 @@ __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
         default: role_streamer_multi<DTV, 8>(M, s, smem); break;      \
     }
     if (M.a[0].variant == 2) {  // row-owning streamer, lag 4 or 6 (host: fp32 tiles, shards of 64..NGP_ROWS_MAX_R rows), 2 chains
+#ifdef NGP_ROWS_MULTI_ONLY  /* resource-usage experiments: one instantiation */
+        role_streamer_rows_multi<NGP_ROWS_MULTI_ONLY, 2>(M, s, smem);
+#else
         if (M.a[0].D == 4) role_streamer_rows_multi<4, 2>(M, s, smem);
         else if (M.a[0].D == 5) role_streamer_rows_multi<5, 2>(M, s, smem);
         else role_streamer_rows_multi<6, 2>(M, s, smem);
+#endif
         return;
     }
     if (M.a[0].D == 6) { NGP_MULTI_K(6) } else { NGP_MULTI_K(8) }
