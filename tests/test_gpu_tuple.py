@@ -148,3 +148,48 @@ def test_tuple_argument_checks(ngp, O):
     with pytest.raises(ngp.NextGPHipError, match="overlap"):
         s.add_marker_set(100, 50, 0, 4.0, v * 0.5, [(0, 50)], [v])      # column 100 is inside the tuple set's last block
     s.add_marker_set(128, 50, 0, 4.0, v * 0.5, [(0, 50)], [v])
+
+
+def test_tuple_sets_through_run_many_and_on_tall_panels(ngp):
+    """Chains with a Tuple set are not fused into one launch (the fused kernel's samplers are compiled without that chain): run_many
+    runs them side by side, each bit for bit the chain it is alone.  And a Tuple set on an fp32 panel too tall for one shard per
+    streamer workgroup (k_sweep_tall) draws the chain of the per-block engine (1e-9: another layout, another summation order)."""
+    rng = np.random.default_rng(1)
+    N, P, k = 3000, 6400, 2
+    v = 0.01; V = v * (0.7 * np.eye(k) + 0.3); nloc = (P // 64) * (64 // k)
+
+    def mk(seed, chain, owner=None):
+        s = ngp.Sampler(device=0, seed=seed, chain=chain, mode=1, lag=8)
+        if owner is None:
+            s.set_max_shards(100); s.generate_panel(N, P)
+        else:
+            s.share_panel(owner)
+        return s
+
+    def model(s, yy):
+        s.add_marker_set_tuple(0, nloc, k, 3.0 + k, V * 0.5, [(0, nloc)], V); s.set_y(yy); s.set_residual_prior(4.0, 0.5)
+
+    first = mk(1001, 0)
+    bt = np.zeros(P); bt[rng.choice(P, 30, replace=False)] = rng.normal(size=30)
+    y = 3 + first.xbeta(bt) + np.random.default_rng(2).normal(size=N)
+    second = mk(1002, 1, owner=first)
+    model(first, y); model(second, y + 0.01)
+    ngp.Sampler.run_many([first, second], 15)
+    assert first.census()["grid"] == 1 + (first.layout()[1] + 31) // 32 + first.layout()[1]     # a grid of its own: not fused
+    for f, (seed, chain, yy) in ((first, (1001, 0, y)), (second, (1002, 1, y + 0.01))):
+        a = mk(seed, chain); model(a, yy); a.run(15)
+        sf, sa = f.get_state(), a.get_state()
+        assert all(np.array_equal(sf[q], sa[q]) for q in ("beta", "ycorr", "varBeta")) and sf["varE"] == sa["varE"]
+    N2, P2 = 70000, 1280
+    nl2 = (P2 // 64) * 32
+    out = []
+    for kw in ({}, dict(mode=0, lag=1)):
+        t = ngp.Sampler(device=0, seed=5, chain=0, **kw); t.generate_panel(N2, P2)
+        if not out:
+            bt = np.zeros(P2); bt[rng.choice(P2, 10, replace=False)] = rng.normal(size=10)
+            y2 = 3 + t.xbeta(bt) + np.random.default_rng(3).normal(size=N2)
+            assert t.config() == (1, 3) and t.layout()[1] % 2 == 0
+        t.add_marker_set_tuple(0, nl2, 2, 5.0, V * 0.5, [(0, nl2)], V); t.set_y(y2); t.set_residual_prior(4.0, 0.5); t.run(6)
+        out.append(t.get_state())
+    st, sr = out
+    assert np.abs(st["beta"] - sr["beta"]).max() <= 1e-9 * max(1e-3, np.abs(sr["beta"]).max()) and abs(st["varE"] - sr["varE"]) <= 1e-9 * sr["varE"]
