@@ -348,7 +348,7 @@ def samples_to_out_files(sample_path, outFolder, sets, intercept, has_fixed):
 # runLMEM (src/MCMC.jl:31-41)
 # ----------------------------------------------------------------------------------------------
 def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=None, outFolder="outMCMC", VCV=None, userPedData=None,
-            summaryStat=None, seed=1, chain=0, device=0, samples="text", overwrite=False, engine=None, storage=None):
+            summaryStat=None, seed=1, chain=0, device=0, samples="text", overwrite=False, engine=None, storage=None, chains=1, max_shards=None):
     """Runs the chain on the GPU and writes the reference's *Out files.
 
     Differences from the reference, all deliberate: (1) `seed`/`chain` key the random streams (the reference never
@@ -356,7 +356,10 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
     src/misc.jl:221-227); (3) samples="none" skips the per-iteration text rows and only returns posterior means;
     (4) storage="u8" keeps the panel one byte per genotype on the device, centred analytically (ngp_set_storage: a quarter of
     the memory, no fp32 rounding of the panel) -- every SNP set must then hold integer codes 0..255 (uint8 arrays, binary panel
-    files, or text files whose values are such integers).
+    files, or text files whose values are such integers); (5) chains=K runs K independent chains (chain ids chain .. chain+K-1, the
+    same seed) over ONE copy of the panel on the device -- one fused sweep launch per iteration where the engine serves it
+    (ngp_share_panel + ngp_run_many), side by side otherwise; every chain is bit for bit the chain it is alone with that layout,
+    writes its own *Out files to outFolder/chain<c>/, and the returned means are pooled over the chains (res["chains"] holds each).
     Returns a dict of posterior means taken from the on-device sums."""
     if userPedData is not None and len(userPedData):
         raise NotImplementedError("userPedData: pedigree effects stay on the Julia path (src/mme.jl:26-46)")
@@ -428,7 +431,17 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
         else:
             units.append(("set", t.name, ncols, mats[by_name[t.name]].shape[1]))
             pieces.append(mats[by_name[t.name]]); ncols += mats[by_name[t.name]].shape[1]
-    smp = Sampler(device=device, seed=seed, chain=chain, storage=storage, **(dict(mode=engine[0], lag=engine[1]) if engine else {}))
+    K = int(chains)
+    if K < 1 or K > 8:
+        raise ValueError("chains: 1..8")
+    if K > 1 and samples == "text-sync":
+        raise ValueError('chains > 1: samples "text", "binary" or "none"')
+    skw = dict(mode=engine[0], lag=engine[1]) if engine else {}
+    smp = Sampler(device=device, seed=seed, chain=chain, storage=storage, **skw)
+    if max_shards:  # an explicit shard count (ngp_set_max_shards): e.g. the layout of a fused run, to repeat one of its chains alone
+        smp.set_max_shards(int(max_shards))
+    elif K > 1:  # the layout with which K chains share one fused sweep launch (fp32 tiles), or the device side by side
+        smp.set_max_shards(smp.shards_for_pass(K) if storage is None else smp.shards_for_chains(K))
     if storage is None and all(np.asarray(pc).dtype != np.uint8 for pc in pieces):
         # the sets go to the device one after another (ngp_begin_panel / ngp_panel_columns_* / ngp_end_panel): no concatenated host copy
         smp.begin_panel(len(y), ncols)
@@ -440,6 +453,29 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
         smp.end_panel()
     else:
         smp.set_panel(np.asfortranarray(np.concatenate(pieces, axis=1)), centre=True)  # centring: src/prepMatVec.jl:129
+    samplers = [smp]
+    for c in range(1, K):  # the other chains share the first one's panel by reference (no copy, no second upload)
+        sc = Sampler(device=device, seed=seed, chain=chain + c, storage=storage, **skw)
+        sc.share_panel(smp)
+        samplers.append(sc)
+    region_cache = {}
+
+    def regions_of(prior, P, map_path, name):
+        if name not in region_cache:
+            region_cache[name] = _regions_for(prior, P, map_path, outFolder, name)
+        return region_cache[name]
+
+    built = [_build_model(sc, VCV, summaryStat, parsed, userData, blockThese, intercept, units, snps, by_name, regions_of, y, nChain, nBurn, nThin)
+             for sc in samplers]
+    sets, fixed_names = built[0]
+    folders = [outFolder] if K == 1 else [os.path.join(outFolder, f"chain{chain + c}") for c in range(K)]
+    for f in folders:
+        os.makedirs(f, exist_ok=True)
+    return _run_model(samplers, folders, sets, fixed_names, intercept, nChain, nBurn, nThin, samples)
+
+
+def _build_model(smp, VCV, summaryStat, parsed, userData, blockThese, intercept, units, snps, by_name, regions_of, y, nChain, nBurn, nThin):
+    """Priors, fixed-effect sets, marker sets, y and the schedule of ONE chain's handle (its panel is set); returns (sets, fixed_names)."""
     # residual prior (src/mme.jl:63-94)
     e_prior = VCV.get("e", Random("I", 100.0))
     if not (e_prior.str in ("I", "", None) or (isinstance(e_prior.str, (list, tuple)) and len(e_prior.str) == 0)):
@@ -486,7 +522,7 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
             vm = np.asarray(prior.v, dtype=np.float64)
             scale = vm * (df - k - 1.0) if k > 1 else vm * (df - 2.0) / df  # src/mme.jl:501
             t0 = snps[by_name[key[0]]]
-            regions = _regions_for(prior, nloc, t0.map, outFolder, "_".join(key))
+            regions = regions_of(prior, nloc, t0.map, "_".join(key))
             sid = smp.add_marker_set_tuple(col0, nloc, k, df, scale, regions, vm)
             cols = tuple_columns(col0, nloc, k)
             sets.append(dict(id=sid, name="_".join(key), members=list(key), cols=cols, P=nloc, prior=prior, nreg=len(regions), nvb=len(regions) * k * k, k=k))
@@ -500,7 +536,7 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
             raise NotImplementedError(f"prior {type(prior).__name__} for {t.name}: only BayesPR, BayesB, BayesC and BayesR are on the accelerated path")
         df = 4.0                                  # 3 + size(v,1), src/mme.jl:493
         scale = prior.v * (df - 2.0) / df         # src/mme.jl:501
-        regions = _regions_for(prior, P, t.map, outFolder, t.name)
+        regions = regions_of(prior, P, t.map, t.name)
         lhs0 = rhs0 = None
         if t.name in summaryStat:                 # src/mme.jl:316-322
             m, v = np.asarray(summaryStat[t.name][0], float), np.asarray(summaryStat[t.name][1], float)
@@ -520,24 +556,56 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
                          nvb=P if isinstance(prior, BayesBType) else len(regions), k=1))
     smp.set_y(y)
     smp.set_schedule(nChain, nBurn, nThin)
-    # header rows (src/mme.jl:543-595)
-    if samples in ("text", "text-sync"):
-        _out(outFolder, "b", fixed_names)
-        _out(outFolder, "varE", ["e"])
-        for s in sets:
-            names = [f"M{i + 1}" for i in range(s["P"])]  # src/prepMatVec.jl:131
-            for nm in s["members"]:
-                _out(outFolder, f"beta{nm}", names)
-                _out(outFolder, f"delta{nm}", names)
-            if isinstance(s["prior"], (BayesBType, BayesCType)):  # src/samplers.jl:80-82
-                _out(outFolder, f"pi{s['name']}", ["pi1", "pi2"])
-            if isinstance(s["prior"], BayesRType):               # one column per class (src/mme.jl:589-591)
-                _out(outFolder, f"pi{s['name']}", [f"pi{v + 1}" for v in range(len(s["prior"].pi))])
-            _out(outFolder, f"var{s['name']}", _var_names(s))
-    # the chain (src/samplers.jl:29-105): kept iterations = burnIn+thin : thin : chainLength
-    done = 0
+    return sets, fixed_names
+
+
+def _run_model(samplers, folders, sets, fixed_names, intercept, nChain, nBurn, nThin, samples):
+    """Header rows, the chain(s), the *Out rows and the posterior means (pooled over the chains when there are several)."""
     if samples not in ("text", "text-sync", "binary", "none"):
         raise ValueError('samples: "text", "text-sync", "binary" or "none"')
+    if len(samplers) > 1:
+        paths = [os.path.join(f, "samples.ngpsmp") for f in folders]
+        for sc, f, pth in zip(samplers, folders, paths):
+            if samples == "text":
+                _write_headers(f, sets, fixed_names)
+            if samples in ("text", "binary"):
+                sc.set_sample_file(pth)
+        Sampler.run_many(samplers, nChain)  # ONE fused sweep launch per iteration for all chains where the engine serves it
+        results = []
+        for sc, f, pth in zip(samplers, folders, paths):
+            if samples in ("text", "binary"):
+                sc.set_sample_file(None)
+            if samples == "text":
+                samples_to_out_files(pth, f, sets, intercept, len(fixed_names) > int(intercept))
+                os.remove(pth)
+            results.append(_posterior_means(sc, sets, fixed_names, intercept))
+        return _pool_results(results)
+    smp, outFolder = samplers[0], folders[0]
+    # header rows (src/mme.jl:543-595)
+    if samples in ("text", "text-sync"):
+        _write_headers(outFolder, sets, fixed_names)
+    return _run_one(smp, outFolder, sets, fixed_names, intercept, nChain, nBurn, nThin, samples)
+
+
+def _write_headers(outFolder, sets, fixed_names):
+    """Header rows of the *Out files (src/mme.jl:543-595)."""
+    _out(outFolder, "b", fixed_names)
+    _out(outFolder, "varE", ["e"])
+    for s in sets:
+        names = [f"M{i + 1}" for i in range(s["P"])]  # src/prepMatVec.jl:131
+        for nm in s["members"]:
+            _out(outFolder, f"beta{nm}", names)
+            _out(outFolder, f"delta{nm}", names)
+        if isinstance(s["prior"], (BayesBType, BayesCType)):  # src/samplers.jl:80-82
+            _out(outFolder, f"pi{s['name']}", ["pi1", "pi2"])
+        if isinstance(s["prior"], BayesRType):               # one column per class (src/mme.jl:589-591)
+            _out(outFolder, f"pi{s['name']}", [f"pi{v + 1}" for v in range(len(s["prior"].pi))])
+        _out(outFolder, f"var{s['name']}", _var_names(s))
+
+
+def _run_one(smp, outFolder, sets, fixed_names, intercept, nChain, nBurn, nThin, samples):
+    # the chain (src/samplers.jl:29-105): kept iterations = burnIn+thin : thin : chainLength
+    done = 0
     smp_path = os.path.join(outFolder, "samples.ngpsmp")
     if samples in ("text", "binary"):
         smp.set_sample_file(smp_path)       # kept samples stream out while the chain runs: ONE ngp_run for the whole chain
@@ -565,6 +633,10 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
     if samples == "text":
         samples_to_out_files(smp_path, outFolder, sets, intercept, len(fixed_names) > int(intercept))
         os.remove(smp_path)
+    return _posterior_means(smp, sets, fixed_names, intercept)
+
+
+def _posterior_means(smp, sets, fixed_names, intercept):
     ps = smp.get_posterior_sums()
     n = max(ps["nKept"], 1)
     res = dict(nKept=ps["nKept"], b=ps["sum_b"] / n, varE=ps["sum_varE"] / n, sets={}, fixed_names=fixed_names,
@@ -582,3 +654,17 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
         vb_off += s["nvb"]
     res["sampler"] = smp
     return res
+
+
+def _pool_results(results):
+    """Posterior means pooled over chains of equal length (the mean of the chains' means); res["chains"] keeps every chain's own."""
+    w = np.array([r["nKept"] for r in results], dtype=np.float64)
+    w = w / w.sum() if w.sum() > 0 else np.full(len(results), 1.0 / len(results))
+    def avg(get):
+        return sum(wi * np.asarray(get(r), dtype=np.float64) for wi, r in zip(w, results))
+    pooled = dict(nKept=int(sum(r["nKept"] for r in results)), b=float(avg(lambda r: r["b"])), varE=float(avg(lambda r: r["varE"])),
+                  fixed_names=results[0]["fixed_names"], fixed=avg(lambda r: r["fixed"]), sets={}, chains=results,
+                  sampler=results[0]["sampler"], samplers=[r["sampler"] for r in results])
+    for nm in results[0]["sets"]:
+        pooled["sets"][nm] = {k: avg(lambda r, k=k: r["sets"][nm][k]) for k in results[0]["sets"][nm]}
+    return pooled

@@ -284,3 +284,46 @@ def test_runLMEM_correlated_marker_sets(ngp, O, tmp_path):
         assert len(lines) == 7 and len(lines[0].split("\t")) == ncol, name
     assert (out / "varA_BOut").read_text().splitlines()[0].split("\t") == ["reg_1_11", "reg_1_12", "reg_1_21", "reg_1_22"]
     assert np.allclose(ngp.summaryMCMC("betaB", outFolder=str(out))[0], res["sets"]["B"]["beta"], rtol=0, atol=1e-12)
+
+
+@pytest.mark.gpu
+def test_runLMEM_with_several_chains_over_one_panel(ngp, O, tmp_path):
+    """runLMEM(..., chains=K): K independent chains (chain ids 0..K-1) over ONE copy of the panel on the device, fused into one sweep
+    launch per iteration; every chain writes its own *Out files, bit for bit the files of the same chain run alone with that layout,
+    and the returned means are the chains' pooled means."""
+    N, P1, P2 = 900, 330, 310
+    X1 = O.generate_panel(N, P1 + P2, seed=5)[0]
+    mu = -X1.astype(np.float64).min(axis=0)
+    G = np.rint(X1.astype(np.float64) + mu)
+    rng = np.random.default_rng(3)
+    bt = np.zeros(P1 + P2); bt[rng.choice(P1 + P2, 12, replace=False)] = rng.normal(size=12)
+    y = 4.0 + (G - G.mean(0)) @ bt + rng.normal(size=N)
+    v = 0.01
+    g1, g2 = tmp_path / "g1.txt", tmp_path / "g2.txt"
+    np.savetxt(g1, G[:, :P1], fmt="%d", delimiter=" ")
+    np.savetxt(g2, G[:, P1:], fmt="%d", delimiter=" ")
+    VCV = {"M1": ngp.BayesPR(9999, v), "M2": ngp.BayesB(0.1, v, estimatePi=True), "e": ngp.Random("I", 0.5 * y.var())}
+    f = f'y ~ 1 + SNP(M1,"{g1}") + SNP(M2,"{g2}")'
+    K = 3
+    out = tmp_path / "outChains"
+    res = ngp.runLMEM(f, {"y": y}, 24, 6, 3, outFolder=str(out), VCV=VCV, seed=9, chains=K)
+    assert len(res["chains"]) == K and res["nKept"] == K * 6
+    first = res["samplers"][0]
+    R, S, _ = first.layout()
+    assert first.census()["grid"] == K + K * ((S + 31) // 32) + S          # ONE fused launch per iteration served the three chains
+    # pooled means = mean of the chains' means
+    for nm in ("M1", "M2"):
+        assert np.allclose(res["sets"][nm]["beta"], np.mean([c["sets"][nm]["beta"] for c in res["chains"]], axis=0), rtol=0, atol=1e-15)
+    assert abs(res["varE"] - np.mean([c["varE"] for c in res["chains"]])) < 1e-12
+    # every chain's files == the files of that chain run alone (same seed, its chain id, the layout of the fused run)
+    for c in (0, K - 1):
+        alone = tmp_path / f"alone{c}"
+        r1 = ngp.runLMEM(f, {"y": y}, 24, 6, 3, outFolder=str(alone), VCV=VCV, seed=9, chain=c, max_shards=S)
+        assert r1["sampler"].layout()[:2] == (R, S)
+        cdir = out / f"chain{c}"
+        assert sorted(p.name for p in cdir.iterdir()) == sorted(p.name for p in alone.iterdir())
+        for pth in alone.iterdir():
+            assert pth.read_bytes() == (cdir / pth.name).read_bytes(), (c, pth.name)
+        assert np.array_equal(r1["sets"]["M2"]["delta"], res["chains"][c]["sets"]["M2"]["delta"])
+    with pytest.raises(ValueError):
+        ngp.runLMEM(f, {"y": y}, 4, 0, 1, outFolder=str(tmp_path / "bad"), VCV=VCV, chains=2, samples="text-sync")
