@@ -80,6 +80,9 @@ int32_t ngp_set_panel_f32(ngp_handle *h, const float *M, int64_t N, int64_t P, i
 int32_t ngp_begin_panel(ngp_handle *h, int64_t N, int64_t P);
 int32_t ngp_panel_columns_f64(ngp_handle *h, int64_t col0, const double *M, int64_t ncol, int64_t ld, int32_t centre);
 int32_t ngp_panel_columns_f32(ngp_handle *h, int64_t col0, const float *M, int64_t ncol, int64_t ld, int32_t centre);
+/* ... and from one byte per genotype (codes 0..255; the tiles of ngp_set_panel_u8 bit for bit): the only form the compact storage
+ * (ngp_set_storage) takes, and a quarter of the host footprint and PCIe transfer for the fp32 tiles. */
+int32_t ngp_panel_columns_u8(ngp_handle *h, int64_t col0, const uint8_t *G, int64_t ncol, int64_t ld, int32_t centre);
 int32_t ngp_end_panel(ngp_handle *h);
 /* Same panel from one byte per genotype (0/1/2 allele counts, or any value 0..255): a quarter of the fp32 host footprint and
  * of the PCIe transfer; centring and the fp32 conversion happen on the device and give bit for bit the tiles of

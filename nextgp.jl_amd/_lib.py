@@ -69,7 +69,7 @@ def tuple_panel(sets):
 # every symbol include/nextgp_hip.h declares
 SYMBOLS = [
     "ngp_abi_version", "ngp_create", "ngp_destroy", "ngp_last_error", "ngp_set_panel_f64", "ngp_set_panel_f32", "ngp_set_panel_u8",
-    "ngp_begin_panel", "ngp_panel_columns_f64", "ngp_panel_columns_f32", "ngp_end_panel",
+    "ngp_begin_panel", "ngp_panel_columns_f64", "ngp_panel_columns_f32", "ngp_panel_columns_u8", "ngp_end_panel",
     "ngp_generate_panel", "ngp_get_layout", "ngp_get_mpm", "ngp_get_gram", "ngp_xbeta", "ngp_add_marker_set", "ngp_set_y",
     "ngp_set_residual_prior", "ngp_set_intercept", "ngp_set_schedule", "ngp_run", "ngp_get_state", "ngp_set_state",
     "ngp_get_trace", "ngp_get_posterior_sums", "ngp_posterior_len", "ngp_export_posterior_device", "ngp_sweep_set",
@@ -259,7 +259,10 @@ class Sampler:
 
     def panel_columns(self, col0, M, centre=False):
         M = np.asarray(M)
-        if M.dtype == np.float32:
+        if M.dtype == np.uint8:     # genotype codes: the only form the compact storage takes
+            M = np.asfortranarray(M)
+            f, t = self.L.ngp_panel_columns_u8, C.c_uint8
+        elif M.dtype == np.float32:
             M = np.asfortranarray(M)
             f, t = self.L.ngp_panel_columns_f32, C.c_float
         else:

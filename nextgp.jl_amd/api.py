@@ -442,7 +442,8 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
         smp.set_max_shards(int(max_shards))
     elif K > 1:  # the layout with which K chains share one fused sweep launch (fp32 tiles), or the device side by side
         smp.set_max_shards(smp.shards_for_pass(K) if storage is None else smp.shards_for_chains(K))
-    if storage is None and all(np.asarray(pc).dtype != np.uint8 for pc in pieces):
+    kinds = {np.asarray(pc).dtype == np.uint8 for pc in pieces if pc.shape[1]}
+    if (storage is None and kinds == {False}) or kinds == {True}:
         # the sets go to the device one after another (ngp_begin_panel / ngp_panel_columns_* / ngp_end_panel): no concatenated host copy
         smp.begin_panel(len(y), ncols)
         c0 = 0

@@ -571,7 +571,6 @@ int build_gram(ngp_handle *h) {
 int begin_panel(ngp_handle *h, int64_t N, int64_t P) {
     int rc;
     if ((rc = enter(h))) return rc;
-    REQUIRE(h->storage == 0, NGP_ERR_ARG, "compact storage takes genotype codes: ngp_set_panel_u8, ngp_load_panel_file or ngp_generate_panel");
     if ((rc = alloc_panel(h, N, P))) return rc;  // (tiles and means are born zero: columns never uploaded stay zero columns)
     h->panel_open = true;
     return NGP_OK;
@@ -586,6 +585,8 @@ int panel_columns(ngp_handle *h, int64_t col0, const TIn *M, int64_t ncol, int64
     REQUIRE(M != nullptr, NGP_ERR_ARG, "null panel pointer");
     REQUIRE(ld >= h->N, NGP_ERR_ARG, "leading dimension smaller than N");
     REQUIRE(col0 >= 0 && ncol > 0 && col0 + ncol <= h->P, NGP_ERR_ARG, "column range outside the panel");
+    REQUIRE(h->storage == 0 || sizeof(TIn) == 1, NGP_ERR_ARG,
+            "compact storage takes genotype codes: ngp_panel_columns_u8, ngp_set_panel_u8, ngp_load_panel_file or ngp_generate_panel");
     const int64_t N = h->N;
     const int64_t cchunk = std::max<int64_t>(1, std::min<int64_t>(ncol, ((int64_t)256 << 20) / (int64_t)(ld * sizeof(TIn))));
     TIn *d_g = nullptr;
@@ -601,6 +602,12 @@ int panel_columns(ngp_handle *h, int64_t col0, const TIn *M, int64_t ncol, int64
         double *d_mu = h->d_mean + col0 + c0;
         hipLaunchKernelGGL(k_cols_mean<TIn>, dim3((unsigned)((nc + 63) / 64)), dim3(64), 0, h->stream, (const TIn *)d_g, (long long)N, (long long)ld,
                            (long long)nc, centre, d_mu, d_bad);
+        if constexpr (sizeof(TIn) == 1) {
+            if (h->storage == 1)  // the codes stay codes (the means are what the analytic centring uses)
+                hipLaunchKernelGGL(k_cols_fill8, dim3((unsigned)((h->L / 16 + 255) / 256), (unsigned)nc), dim3(256), 0, h->stream, (uint8_t *)h->d_tiles,
+                                   (const uint8_t *)d_g, (long long)N, (long long)ld, (long long)(col0 + c0), (int)h->R, (int)h->S);
+        }
+        if (h->storage == 0)
         hipLaunchKernelGGL(k_cols_fill<TIn>, dim3((unsigned)((h->L / 4 + 255) / 256), (unsigned)nc), dim3(256), 0, h->stream, h->d_tiles, (const TIn *)d_g,
                            (long long)N, (long long)ld, (long long)(col0 + c0), (int)h->R, (int)h->S, (const double *)d_mu);
         e = hipStreamSynchronize(h->stream);  // the staging buffer is reused by the next chunk
@@ -1101,6 +1108,11 @@ int32_t ngp_panel_columns_f64(ngp_handle *h, int64_t col0, const double *M, int6
 int32_t ngp_panel_columns_f32(ngp_handle *h, int64_t col0, const float *M, int64_t ncol, int64_t ld, int32_t centre) {
     NGP_TRY
     return panel_columns<float>(h, col0, M, ncol, ld, centre);
+    NGP_CATCH(h)
+}
+int32_t ngp_panel_columns_u8(ngp_handle *h, int64_t col0, const uint8_t *G, int64_t ncol, int64_t ld, int32_t centre) {
+    NGP_TRY
+    return panel_columns<uint8_t>(h, col0, G, ncol, ld, centre);
     NGP_CATCH(h)
 }
 int32_t ngp_end_panel(ngp_handle *h) {

@@ -1056,6 +1056,31 @@ __global__ __launch_bounds__(256) void k_cols_fill(float *__restrict__ tiles, co
     *(float4 *)tp = make_float4(v[0], v[1], v[2], v[3]);
 }
 
+// compact storage, a column range of genotype codes: thread = (column c of the chunk, unit U of 16 rows of the padded panel) -> the
+// unit's 16 bytes of that column (tile8_off: units of 16 rows, a column's 16 bytes contiguous); rows beyond N are zero
+__global__ __launch_bounds__(256) void k_cols_fill8(uint8_t *__restrict__ tiles8, const uint8_t *__restrict__ g, long long N, long long ld,
+                                                    long long col0, int R, int S) {
+    const long long U = (long long)blockIdx.x * 256 + threadIdx.x;
+    const long long i0 = 16 * U;
+    if (i0 >= (long long)R * S) return;
+    const long long c = blockIdx.y, j = col0 + c;
+    const int s = (int)(i0 / R), ii = (int)(i0 - (long long)s * R), jj = (int)(j & (NGP_BLK - 1));
+    const uint8_t *col = g + (size_t)c * ld;
+    unsigned w[4];
+#pragma unroll
+    for (int q = 0; q < 4; q++) {
+        unsigned v = 0;
+#pragma unroll
+        for (int r = 0; r < 4; r++) {
+            const long long i = i0 + 4 * q + r;
+            v |= (unsigned)((i < N) ? col[i] : (uint8_t)0) << (8 * r);
+        }
+        w[q] = v;
+    }
+    uint8_t *tp = tiles8 + ((size_t)(j >> 6) * S + s) * ((size_t)R * NGP_BLK) + tile8_off(ii, jj);
+    *(uint4 *)tp = make_uint4(w[0], w[1], w[2], w[3]);
+}
+
 // compact genotype input (one byte per genotype, column-major staging chunk of ncols columns, leading dimension ld):
 // integer column sums -> mean = sum / N exactly as the host path computes it, then centred fp32 quad-major tiles
 __global__ __launch_bounds__(256) void k_u8_colmean(const uint8_t *__restrict__ G, long long N, long long ld, int centre,

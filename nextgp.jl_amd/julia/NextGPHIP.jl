@@ -52,6 +52,9 @@ panel_columns!(h::Handle, col0::Integer, data::Matrix{Float64}; centre::Bool=fal
 panel_columns!(h::Handle, col0::Integer, data::Matrix{Float32}; centre::Bool=false) =
     check(h, ccall((:ngp_panel_columns_f32, LIB), Int32, (Ptr{Cvoid}, Int64, Ptr{Float32}, Int64, Int64, Int32),
                    h.ptr, col0, data, size(data, 2), stride(data, 2), centre))
+panel_columns!(h::Handle, col0::Integer, data::Matrix{UInt8}; centre::Bool=true) =      # genotype codes (the compact storage takes only these)
+    check(h, ccall((:ngp_panel_columns_u8, LIB), Int32, (Ptr{Cvoid}, Int64, Ptr{UInt8}, Int64, Int64, Int32),
+                   h.ptr, col0, data, size(data, 2), stride(data, 2), centre))
 end_panel!(h::Handle) = check(h, ccall((:ngp_end_panel, LIB), Int32, (Ptr{Cvoid},), h.ptr))
 
 # one byte per genotype (raw allele counts, e.g. read from a binary file instead of src/prepMatVec.jl:116): centred on the device

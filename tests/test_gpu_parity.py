@@ -125,6 +125,25 @@ def test_panel_in_column_ranges_equals_whole_panel(ngp, O):
     assert np.array_equal(f.xbeta(e), F[:, 70].astype(np.float64)) and not f.means().any()
     e = np.zeros(P); e[10] = 1.0
     assert not f.xbeta(e).any() and f.mpm()[10] == 0.0
+    # genotype codes in column ranges, fp32 tiles and compact storage: the panel of ngp_set_panel_u8 bit for bit
+    C8 = rng.integers(0, 3, size=(N, P)).astype(np.uint8)
+    yy = rng.normal(size=N)
+    for storage in (None, "u8"):
+        w8 = ngp.Sampler(device=0, seed=1, chain=0, storage=storage); w8.set_panel(C8, centre=True)
+        p8 = ngp.Sampler(device=0, seed=1, chain=0, storage=storage); p8.begin_panel(N, P)
+        for a, b in ((200, 300), (0, 61), (61, 200)):
+            p8.panel_columns(a, C8[:, a:b], centre=True)
+        p8.end_panel()
+        assert np.array_equal(w8.means(), p8.means()) and np.array_equal(w8.mpm(), p8.mpm()) and w8.layout() == p8.layout()
+        for t in range((P + 63) // 64):
+            assert np.array_equal(w8.gram(t), p8.gram(t))
+        for q in (w8, p8):
+            q.add_marker_set(0, P, 0, 4.0, 0.01, [(0, P)], [0.02]); q.set_y(yy); q.set_residual_prior(4.0, 0.5); q.run(6)
+        sa, sb = w8.get_state(), p8.get_state()
+        assert np.array_equal(sa["beta"], sb["beta"]) and np.array_equal(sa["ycorr"], sb["ycorr"]) and sa["varE"] == sb["varE"]
+    cs = ngp.Sampler(device=0, seed=1, chain=0, storage="u8"); cs.begin_panel(N, P)
+    with pytest.raises(ngp.NextGPHipError, match="genotype codes"):
+        cs.panel_columns(0, G[:, :10])
     bad = G.copy(); bad[5, 7] = np.inf
     b = ngp.Sampler(device=0, seed=1, chain=0)
     with pytest.raises(ngp.NextGPHipError, match="non-finite"):
