@@ -86,7 +86,8 @@ struct ngp_handle {
     hipStream_t stream = nullptr;
     int64_t N = 0, P = 0, R = 0, S = 0, NBLK = 0, Ppad = 0, L = 0;
     size_t lds_step = 0, lds_sweep = 0, lds_rows = 0;
-    size_t lds_sweep_lean = 0;  // the same without the sampler's staging area of BayesR / Tuple coefficients: what k_sweep<false> is launched with
+    size_t lds_sweep_lean = 0;  // the same without the sampler's staging area of Tuple coefficients: what k_sweep<false> is launched with
+    size_t lds_sweep_r = 0;     // with the BayesR staging area as well: what k_sweep_r is launched with (0: does not fit -> k_sweep_tup)
     int mode = 1;      // 1: persistent sweep kernel, 0: one streaming + one recursion launch per block
     int lag = 8;       // look-ahead D of the persistent sweep (blocks); shards taller than 128 rows are capped at 5
     bool lag_auto = true;  // lag not chosen by the caller (ngp_configure): tall shards then take the measured best
@@ -485,6 +486,13 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P, ngp_handle *owner = nullptr
             h->lds_sweep_lean = std::max(streamer_need, lean_sampler);
             if (streamer_need + 8192 <= lds_max) h->lds_sweep_lean = std::max(h->lds_sweep_lean, streamer_need + 8192);
         }
+        {   // k_sweep_r: the sampler's BayesR staging area on top
+            const size_t streamer_need = (h->streamer >= 2) ? h->lds_rows : 2 * TB + misc;
+            size_t r = std::max(streamer_need, lds_sampler + (size_t)NGP_SAMPLER_R_LDS);
+            if (streamer_need + 8192 <= lds_max) r = std::max(r, streamer_need + 8192);
+            h->lds_sweep_r = (r <= lds_max) ? r : 0;
+            if (h->lds_sweep_r) HCHK(sweep_r_set_max_lds((int)h->lds_sweep_r));
+        }
         if (h->lds_sweep > lds_max) return fail(h, NGP_ERR_ARG, "panel too tall for the persistent sweep (LDS)");
         HCHK(sweep_set_max_lds_0((int)h->lds_sweep));
         HCHK(sweep_set_max_lds_1((int)h->lds_sweep));
@@ -718,6 +726,8 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
             sweep_tall_launch((unsigned)h->last_grid, h->lds_sweep, h->stream, A);
         else if (h->d_dbg || h->dbg_mode)  // diagnostic instantiation: stamps and timing modes exist only there
             sweep_launch_1((unsigned)h->last_grid, h->lds_sweep, h->stream, A);
+        else if (h->nclass_total > 0 && h->lds_sweep_r && !(h->knob & 65536))  // a BayesR set: the flavour that fetches its coefficients ahead
+            sweep_r_launch((unsigned)h->last_grid, h->lds_sweep_r, h->stream, A);
         // Models with a Tuple or a BayesR set run the kernel that carries those chains (k_sweep<false>, the kernel of BayesPR / BayesB /
         // BayesC, does not: ngp_sweep.h, role_sampler).  The two are otherwise the same program, and which one is faster for a model
         // both can run is a matter of code layout -- measured, interleaved with the library of mid-round (tools/ab3.sh, four to five

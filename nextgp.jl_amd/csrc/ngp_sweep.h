@@ -1479,7 +1479,10 @@ __device__ __attribute__((always_inline)) inline void publish_block(const SweepA
 // k_sweep_tup, the full kernel): the four unrolled chains of the tuple path in the critical wave's loop cost the Symbol methods
 // 3-7 % at 10k x 100k although none of it executes there (code layout / register allocation of a 240-VGPR kernel; measured against
 // the previous library on the same box).
-template <bool DBG, bool NGBIG = false, bool TUP = true, bool RCLS = true>
+// RCLS: 0 = no BayesR chain, 1 = BayesR with the lane coefficients fetched inside the block, 2 = fetched one block ahead through LDS by
+// wave 1 like the Tuple ones (10.4 -> 8.9 us per block; a flavour of its own, k_sweep_r: inside the full kernel this code cost the
+// 50k x 600k sweep of the other methods 2 %)
+template <bool DBG, bool NGBIG = false, bool TUP = true, int RCLS = 1>
 __device__ __attribute__((always_inline)) inline void role_sampler(const SweepArgs &A, char *smem) {
     NGP_DBG_LOCALS
     const int D = A.D, tid = threadIdx.x, wv = tid >> 6, j = tid & 63;
@@ -1523,6 +1526,42 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
         dst[2 * NGP_KMAX * NGP_BLK] = TL.ww;
         if (j == 0) { meta[0] = k; meta[1] = nvalid; }
     };
+    // BayesR sets (RCLS == 2): the lane's method and class count, its class coefficients of the first four classes and M.rhs
+    // (17 x 64), the classes 5..8 of the lanes that have them (16 x 64), two parities -- the same one-block-ahead fetch by wave 1
+    double *rl = (double *)(tmeta + 16);               // 2 x 17 x 64
+    int *rlm = (int *)(rl + 2 * 17 * NGP_BLK);         // 2 x (64 methods | 64 class counts)
+    int *rmeta = rlm + 2 * 128;                        // 2 x 4: the block holds a BayesR locus
+    double *rlx = (double *)(rmeta + 16);              // 2 x (4 arrays x 4 classes x 64)
+    auto rcls_prefetch = [&](const int ub) __attribute__((always_inline)) {  // wave 1; ub: local block
+        if (RCLS != 2 || !A.rcls || ub >= nb) return;
+        const long long kcol = (long long)(A.t0 + ub) * NGP_BLK + j;
+        const int si = A.setof[kcol];
+        const int meth = (si >= 0) ? smeth[si] : -1;
+        const int Kc = (si >= 0) ? sK[si] : 2;
+        const unsigned long long mask = __ballot(meth == 3);
+        if (j == 0) rmeta[(ub & 1) * 4] = (mask != 0ull) ? 1 : 0;
+        if (mask == 0ull) return;
+        RLane RL = empty_rlane();
+        if (meth == 3) RL = load_rlane(A.rcls, A.Ppad, kcol, Kc, A.rhs0);
+        double *dst = rl + (size_t)(ub & 1) * (17 * NGP_BLK) + j;
+#pragma unroll
+        for (int v = 0; v < NGP_RREG; v++) {
+            dst[v * NGP_BLK] = RL.q[v]; dst[(4 + v) * NGP_BLK] = RL.a[v]; dst[(8 + v) * NGP_BLK] = RL.t[v]; dst[(12 + v) * NGP_BLK] = RL.u[v];
+        }
+        dst[16 * NGP_BLK] = RL.rhs0;
+        rlm[(ub & 1) * 128 + j] = meth;
+        rlm[(ub & 1) * 128 + 64 + j] = Kc;
+        if (__ballot(meth == 3 && Kc > NGP_RREG) != 0ull) {  // classes 5..8: array arr of class v at rlx[(arr * 4 + v - 4) * 64 + lane]
+            double *dx = rlx + (size_t)(ub & 1) * (16 * NGP_BLK) + j;
+#pragma unroll
+            for (int arr = 0; arr < 4; arr++)
+#pragma unroll
+                for (int v = NGP_RREG; v < NGP_RMAX; v++) {
+                    const bool on = (meth == 3) && v < Kc;
+                    dx[(arr * 4 + v - NGP_RREG) * NGP_BLK] = on ? A.rcls[((size_t)arr * NGP_RMAX + v) * (size_t)A.Ppad + (size_t)kcol] : 0.0;
+                }
+        }
+    };
     if (tid < 16) {
         smeth[tid] = A.sets[tid].method;
         ssdf[tid] = A.sets[tid].sdf;
@@ -1549,7 +1588,7 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
         if (fetch_group_sums<DBG, NGBIG>(A, 0, j, &tot)) r0[j] = tot;
         else if (j == 0) *sabort = 1;
     }
-    if (wv == 1) tuple_prefetch(0);
+    if (wv == 1) { tuple_prefetch(0); rcls_prefetch(0); }
     __syncthreads();
     if (*sabort) return;
 #define NGP_END_OF_BLOCK()                                                                       \
@@ -1562,6 +1601,10 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
     if (wv == 0) {
         // ---------------- critical wave: LDS + ALU only ----------------
         CoefRegs cur = load_coef(A, (long long)A.t0 * NGP_BLK + j), nxt = cur;
+        double iVarE_sweep = 0.0;  // (RCLS == 2: 1 / varE of this iteration, constant during the sweep)
+        if constexpr (RCLS == 2) {
+            if (A.rcls) iVarE_sweep = A.scal->iVarE;
+        }
         for (int u = 0; u < nb; ++u) {
             const int t = A.t0 + u, buf = u & 1, slot = u % NGP_RING, rs = u & 3;
             if (u + 1 < nb) nxt = load_coef(A, (long long)(t + 1) * NGP_BLK + j);
@@ -1599,10 +1642,15 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
             double dsave;
             int isave = 1;
             // BayesR: the lane's set and method (one byte per lane, read only when the model has a BayesR set at all)
-            int meth0 = -1, si0 = -1;
-            if (RCLS && A.rcls) {
-                si0 = A.setof[(long long)t * NGP_BLK + j];
-                meth0 = (si0 >= 0) ? smeth[si0] : -1;
+            int meth0 = -1, si0 = -1, rblk = 0;
+            if constexpr (RCLS == 1) {
+                if (A.rcls) {
+                    si0 = A.setof[(long long)t * NGP_BLK + j];
+                    meth0 = (si0 >= 0) ? smeth[si0] : -1;
+                }
+            } else if constexpr (RCLS == 2) {
+                if (A.rcls) rblk = __builtin_amdgcn_readfirstlane(rmeta[buf * 4]);
+                if (rblk) meth0 = rlm[buf * 128 + j];
             }
             int tk = 0;
             if constexpr (TUP) {
@@ -1619,12 +1667,27 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
                 TL.ww = tsrc[2 * NGP_KMAX * NGP_BLK];
                 dsave = tuple_chain_nv(tk, nvalid, j, tot, bo, TL, [&](int sl, int cc2) { return Gd[(u % 3) * 4096 + sl * NGP_BLK + cc2]; });
                 isave = 1;
-            } else if (RCLS && A.rcls && __ballot(meth0 == 3) != 0ull) {
+            } else if (RCLS != 0 && A.rcls && (RCLS == 2 ? rblk != 0 : __ballot(meth0 == 3) != 0ull)) {
                 // r-form chain (eval_rform, ngp_kernels.h): candidates of all lanes from the current r, the first non-zero one at
                 // or behind the cursor takes its step.  With most loci in the zero class that is a few steps per block.
                 RLane RL = empty_rlane();
-                if (meth0 == 3) RL = load_rlane(A.rcls, A.Ppad, (long long)t * NGP_BLK + j, sK[si0], A.rhs0);
-                const double iVarE = A.scal->iVarE;
+                double iVarE;
+                if constexpr (RCLS == 2) {  // the coefficients wait in LDS (wave 1, one block ahead), the classes 5..8 too
+                    const double *src = rl + (size_t)buf * (17 * NGP_BLK) + j;
+#pragma unroll
+                    for (int v = 0; v < NGP_RREG; v++) {
+                        RL.q[v] = src[v * NGP_BLK]; RL.a[v] = src[(4 + v) * NGP_BLK]; RL.t[v] = src[(8 + v) * NGP_BLK]; RL.u[v] = src[(12 + v) * NGP_BLK];
+                    }
+                    RL.rhs0 = src[16 * NGP_BLK];
+                    RL.K = rlm[buf * 128 + 64 + j];
+                    RL.ext = rlx + (size_t)buf * (16 * NGP_BLK) + j - NGP_RREG * NGP_BLK;  // class stride 64, array stride 4 x 64
+                    RL.Ppad = NGP_BLK;
+                    RL.astride = 4 * NGP_BLK;
+                    iVarE = iVarE_sweep;
+                } else {
+                    if (meth0 == 3) RL = load_rlane(A.rcls, A.Ppad, (long long)t * NGP_BLK + j, sK[si0], A.rhs0);
+                    iVarE = A.scal->iVarE;
+                }
                 double rcur = r, dfin = 0.0;
                 int cfin = 1, kstart = 0;
                 for (int guard = 0; guard < NGP_BLK + 1; ++guard) {
@@ -1713,6 +1776,7 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
     } else if (wv == 1) {
         for (int u = 0; u < nb; ++u) {
             tuple_prefetch(u + 1);
+            rcls_prefetch(u + 1);
             if (u >= 1) publish_block<DBG>(A, u - 1, j, hist, outb, outi, smeth, ssdf);
             NGP_END_OF_BLOCK();
         }
@@ -1918,11 +1982,20 @@ __device__ __attribute__((always_inline)) inline bool sweep_census(const SweepAr
 template <bool DBG>
 __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sweep(SweepArgs A) {
     constexpr bool TUP = DBG;
+    constexpr int RCLSV = DBG ? 1 : 0;
 #include "ngp_sweep_body.inc"
 }
 #if defined(NGP_INST_DBG) && NGP_INST_DBG == 2
 __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sweep_tup(SweepArgs A) {
     constexpr bool DBG = false, TUP = true;
+    constexpr int RCLSV = 1;
+#include "ngp_sweep_body.inc"
+}
+#endif
+#if defined(NGP_INST_DBG) && NGP_INST_DBG == 3  // models with a BayesR set: its coefficients fetched one block ahead (fourth translation unit)
+__global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sweep_r(SweepArgs A) {
+    constexpr bool DBG = false, TUP = true;
+    constexpr int RCLSV = 2;
 #include "ngp_sweep_body.inc"
 }
 #endif
@@ -2510,7 +2583,7 @@ __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) 
 #endif
     if ((b % NGP_MULTI_STRIDE) == 0 && (b / NGP_MULTI_STRIDE) < K) {
         // (without the Tuple chain, like k_sweep<false>: chains with a Tuple set are not fused -- fusable(), ngp_api.hip)
-        role_sampler<false, false, false, true>(multi_chain_args(__builtin_amdgcn_readfirstlane(b / NGP_MULTI_STRIDE)), smem);
+        role_sampler<false, false, false, 1>(multi_chain_args(__builtin_amdgcn_readfirstlane(b / NGP_MULTI_STRIDE)), smem);
         return;
     }
     const int idx = b - min(K, (b + NGP_MULTI_STRIDE - 1) / NGP_MULTI_STRIDE);  // rank among the blocks that are not samplers

@@ -17,6 +17,9 @@
 #endif
 #define NGP_QS 1040
 #define NGP_SAMPLER_TUPLE_LDS (2 * 9 * 64 * 8 + 64)  // sampler workgroup: lane coefficients of a Tuple block, two parities, + (k, used lanes)
+// ... and behind them, in k_sweep_r only: lane coefficients of a BayesR block (17 x 64 doubles, two parities), (method, classes) per lane,
+// flags, classes 5..8 (16 x 64 doubles, two parities)
+#define NGP_SAMPLER_R_LDS (2 * 17 * 64 * 8 + 2 * 128 * 4 + 64 + 2 * 16 * 64 * 8)
 #define NGP_ABORT_CENSUS 9u        // abort code: the grid was not co-resident within NGP_CENSUS_TICKS (no state was modified)
 #define NGP_CENSUS_TICKS 2000000ull  // 20 ms of the 100 MHz wall clock
 #define NGP_DBG_STREAM (1u << 20)  // offset of streamer 0's stamps in the debug buffer
@@ -134,6 +137,9 @@ hipError_t sweep_set_max_lds_0(int bytes);
 hipError_t sweep_set_max_lds_1(int bytes);
 hipError_t sweep_occupancy_0(int *wg_per_cu, size_t lds_bytes);
 void sweep_launch_0(unsigned grid, size_t lds_bytes, hipStream_t stream, const SweepArgs &A);
+// k_sweep_r (models with a BayesR set; fourth translation unit, -DNGP_INST_DBG=3)
+hipError_t sweep_r_set_max_lds(int bytes);
+void sweep_r_launch(unsigned grid, size_t lds_bytes, hipStream_t stream, const SweepArgs &A);
 // k_sweep_tup (models with a Tuple set; third translation unit, -DNGP_INST_DBG=2)
 hipError_t sweep_tup_set_max_lds(int bytes);
 void sweep_tup_launch(unsigned grid, size_t lds_bytes, hipStream_t stream, const SweepArgs &A);

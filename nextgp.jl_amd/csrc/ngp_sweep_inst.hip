@@ -1,17 +1,25 @@
 // ngp_sweep_inst.hip -- one instantiation of the persistent sweep kernel (ngp_sweep.h) and its host-side launch stubs.
-// Compiled three times: -DNGP_INST_DBG=0 (production kernel, K chains per pass), =1 (diagnostic kernel: time stamps, timing modes;
-// tall fp32 panels), =2 (production kernel of models with a Tuple set).
+// Compiled four times: -DNGP_INST_DBG=0 (lean production kernel, K chains per pass), =1 (diagnostic kernel: time stamps, timing modes;
+// tall fp32 panels), =2 (full production kernel: Tuple sets, tall shards), =3 (models with a BayesR set).
 #include <hip/hip_runtime.h>
 
 #include "ngp_sweep.h"
 
 #ifndef NGP_INST_DBG
-#error "compile with -DNGP_INST_DBG=0, 1 or 2"
+#error "compile with -DNGP_INST_DBG=0, 1, 2 or 3"
 #endif
 
 namespace ngp {
 
-#if NGP_INST_DBG == 2
+#if NGP_INST_DBG == 3
+// the production kernel of models with a BayesR set (its coefficients fetched one block ahead through LDS): a translation unit of its own
+hipError_t sweep_r_set_max_lds(int bytes) {
+    return hipFuncSetAttribute((const void *)k_sweep_r, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+void sweep_r_launch(unsigned grid, size_t lds_bytes, hipStream_t stream, const SweepArgs &A) {
+    hipLaunchKernelGGL(k_sweep_r, dim3(grid), dim3(NGP_WG), lds_bytes, stream, A);
+}
+#elif NGP_INST_DBG == 2
 // the production kernel of models with a Tuple (correlated BayesPR) set: a translation unit of its own (the units compile in parallel)
 hipError_t sweep_tup_set_max_lds(int bytes) {
     return hipFuncSetAttribute((const void *)k_sweep_tup, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
