@@ -24,7 +24,7 @@
 extern "C" {
 #endif
 
-#define NGP_ABI_VERSION 3
+#define NGP_ABI_VERSION 4
 
 #define NGP_OK 0
 #define NGP_ERR_ARG (-1)     /* bad argument (null, size mismatch, non-finite value) */
@@ -62,6 +62,12 @@ int32_t ngp_get_config(ngp_handle *h, int32_t *mode, int32_t *lag);
  * 4 on its shards taller than 128 rows; 2 with the row-owning streamer from 64-row shards on); to be chosen before the panel is set.  ngp_get_near_lags reports the value in force. */
 int32_t ngp_set_near_lags(ngp_handle *h, int32_t near);
 int32_t ngp_get_near_lags(ngp_handle *h, int32_t *near);
+/* Form of the block chain of BayesPR blocks (every lane BayesPR or unowned; replaces the per-SNP loop of src/functions.jl:124-136).
+ * 1 (default): dlt = T e0 with T = inv(I + diag(c) strictLower(G)) of the block formed explicitly before every sweep (k_tinv) -- the
+ * forward substitution the 64 serial steps carry out, as one 64 x 64 product; 0: the 64 serial steps.  The same Markov chain in real
+ * arithmetic; the floating-point order differs, so the blocked oracle is told (ora_set_tform).  Any time before ngp_run. */
+int32_t ngp_set_chain_form(ngp_handle *h, int32_t form);
+int32_t ngp_get_chain_form(ngp_handle *h, int32_t *form);
 /* Diagnostic only: enable != 0 makes the persistent kernel write 100 MHz time stamps (sampler: 4 words per
  * block at [4u..4u+3]; streamer 0: 2 words per block from word 2^20); out/n copies the first n words back. */
 int32_t ngp_debug_stamps(ngp_handle *h, int32_t enable, uint64_t *out, int64_t n);

@@ -114,6 +114,12 @@ struct ngp_handle {
     float *d_tiles = nullptr;
     double *d_gramx = nullptr, *d_mpm = nullptr, *d_lhs0 = nullptr, *d_rhs0 = nullptr, *d_beta = nullptr;
     double *d_c = nullptr, *d_w = nullptr, *d_q = nullptr, *d_T = nullptr, *d_chi = nullptr;
+    // inverse form of the linear blocks' chain (k_tinv): T per block, written before every sweep
+    double *d_tinv = nullptr;
+    int64_t tinv_blocks = 0;  // blocks d_tinv was allocated for
+    LinRanges lin_all = {{0, 0, 0, 0}, {0, 0, 0, 0}};  // runs of linear blocks of the whole model (recomputed with the tables)
+    LinRanges lin_now = {{0, 0, 0, 0}, {0, 0, 0, 0}};  // ... of the sweep being launched (launch_tinv; a fine-seam call has its own)
+    int chain_form = 1;       // ngp_set_chain_form: 1 = linear blocks as dlt = T e0 (default), 0 = every block by the 64-step chain
     int8_t *d_setof = nullptr;
     int32_t *d_loc = nullptr, *d_vbidx = nullptr;
     uint8_t *d_delta = nullptr;
@@ -648,9 +654,45 @@ int set_panel_host(ngp_handle *h, const TIn *M, int64_t N, int64_t P, int64_t ld
     return end_panel(h);
 }
 
+// does any block of this model take the inverse form?  (a BayesPR set must exist: blocks without an owner are all zeros either way)
+bool wants_tinv(const ngp_handle *h) {
+    if (h->chain_form != 1) return false;
+    for (const HSet &st : h->sets)
+        if (st.method == NGP_METHOD_BAYESPR) return true;
+    return false;
+}
+
+// Runs of linear blocks (ngp_common.h, LinRanges): blocks no lane of which belongs to a set that is not BayesPR -- in a fine-seam call
+// (active_set >= 0) only the sampled set counts, every other lane is inactive.  A Tuple set owns its blocks to the end of the last one.
+// The first NGP_TRANGES runs in block order; none when the inverse form is off.
+LinRanges linear_ranges(const ngp_handle *h, int active_set) {
+    LinRanges L = {{0, 0, 0, 0}, {0, 0, 0, 0}};
+    if (!wants_tinv(h)) return L;
+    std::vector<std::pair<int64_t, int64_t>> nl;  // block intervals [a, b) that hold a lane of a non-BayesPR set
+    for (size_t si = 0; si < h->sets.size(); si++) {
+        const HSet &st = h->sets[si];
+        if (st.method == NGP_METHOD_BAYESPR || (active_set >= 0 && (int)si != active_set)) continue;
+        nl.emplace_back(st.col0 / NGP_BLK, (st.col0 + st.ncol - 1) / NGP_BLK + 1);  // (a Tuple set: ncol = its span)
+    }
+    std::sort(nl.begin(), nl.end());
+    int n = 0;
+    int64_t at = 0;
+    for (size_t i = 0; i <= nl.size() && n < NGP_TRANGES; i++) {
+        const int64_t a = i < nl.size() ? nl[i].first : h->NBLK, b = i < nl.size() ? nl[i].second : h->NBLK;
+        if (a > at) { L.lo[n] = (int)at; L.hi[n] = (int)std::min<int64_t>(a, h->NBLK); n++; }
+        at = std::max(at, b);
+    }
+    return L;
+}
+
 int sync_tables(ngp_handle *h) {
-    if (!h->tables_dirty) return NGP_OK;
     int rc;
+    if (wants_tinv(h) && h->tinv_blocks != h->NBLK) {
+        if ((rc = dalloc(h, &h->d_tinv, (size_t)h->NBLK * NGP_BLK * NGP_BLK))) return rc;
+        h->tinv_blocks = h->NBLK;
+    }
+    h->lin_all = linear_ranges(h, -1);
+    if (!h->tables_dirty) return NGP_OK;
     const size_t pp = (size_t)h->Ppad;
     HCHK(hipMemcpy(h->d_setof, h->h_setof.data(), pp, hipMemcpyHostToDevice));
     HCHK(hipMemcpy(h->d_loc, h->h_loc.data(), pp * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -692,6 +734,9 @@ bool is_kept(const ngp_handle *h, int64_t it) {  // src/samplers.jl:26
 void fill_sweep_args(ngp_handle *h, int64_t tb0, int64_t tb1, SweepArgs &A) {
     const int R = (int)h->R, S = (int)h->S;
     A.tiles = h->d_tiles; A.ycorr = h->d_ycorr; A.gramx = h->d_gramx;
+    const bool tf = wants_tinv(h) && h->tinv_blocks == h->NBLK;
+    A.tinv = tf ? h->d_tinv : nullptr;
+    A.lin = tf ? h->lin_now : LinRanges{{0, 0, 0, 0}, {0, 0, 0, 0}};
     A.V = h->V; A.D = h->D; A.R = R; A.S = S; A.NG = h->NG; A.near = h->near; A.fine_ok = 0; A.t0 = (int)tb0; A.t1 = (int)tb1;
     A.beta = h->d_beta; A.delta = h->d_delta; A.c = h->d_c; A.w = h->d_w; A.q = h->d_q; A.mpm = h->d_mpm; A.chi = h->d_chi;
     A.setof = h->d_setof; A.vbidx = h->d_vbidx; A.sets = h->d_sets; A.varBeta = h->d_varBeta;
@@ -754,7 +799,8 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
         if (do_gemv)
             hipLaunchKernelGGL(k_recur, dim3(1), dim3(256), 0, h->stream, h->d_part, h->d_gramx, h->D, S, (int)t, h->d_beta, h->d_delta,
                                h->d_c, h->d_w, h->d_q, h->d_mpm, h->d_chi, h->d_setof, h->d_vbidx, h->d_sets, h->d_varBeta, h->d_dlt, h->d_rcls,
-                               (long long)h->Ppad, h->d_rhs0, h->d_scal, h->d_tup, h->d_tupc, h->d_tupg);
+                               (long long)h->Ppad, h->d_rhs0, h->d_scal, h->d_tup, h->d_tupc, h->d_tupg,
+                               (const double *)((wants_tinv(h) && h->tinv_blocks == h->NBLK) ? h->d_tinv : nullptr), h->lin_now);
     }
     h->sweep_launches += 2 * (tb1 - tb0) + 1;
 }
@@ -835,6 +881,16 @@ void launch_variance(ngp_handle *h, int active_set, uint64_t it) {
 // with nothing changed and is launched again, k_prep first (it redraws the same keyed numbers and clears the hand-off counters)
 int sample_enqueue(ngp_handle *h);  // (below)
 
+// T = inv(L) of every linear block from this iteration's coefficients (k_tinv; behind k_prep in the stream, in front of the sweep)
+void launch_tinv(ngp_handle *h, int active_set) {
+    h->lin_now = LinRanges{{0, 0, 0, 0}, {0, 0, 0, 0}};
+    if (!wants_tinv(h) || h->tinv_blocks != h->NBLK) return;
+    h->lin_now = active_set < 0 ? h->lin_all : linear_ranges(h, active_set);
+    if (h->lin_now.hi[0] <= h->lin_now.lo[0]) return;  // no linear block
+    hipLaunchKernelGGL(k_tinv, dim3((unsigned)h->NBLK), dim3(64), 0, h->stream, (const double *)h->d_gramx, h->D, (const double *)h->d_c,
+                       h->lin_now, h->d_tinv, (const unsigned *)h->d_abort);
+}
+
 void iteration_pre(ngp_handle *h, int64_t trace_idx, bool resume_mid) {  // everything in front of the sweep
     const uint64_t it = (uint64_t)(h->iter + 1);
     if (!resume_mid) {
@@ -849,6 +905,7 @@ void iteration_pre(ngp_handle *h, int64_t trace_idx, bool resume_mid) {  // ever
                        h->d_vbidx, h->d_sets, h->d_scal, h->d_varBeta, h->d_mpm, h->d_lhs0, h->d_rhs0, h->d_beta, h->d_c, h->d_w,
                        h->d_q, h->d_T, h->d_chi, -1, h->seed, (uint64_t)h->chain, it, (long long)h->h_regs.size(), h->d_regs, h->d_regchi, h->d_rcls,
                        h->d_ccnt, (long long)(h->mode == 1 ? h->ccnt_words : 0), h->d_abort, h->d_tup, h->d_tupc, h->d_tupg);
+    launch_tinv(h, -1);
 }
 
 int iteration_post(ngp_handle *h, int64_t trace_idx) {  // variance / pi draws, traces and posterior sums; advances h->iter
@@ -1078,6 +1135,7 @@ int32_t ngp_destroy(ngp_handle *h) {
     release_panel(h);
      dfree(h->d_cpart); dfree(h->d_cgsum); dfree(h->d_cdlt); dfree(h->d_cdltg); dfree(h->d_rcls); dfree(h->d_seg_set); dfree(h->d_ccnt); dfree(h->d_abort); dfree(h->d_dbg); dfree(h->d_mpm); dfree(h->d_lhs0); dfree(h->d_rhs0); dfree(h->d_beta);
     dfree(h->d_c); dfree(h->d_w); dfree(h->d_q); dfree(h->d_T); dfree(h->d_chi); dfree(h->d_setof); dfree(h->d_loc);
+    dfree(h->d_tinv);
     dfree(h->d_vbidx); dfree(h->d_delta); dfree(h->d_sum_beta); dfree(h->d_sum_beta2); dfree(h->d_sum_delta);
     dfree(h->d_ycorr); dfree(h->d_part); dfree(h->d_dlt); dfree(h->d_sets); dfree(h->d_scal); dfree(h->d_varBeta);
     dfree(h->d_sum_varBeta); dfree(h->d_regs); dfree(h->d_seg_k0); dfree(h->d_seg_len); dfree(h->d_segpart); dfree(h->d_regchi);
@@ -1875,6 +1933,7 @@ int32_t ngp_sweep_set(ngp_handle *h, int32_t set_id, double varE, double *ycorr,
                            h->d_vbidx, h->d_sets, h->d_scal, h->d_varBeta, h->d_mpm, h->d_lhs0, h->d_rhs0, h->d_beta, h->d_c, h->d_w,
                            h->d_q, h->d_T, h->d_chi, (int)set_id, h->seed, (uint64_t)h->chain, it, (long long)h->h_regs.size(), h->d_regs, h->d_regchi, h->d_rcls,
                            h->d_ccnt, (long long)(h->mode == 1 ? h->ccnt_words : 0), h->d_abort, h->d_tup, h->d_tupc, h->d_tupg);
+        launch_tinv(h, (int)set_id);
         launch_sweep(h, tb0, tb1, nullptr);
         launch_variance(h, (int)set_id, it);
         HCHK(hipStreamSynchronize(h->stream));
@@ -1993,6 +2052,25 @@ int32_t ngp_get_near_lags(ngp_handle *h, int32_t *near) {
     int rc;
     if ((rc = enter(h))) return rc;
     if (near) *near = h->near;
+    return NGP_OK;
+    NGP_CATCH(h)
+}
+
+int32_t ngp_set_chain_form(ngp_handle *h, int32_t form) {
+    NGP_TRY
+    int rc;
+    if ((rc = enter(h))) return rc;
+    REQUIRE(form == 0 || form == 1, NGP_ERR_ARG, "chain form: 0 (64 steps per block) or 1 (linear blocks by the inverse form)");
+    h->chain_form = form;
+    return NGP_OK;
+    NGP_CATCH(h)
+}
+
+int32_t ngp_get_chain_form(ngp_handle *h, int32_t *form) {
+    NGP_TRY
+    int rc;
+    if ((rc = enter(h))) return rc;
+    if (form) *form = h->chain_form;
     return NGP_OK;
     NGP_CATCH(h)
 }

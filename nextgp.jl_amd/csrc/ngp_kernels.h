@@ -329,6 +329,86 @@ __global__ __launch_bounds__(256) void k_prep(long long Ppad, const int8_t *__re
 }
 
 // ------------------------------------------------------------------------------------------
+// Inverse form of the LINEAR blocks.  In a block whose lanes are all BayesPR (always included,
+// src/functions.jl:124-136) or unowned, the 64 serial steps  dlt_k = e_k, e_j += H_jk dlt_k (j > k)  are the forward
+// substitution of  L dlt = e0,  L = I + diag(c) strictLower(G') : dlt = T e0 with T = inv(L).  L depends on this iteration's
+// c (k_prep) and on the Gram block only -- not on the residual -- so T is formed here, before the sweep, for every such block
+// at once (one wave per block, the whole device), and the sampler's critical wave replaces its 64 dependent cross-lane steps
+// (v_readlane -> SGPR -> fma: 24.6 clocks each) by one 64 x 64 product from LDS.
+// Lane i forms column i of T by forward substitution, in the order of the steps it replaces:
+//   x_m = 0 (m < i), 1 (m = i), -(c_m acc_m) (m > i);   then acc_j = fma(G[m][j], x_m, acc_j) for j > m
+// (G[m][j], c_m are wave-uniform: scalar loads; nothing crosses a lane).  Output: tinv[t][i][j] = T[j][i], the layout of the
+// one-sided diagonal Gram block it stands in for (lane j of the chain reads row j with stride 64).
+// ------------------------------------------------------------------------------------------
+typedef double ngp_v8d __attribute__((ext_vector_type(8)));
+// sixteen consecutive doubles at a wave-uniform address into SGPRs (two s_load_dwordx16), and the wait that hands them over.
+// Written out because the compiler, given plain uniform loads in the unrolled substitution below, hoists all 2016 of them to the
+// top of the kernel and spills them through v_writelane / v_readlane (25,000 readlanes for 2,000 fma).
+__device__ __attribute__((always_inline)) inline void sload16(const double *p, ngp_v8d &a, ngp_v8d &b) {
+    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=&s"(a), "=&s"(b) : "s"(p) : "memory");
+}
+__device__ __attribute__((always_inline)) inline void swait16(ngp_v8d &a, ngp_v8d &b) {
+    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)::"memory");
+}
+// step n = (panel p, row m) of the substitution, 16 + 32 + 48 + 64 steps; templates, because the unroller leaves a 160-trip loop
+// with inline asm in its body rolled (and the accumulators then live in scratch)
+template <int n>
+__device__ __attribute__((always_inline)) inline void tinv_step(double (&acc)[NGP_BLK], ngp_v8d &a0, ngp_v8d &a1, ngp_v8d &b0, ngp_v8d &b1,
+                                                                const double *G1, const double cv, const int i) {
+    constexpr int p = n < 16 ? 0 : (n < 48 ? 1 : (n < 96 ? 2 : 3));
+    constexpr int m = n - (p == 0 ? 0 : (p == 1 ? 16 : (p == 2 ? 48 : 96)));
+    constexpr int n1 = n + 1;
+    constexpr int pn = n1 < 16 ? 0 : (n1 < 48 ? 1 : (n1 < 96 ? 2 : 3));
+    constexpr int mn = n1 - (pn == 0 ? 0 : (pn == 1 ? 16 : (pn == 2 ? 48 : 96)));
+    if constexpr ((n & 1) == 0) {
+        swait16(a0, a1);
+        if constexpr (n1 < 160) sload16(G1 + mn * NGP_BLK + 16 * pn, b0, b1);
+    } else {
+        swait16(b0, b1);
+        if constexpr (n1 < 160) sload16(G1 + mn * NGP_BLK + 16 * pn, a0, a1);
+    }
+    if constexpr (m >= 16 * p) {  // acc_m is complete: x_m
+        const double cm = readlane_d(cv, m);
+        const double tcm = cm * acc[m];
+        acc[m] = (i == m) ? 1.0 : ((i > m) ? 0.0 : -tcm);
+    }
+    const double xm = acc[m];
+#pragma unroll
+    for (int jj = 0; jj < 16; jj++) {
+        const int j = 16 * p + jj;
+        if (j <= m) continue;
+        const double g = (n & 1) == 0 ? (jj < 8 ? a0[jj & 7] : a1[jj & 7]) : (jj < 8 ? b0[jj & 7] : b1[jj & 7]);
+        acc[j] = __builtin_fma(g, xm, acc[j]);
+    }
+    // (the sixteen fma stay in front of the next step's wait: sunk below it, their SGPR operands outlive the next load and spill)
+    asm volatile("" : "+v"(acc[16 * p + 0]), "+v"(acc[16 * p + 1]), "+v"(acc[16 * p + 2]), "+v"(acc[16 * p + 3]), "+v"(acc[16 * p + 4]),
+                      "+v"(acc[16 * p + 5]), "+v"(acc[16 * p + 6]), "+v"(acc[16 * p + 7]), "+v"(acc[16 * p + 8]), "+v"(acc[16 * p + 9]),
+                      "+v"(acc[16 * p + 10]), "+v"(acc[16 * p + 11]), "+v"(acc[16 * p + 12]), "+v"(acc[16 * p + 13]), "+v"(acc[16 * p + 14]),
+                      "+v"(acc[16 * p + 15]));
+    if constexpr (n1 < 160) tinv_step<n1>(acc, a0, a1, b0, b1, G1, cv, i);
+}
+__global__ __launch_bounds__(64) void k_tinv(const double *__restrict__ gramx, int D, const double *__restrict__ c, LinRanges lin,
+                                             double *__restrict__ tinv, const unsigned *__restrict__ abort_w) {
+    if (abort_w && *abort_w != 0u) return;
+    const int t = blockIdx.x, i = threadIdx.x;
+    if (!block_linear(lin, t)) return;  // (the host lists the runs of linear blocks: ngp_api.hip, linear_ranges)
+    const double *G1 = gramx + (size_t)t * D * (NGP_BLK * NGP_BLK);  // element (m, j) at m * 64 + j, zero for j <= m
+    const double cv = c[(size_t)t * NGP_BLK + i];                    // lane m holds c_m
+    double acc[NGP_BLK];
+#pragma unroll
+    for (int j = 0; j < NGP_BLK; j++) acc[j] = 0.0;
+    // Panels of 16 columns j, rows m ascending inside a panel: every acc_j still receives its terms in the order m = 0, 1, .., j-1
+    // (the order of the row sweep), and the loop is regular -- one 128-byte piece of row m per step, the next one requested
+    // before the sixteen fma of this one (SMEM returns out of order: only lgkmcnt(0) is a safe wait, so one piece is in flight).
+    ngp_v8d a0, a1, b0, b1;
+    sload16(G1, a0, a1);
+    tinv_step<0>(acc, a0, a1, b0, b1, G1, cv, i);
+    double2 *dst = (double2 *)(tinv + (size_t)t * (NGP_BLK * NGP_BLK) + (size_t)i * NGP_BLK);
+#pragma unroll
+    for (int jj = 0; jj < NGP_BLK / 2; jj++) dst[jj] = make_double2(acc[2 * jj], acc[2 * jj + 1]);
+}
+
+// ------------------------------------------------------------------------------------------
 // streaming step of block t: (U) ycorr -= X_{t-1} dlt_{t-1}  then  (G) partial r = X_t' ycorr.
 // grid = S shards, 256 threads; tile (t,s) = [64 columns][R rows] fp32, contiguous.
 // Tile (t, s) = R rows x 64 columns of fp32, stored QUAD-MAJOR: element (row i, column j) sits at
@@ -408,7 +488,8 @@ __global__ __launch_bounds__(256) void k_recur(const double *__restrict__ part, 
                                                const int32_t *__restrict__ vbidx, DSet *__restrict__ sets,
                                                double *__restrict__ varBeta, double *__restrict__ dlt, const double *__restrict__ rcls,
                                                long long Ppad, const double *__restrict__ rhs0, const DScal *__restrict__ sc,
-                                               const DTup *__restrict__ tup, const double *__restrict__ tupc, const double *__restrict__ tupg) {
+                                               const DTup *__restrict__ tup, const double *__restrict__ tupc, const double *__restrict__ tupg,
+                                               const double *__restrict__ tinv, LinRanges lin) {
     __shared__ double gs[32 * NGP_BLK];
     const int tid = threadIdx.x, j = tid & 63, g4 = tid >> 6;
     const int ngroups = (S + NGP_GRP - 1) / NGP_GRP;
@@ -429,6 +510,25 @@ __global__ __launch_bounds__(256) void k_recur(const double *__restrict__ part, 
     const double r = __builtin_fma(gd, bo, tot);
     const int si0 = setof[k];
     const int meth0 = (si0 >= 0) ? sets[si0].method : -1;
+    if (tinv && block_linear(lin, t)) {  // linear block: dlt = T e0 (k_tinv)
+        const double *Tt = tinv + (size_t)t * (NGP_BLK * NGP_BLK) + j;  // element (i, j) = T[j][i]
+        const double e0 = __builtin_fma(r, cc, ww);
+        gs[j] = e0;  // (only wave 0 is left and it has read its group sums: LDS serves a wave in order, no barrier needed)
+        __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
+        double s4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll 16
+        for (int i = 0; i < NGP_BLK; i += 4) {
+            s4[0] = __builtin_fma(Tt[(size_t)(i + 0) * NGP_BLK], gs[i + 0], s4[0]);
+            s4[1] = __builtin_fma(Tt[(size_t)(i + 1) * NGP_BLK], gs[i + 1], s4[1]);
+            s4[2] = __builtin_fma(Tt[(size_t)(i + 2) * NGP_BLK], gs[i + 2], s4[2]);
+            s4[3] = __builtin_fma(Tt[(size_t)(i + 3) * NGP_BLK], gs[i + 3], s4[3]);
+        }
+        const double dfin = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        beta[k] = bo + dfin;
+        delta[k] = (uint8_t)1;
+        dlt[j] = dfin;
+        return;
+    }
     {
         const unsigned long long tm = __ballot(meth0 == NGP_METHOD_TUPLE_DEV);
         if (tm != 0ull) {  // a block of a Tuple set: one step per locus (tuple_chain)

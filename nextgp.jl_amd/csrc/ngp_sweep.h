@@ -124,14 +124,26 @@ __device__ inline void dma16_lds(const void *gsrc_lane, const void *lds_base_uni
                  : "memory");
 }
 
+// cache policy of the loader wave's tile requests (the panel is read once per sweep): "" default, " nt" non-temporal
+#ifndef NGP_DMA_POLICY
+#define NGP_DMA_POLICY ""
+#endif
 // Lean form for a wave that does nothing but request tiles: LDS address and the 64-bit global base are wave-uniform (SGPRs),
 // the per-lane part is one 32-bit VGPR offset (lane * 16), so a request costs a handful of scalar instructions.  With
 // per-lane 64-bit addresses and a v_readfirstlane per request (dma16_lds) ONE wave issues about 18 KiB per us, below a CU's
 // share of the stream; in this form it keeps up (tools/microbench/dma_bench.hip: 2.69 -> 2.16 us per 51 KiB tile, every CU
 // streaming; a second issuing wave would give 2.04).
-__device__ __attribute__((always_inline)) inline void dma16_s(unsigned lds_addr_uniform, const void *gbase_uniform, unsigned voff) {
+// (default cache policy: the L2-warming requests of the Gram blocks, which are meant to stay in L2)
+__device__ __attribute__((always_inline)) inline void dma16_warm(unsigned lds_addr_uniform, const void *gbase_uniform, unsigned voff) {
     unsigned keep_m0;
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep_m0)
+                 : "s"(lds_addr_uniform), "v"(voff), "s"(gbase_uniform)
+                 : "memory");
+}
+__device__ __attribute__((always_inline)) inline void dma16_s(unsigned lds_addr_uniform, const void *gbase_uniform, unsigned voff) {
+    unsigned keep_m0;
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3" NGP_DMA_POLICY "\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep_m0)
                  : "s"(lds_addr_uniform), "v"(voff), "s"(gbase_uniform)
                  : "memory");
@@ -146,10 +158,10 @@ __device__ __attribute__((always_inline)) inline void dma16_s4(unsigned lds_addr
     const unsigned m1 = lds_addr_uniform + (NGP_QS - 1024), m2 = lds_addr_uniform + 2 * (NGP_QS - 1024), m3 = lds_addr_uniform + 3 * (NGP_QS - 1024);
     asm volatile(
         "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %6\n\t"
-        "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %6 offset:1024\n\t"
-        "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %6 offset:2048\n\t"
-        "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %6 offset:3072\n\t"
+        "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %6" NGP_DMA_POLICY "\n\t"
+        "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %6 offset:1024" NGP_DMA_POLICY "\n\t"
+        "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %6 offset:2048" NGP_DMA_POLICY "\n\t"
+        "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %5, %6 offset:3072" NGP_DMA_POLICY "\n\t"
         "s_mov_b32 m0, %0"
         : "=&s"(keep_m0)
         : "s"(lds_addr_uniform), "s"(m1), "s"(m2), "s"(m3), "v"(voff), "s"(gbase_uniform)
@@ -193,6 +205,19 @@ __device__ inline unsigned sld_u32(const unsigned *p) {
     unsigned v;
     asm volatile("s_load_dword %0, %1, 0x0 glc\n\ts_waitcnt lgkmcnt(0)" : "=s"(v) : "s"(p) : "memory");
     return v;
+}
+
+// the 32 KiB the sampler stages for the chain of block t: T of a linear block, else the one-sided diagonal Gram block
+__device__ inline const double *chain_block_src(const SweepArgs &A, const long long t) {
+    const bool lin = block_linear(A.lin, (int)t);
+    return lin ? A.tinv + (size_t)t * (NGP_BLK * NGP_BLK) : A.gramx + ((size_t)t * A.D + 0) * (NGP_BLK * NGP_BLK);
+}
+// L2 warming (speed only): the 1 KiB piece at byte offset `off` of what the sampler CU reads for block t -- [chain block | cross Gram
+// planes 1, 2, ..]: the chain block is T for a linear block (tinv), the diagonal Gram block otherwise.  (T not warmed: the sampler's
+// 32 KiB per block then come from HBM, and every other load of that CU queues behind them -- 10k x 100k 1.80 -> 2.05 us per block.)
+__device__ __attribute__((always_inline)) inline const char *warm_piece(const SweepArgs &A, const long long t, const size_t off, const int D) {
+    if (off < (size_t)(NGP_BLK * NGP_BLK * sizeof(double)) && block_linear(A.lin, (int)t)) return (const char *)(A.tinv + (size_t)t * (NGP_BLK * NGP_BLK)) + off;
+    return (const char *)(A.gramx + (size_t)t * D * (NGP_BLK * NGP_BLK)) + off;
 }
 
 // gemv4: v_j = sum_k G[k][j] * d[k], four interleaved partial sums, ((s0+s1)+(s2+s3))
@@ -329,10 +354,9 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
                 if (u + 1 < nb) dma_tile(u + 1);
                 if ((u & 7) == 0 && !same_xcd) same_xcd = (ld_u32(A.xcc_w) == my_xcc);
                 if (same_xcd && u + 1 < nb) {  // fire-and-forget: the lines only have to reach this XCD's L2
-                    const char *gb = (const char *)(A.gramx + (size_t)(A.t0 + u + 1) * DT * NGP_BLK * NGP_BLK);
                     const size_t lo = (size_t)slice * slice_bytes, hi = min((size_t)(slice + 1) * slice_bytes, gram_bytes);
                     for (size_t off = lo + (size_t)(wv - 4) * 1024; off + 1024 <= hi; off += 3 * 1024)
-                        dma16_lds(gb + off + (size_t)j * 16, scratch + (wv - 4) * 1024);
+                        dma16_lds(warm_piece(A, A.t0 + u + 1, off, DT) + (size_t)j * 16, scratch + (wv - 4) * 1024);
                 }
             } else if (wv == 7 && dbg_mode != 1) {
                 if (DT <= 2 || u == 0) poll_dlt(u);  // lags 1-2 cannot poll ahead: the flag would (transitively, through the
@@ -741,9 +765,8 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows(const S
                 same_xcd = (x == my_xcc);
             }
             if (same_xcd && u + 1 < nb && !no_dma) {
-                const char *gb = (const char *)(A.gramx + (size_t)(A.t0 + u + 1) * DT * NGP_BLK * NGP_BLK);
                 const size_t lo = (size_t)slice * slice_bytes, hi = min((size_t)(slice + 1) * slice_bytes, gram_bytes);
-                for (size_t off = lo; off + 1024 <= hi; off += 1024) dma16_s(scratch0, gb + off, voff);
+                for (size_t off = lo; off + 1024 <= hi; off += 1024) dma16_warm(scratch0, warm_piece(A, A.t0 + u + 1, off, DT), voff);
             }
             // (Requesting more of tile u+2 here -- into the slots of tile u, which the row waves have left 1.7 us into the block,
             // so that more than H requests are in flight while the loader sits at the barrier -- was built and measured: 50k x 600k
@@ -1149,9 +1172,8 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows_tall(co
                     same_xcd = (x == my_xcc);
                 }
                 if (same_xcd && u + 1 < nb) {
-                    const char *gb = (const char *)(A.gramx + (size_t)(A.t0 + u + 1) * DT * NGP_BLK * NGP_BLK);
                     const size_t lo = (size_t)slice * slice_bytes, hi = min((size_t)(slice + 1) * slice_bytes, gram_bytes);
-                    for (size_t off = lo; off + 1024 <= hi; off += 1024) dma16_s(scratch0, gb + off, voff);
+                    for (size_t off = lo; off + 1024 <= hi; off += 1024) dma16_warm(scratch0, warm_piece(A, A.t0 + u + 1, off, DT), voff);
                 }
             }
             dma_quads(w + 1, H, NQ, base1);
@@ -1381,6 +1403,7 @@ __device__ __attribute__((always_inline)) inline void role_reducer(const SweepAr
 // ------------------------------------------------------------------------------------------
 struct CoefRegs {
     double bo, cc, ww, st, gd;
+    unsigned tf;  // the block is linear: its chain is dlt = T e0 (k_tinv), T staged in place of the diagonal Gram block
 };
 __device__ inline CoefRegs load_coef(const SweepArgs &A, long long k) {
     CoefRegs c;
@@ -1389,11 +1412,9 @@ __device__ inline CoefRegs load_coef(const SweepArgs &A, long long k) {
     c.ww = A.w[k];
     c.st = A.q[k];  // inclusion threshold on f = c r: included iff |f| > st (st < 0: always)
     c.gd = A.mpm[k];
+    c.tf = block_linear(A.lin, (int)(k >> 6)) ? 1u : 0u;
     return c;
 }
-
-// workgroup barrier that drains LDS traffic only: global loads issued before it stay in flight
-
 // group sums of local block u -> per-lane total (lane 0 polls, whole wave loads); false on abort
 template <bool DBG, bool NGBIG = false>
 __device__ __attribute__((always_inline)) inline bool fetch_group_sums(const SweepArgs &A, int u, int j, double *tot_out) {
@@ -1575,10 +1596,10 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
     }
     // prologue: diagonal Gram block of local block 0 (all waves) and its group sums (wave 2)
     {
-        const double *gd = A.gramx + ((size_t)A.t0 * D + 0) * bsz;
+        const double *gd = chain_block_src(A, A.t0);
         for (int idx = tid; idx < 4096; idx += NGP_WG) Gd[idx] = gd[idx];
         if (nb > 1) {
-            const double *gd1 = A.gramx + ((size_t)(A.t0 + 1) * D + 0) * bsz;
+            const double *gd1 = chain_block_src(A, A.t0 + 1);
             for (int idx = tid; idx < 4096; idx += NGP_WG) Gd[4096 + idx] = gd1[idx];
         }
     }
@@ -1609,6 +1630,20 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
             const int t = A.t0 + u, buf = u & 1, slot = u % NGP_RING, rs = u & 3;
             if (u + 1 < nb) nxt = load_coef(A, (long long)(t + 1) * NGP_BLK + j);
             if (dbg && j == 0) dbg[4 * (size_t)u] = wall_clock64();
+            // The lane's 64 values of the block staged for the chain -- column j of the one-sided diagonal Gram block, or row j of
+            // T = inv(L) for a linear block (k_tinv) -- go into registers BEFORE the total of the block is awaited: off the serial
+            // path.  (Always, for every kind of block: loaded under a condition, the array became loop-carried -- its "undefined"
+            // value on the other path is the previous block's -- and the kernel spilled.)
+            // The lean kernel only: beside the Tuple / BayesR chains of the full kernels the 128 early registers spill; there the
+            // step chains load their Gram rows behind the wait, as they always did, and the inverse form reads T chunk by chunk.
+            constexpr bool PRELOAD = (!TUP && RCLS == 0);
+            const bool tform = __builtin_amdgcn_readfirstlane((int)cur.tf) != 0;
+            const double *gdb = Gd + (u % 3) * 4096 + j;
+            double G[NGP_BLK];
+            if constexpr (PRELOAD) {
+#pragma unroll
+                for (int kk = 0; kk < NGP_BLK; kk++) G[kk] = gdb[kk * NGP_BLK];
+            }
             double tot;
             if (D == 1) {  // lag 1: nothing can be fetched or corrected ahead
                 tot = r0[rs * NGP_BLK + j];
@@ -1627,16 +1662,14 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
                 asm volatile("" ::: "memory");  // r0 is read after the flag (LDS serves a wave in order)
                 tot = r0[rs * NGP_BLK + j];
             }
-            const double *gdb = Gd + (u % 3) * 4096 + j;
             const double bo = cur.bo, cc = cur.cc, ww = cur.ww, st = cur.st;
             const double r = __builtin_fma(cur.gd, bo, tot);
             // scaled recursion: e = c r + w is the candidate draw, f = c r feeds the
             // inclusion test |f| > thr.  The stored diagonal block is zero for lanes <= k, so a lane's e and f freeze at
             // its own step and nothing has to be captured.  H_k = -(c G[k][.]) is formed four steps ahead, in the
             // latency shadow of the serial path: v_readlane -> ONE fma per step (BayesPR), + compare / select (BayesB).
-            double G[NGP_BLK];
 #define NGP_LOAD_G()                                                           \
-    _Pragma("unroll") for (int kk = 0; kk < NGP_BLK; kk++) G[kk] = gdb[kk * NGP_BLK]; \
+    if constexpr (!PRELOAD) { _Pragma("unroll") for (int kk = 0; kk < NGP_BLK; kk++) G[kk] = gdb[kk * NGP_BLK]; } \
     double H0 = -(cc * G[0]), H1 = -(cc * G[1]), H2 = -(cc * G[2]), H3 = -(cc * G[3]);
             double e = __builtin_fma(r, cc, ww);
             double dsave;
@@ -1656,7 +1689,32 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
             if constexpr (TUP) {
                 if (A.tup) tk = __builtin_amdgcn_readfirstlane(tmeta[buf * 4]);
             }
-            if (TUP && tk != 0) {
+            if (tform && dbg_mode != 5) {
+                // dlt = T e0: e0 goes through the r0 slot of this block (free once the total has been
+                // read) and comes back as broadcast reads, 16 values at a time; four accumulators over i mod 4, ((s0+s1)+(s2+s3))
+                r0[rs * NGP_BLK + j] = e;
+                typedef const __attribute__((address_space(3))) double *lds_cdp;
+                const lds_cdp ek = (lds_cdp)(r0 + rs * NGP_BLK);
+                double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+#pragma unroll
+                for (int kk = 0; kk < NGP_BLK; kk += 16) {
+                    double ev[16], tv[16];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) ev[i] = ek[kk + i];
+#pragma unroll
+                    for (int i = 0; i < 16; i++) tv[i] = PRELOAD ? G[kk + i] : gdb[(kk + i) * NGP_BLK];
+#pragma unroll
+                    for (int i = 0; i < 16; i += 4) {
+                        s0 = __builtin_fma(tv[i + 0], ev[i + 0], s0);
+                        s1 = __builtin_fma(tv[i + 1], ev[i + 1], s1);
+                        s2 = __builtin_fma(tv[i + 2], ev[i + 2], s2);
+                        s3 = __builtin_fma(tv[i + 3], ev[i + 3], s3);
+                    }
+                    asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));
+                }
+                dsave = (s0 + s1) + (s2 + s3);
+                isave = 1;
+            } else if (TUP && tk != 0) {
                 // a block of a Tuple set: one step per locus, its k effects drawn together (tuple_chain, ngp_common.h); the lane
                 // coefficients wait in LDS (wave 1, one block ahead)
                 const int nvalid = __builtin_amdgcn_readfirstlane(tmeta[buf * 4 + 1]);
@@ -1852,7 +1910,7 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
         // would make the compiler drain the DMA): it sees an abort through a scalar load of the abort word.
         for (int u = 0; u < nb; ++u) {
             if (u + 2 < nb) {
-                const char *gsrc = (const char *)(A.gramx + ((size_t)(A.t0 + u + 2) * D + 0) * bsz) + (size_t)j * 16;
+                const char *gsrc = (const char *)chain_block_src(A, A.t0 + u + 2) + (size_t)j * 16;
                 char *gdst = (char *)(Gd + ((u + 2) % 3) * 4096);
 #pragma unroll
                 for (int i = 0; i < 32; i++)
@@ -2153,10 +2211,9 @@ __device__ __attribute__((always_inline)) inline void role_streamer_multi(const 
                 if (u + 1 < nb) dma_tile(u + 1);
                 if ((u & 7) == 0 && !same_xcd) same_xcd = (ld_u32(A.xcc_w) == my_xcc);
                 if (same_xcd && u + 1 < nb) {
-                    const char *gb = (const char *)(A.gramx + (size_t)(A.t0 + u + 1) * DT * NGP_BLK * NGP_BLK);
                     const size_t lo = (size_t)slice * slice_bytes, hi = min((size_t)(slice + 1) * slice_bytes, gram_bytes);
                     for (size_t off = lo + (size_t)(wv - 4) * 1024; off + 1024 <= hi; off += 3 * 1024)
-                        dma16_lds(gb + off + (size_t)j * 16, scratch + (wv - 4) * 1024);
+                        dma16_lds(warm_piece(A, A.t0 + u + 1, off, DT) + (size_t)j * 16, scratch + (wv - 4) * 1024);
                 }
             }
             try_signal(false);
@@ -2382,9 +2439,8 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows_multi(c
                 same_xcd = (x == my_xcc);
             }
             if (same_xcd && u + 1 < nb) {
-                const char *gb = (const char *)(A.gramx + (size_t)(A.t0 + u + 1) * DT * NGP_BLK * NGP_BLK);
                 const size_t lo = (size_t)slice * slice_bytes, hi = min((size_t)(slice + 1) * slice_bytes, gram_bytes);
-                for (size_t off = lo; off + 1024 <= hi; off += 1024) dma16_s(scratch0, gb + off, voff);
+                for (size_t off = lo; off + 1024 <= hi; off += 1024) dma16_warm(scratch0, warm_piece(A, A.t0 + u + 1, off, DT), voff);
             }
             if (u + 1 < nb) dma_quads(u + 1, H, NQ, base1);
             int n2 = 0;

@@ -417,6 +417,8 @@ typedef struct {
     int64_t D;                /* lag of the pipelined sweep (1 = no look-ahead) */
     int64_t near;             /* look-ahead lags 1..near corrected by the sampler, farther ones folded into the group sums */
     int64_t nchain;           /* GEMV chains of a shard partial: 8 (phase streamer, per-block engine) or 7 (row-owning waves) */
+    int tform;                /* blocked order: linear blocks (every lane BayesPR or unowned) take the chain as dlt = T e0 with the
+                                 explicit inverse T of the block's unit lower-triangular system */
     double *gramx;            /* [t][d][k][j], d = 1..D-1: x_{t-d,k}' x_{t,j} */
     float *tiles;             /* [s][t][j][i] */
     int storage;              /* 0: fp32 centred tiles; 1: compact -- one byte per genotype + fp64 column means, centred analytically */
@@ -461,7 +463,7 @@ int ora_create(int order, uint64_t seed, uint32_t chain, ora_t **out) {
     h->order = order; h->seed = seed; h->chain = chain;
     h->e_df = 4.0; h->e_scale = 0.0005; h->intercept = 1;
     h->chainLength = 0; h->burnIn = 0; h->thin = 1;
-    h->near = 3; h->nchain = 8;
+    h->near = 3; h->nchain = 8; h->tform = 1;
     *out = h; return ORA_OK;
 }
 /* which look-ahead lags the sampler corrects itself (the library reports its choice: ngp_get_near_lags) */
@@ -474,6 +476,8 @@ int ora_set_nchain(ora_t *h, int64_t n) {
     if (n != 7 && n != 8) { snprintf(h->err, 256, "GEMV chains must be 7 or 8"); return ORA_ERR; }
     h->nchain = n; return ORA_OK;
 }
+/* chain form of the linear blocks (the library reports its choice: ngp_get_chain_form): 1 = inverse form (default), 0 = 64 steps */
+int ora_set_tform(ora_t *h, int on) { h->tform = on ? 1 : 0; return ORA_OK; }
 static void free_sets(ora_t *h) {
     for (int s = 0; s < h->nsets; s++) { free(h->sets[s].reg_start); free(h->sets[s].reg_stop); free(h->sets[s].tmpm); }
 }
@@ -1368,6 +1372,7 @@ static void iter_blocked(ora_t *h) {
     const int64_t D = h->D;
     double *part = (double *)malloc(sizeof(double) * S * BLK);
     double *hist = (double *)calloc((size_t)NBLK * BLK, sizeof(double)); /* dlt of every block */
+    int lin_runs = 0, prev_raw_linear = 0;
     for (int64_t tb = 0; tb < NBLK + D; tb++) {
         if (tb >= D && h->storage == 1) { /* compact storage: y_i -= (sum_j g_ij dlt_j - sum_j m_j dlt_j), valid rows only */
             const int64_t a = tb - D;
@@ -1471,6 +1476,13 @@ static void iter_blocked(ora_t *h) {
             if (lane_set[j] >= 0 && h->sets[lane_set[j]].method == METHOD_R) has_r = 1;
             if (lane_set[j] >= 0 && h->sets[lane_set[j]].method == METHOD_T) has_t = lane_set[j];
         }
+        /* linear block: every lane BayesPR or unowned.  The device passes the RUNS of linear blocks as kernel arguments, four of
+           them (csrc/ngp_common.h, LinRanges): linear blocks of a fifth run and beyond take the 64 steps. */
+        int raw_linear = 1;
+        for (int j = 0; j < BLK; j++)
+            if (lane_set[j] >= 0 && h->sets[lane_set[j]].method != METHOD_PR) raw_linear = 0;
+        if (raw_linear && !prev_raw_linear) lin_runs++;
+        prev_raw_linear = raw_linear;
         for (int j = 0; j < BLK; j++) {
             /* group sums: shards of a group added in order */
             double gs[64];
@@ -1603,6 +1615,40 @@ static void iter_blocked(ora_t *h) {
         for (int j = 0; j < BLK; j++) {
             ee[j] = __builtin_fma(rr[j], h->c[k0 + j], h->w[k0 + j]);
             ff[j] = rr[j] * h->c[k0 + j];
+        }
+        /* Linear block -- every lane BayesPR (always included: src/functions.jl:124-136) or unowned: the 64 steps
+             dlt_k = e_k,  e_j += H_jk dlt_k (j > k)
+           are the forward substitution of L dlt = e0, L = I + diag(c) strictLower(G): dlt = T e0 with T = inv(L) formed explicitly
+           (k_tinv) -- the same chain in real arithmetic, a 64 x 64 product instead of 64 dependent cross-lane steps.
+           Formation, column i of T (lane i of k_tinv): x_m = 0 (m < i), 1 (m = i), -(c_m acc_m) (m > i); after every x_m:
+           acc_j = fma(G[m][j], x_m, acc_j) for j > m.  Application: four accumulators over i mod 4, ((s0+s1)+(s2+s3)). */
+        const int linear = h->tform && raw_linear && lin_runs <= 4;
+        if (linear) {
+            double Tm[BLK][BLK];
+            for (int i = 0; i < BLK; i++) {
+                double acc[BLK], x[BLK];
+                for (int j = 0; j < BLK; j++) acc[j] = 0.0;
+                for (int m = 0; m < BLK; m++) {
+                    double xm;
+                    if (m < i) xm = 0.0;
+                    else if (m == i) xm = 1.0;
+                    else { double tcm = h->c[k0 + m] * acc[m]; xm = -tcm; }
+                    x[m] = xm;
+                    for (int j = m + 1; j < BLK; j++) acc[j] = __builtin_fma(G[j * BLK + m], xm, acc[j]);
+                }
+                for (int m = 0; m < BLK; m++) Tm[m][i] = x[m];
+            }
+            for (int j = 0; j < BLK; j++) {
+                double s4[4] = {0, 0, 0, 0};
+                for (int i = 0; i < BLK; i++) s4[i & 3] = __builtin_fma(Tm[j][i], ee[i], s4[i & 3]);
+                dlt[j] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+            }
+            for (int k = 0; k < BLK; k++) {
+                hist[tb * BLK + k] = dlt[k];
+                h->beta[k0 + k] = h->beta[k0 + k] + dlt[k];
+                h->delta[k0 + k] = 1;
+            }
+            continue;
         }
         for (int k = 0; k < BLK; k++) {
             int in = fabs(ff[k]) > h->q[k0 + k];

@@ -135,6 +135,10 @@ class Oracle:
         self._chk(self.L.ora_set_panel_f32(self.h, _p(X, C.c_float), C.c_int64(self.N), C.c_int64(self.P), C.c_int64(R),
                                            C.c_int64(S), C.c_int64(D)))
 
+    def set_tform(self, on=True):
+        """Blocked order: linear blocks as dlt = T e0 (the library's default, ngp_get_chain_form) or as the 64-step chain."""
+        self._chk(self.L.ora_set_tform(self.h, C.c_int(1 if on else 0)))
+
     def set_panel_u8(self, G, R=0, S=0, D=1, near=3, centre=True):
         """Compact storage (one byte per genotype, analytic centring).  Blocked order: the layout the library reports; reference
         order: the Float64 panel the reference would hold for these genotypes (g - mean, mean = integer column sum / N)."""

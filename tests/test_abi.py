@@ -24,7 +24,7 @@ def test_library_exports_every_declared_symbol(ngp):
         assert hasattr(lib, s), f"{s} declared in include/nextgp_hip.h but not exported"
     assert sorted(ngp.SYMBOLS) == syms
     lib.ngp_abi_version.restype = C.c_int32
-    assert lib.ngp_abi_version() == 3
+    assert lib.ngp_abi_version() == 4
 
 
 def test_no_cpu_fallback(ngp):

@@ -81,6 +81,7 @@ def test_one_set_tuple_is_the_symbol_method_on_the_device(ngp, O):
     res = []
     for tup in (True, False):
         s = ngp.Sampler(device=0, seed=9, chain=2)
+        s.set_chain_form(0)   # step chains on both sides (BayesPR blocks otherwise take the inverse form, ngp_set_chain_form)
         s.set_panel(X)
         if tup:
             s.add_marker_set_tuple(0, nloc, 1, 4.0, [[sv * 4.0]], regions, [[v]])

@@ -12,6 +12,7 @@ dbgmode = int(os.environ.get("NGP_TOOL_DEBUG_MODE", "0"))  # tools only: the lib
 s = ngp.Sampler(device=0, seed=1001, chain=0, mode=mode, lag=lag, streamer=streamer if ("NGP_HIP_LIB" not in os.environ or "NGP_FORCE_STREAMER" in os.environ) else None,
                 storage=os.environ.get("NGP_TOOL_STORAGE"))
 if "NGP_TOOL_SHARDS" in os.environ: s.set_max_shards(int(os.environ["NGP_TOOL_SHARDS"]))
+if "NGP_TOOL_CHAIN_FORM" in os.environ: s.set_chain_form(int(os.environ["NGP_TOOL_CHAIN_FORM"]))
 if dbgmode: s.debug_set_mode(dbgmode)
 if "NGP_TOOL_KNOB" in os.environ: s.debug_set_knob(int(os.environ["NGP_TOOL_KNOB"]))
 if "NGP_TOOL_NEAR" in os.environ: s.set_near(int(os.environ["NGP_TOOL_NEAR"]))

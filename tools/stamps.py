@@ -8,6 +8,7 @@ N = int(sys.argv[2]) if len(sys.argv)>2 else 10000
 P = int(sys.argv[3]) if len(sys.argv)>3 else 100000
 s = ngp.Sampler(device=0, seed=1001, chain=0, mode=1, lag=lag, streamer=int(sys.argv[4]) if len(sys.argv) > 4 else None,
               storage=os.environ.get("NGP_TOOL_STORAGE"))
+if "NGP_TOOL_CHAIN_FORM" in os.environ: s.set_chain_form(int(os.environ["NGP_TOOL_CHAIN_FORM"]))
 if "NGP_TOOL_KNOB" in os.environ: s.debug_set_knob(int(os.environ["NGP_TOOL_KNOB"]))
 if "NGP_TOOL_NEAR" in os.environ: s.set_near(int(os.environ["NGP_TOOL_NEAR"]))
 s.generate_panel(N,P)
