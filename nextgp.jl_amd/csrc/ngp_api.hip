@@ -117,8 +117,9 @@ struct ngp_handle {
     // inverse form of the linear blocks' chain (k_tinv): T per block, written before every sweep
     double *d_tinv = nullptr;
     int64_t tinv_blocks = 0;  // blocks d_tinv was allocated for
-    LinRanges lin_all = {{0, 0, 0, 0}, {0, 0, 0, 0}};  // runs of linear blocks of the whole model (recomputed with the tables)
-    LinRanges lin_now = {{0, 0, 0, 0}, {0, 0, 0, 0}};  // ... of the sweep being launched (launch_tinv; a fine-seam call has its own)
+    unsigned *d_blin = nullptr;   // [NBLK] 1 = linear block (static for a model and an active set: written by sync_linear_blocks)
+    int blin_for = -2;            // active set d_blin was written for (-1: the whole model, -2: stale)
+    int lin_all = 0, lin_any = 0; // every / any block of d_blin is linear
     int chain_form = 1;       // ngp_set_chain_form: 1 = linear blocks as dlt = T e0 (default), 0 = every block by the 64-step chain
     int8_t *d_setof = nullptr;
     int32_t *d_loc = nullptr, *d_vbidx = nullptr;
@@ -662,36 +663,37 @@ bool wants_tinv(const ngp_handle *h) {
     return false;
 }
 
-// Runs of linear blocks (ngp_common.h, LinRanges): blocks no lane of which belongs to a set that is not BayesPR -- in a fine-seam call
-// (active_set >= 0) only the sampled set counts, every other lane is inactive.  A Tuple set owns its blocks to the end of the last one.
-// The first NGP_TRANGES runs in block order; none when the inverse form is off.
-LinRanges linear_ranges(const ngp_handle *h, int active_set) {
-    LinRanges L = {{0, 0, 0, 0}, {0, 0, 0, 0}};
-    if (!wants_tinv(h)) return L;
-    std::vector<std::pair<int64_t, int64_t>> nl;  // block intervals [a, b) that hold a lane of a non-BayesPR set
+// Which blocks are linear (every lane BayesPR, unowned or -- in a fine-seam call, active_set >= 0 -- of another set than the sampled
+// one: those lanes are inactive): their chain takes the inverse form (k_tinv).  Static for a model; the table goes to the device when
+// the model or the active set changed.  A Tuple set owns its blocks to the end of the last one (ncol = its span).
+int sync_linear_blocks(ngp_handle *h, int active_set) {
+    if (!wants_tinv(h) || h->tinv_blocks != h->NBLK) { h->lin_all = 0; h->lin_any = 0; return NGP_OK; }
+    if (h->blin_for == active_set) return NGP_OK;
+    std::vector<unsigned> bl((size_t)h->NBLK, 1u);
     for (size_t si = 0; si < h->sets.size(); si++) {
         const HSet &st = h->sets[si];
         if (st.method == NGP_METHOD_BAYESPR || (active_set >= 0 && (int)si != active_set)) continue;
-        nl.emplace_back(st.col0 / NGP_BLK, (st.col0 + st.ncol - 1) / NGP_BLK + 1);  // (a Tuple set: ncol = its span)
+        for (int64_t t = st.col0 / NGP_BLK; t <= (st.col0 + st.ncol - 1) / NGP_BLK && t < h->NBLK; t++) bl[(size_t)t] = 0u;
     }
-    std::sort(nl.begin(), nl.end());
-    int n = 0;
-    int64_t at = 0;
-    for (size_t i = 0; i <= nl.size() && n < NGP_TRANGES; i++) {
-        const int64_t a = i < nl.size() ? nl[i].first : h->NBLK, b = i < nl.size() ? nl[i].second : h->NBLK;
-        if (a > at) { L.lo[n] = (int)at; L.hi[n] = (int)std::min<int64_t>(a, h->NBLK); n++; }
-        at = std::max(at, b);
-    }
-    return L;
+    int64_t n = 0;
+    for (unsigned v : bl) n += v;
+    h->lin_all = (n == h->NBLK) ? 1 : 0;
+    h->lin_any = (n > 0) ? 1 : 0;
+    HCHK(hipMemcpyAsync(h->d_blin, bl.data(), (size_t)h->NBLK * sizeof(unsigned), hipMemcpyHostToDevice, h->stream));
+    HCHK(hipStreamSynchronize(h->stream));  // (bl is a local)
+    h->blin_for = active_set;
+    return NGP_OK;
 }
 
 int sync_tables(ngp_handle *h) {
     int rc;
     if (wants_tinv(h) && h->tinv_blocks != h->NBLK) {
         if ((rc = dalloc(h, &h->d_tinv, (size_t)h->NBLK * NGP_BLK * NGP_BLK))) return rc;
+        if ((rc = dalloc(h, &h->d_blin, (size_t)h->NBLK))) return rc;
         h->tinv_blocks = h->NBLK;
+        h->blin_for = -2;
     }
-    h->lin_all = linear_ranges(h, -1);
+    if (h->tables_dirty) h->blin_for = -2;
     if (!h->tables_dirty) return NGP_OK;
     const size_t pp = (size_t)h->Ppad;
     HCHK(hipMemcpy(h->d_setof, h->h_setof.data(), pp, hipMemcpyHostToDevice));
@@ -735,8 +737,9 @@ void fill_sweep_args(ngp_handle *h, int64_t tb0, int64_t tb1, SweepArgs &A) {
     const int R = (int)h->R, S = (int)h->S;
     A.tiles = h->d_tiles; A.ycorr = h->d_ycorr; A.gramx = h->d_gramx;
     const bool tf = wants_tinv(h) && h->tinv_blocks == h->NBLK;
-    A.tinv = tf ? h->d_tinv : nullptr;
-    A.lin = tf ? h->lin_now : LinRanges{{0, 0, 0, 0}, {0, 0, 0, 0}};
+    A.tinv = (tf && h->lin_any) ? h->d_tinv : nullptr;
+    A.blin = (tf && h->lin_any) ? h->d_blin : nullptr;
+    A.lin_all = (tf && h->lin_any) ? h->lin_all : 0;
     A.V = h->V; A.D = h->D; A.R = R; A.S = S; A.NG = h->NG; A.near = h->near; A.fine_ok = 0; A.t0 = (int)tb0; A.t1 = (int)tb1;
     A.beta = h->d_beta; A.delta = h->d_delta; A.c = h->d_c; A.w = h->d_w; A.q = h->d_q; A.mpm = h->d_mpm; A.chi = h->d_chi;
     A.setof = h->d_setof; A.vbidx = h->d_vbidx; A.sets = h->d_sets; A.varBeta = h->d_varBeta;
@@ -800,7 +803,7 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
             hipLaunchKernelGGL(k_recur, dim3(1), dim3(256), 0, h->stream, h->d_part, h->d_gramx, h->D, S, (int)t, h->d_beta, h->d_delta,
                                h->d_c, h->d_w, h->d_q, h->d_mpm, h->d_chi, h->d_setof, h->d_vbidx, h->d_sets, h->d_varBeta, h->d_dlt, h->d_rcls,
                                (long long)h->Ppad, h->d_rhs0, h->d_scal, h->d_tup, h->d_tupc, h->d_tupg,
-                               (const double *)((wants_tinv(h) && h->tinv_blocks == h->NBLK) ? h->d_tinv : nullptr), h->lin_now);
+                               (const double *)((wants_tinv(h) && h->tinv_blocks == h->NBLK && h->lin_any) ? h->d_tinv : nullptr), (const unsigned *)h->d_blin);
     }
     h->sweep_launches += 2 * (tb1 - tb0) + 1;
 }
@@ -882,13 +885,10 @@ void launch_variance(ngp_handle *h, int active_set, uint64_t it) {
 int sample_enqueue(ngp_handle *h);  // (below)
 
 // T = inv(L) of every linear block from this iteration's coefficients (k_tinv; behind k_prep in the stream, in front of the sweep)
-void launch_tinv(ngp_handle *h, int active_set) {
-    h->lin_now = LinRanges{{0, 0, 0, 0}, {0, 0, 0, 0}};
-    if (!wants_tinv(h) || h->tinv_blocks != h->NBLK) return;
-    h->lin_now = active_set < 0 ? h->lin_all : linear_ranges(h, active_set);
-    if (h->lin_now.hi[0] <= h->lin_now.lo[0]) return;  // no linear block
+void launch_tinv(ngp_handle *h) {  // (sync_linear_blocks has run for this call's active set)
+    if (!wants_tinv(h) || h->tinv_blocks != h->NBLK || !h->lin_any) return;
     hipLaunchKernelGGL(k_tinv, dim3((unsigned)h->NBLK), dim3(64), 0, h->stream, (const double *)h->d_gramx, h->D, (const double *)h->d_c,
-                       h->lin_now, h->d_tinv, (const unsigned *)h->d_abort);
+                       (const unsigned *)h->d_blin, h->d_tinv, (const unsigned *)h->d_abort);
 }
 
 void iteration_pre(ngp_handle *h, int64_t trace_idx, bool resume_mid) {  // everything in front of the sweep
@@ -905,7 +905,7 @@ void iteration_pre(ngp_handle *h, int64_t trace_idx, bool resume_mid) {  // ever
                        h->d_vbidx, h->d_sets, h->d_scal, h->d_varBeta, h->d_mpm, h->d_lhs0, h->d_rhs0, h->d_beta, h->d_c, h->d_w,
                        h->d_q, h->d_T, h->d_chi, -1, h->seed, (uint64_t)h->chain, it, (long long)h->h_regs.size(), h->d_regs, h->d_regchi, h->d_rcls,
                        h->d_ccnt, (long long)(h->mode == 1 ? h->ccnt_words : 0), h->d_abort, h->d_tup, h->d_tupc, h->d_tupg);
-    launch_tinv(h, -1);
+    launch_tinv(h);
 }
 
 int iteration_post(ngp_handle *h, int64_t trace_idx) {  // variance / pi draws, traces and posterior sums; advances h->iter
@@ -1088,7 +1088,9 @@ int ready(ngp_handle *h) {
     REQUIRE(!h->panel_open, NGP_ERR_STATE, "the panel is still open: ngp_end_panel builds the Gram window the sweep needs");
     REQUIRE(h->have_y, NGP_ERR_STATE, "y not set");
     REQUIRE(!h->sets.empty(), NGP_ERR_STATE, "no marker set added");
-    return sync_tables(h);
+    int rc;
+    if ((rc = sync_tables(h))) return rc;
+    return sync_linear_blocks(h, -1);
 }
 
 }  // namespace
@@ -1135,7 +1137,7 @@ int32_t ngp_destroy(ngp_handle *h) {
     release_panel(h);
      dfree(h->d_cpart); dfree(h->d_cgsum); dfree(h->d_cdlt); dfree(h->d_cdltg); dfree(h->d_rcls); dfree(h->d_seg_set); dfree(h->d_ccnt); dfree(h->d_abort); dfree(h->d_dbg); dfree(h->d_mpm); dfree(h->d_lhs0); dfree(h->d_rhs0); dfree(h->d_beta);
     dfree(h->d_c); dfree(h->d_w); dfree(h->d_q); dfree(h->d_T); dfree(h->d_chi); dfree(h->d_setof); dfree(h->d_loc);
-    dfree(h->d_tinv);
+    dfree(h->d_tinv); dfree(h->d_blin);
     dfree(h->d_vbidx); dfree(h->d_delta); dfree(h->d_sum_beta); dfree(h->d_sum_beta2); dfree(h->d_sum_delta);
     dfree(h->d_ycorr); dfree(h->d_part); dfree(h->d_dlt); dfree(h->d_sets); dfree(h->d_scal); dfree(h->d_varBeta);
     dfree(h->d_sum_varBeta); dfree(h->d_regs); dfree(h->d_seg_k0); dfree(h->d_seg_len); dfree(h->d_segpart); dfree(h->d_regchi);
@@ -1914,6 +1916,7 @@ int32_t ngp_sweep_set(ngp_handle *h, int32_t set_id, double varE, double *ycorr,
     REQUIRE(ycorr && beta && varBeta, NGP_ERR_ARG, "null state pointer");
     REQUIRE(std::isfinite(varE) && varE > 0.0, NGP_ERR_ARG, "varE must be finite and positive");
     if ((rc = sync_tables(h))) return rc;
+    if ((rc = sync_linear_blocks(h, (int)set_id))) return rc;
     HSet &hs = h->sets[set_id];
     const int64_t nvbs = (int64_t)hs.vb0.size();  // variance entries of the set: regions (loci for BayesB), k x k per region for a tuple set
     for (int64_t r = 0; r < nvbs; r++) REQUIRE(std::isfinite(varBeta[r]) && (varBeta[r] >= 0.0 || hs.tk > 1), NGP_ERR_ARG, "varBeta must be finite, >= 0");
@@ -1933,7 +1936,7 @@ int32_t ngp_sweep_set(ngp_handle *h, int32_t set_id, double varE, double *ycorr,
                            h->d_vbidx, h->d_sets, h->d_scal, h->d_varBeta, h->d_mpm, h->d_lhs0, h->d_rhs0, h->d_beta, h->d_c, h->d_w,
                            h->d_q, h->d_T, h->d_chi, (int)set_id, h->seed, (uint64_t)h->chain, it, (long long)h->h_regs.size(), h->d_regs, h->d_regchi, h->d_rcls,
                            h->d_ccnt, (long long)(h->mode == 1 ? h->ccnt_words : 0), h->d_abort, h->d_tup, h->d_tupc, h->d_tupg);
-        launch_tinv(h, (int)set_id);
+        launch_tinv(h);
         launch_sweep(h, tb0, tb1, nullptr);
         launch_variance(h, (int)set_id, it);
         HCHK(hipStreamSynchronize(h->stream));

@@ -82,21 +82,6 @@ __device__ inline int t_chol1(const double *S, int k, double *L) {
     return t_chol(S, k, L);
 }
 
-// Runs of LINEAR blocks (every lane BayesPR or unowned or, in a fine-seam call, of another set than the one being sampled): their chain
-// is dlt = T e0 with T formed by k_tinv.  Block ranges [lo, hi) in ascending order, as kernel arguments
-// -- the sampler's DMA wave and the streamers' L2 warming need "is block t linear" without a memory access.  Linear blocks beyond the
-// NGP_TRANGES-th run take the 64-step chain (the blocked oracle applies the same rule).
-#define NGP_TRANGES 4
-struct LinRanges {
-    int lo[NGP_TRANGES], hi[NGP_TRANGES];
-};
-__host__ __device__ inline bool block_linear(const LinRanges &L, const int t) {
-    bool r = false;
-#pragma unroll
-    for (int i = 0; i < NGP_TRANGES; i++) r = r || (t >= L.lo[i] && t < L.hi[i]);
-    return r;
-}
-
 struct DReg {  // one BayesPR variance region
     long long seg0;
     int nseg, set, rg, vb;

@@ -387,11 +387,11 @@ __device__ __attribute__((always_inline)) inline void tinv_step(double (&acc)[NG
                       "+v"(acc[16 * p + 15]));
     if constexpr (n1 < 160) tinv_step<n1>(acc, a0, a1, b0, b1, G1, cv, i);
 }
-__global__ __launch_bounds__(64) void k_tinv(const double *__restrict__ gramx, int D, const double *__restrict__ c, LinRanges lin,
-                                             double *__restrict__ tinv, const unsigned *__restrict__ abort_w) {
+__global__ __launch_bounds__(64) void k_tinv(const double *__restrict__ gramx, int D, const double *__restrict__ c,
+                                             const unsigned *__restrict__ blin, double *__restrict__ tinv, const unsigned *__restrict__ abort_w) {
     if (abort_w && *abort_w != 0u) return;
     const int t = blockIdx.x, i = threadIdx.x;
-    if (!block_linear(lin, t)) return;  // (the host lists the runs of linear blocks: ngp_api.hip, linear_ranges)
+    if (blin[t] == 0u) return;  // (which blocks are linear is static for a model: the host's table, ngp_api.hip sync_linear_blocks)
     const double *G1 = gramx + (size_t)t * D * (NGP_BLK * NGP_BLK);  // element (m, j) at m * 64 + j, zero for j <= m
     const double cv = c[(size_t)t * NGP_BLK + i];                    // lane m holds c_m
     double acc[NGP_BLK];
@@ -489,7 +489,7 @@ __global__ __launch_bounds__(256) void k_recur(const double *__restrict__ part, 
                                                double *__restrict__ varBeta, double *__restrict__ dlt, const double *__restrict__ rcls,
                                                long long Ppad, const double *__restrict__ rhs0, const DScal *__restrict__ sc,
                                                const DTup *__restrict__ tup, const double *__restrict__ tupc, const double *__restrict__ tupg,
-                                               const double *__restrict__ tinv, LinRanges lin) {
+                                               const double *__restrict__ tinv, const unsigned *__restrict__ blin) {
     __shared__ double gs[32 * NGP_BLK];
     const int tid = threadIdx.x, j = tid & 63, g4 = tid >> 6;
     const int ngroups = (S + NGP_GRP - 1) / NGP_GRP;
@@ -510,7 +510,7 @@ __global__ __launch_bounds__(256) void k_recur(const double *__restrict__ part, 
     const double r = __builtin_fma(gd, bo, tot);
     const int si0 = setof[k];
     const int meth0 = (si0 >= 0) ? sets[si0].method : -1;
-    if (tinv && block_linear(lin, t)) {  // linear block: dlt = T e0 (k_tinv)
+    if (tinv && blin[t] != 0u) {  // linear block: dlt = T e0 (k_tinv)
         const double *Tt = tinv + (size_t)t * (NGP_BLK * NGP_BLK) + j;  // element (i, j) = T[j][i]
         const double e0 = __builtin_fma(r, cc, ww);
         gs[j] = e0;  // (only wave 0 is left and it has read its group sums: LDS serves a wave in order, no barrier needed)

@@ -207,17 +207,31 @@ __device__ inline unsigned sld_u32(const unsigned *p) {
     return v;
 }
 
+// two words in one scalar round trip: p0 past the scalar cache (a word others write), p1 through it (read-only during the launch)
+__device__ inline void sld_u32x2(const unsigned *p0, const unsigned *p1, unsigned &v0, unsigned &v1) {
+    const unsigned long long a0 = (unsigned long long)p0, a1 = (unsigned long long)p1;
+    p0 = (const unsigned *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a0 >> 32)) << 32) |
+                            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a0));
+    p1 = (const unsigned *)(((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(a1 >> 32)) << 32) |
+                            (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)a1));
+    asm volatile("s_load_dword %0, %2, 0x0 glc\n\ts_load_dword %1, %3, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=&s"(v0), "=&s"(v1) : "s"(p0), "s"(p1) : "memory");
+}
 // the 32 KiB the sampler stages for the chain of block t: T of a linear block, else the one-sided diagonal Gram block
-__device__ inline const double *chain_block_src(const SweepArgs &A, const long long t) {
-    const bool lin = block_linear(A.lin, (int)t);
+__device__ inline const double *chain_block_src(const SweepArgs &A, const long long t, const bool lin) {
     return lin ? A.tinv + (size_t)t * (NGP_BLK * NGP_BLK) : A.gramx + ((size_t)t * A.D + 0) * (NGP_BLK * NGP_BLK);
 }
-// L2 warming (speed only): the 1 KiB piece at byte offset `off` of what the sampler CU reads for block t -- [chain block | cross Gram
-// planes 1, 2, ..]: the chain block is T for a linear block (tinv), the diagonal Gram block otherwise.  (T not warmed: the sampler's
-// 32 KiB per block then come from HBM, and every other load of that CU queues behind them -- 10k x 100k 1.80 -> 2.05 us per block.)
-__device__ __attribute__((always_inline)) inline const char *warm_piece(const SweepArgs &A, const long long t, const size_t off, const int D) {
-    if (off < (size_t)(NGP_BLK * NGP_BLK * sizeof(double)) && block_linear(A.lin, (int)t)) return (const char *)(A.tinv + (size_t)t * (NGP_BLK * NGP_BLK)) + off;
-    return (const char *)(A.gramx + (size_t)t * D * (NGP_BLK * NGP_BLK)) + off;
+// L2 warming (speed only) of what the sampler CU reads for block t, as 1 KiB pieces at byte offset `off` of
+//   [ T (models with linear blocks) | diagonal Gram block (unless every block is linear) | cross Gram planes 1, 2, .. ]
+// (T not warmed: the sampler's 32 KiB per block then come from HBM and every other load of that CU queues behind them -- 10k x 100k
+// 1.80 -> 2.05 us per block.  No look at the block's flag here: a streamer's loader would pay a memory round trip for it.)
+__device__ __attribute__((always_inline)) inline size_t warm_bytes(const SweepArgs &A, const int planes) {
+    return (size_t)(planes + ((A.tinv && !A.lin_all) ? 1 : 0)) * (NGP_BLK * NGP_BLK * sizeof(double));
+}
+// (per block: tb = T of the block, gb = its Gram planes; a piece at virtual offset off comes from tb + off below t_hi, else from
+// gb + off - shift; t_hi and shift are fixed for the sweep -- one scalar compare per piece, nothing else in the loaders' issue loops)
+__device__ __attribute__((always_inline)) inline size_t warm_t_hi(const SweepArgs &A) { return A.tinv ? (size_t)(NGP_BLK * NGP_BLK * sizeof(double)) : 0; }
+__device__ __attribute__((always_inline)) inline size_t warm_shift(const SweepArgs &A) {
+    return (A.tinv && !A.lin_all) ? (size_t)(NGP_BLK * NGP_BLK * sizeof(double)) : 0;
 }
 
 // gemv4: v_j = sum_k G[k][j] * d[k], four interleaved partial sums, ((s0+s1)+(s2+s3))
@@ -320,7 +334,7 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
     const unsigned my_xcc = xcc_id() + 1u;
     const int nslice = max(1, S / 8);
     const int slice = (s / 8) % nslice;
-    const size_t gram_bytes = (size_t)DT * NGP_BLK * NGP_BLK * sizeof(double);
+    const size_t gram_bytes = warm_bytes(A, DT), w_thi = warm_t_hi(A), w_shift = warm_shift(A);
     const size_t slice_bytes = ((gram_bytes / nslice + 1023) / 1024) * 1024;
     bool same_xcd = false;
     // Lag >= NGP_LAZY_LAG (long lags have the slack for a slightly later hand-off): the publisher (wave 1) does not sit out
@@ -354,9 +368,11 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
                 if (u + 1 < nb) dma_tile(u + 1);
                 if ((u & 7) == 0 && !same_xcd) same_xcd = (ld_u32(A.xcc_w) == my_xcc);
                 if (same_xcd && u + 1 < nb) {  // fire-and-forget: the lines only have to reach this XCD's L2
+                    const char *gb = (const char *)(A.gramx + (size_t)(A.t0 + u + 1) * DT * NGP_BLK * NGP_BLK) - w_shift;
+                    const char *tb = (const char *)(A.tinv + (size_t)(A.t0 + u + 1) * NGP_BLK * NGP_BLK);
                     const size_t lo = (size_t)slice * slice_bytes, hi = min((size_t)(slice + 1) * slice_bytes, gram_bytes);
                     for (size_t off = lo + (size_t)(wv - 4) * 1024; off + 1024 <= hi; off += 3 * 1024)
-                        dma16_lds(warm_piece(A, A.t0 + u + 1, off, DT) + (size_t)j * 16, scratch + (wv - 4) * 1024);
+                        dma16_lds((off < w_thi ? tb : gb) + off + (size_t)j * 16, scratch + (wv - 4) * 1024);
                 }
             } else if (wv == 7 && dbg_mode != 1) {
                 if (DT <= 2 || u == 0) poll_dlt(u);  // lags 1-2 cannot poll ahead: the flag would (transitively, through the
@@ -743,7 +759,7 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows(const S
         const int nslice = max(1, S / 8);
         const int slice = (s / 8) % nslice;
         // (only the planes the sampler itself reads: the diagonal block and the near lags; the far ones go to the reducers' CUs)
-        const size_t gram_bytes = (size_t)min(DT, A.near + 1) * NGP_BLK * NGP_BLK * sizeof(double);
+        const size_t gram_bytes = warm_bytes(A, min(DT, A.near + 1)), w_thi = warm_t_hi(A), w_shift = warm_shift(A);
         const size_t slice_bytes = ((gram_bytes / nslice + 1023) / 1024) * 1024;
         bool same_xcd = false, xcc_known = false;
         __builtin_amdgcn_s_setprio(3);  // the loader's few scalar instructions go first on its SIMD: a late request costs the whole CU
@@ -765,8 +781,10 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows(const S
                 same_xcd = (x == my_xcc);
             }
             if (same_xcd && u + 1 < nb && !no_dma) {
+                const char *gb = (const char *)(A.gramx + (size_t)(A.t0 + u + 1) * DT * NGP_BLK * NGP_BLK) - w_shift;
+                const char *tb = (const char *)(A.tinv + (size_t)(A.t0 + u + 1) * NGP_BLK * NGP_BLK);
                 const size_t lo = (size_t)slice * slice_bytes, hi = min((size_t)(slice + 1) * slice_bytes, gram_bytes);
-                for (size_t off = lo; off + 1024 <= hi; off += 1024) dma16_warm(scratch0, warm_piece(A, A.t0 + u + 1, off, DT), voff);
+                for (size_t off = lo; off + 1024 <= hi; off += 1024) dma16_warm(scratch0, (off < w_thi ? tb : gb) + off, voff);
             }
             // (Requesting more of tile u+2 here -- into the slots of tile u, which the row waves have left 1.7 us into the block,
             // so that more than H requests are in flight while the loader sits at the barrier -- was built and measured: 50k x 600k
@@ -1154,7 +1172,7 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows_tall(co
         const int W = S / V;
         const int nslice = max(1, W / 8);
         const int slice = (s / 8) % nslice;
-        const size_t gram_bytes = (size_t)min(DT, A.near + 1) * NGP_BLK * NGP_BLK * sizeof(double);
+        const size_t gram_bytes = warm_bytes(A, min(DT, A.near + 1)), w_thi = warm_t_hi(A), w_shift = warm_shift(A);
         const size_t slice_bytes = ((gram_bytes / nslice + 1023) / 1024) * 1024;
         bool same_xcd = false, xcc_known = false;
         __builtin_amdgcn_s_setprio(3);
@@ -1172,8 +1190,10 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows_tall(co
                     same_xcd = (x == my_xcc);
                 }
                 if (same_xcd && u + 1 < nb) {
+                    const char *gb = (const char *)(A.gramx + (size_t)(A.t0 + u + 1) * DT * NGP_BLK * NGP_BLK) - w_shift;
+                    const char *tb = (const char *)(A.tinv + (size_t)(A.t0 + u + 1) * NGP_BLK * NGP_BLK);
                     const size_t lo = (size_t)slice * slice_bytes, hi = min((size_t)(slice + 1) * slice_bytes, gram_bytes);
-                    for (size_t off = lo; off + 1024 <= hi; off += 1024) dma16_warm(scratch0, warm_piece(A, A.t0 + u + 1, off, DT), voff);
+                    for (size_t off = lo; off + 1024 <= hi; off += 1024) dma16_warm(scratch0, (off < w_thi ? tb : gb) + off, voff);
                 }
             }
             dma_quads(w + 1, H, NQ, base1);
@@ -1412,7 +1432,7 @@ __device__ inline CoefRegs load_coef(const SweepArgs &A, long long k) {
     c.ww = A.w[k];
     c.st = A.q[k];  // inclusion threshold on f = c r: included iff |f| > st (st < 0: always)
     c.gd = A.mpm[k];
-    c.tf = block_linear(A.lin, (int)(k >> 6)) ? 1u : 0u;
+    c.tf = A.lin_all ? 1u : (A.blin ? A.blin[k >> 6] : 0u);
     return c;
 }
 // group sums of local block u -> per-lane total (lane 0 polls, whole wave loads); false on abort
@@ -1596,10 +1616,10 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
     }
     // prologue: diagonal Gram block of local block 0 (all waves) and its group sums (wave 2)
     {
-        const double *gd = chain_block_src(A, A.t0);
+        const double *gd = chain_block_src(A, A.t0, A.lin_all || (A.blin && A.blin[A.t0] != 0u));
         for (int idx = tid; idx < 4096; idx += NGP_WG) Gd[idx] = gd[idx];
         if (nb > 1) {
-            const double *gd1 = chain_block_src(A, A.t0 + 1);
+            const double *gd1 = chain_block_src(A, A.t0 + 1, A.lin_all || (A.blin && A.blin[A.t0 + 1] != 0u));
             for (int idx = tid; idx < 4096; idx += NGP_WG) Gd[4096 + idx] = gd1[idx];
         }
     }
@@ -1630,20 +1650,13 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
             const int t = A.t0 + u, buf = u & 1, slot = u % NGP_RING, rs = u & 3;
             if (u + 1 < nb) nxt = load_coef(A, (long long)(t + 1) * NGP_BLK + j);
             if (dbg && j == 0) dbg[4 * (size_t)u] = wall_clock64();
-            // The lane's 64 values of the block staged for the chain -- column j of the one-sided diagonal Gram block, or row j of
-            // T = inv(L) for a linear block (k_tinv) -- go into registers BEFORE the total of the block is awaited: off the serial
-            // path.  (Always, for every kind of block: loaded under a condition, the array became loop-carried -- its "undefined"
-            // value on the other path is the previous block's -- and the kernel spilled.)
-            // The lean kernel only: beside the Tuple / BayesR chains of the full kernels the 128 early registers spill; there the
-            // step chains load their Gram rows behind the wait, as they always did, and the inverse form reads T chunk by chunk.
-            constexpr bool PRELOAD = (!TUP && RCLS == 0);
+            // Linear block (k_tinv): its chain is dlt = T e0, T staged in place of the diagonal Gram block.  (Row j of T is read chunk by
+            // chunk inside the product, behind the total: loaded into registers ahead of the wait -- right after the block's barrier --
+            // its 64 LDS reads compete with the lag-1 product of wave 5, which is what the chain waits for: measured slower.)
+            constexpr bool PRELOAD = false;
             const bool tform = __builtin_amdgcn_readfirstlane((int)cur.tf) != 0;
             const double *gdb = Gd + (u % 3) * 4096 + j;
             double G[NGP_BLK];
-            if constexpr (PRELOAD) {
-#pragma unroll
-                for (int kk = 0; kk < NGP_BLK; kk++) G[kk] = gdb[kk * NGP_BLK];
-            }
             double tot;
             if (D == 1) {  // lag 1: nothing can be fetched or corrected ahead
                 tot = r0[rs * NGP_BLK + j];
@@ -1908,9 +1921,14 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
         // issued per block, and only the PREVIOUS block's 32 instructions have to be complete at the barrier
         // (counted vmcnt), so each transfer has a whole block period to land.  This wave never reads LDS (an LDS read
         // would make the compiler drain the DMA): it sees an abort through a scalar load of the abort word.
+        // (is block u+2 linear: the word travels with the abort word of the previous block's end -- one scalar round trip for both,
+        // outside vmcnt, which counts this wave's DMA)
+        const bool per_block = !A.lin_all && A.blin != nullptr;
+        unsigned lin2 = A.lin_all ? 1u : 0u;
+        if (per_block && nb > 2) lin2 = sld_u32(A.blin + A.t0 + 2);
         for (int u = 0; u < nb; ++u) {
             if (u + 2 < nb) {
-                const char *gsrc = (const char *)chain_block_src(A, A.t0 + u + 2) + (size_t)j * 16;
+                const char *gsrc = (const char *)chain_block_src(A, A.t0 + u + 2, lin2 != 0u) + (size_t)j * 16;
                 char *gdst = (char *)(Gd + ((u + 2) % 3) * 4096);
 #pragma unroll
                 for (int i = 0; i < 32; i++)
@@ -1922,7 +1940,10 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
             }
             if (dbg && j == 0) dbg[NGP_DBG_WAVES + 8 * (size_t)u + wv] = wall_clock64();
             wg_barrier();
-            if (sld_u32(A.abort_w) != 0u) return;
+            unsigned ab;
+            if (per_block && u + 3 < nb) sld_u32x2(A.abort_w, A.blin + A.t0 + u + 3, ab, lin2);
+            else ab = sld_u32(A.abort_w);
+            if (ab != 0u) return;
         }
     } else if (wv == 5) {
         // finishes r0 for the critical wave: total - ((lag-3 + lag-2 terms) + lag-1 term), then raises the LDS flag.
@@ -2185,7 +2206,7 @@ __device__ __attribute__((always_inline)) inline void role_streamer_multi(const 
     const unsigned my_xcc = xcc_id() + 1u;
     const int nslice = max(1, S / 8);
     const int slice = (s / 8) % nslice;
-    const size_t gram_bytes = (size_t)DT * NGP_BLK * NGP_BLK * sizeof(double);
+    const size_t gram_bytes = warm_bytes(A, DT), w_thi = warm_t_hi(A), w_shift = warm_shift(A);
     const size_t slice_bytes = ((gram_bytes / nslice + 1023) / 1024) * 1024;
     bool same_xcd = false;
     constexpr bool LAZY = (DT >= NGP_LAZY_LAG);
@@ -2211,9 +2232,11 @@ __device__ __attribute__((always_inline)) inline void role_streamer_multi(const 
                 if (u + 1 < nb) dma_tile(u + 1);
                 if ((u & 7) == 0 && !same_xcd) same_xcd = (ld_u32(A.xcc_w) == my_xcc);
                 if (same_xcd && u + 1 < nb) {
+                    const char *gb = (const char *)(A.gramx + (size_t)(A.t0 + u + 1) * DT * NGP_BLK * NGP_BLK) - w_shift;
+                    const char *tb = (const char *)(A.tinv + (size_t)(A.t0 + u + 1) * NGP_BLK * NGP_BLK);
                     const size_t lo = (size_t)slice * slice_bytes, hi = min((size_t)(slice + 1) * slice_bytes, gram_bytes);
                     for (size_t off = lo + (size_t)(wv - 4) * 1024; off + 1024 <= hi; off += 3 * 1024)
-                        dma16_lds(warm_piece(A, A.t0 + u + 1, off, DT) + (size_t)j * 16, scratch + (wv - 4) * 1024);
+                        dma16_lds((off < w_thi ? tb : gb) + off + (size_t)j * 16, scratch + (wv - 4) * 1024);
                 }
             }
             try_signal(false);
@@ -2423,7 +2446,7 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows_multi(c
         const unsigned my_xcc = xcc_id() + 1u;
         const int nslice = max(1, S / 8);
         const int slice = (s / 8) % nslice;
-        const size_t gram_bytes = (size_t)min(DT, A.near + 1) * NGP_BLK * NGP_BLK * sizeof(double);
+        const size_t gram_bytes = warm_bytes(A, min(DT, A.near + 1)), w_thi = warm_t_hi(A), w_shift = warm_shift(A);
         const size_t slice_bytes = ((gram_bytes / nslice + 1023) / 1024) * 1024;
         bool same_xcd = false, xcc_known = false;
         __builtin_amdgcn_s_setprio(3);
@@ -2439,8 +2462,10 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows_multi(c
                 same_xcd = (x == my_xcc);
             }
             if (same_xcd && u + 1 < nb) {
+                const char *gb = (const char *)(A.gramx + (size_t)(A.t0 + u + 1) * DT * NGP_BLK * NGP_BLK) - w_shift;
+                const char *tb = (const char *)(A.tinv + (size_t)(A.t0 + u + 1) * NGP_BLK * NGP_BLK);
                 const size_t lo = (size_t)slice * slice_bytes, hi = min((size_t)(slice + 1) * slice_bytes, gram_bytes);
-                for (size_t off = lo; off + 1024 <= hi; off += 1024) dma16_warm(scratch0, warm_piece(A, A.t0 + u + 1, off, DT), voff);
+                for (size_t off = lo; off + 1024 <= hi; off += 1024) dma16_warm(scratch0, (off < w_thi ? tb : gb) + off, voff);
             }
             if (u + 1 < nb) dma_quads(u + 1, H, NQ, base1);
             int n2 = 0;

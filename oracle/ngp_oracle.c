@@ -1372,7 +1372,6 @@ static void iter_blocked(ora_t *h) {
     const int64_t D = h->D;
     double *part = (double *)malloc(sizeof(double) * S * BLK);
     double *hist = (double *)calloc((size_t)NBLK * BLK, sizeof(double)); /* dlt of every block */
-    int lin_runs = 0, prev_raw_linear = 0;
     for (int64_t tb = 0; tb < NBLK + D; tb++) {
         if (tb >= D && h->storage == 1) { /* compact storage: y_i -= (sum_j g_ij dlt_j - sum_j m_j dlt_j), valid rows only */
             const int64_t a = tb - D;
@@ -1476,13 +1475,10 @@ static void iter_blocked(ora_t *h) {
             if (lane_set[j] >= 0 && h->sets[lane_set[j]].method == METHOD_R) has_r = 1;
             if (lane_set[j] >= 0 && h->sets[lane_set[j]].method == METHOD_T) has_t = lane_set[j];
         }
-        /* linear block: every lane BayesPR or unowned.  The device passes the RUNS of linear blocks as kernel arguments, four of
-           them (csrc/ngp_common.h, LinRanges): linear blocks of a fifth run and beyond take the 64 steps. */
+        /* linear block: every lane BayesPR or unowned */
         int raw_linear = 1;
         for (int j = 0; j < BLK; j++)
             if (lane_set[j] >= 0 && h->sets[lane_set[j]].method != METHOD_PR) raw_linear = 0;
-        if (raw_linear && !prev_raw_linear) lin_runs++;
-        prev_raw_linear = raw_linear;
         for (int j = 0; j < BLK; j++) {
             /* group sums: shards of a group added in order */
             double gs[64];
@@ -1622,7 +1618,7 @@ static void iter_blocked(ora_t *h) {
            (k_tinv) -- the same chain in real arithmetic, a 64 x 64 product instead of 64 dependent cross-lane steps.
            Formation, column i of T (lane i of k_tinv): x_m = 0 (m < i), 1 (m = i), -(c_m acc_m) (m > i); after every x_m:
            acc_j = fma(G[m][j], x_m, acc_j) for j > m.  Application: four accumulators over i mod 4, ((s0+s1)+(s2+s3)). */
-        const int linear = h->tform && raw_linear && lin_runs <= 4;
+        const int linear = h->tform && raw_linear;
         if (linear) {
             double Tm[BLK][BLK];
             for (int i = 0; i < BLK; i++) {
