@@ -105,7 +105,9 @@ struct ngp_handle {
     int D = 1;         // Gram planes stored per block (= lag in mode 1, 1 in mode 0)
     int NG = 1;        // reducer groups = ceil(S/32)
     int cu_count = 256;
-    double *d_cpart = nullptr, *d_cgsum = nullptr, *d_cdlt = nullptr;
+    double *d_cdlt = nullptr;
+    unsigned long long *d_cacc = nullptr;   // fixed-point accumulators of X_t'ycorr (inside d_ccnt: zeroed with the counters by k_prep)
+    double mpm_max = 0.0;                   // max_j x_j'x_j of the panel (scale of the accumulators, k_head)
     unsigned long long *d_cdltg = nullptr;  // dlt as tagged granules
     unsigned launch_seq = 0;                // launch nonce of the granule tags
     unsigned *d_ccnt = nullptr, *d_abort = nullptr;
@@ -423,6 +425,7 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P, ngp_handle *owner = nullptr
     const size_t pp = (size_t)h->Ppad;
     if (owner) {
         h->d_tiles = owner->d_tiles; h->d_mean = owner->d_mean; h->d_gramx = owner->d_gramx; h->d_mpm = owner->d_mpm;
+        h->mpm_max = owner->mpm_max;
         h->pm = owner->pm; h->pm->refs.fetch_add(1);
     } else {
     // column means: what the analytic centring of the compact storage uses; kept for the fp32 tiles too (ngp_get_storage: a host
@@ -513,18 +516,27 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P, ngp_handle *owner = nullptr
         if (wg_per_cu < 1 || 1 + h->NG + h->S / h->V > (int64_t)wg_per_cu * h->cu_count)
             return fail(h, NGP_ERR_STATE, "persistent sweep: grid of " + std::to_string(1 + h->NG + h->S / h->V) + " workgroups cannot be co-resident (" +
                                               std::to_string(wg_per_cu) + " per CU x " + std::to_string(h->cu_count) + " CUs); use ngp_configure(mode 0)");
-        if ((rc = dalloc(h, &h->d_cpart, (size_t)NGP_RING * h->S * NGP_BLK))) return rc;
-        if ((rc = dalloc(h, &h->d_cgsum, (size_t)NGP_RING * h->NG * NGP_BLK))) return rc;
         if ((rc = dalloc(h, &h->d_cdlt, (size_t)NGP_RING * NGP_BLK))) return rc;
         if ((rc = dalloc(h, &h->d_cdltg, (size_t)NGP_RING * NGP_BLK * 2))) return rc;
-        // hand-off counters | census counters (one line) | census table (placement of each workgroup, 2 words each); all zeroed by k_prep
-        h->census_off = (size_t)NGP_RING * h->NG * 32 + (size_t)NGP_RING * 32 + 32;
+        // fixed-point accumulators (RING x 8 copies x 64 x 8 bytes) | dlt flag (one line) | census counters (one line) | census table
+        // (placement of each workgroup, 2 words each); all zeroed by k_prep
+        h->census_off = (size_t)NGP_RING * NGP_FX_COPIES * NGP_BLK * 2 + 32;
         h->ccnt_words = h->census_off + 32 + 2 * (size_t)320;  // (320 >= any grid, also the fused grid of K chains per pass)
         if ((rc = dalloc(h, &h->d_ccnt, h->ccnt_words))) return rc;
         h->d_census_tbl = (unsigned long long *)(h->d_ccnt + h->census_off + 32);
     }
     if ((rc = dalloc(h, &h->d_abort, 32))) return rc;
     HCHK(hipStreamSynchronize(h->stream));
+    return NGP_OK;
+}
+
+// max_j x_j'x_j: with ycorr'ycorr it bounds every X_t'ycorr (the scale of the fixed-point accumulators, k_head)
+int refresh_mpm_max(ngp_handle *h) {
+    std::vector<double> m((size_t)h->Ppad);
+    HCHK(hipMemcpy(m.data(), h->d_mpm, (size_t)h->Ppad * sizeof(double), hipMemcpyDeviceToHost));
+    double mx = 0.0;
+    for (double v : m) if (v > mx) mx = v;
+    h->mpm_max = mx;
     return NGP_OK;
 }
 
@@ -549,7 +561,7 @@ int build_gram8(ngp_handle *h) {  // compact storage: exact integer dot products
     if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("gram: ") + hipGetErrorString(e));
     e = hipGetLastError();
     if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("gram launch: ") + hipGetErrorString(e));
-    return NGP_OK;
+    return refresh_mpm_max(h);
 }
 
 int build_gram(ngp_handle *h) {
@@ -579,7 +591,7 @@ int build_gram(ngp_handle *h) {
     if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("gram: ") + hipGetErrorString(e));
     e = hipGetLastError();
     if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("gram launch: ") + hipGetErrorString(e));
-    return NGP_OK;
+    return refresh_mpm_max(h);
 }
 
 // ---- host panels in Float64 / Float32, whole or in column ranges (ngp_begin_panel / ngp_panel_columns_* / ngp_end_panel) ----
@@ -745,11 +757,10 @@ void fill_sweep_args(ngp_handle *h, int64_t tb0, int64_t tb1, SweepArgs &A) {
     A.setof = h->d_setof; A.vbidx = h->d_vbidx; A.sets = h->d_sets; A.varBeta = h->d_varBeta;
     A.rcls = h->d_rcls; A.rhs0 = h->d_rhs0; A.scal = h->d_scal; A.Ppad = h->Ppad;
     A.tup = h->ntuple ? h->d_tup : nullptr; A.tupc = h->d_tupc; A.tupg = h->d_tupg;
-    A.part = h->d_cpart; A.gsum = h->d_cgsum; A.dlt = h->d_cdlt; A.dltg = h->d_cdltg;
+    A.acc = (unsigned long long *)h->d_ccnt; A.dlt = h->d_cdlt; A.dltg = h->d_cdltg;
     h->launch_seq = (h->launch_seq % 4095u) + 1u;  // 1..4095: never the zero the ring is born with
     A.nonce = h->launch_seq;
-    A.cnt_part = h->d_ccnt; A.cnt_gs = h->d_ccnt + (size_t)NGP_RING * h->NG * 32;
-    A.flag_dlt = A.cnt_gs + (size_t)NGP_RING * 32; A.abort_w = h->d_abort; A.xcc_w = h->d_abort + 16;
+    A.flag_dlt = h->d_ccnt + (size_t)NGP_RING * NGP_FX_COPIES * NGP_BLK * 2; A.abort_w = h->d_abort; A.xcc_w = h->d_abort + 16;
     A.census = (h->dbg_mode == 0) ? h->d_ccnt + h->census_off : nullptr;  // timing modes leave roles out: no census there
     A.census_tbl = h->d_census_tbl; A.iter_tag = (unsigned)(h->iter + 1);
     A.census_fail = (h->dbg_census_fail_iter > 0 && !h->exclusive) ? (unsigned)h->dbg_census_fail_iter : 0u;
@@ -853,6 +864,9 @@ int check_abort(ngp_handle *h, int64_t *iter_failed = nullptr) {
     if (w[0] == NGP_ABORT_CENSUS)
         return fail(h, NGP_ERR_HIP, "persistent sweep: the grid did not become resident although this call had leased the whole device (" +
                                         census_report(h) + "): another process holding CUs?  The chain state is invalid until ngp_set_y / ngp_set_state");
+    if (w[0] == 7u)  // NGP_ABORT_FX
+        return fail(h, NGP_ERR_HIP, "persistent sweep: a partial dot product left the fixed-point range of its accumulator (non-finite residual or effects, "
+                                    "or the residual grew more than 32-fold within one sweep); the chain state is invalid until ngp_set_y / ngp_set_state");
     return fail(h, NGP_ERR_HIP, "persistent sweep kernel gave up waiting (role code " + std::to_string(w[0]) +
                                     "): workgroups not co-resident (another kernel holding CUs?) or a hand-off was lost; the chain "
                                     "state is invalid until ngp_set_y / ngp_set_state");
@@ -895,7 +909,7 @@ void iteration_pre(ngp_handle *h, int64_t trace_idx, bool resume_mid) {  // ever
     const uint64_t it = (uint64_t)(h->iter + 1);
     if (!resume_mid) {
     hipLaunchKernelGGL(k_head, dim3(1), dim3(1024), 0, h->stream, h->d_ycorr, (long long)h->L, (long long)h->N, h->d_scal, h->e_df,
-                       h->e_scale, h->intercept, 1, h->seed, (uint64_t)h->chain, it, h->d_tr_varE, h->d_tr_b, (long long)trace_idx, h->d_abort);
+                       h->e_scale, h->intercept, 1, h->seed, (uint64_t)h->chain, it, h->d_tr_varE, h->d_tr_b, (long long)trace_idx, h->d_abort, h->mpm_max);
     for (size_t f = 0; f < h->fix.size(); f++)  // the other fixed-effect sets, in the order they were added (src/samplers.jl:39-41)
         hipLaunchKernelGGL(k_fixed, dim3(1), dim3(1024), 0, h->stream, h->d_ycorr, (long long)h->N, h->fix[f].d_X, (int)h->fix[f].ncol, h->fix[f].d_xpx0,
                            h->fix[f].d_xpxR, h->fix[f].d_lhs0, h->fix[f].d_rhs0, h->d_bfix + h->fix[f].off, h->d_scal, (int)f, h->seed,
@@ -1135,7 +1149,7 @@ int32_t ngp_destroy(ngp_handle *h) {
     if (h->stream) (void)hipStreamSynchronize(h->stream);
     sample_close(h);
     release_panel(h);
-     dfree(h->d_cpart); dfree(h->d_cgsum); dfree(h->d_cdlt); dfree(h->d_cdltg); dfree(h->d_rcls); dfree(h->d_seg_set); dfree(h->d_ccnt); dfree(h->d_abort); dfree(h->d_dbg); dfree(h->d_mpm); dfree(h->d_lhs0); dfree(h->d_rhs0); dfree(h->d_beta);
+     dfree(h->d_cdlt); dfree(h->d_cdltg); dfree(h->d_rcls); dfree(h->d_seg_set); dfree(h->d_ccnt); dfree(h->d_abort); dfree(h->d_dbg); dfree(h->d_mpm); dfree(h->d_lhs0); dfree(h->d_rhs0); dfree(h->d_beta);
     dfree(h->d_c); dfree(h->d_w); dfree(h->d_q); dfree(h->d_T); dfree(h->d_chi); dfree(h->d_setof); dfree(h->d_loc);
     dfree(h->d_tinv); dfree(h->d_blin);
     dfree(h->d_vbidx); dfree(h->d_delta); dfree(h->d_sum_beta); dfree(h->d_sum_beta2); dfree(h->d_sum_delta);
@@ -1932,6 +1946,9 @@ int32_t ngp_sweep_set(ngp_handle *h, int32_t set_id, double varE, double *ycorr,
         if (hs.method != NGP_METHOD_BAYESPR && hs.method != NGP_METHOD_TUPLE)
             hipLaunchKernelGGL(k_set_pi, dim3(1), dim3(1), 0, h->stream, h->d_sets, (int)set_id, piHat[0], piHat[1]);
         hipLaunchKernelGGL(k_set_varE, dim3(1), dim3(1), 0, h->stream, h->d_scal, varE);
+        // (no draws, no intercept: ycorr'ycorr of the caller's residual sets the scale of the fixed-point accumulators)
+        hipLaunchKernelGGL(k_head, dim3(1), dim3(1024), 0, h->stream, h->d_ycorr, (long long)h->L, (long long)h->N, h->d_scal, h->e_df,
+                           h->e_scale, 0, 0, h->seed, (uint64_t)h->chain, it, (double *)nullptr, (double *)nullptr, (long long)0, h->d_abort, h->mpm_max);
         hipLaunchKernelGGL(k_prep, dim3((unsigned)(h->Ppad / 256 + 1)), dim3(256), 0, h->stream, (long long)h->Ppad, h->d_setof, h->d_loc,
                            h->d_vbidx, h->d_sets, h->d_scal, h->d_varBeta, h->d_mpm, h->d_lhs0, h->d_rhs0, h->d_beta, h->d_c, h->d_w,
                            h->d_q, h->d_T, h->d_chi, (int)set_id, h->seed, (uint64_t)h->chain, it, (long long)h->h_regs.size(), h->d_regs, h->d_regchi, h->d_rcls,

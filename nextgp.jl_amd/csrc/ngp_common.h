@@ -92,7 +92,53 @@ struct DScal {  // chain scalars
     double varE, iVarE, b, db;
     double sum_varE, sum_b;
     long long nKept;
+    double fx_scale, fx_inv;  // fixed-point scale of this iteration's dot-product accumulators and its reciprocal (powers of two, k_head)
 };
+
+// ------------------------------------------------------------------------------------------
+// X_t'ycorr over the shards as an ORDER-FREE sum.  Every shard partial p_s (and every far look-ahead
+// term -v_d) is scaled by a power of two, rounded to the nearest integer and added -- by a 64-bit integer atomic -- into the block's
+// accumulator: integer addition is associative, so the total does not depend on the order the terms arrive in, and the hand-off
+// needs no reducer stage (streamer -> reducer -> sampler was two cross-CU hops of the sweep's latency loop).  The low
+// NGP_FX_CNT_BITS bits of every term carry a 1: the accumulator counts its own terms, the reader knows when the sum is complete.
+//   term = (rn(p * scale) << CNT) + 1;   total = fx_to_f64(sum >> CNT) * (1 / scale);   complete: (sum & (2^CNT - 1)) == terms
+// scale = 2^(52 - E), 2^E > 16 sqrt(max_j x_j'x_j * ycorr'ycorr) at the head of the iteration (Cauchy-Schwarz bounds sum_s |p_s|
+// by the square root, so the sum stays below 2^48 of the 2^53 it may reach: 32 x head room for what ycorr does during the sweep);
+// a term beyond 2^53 stops the sweep (abort 7).
+// ------------------------------------------------------------------------------------------
+#define NGP_FX_CNT_BITS 10  // up to 1023 terms per block (699 shards of the tall layouts + far lags)
+#define NGP_FX_COPIES 8     // accumulator copies per block (shard s adds to copy s mod 8: eight memory lines share the atomics)
+// exact conversions (|x| <= 2^53: x is rounded to an integer first, then split into halves the 32-bit converts carry exactly)
+__host__ __device__ inline long long fx_from_f64(const double x) {
+    const double r = __builtin_rint(x);  // round to nearest, ties to even
+    const double hi = __builtin_floor(r * 0x1p-32);
+    const double lo = __builtin_fma(-hi, 0x1p32, r);
+    return (long long)(((unsigned long long)(unsigned)(int)hi << 32) | (unsigned long long)(unsigned)lo);
+}
+__host__ __device__ inline double fx_to_f64(const long long q) {  // = (double)q, one rounding
+    const double hi = (double)(int)(q >> 32), lo = (double)(unsigned)q;
+    return __builtin_fma(hi, 0x1p32, lo);
+}
+__host__ __device__ inline unsigned long long fx_term(const double p, const double scale) {
+    return ((unsigned long long)fx_from_f64(p * scale) << NGP_FX_CNT_BITS) + 1ull;
+}
+// scale exponent from m = max x'x * ycorr'ycorr: E = floor(ilogb(m) / 2) + 5 (2^E > 16 sqrt(m)), clamped; scale = 2^(52 - E)
+__host__ __device__ inline int fx_exponent(const double m) {
+    union { double d; unsigned long long u; } v;
+    v.d = m;
+    const int ef = (int)((v.u >> 52) & 0x7ffull);
+    int e2 = 0;
+    if (m > 0.0 && ef != 0x7ff) e2 = ef - 1023;
+    int e = (e2 >> 1) + 5;
+    if (e < -900) e = -900;
+    if (e > 900) e = 900;
+    return e;
+}
+__host__ __device__ inline double fx_pow2(const int e) {  // 2^e, -1022 <= e <= 1023
+    union { double d; unsigned long long u; } v;
+    v.u = (unsigned long long)(1023 + e) << 52;
+    return v.d;
+}
 
 __device__ inline double readlane_d(double v, int lane) {
     int lo = __double2loint(v), hi = __double2hiint(v);

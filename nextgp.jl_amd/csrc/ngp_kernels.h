@@ -23,7 +23,8 @@ namespace ngp {
 __global__ __launch_bounds__(1024) void k_head(double *__restrict__ ycorr, long long L, long long N, DScal *__restrict__ sc,
                                                double e_df, double e_scale, int intercept, int draw_varE, uint64_t seed,
                                                uint64_t chain, uint64_t it, double *__restrict__ tr_varE,
-                                               double *__restrict__ tr_b, long long trace_idx, const unsigned *__restrict__ abort_w) {
+                                               double *__restrict__ tr_b, long long trace_idx, const unsigned *__restrict__ abort_w,
+                                               double mpm_max) {
     if (abort_w && *abort_w != 0u) return;  // an earlier sweep of this call gave up (ngp_sweep_args.h, abort_w)
     __shared__ double wyy[16], wsy[16];
     __shared__ double s_db;
@@ -49,6 +50,11 @@ __global__ __launch_bounds__(1024) void k_head(double *__restrict__ ycorr, long 
         for (int k = 1; k < 16; k++) {
             yy = yy + wyy[k];
             sy = sy + wsy[k];
+        }
+        {   // fixed-point scale of this iteration's X_t'ycorr accumulators (ngp_common.h): from ycorr'ycorr as it stands here
+            const int fe = fx_exponent(mpm_max * yy);
+            sc->fx_scale = fx_pow2(52 - fe);
+            sc->fx_inv = fx_pow2(fe - 52);
         }
         double varE = sc->varE, iVarE = sc->iVarE;
         if (draw_varE) {
@@ -490,19 +496,19 @@ __global__ __launch_bounds__(256) void k_recur(const double *__restrict__ part, 
                                                long long Ppad, const double *__restrict__ rhs0, const DScal *__restrict__ sc,
                                                const DTup *__restrict__ tup, const double *__restrict__ tupc, const double *__restrict__ tupg,
                                                const double *__restrict__ tinv, const unsigned *__restrict__ blin) {
+    // the S shard partials as the order-free fixed-point sum of the persistent sweep (ngp_common.h): four waves, integer addition
     __shared__ double gs[32 * NGP_BLK];
+    __shared__ long long qs[4 * NGP_BLK];
     const int tid = threadIdx.x, j = tid & 63, g4 = tid >> 6;
-    const int ngroups = (S + NGP_GRP - 1) / NGP_GRP;
-    for (int g = g4; g < ngroups; g += 4) {
-        int s0 = g * NGP_GRP, s1 = min(s0 + NGP_GRP, S);
-        double v = part[(size_t)s0 * NGP_BLK + j];
-        for (int s = s0 + 1; s < s1; s++) v = v + part[(size_t)s * NGP_BLK + j];
-        gs[g * NGP_BLK + j] = v;
+    const double fxs = sc->fx_scale, fxi = sc->fx_inv;
+    {
+        long long q = 0;
+        for (int s = g4; s < S; s += 4) q += fx_from_f64(part[(size_t)s * NGP_BLK + j] * fxs);
+        qs[g4 * NGP_BLK + j] = q;
     }
     __syncthreads();
     if (g4 != 0) return;
-    double tot = gs[j];
-    for (int g = 1; g < ngroups; g++) tot = tot + gs[g * NGP_BLK + j];
+    const double tot = fx_to_f64(((qs[j] + qs[NGP_BLK + j]) + (qs[2 * NGP_BLK + j] + qs[3 * NGP_BLK + j]))) * fxi;
     const long long k = (long long)t * NGP_BLK + j;
     const double *G = gramx + (size_t)t * D * NGP_BLK * NGP_BLK;
     const double gd = mpm[k];

@@ -101,6 +101,16 @@ __device__ inline bool wait_dlt_granules_all(const unsigned long long *dltg, con
         g1 = ld_u64(g + 1);
     }
 }
+// one term of the fixed-point accumulator of local block `slot` (ngp_common.h): fire and forget -- no acknowledgement is waited for,
+// no counter follows (the accumulator counts its own terms)
+#define NGP_ABORT_FX 7u  // abort code: a term outside the fixed-point range (a non-finite partial sum, or ycorr grew 32-fold within a sweep)
+__device__ __attribute__((always_inline)) inline void acc_add(unsigned long long *acc, unsigned *abort_w, const int slot, const int copy, const int lane,
+                                                              const double p, const double fxs) {
+    const double x = p * fxs;
+    if (!(__builtin_fabs(x) < 0x1p53)) { st_u32(abort_w, NGP_ABORT_FX); return; }
+    unsigned long long *a = acc + ((size_t)(slot * NGP_FX_COPIES + (copy & (NGP_FX_COPIES - 1))) * NGP_BLK + lane);
+    (void)__hip_atomic_fetch_add(a, ((unsigned long long)fx_from_f64(x) << NGP_FX_CNT_BITS) + 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 // XCC (XCD) id of the executing wave: HW_REG_XCC_ID (id 20), bits 3:0
 __device__ inline unsigned xcc_id() { return (unsigned)__builtin_amdgcn_s_getreg((3 << 11) | 20) & 0xFu; }
 __device__ inline void drain_vm() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
@@ -337,20 +347,10 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
     const size_t gram_bytes = warm_bytes(A, DT), w_thi = warm_t_hi(A), w_shift = warm_shift(A);
     const size_t slice_bytes = ((gram_bytes / nslice + 1023) / 1024) * 1024;
     bool same_xcd = false;
-    // Lag >= NGP_LAZY_LAG (long lags have the slack for a slightly later hand-off): the publisher (wave 1) does not sit out
-    // the round trip of its partial-sum store (store -> acknowledgement, about 1.4 us, then the counter).  It looks at its
-    // own VM_CNT (HW_REG_IB_STS) whenever it passes a phase boundary and counts the partial at the first boundary where the
-    // store has been acknowledged; it only blocks right before the next partial is stored.  Pays since the sampler stopped
-    // being the slower stage: 3.09 -> 2.86 ms at 10k x 100k, lag 8; at lags <= 6 the later hand-off costs more than it saves.
-    constexpr bool LAZY = (DT >= NGP_LAZY_LAG);
-    int sig_pending = -1;  // ring slot of the stored, not yet counted partial
-    auto try_signal = [&](bool force) {
-        if (!LAZY || wv != 1 || sig_pending < 0) return;
-        if (force) drain_vm();
-        else if ((__builtin_amdgcn_s_getreg((23 << 11) | 7) & 0xC0000Fu) != 0u) return;  // VM_CNT [3:0] and [23:22]
-        if (j == 0) atomicAdd(&A.cnt_part[((size_t)sig_pending * A.NG + g) * 32], 1u);
-        sig_pending = -1;
-    };
+    // (the partial sums leave as fire-and-forget atomic adds since round 4: the lazy counting of round 1-3 -- store, acknowledgement
+    // watched through VM_CNT, counter -- is gone with the counters)
+    const double fxs = A.scal->fx_scale;
+    auto try_signal = [&](bool) {};
     unsigned long long accA = 0, accB = 0, accC = 0, accP = 0, tt0 = 0;
     __syncthreads();
     for (int u0 = 0; u0 < nb + DT; u0 += DT) {
@@ -504,14 +504,7 @@ __device__ inline void role_streamer(const SweepArgs &A, const int s, char *smem
                 if (wv == 1 && dbg_mode != 1) {
                     const int slot = u % NGP_RING;
                     double p = ((red[j] + red[64 + j]) + (red[128 + j] + red[192 + j])) + ((red[256 + j] + red[320 + j]) + (red[384 + j] + red[448 + j]));
-                    try_signal(true);  // the previous partial, if its store was still under way at every boundary
-                    st_f64(&A.part[((size_t)slot * S + s) * NGP_BLK + j], p);
-                    if (LAZY) {
-                        sig_pending = slot;
-                    } else {
-                        drain_vm();
-                        if (j == 0) atomicAdd(&A.cnt_part[((size_t)slot * A.NG + g) * 32], 1u);
-                    }
+                    acc_add(A.acc, A.abort_w, slot, s, j, p, fxs);
                     if (j == 0) {
                         if (dbg && s == 0) dbg[NGP_DBG_STREAM + 2 * (size_t)u] = wall_clock64();
                         if (dbg && (u == 800 || u == 1200)) {
@@ -845,14 +838,8 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows(const S
         double mpub = 0.0;                    // publisher, compact storage: column mean of the block published next
         if (U8 && wv == NGP_ROWS_PUBW && nb > 0) mpub = A.mean[(size_t)A.t0 * NGP_BLK + lane];
         // publisher: the stored, not yet counted partial (ring slot), counted once VM_CNT of this wave reads zero
-        int sig_pending = -1;
-        auto try_signal = [&](bool force) __attribute__((always_inline)) {
-            if (wv != NGP_ROWS_PUBW || sig_pending < 0) return;
-            if (force) drain_vm();
-            else if ((__builtin_amdgcn_s_getreg((23 << 11) | 7) & 0xC0000Fu) != 0u) return;  // VM_CNT [3:0] and [23:22]
-            if (lane == 0) atomicAdd(&A.cnt_part[((size_t)sig_pending * A.NG + g) * 32], 1u);
-            sig_pending = -1;
-        };
+        const double fxs = A.scal->fx_scale;
+        auto try_signal = [&](bool) __attribute__((always_inline)) {};  // (nothing to count since the partial sums are atomic adds)
         // the 64 partial dot products of block u: the 7 chains in their fixed tree (compact storage: minus m_j x the shard's sum of y)
         auto publish = [&](const int u) __attribute__((always_inline)) {
             const int slot = u % NGP_RING;
@@ -864,10 +851,10 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows(const S
                 const double ms = mpub * sy;
                 p = p - ms;
             }
-            try_signal(true);  // the previous partial, if its store was still under way at every look
-            st_f64(&A.part[((size_t)slot * S + s) * NGP_BLK + lane], p);
-            sig_pending = slot;
+            // (the next block's column means are requested BEFORE the atomic add leaves: memory operations of a wave return in order,
+            // and the add's acknowledgement -- a read-modify-write at the memory side -- is the slowest of them)
             if (U8 && u + 1 < nb) mpub = A.mean[(size_t)(A.t0 + u + 1) * NGP_BLK + lane];
+            acc_add(A.acc, A.abort_w, slot, s, lane, p, fxs);
             if (DBG && dbg && s == 0 && lane == 0) dbg[NGP_DBG_STREAM + 2 * (size_t)u] = wall_clock64();
         };
         wg_barrier();
@@ -1219,21 +1206,13 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows_tall(co
 #pragma unroll
                 for (int jj = 0; jj < 8; jj++) keep[d][hh][jj] = make_float4(0.f, 0.f, 0.f, 0.f);
         unsigned long long pg0 = 0, pg1 = 0;
-        int sig_pending = -1;  // counter (slot x NG + group) of the stored, not yet counted partial
-        auto try_signal = [&](bool force) __attribute__((always_inline)) {
-            if (wv != NGP_ROWS_PUBW || sig_pending < 0) return;
-            if (force) drain_vm();
-            else if ((__builtin_amdgcn_s_getreg((23 << 11) | 7) & 0xC0000Fu) != 0u) return;
-            if (lane == 0) atomicAdd(&A.cnt_part[(size_t)sig_pending * 32], 1u);
-            sig_pending = -1;
-        };
+        const double fxs = A.scal->fx_scale;
+        auto try_signal = [&](bool) __attribute__((always_inline)) {};
         auto publish = [&](const int u, const int hh, const int par) __attribute__((always_inline)) {
             const int slot = u % NGP_RING;
             const double *rp = red + par * NGP_ROWS_NW * NGP_BLK + lane;
             const double p = ((rp[0] + rp[NGP_BLK]) + (rp[2 * NGP_BLK] + rp[3 * NGP_BLK])) + ((rp[4 * NGP_BLK] + rp[5 * NGP_BLK]) + rp[6 * NGP_BLK]);
-            try_signal(true);
-            st_f64(&A.part[((size_t)slot * S + sh0 + hh) * NGP_BLK + lane], p);
-            sig_pending = slot * A.NG + (sh0 + hh) / NGP_GRP;
+            acc_add(A.acc, A.abort_w, slot, sh0 + hh, lane, p, fxs);
         };
         wg_barrier();
         for (int u0 = 0; u0 < nb + DT; u0 += DT) {
@@ -1347,36 +1326,25 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows_tall(co
 }
 
 // ------------------------------------------------------------------------------------------
-// reducer g: every wave works on its own blocks (u = wave, wave+8, ...), no workgroup barrier
+// "reducer" g (the name of rounds 1-3, when these workgroups also added the shard partials): the FAR look-ahead corrections.  Lag
+// d = near + 1 + g, + NG, .. (< D) of every block u: -G[u, u-d]' dlt_{u-d} goes into block u's accumulator as one more fixed-point
+// term (ngp_common.h) -- off the sweep's latency loop: dlt_{u-d} is more than `near` blocks old when the sampler needs block u.
+// Every wave works on its own blocks (u = wave, wave + 8, ...), no workgroup barrier
 // (waves wv0 .. wv0 + nwv - 1 of the workgroup serve this chain's group: all eight, or four when the workgroup serves two chains)
 template <bool DBG>
 __device__ __attribute__((always_inline)) inline void role_reducer(const SweepArgs &A, const int g, char *smem, const int wv0 = 0,
                                                                    const int nwv = NGP_WG / 64) {
     NGP_DBG_LOCALS
-    const int S = A.S, tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
-    const int s0 = g * NGP_GRP, s1 = min(s0 + NGP_GRP, S), gsize = s1 - s0;
+    const int tid = threadIdx.x, wv = tid >> 6, lane = tid & 63;
     const int nb = A.t1 - A.t0;
+    if (A.near + 1 + g >= A.D) return;  // no far lag falls to this workgroup
+    const double fxs = A.scal->fx_scale;
     for (int u = wv - wv0; u < nb; u += nwv) {
-        const int slot = u % NGP_RING, round = u / NGP_RING;
-        int ok = 1;
-        if (lane == 0) ok = wait_ge(&A.cnt_part[((size_t)slot * A.NG + g) * 32], (unsigned)((round + 1) * gsize), A.abort_w, 2u) ? 1 : 0;
-        ok = __builtin_amdgcn_readfirstlane(ok);
-        if (!ok) return;
-        if (dbg && g == 0 && lane == 0) dbg[NGP_DBG_RED + 2 * (size_t)u] = wall_clock64();
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-        const double *p = A.part + ((size_t)slot * S + s0) * NGP_BLK + lane;
-        double vals[NGP_GRP];
-#pragma unroll
-        for (int s = 0; s < NGP_GRP; s++) vals[s] = ld_f64(p + (size_t)min(s, gsize - 1) * NGP_BLK);
-        double v = vals[0];
-#pragma unroll
-        for (int s = 1; s < NGP_GRP; s++)
-            if (s < gsize) v = v + vals[s];
-        // far look-ahead corrections folded into this group's sum: lags d = near + 1 + g, + NG, ... (< D).  The Gram rows
-        // are requested before dlt of block u-d is awaited, so only the 64 fma follow the hand-off.
+        const int slot = u % NGP_RING;
         for (int d = A.near + 1 + g; d < A.D; d += A.NG) {
             const int a = u - d;
             if (a < 0) continue;
+            // (the Gram rows are requested before dlt of block u-d is awaited)
             double gr[NGP_BLK];
             load_rows_pair(A.gramx + ((size_t)(A.t0 + u) * A.D + d) * (NGP_BLK * NGP_BLK), lane, gr);
             unsigned long long q0, q1;
@@ -1388,8 +1356,7 @@ __device__ __attribute__((always_inline)) inline void role_reducer(const SweepAr
             if (!(dbg_mode == 3 || dbg_mode == 4 || dbg_mode == 6) && !wait_dlt_granules_all(A.dltg, A.nonce, a, lane, A.abort_w, 4u, q0, q1)) return;
             const double dreg = dlt_granules_value(q0, q1);  // lane k holds dlt_k
             // dlt goes through this wave's 512 bytes of LDS and comes back as broadcast reads (every lane the same 16 bytes): 32 LDS
-            // instructions instead of 128 v_readlane, each of which is a 20-clock trip through an SGPR, in front of the 64 fma --
-            // this term sits in the hand-off loop between the sampler's dlt and the group sum it waits for
+            // instructions instead of 128 v_readlane, each of which is a 20-clock trip through an SGPR, in front of the 64 fma
             double *ldw = (double *)smem + (size_t)wv * NGP_BLK;
             ldw[lane] = dreg;
             typedef const __attribute__((address_space(3))) double *lds_cdp;
@@ -1409,13 +1376,9 @@ __device__ __attribute__((always_inline)) inline void role_reducer(const SweepAr
                 }
                 asm volatile("" : "+v"(s0), "+v"(s1), "+v"(s2), "+v"(s3));
             }
-            v = v - ((s0 + s1) + (s2 + s3));
-        }
-        st_f64(&A.gsum[((size_t)slot * A.NG + g) * NGP_BLK + lane], v);
-        drain_vm();
-        if (lane == 0) {
-            atomicAdd(&A.cnt_gs[(size_t)slot * 32], 1u);
-            if (dbg && g == 0) dbg[NGP_DBG_RED + 2 * (size_t)u + 1] = wall_clock64();
+            const double v = (s0 + s1) + (s2 + s3);
+            acc_add(A.acc, A.abort_w, slot, d, lane, -v, fxs);
+            if (dbg && g == 0 && lane == 0) dbg[NGP_DBG_RED + 2 * (size_t)u + 1] = wall_clock64();
         }
     }
 }
@@ -1435,34 +1398,52 @@ __device__ inline CoefRegs load_coef(const SweepArgs &A, long long k) {
     c.tf = A.lin_all ? 1u : (A.blin ? A.blin[k >> 6] : 0u);
     return c;
 }
-// group sums of local block u -> per-lane total (lane 0 polls, whole wave loads); false on abort
+// terms of local block u's accumulator: one per shard, one per far lag whose block exists
+__device__ __attribute__((always_inline)) inline unsigned acc_terms(const SweepArgs &A, const int u) {
+    const int nfar = max(0, min(A.D - 1, u) - A.near);
+    return (unsigned)(A.S + nfar);
+}
+// the eight copies of a block's accumulator, added: low NGP_FX_CNT_BITS bits = terms so far, the rest = their fixed-point sum
+__device__ __attribute__((always_inline)) inline unsigned long long acc_load(const SweepArgs &A, const int u, const int j) {
+    const unsigned long long *ap = A.acc + (size_t)(u % NGP_RING) * NGP_FX_COPIES * NGP_BLK + j;
+    unsigned long long qv[NGP_FX_COPIES];
+#pragma unroll
+    for (int c = 0; c < NGP_FX_COPIES; c++) qv[c] = ld_u64(ap + (size_t)c * NGP_BLK);
+    unsigned long long q = qv[0];
+#pragma unroll
+    for (int c = 1; c < NGP_FX_COPIES; c++) q += qv[c];
+    return q;
+}
+__device__ __attribute__((always_inline)) inline bool acc_complete(const unsigned long long q, const unsigned terms) {
+    return __ballot((unsigned)(q & ((1ull << NGP_FX_CNT_BITS) - 1ull)) == terms) == ~0ull;
+}
+// a complete sum -> X_t'ycorr of this lane's column; the accumulator goes back to zero for the block that takes the slot 16 blocks on
+// (that block's terms are more than a lag behind this store: a streamer adds them only after it has seen dlt of a LATER block)
+__device__ __attribute__((always_inline)) inline double acc_take(const SweepArgs &A, const int u, const int j, const unsigned long long q, const double fxi) {
+    unsigned long long *ap = A.acc + (size_t)(u % NGP_RING) * NGP_FX_COPIES * NGP_BLK + j;
+#pragma unroll
+    for (int c = 0; c < NGP_FX_COPIES; c++) st_u64(ap + (size_t)c * NGP_BLK, 0ull);
+    return fx_to_f64((long long)q >> NGP_FX_CNT_BITS) * fxi;
+}
+// blocking form (whole wave polls the accumulator itself: one round trip from "last term added" to "in registers"); false on abort
 template <bool DBG, bool NGBIG = false>
 __device__ __attribute__((always_inline)) inline bool fetch_group_sums(const SweepArgs &A, int u, int j, double *tot_out) {
     NGP_DBG_LOCALS
-    const int NG = A.NG, slot = u % NGP_RING;
-    int ok = 1;
-    if (j == 0) ok = (dbg_mode == 2 || wait_ge(&A.cnt_gs[(size_t)slot * 32], (unsigned)((u / NGP_RING + 1) * NG), A.abort_w, 3u)) ? 1 : 0;
-    ok = __builtin_amdgcn_readfirstlane(ok);
-    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-    if (!ok) return false;
-    const double *gp = A.gsum + (size_t)slot * NG * NGP_BLK + j;
-    double gv[8];
-#pragma unroll
-    for (int g = 0; g < 8; g++) gv[g] = ld_f64(gp + (size_t)min(g, NG - 1) * NGP_BLK);
-    double tot = gv[0];
-#pragma unroll
-    for (int g = 1; g < 8; g++)
-        if (g < NG) tot = tot + gv[g];
-    if constexpr (NGBIG)
-    for (int g0 = 8; g0 < NG; g0 += 8) {  // several shards per streamer workgroup (lags 2-3): up to 699 shards = 22 groups, same order
-#pragma unroll
-        for (int g = 0; g < 8; g++) gv[g] = ld_f64(gp + (size_t)min(g0 + g, NG - 1) * NGP_BLK);
-#pragma unroll
-        for (int g = 0; g < 8; g++)
-            if (g0 + g < NG) tot = tot + gv[g];
+    const unsigned terms = acc_terms(A, u);
+    const double fxi = A.scal->fx_inv;
+    for (unsigned spins = 0;; ++spins) {
+        const unsigned long long q = acc_load(A, u, j);
+        if (dbg_mode == 2 || acc_complete(q, terms)) {
+            *tot_out = acc_take(A, u, j, q, fxi);
+            return true;
+        }
+        if ((spins & 7u) == 7u && ld_u32(A.abort_w) != 0u) return false;
+        if (spins > (NGP_SPIN_LIMIT >> 3)) {  // every turn is a memory round trip
+            st_u32(A.abort_w, 3u);
+            return false;
+        }
+        __builtin_amdgcn_s_sleep(2);
     }
-    *tot_out = tot;
-    return true;
 }
 
 // results of a finished block: beta / delta / varBeta (dlt itself left as granules when the chain ended, see role_sampler)
@@ -1853,57 +1834,54 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
         }
         if (nb >= 1) publish_block<DBG>(A, nb - 1, j, hist, outb, outi, smeth, ssdf);
     } else if (wv == 2) {
-        // group sums -> r0 ring.  Lag >= 4: two blocks ahead -- the loads of block u+2 (and a probe of the counter of
-        // block u+3) are issued during block u and consumed at the start of block u+1, so the memory round trip of this
-        // busy CU never sits on the block period.  Lags 2-3: one block ahead, blocking.
-        // (A streamer with lag >= 3 polls dlt_{u+1-D} before it publishes partial u, so the group sums of block u+2
-        // exist during block u only when D >= 4.)
-        const int NG = A.NG;
+        // X_t'ycorr of the coming blocks -> r0 ring, from the blocks' fixed-point accumulators (ngp_common.h).  Lag >= 4: up to two blocks
+        // ahead -- the eight copies of the next accumulator are requested at the end of a block and looked at at the start of the
+        // following one (the load is the probe: a complete count means the sum is final), so the memory round trip of this busy CU
+        // never sits on the block period.  Lags 2-3: one block ahead, blocking.
+        // (A streamer with lag >= 3 polls dlt_{u+1-D} before it publishes partial u, so the sum of block u+2 exists during block u
+        // only when D >= 4.)
         if (D >= 4) {
-            double gv[8];
-#pragma unroll
-            for (int g = 0; g < 8; g++) gv[g] = 0.0;
-            auto target_of = [&](int ub) { return (unsigned)((ub / NGP_RING + 1) * NG); };
-            auto issue = [&](int ub) {  // counter of block ub known complete: start the loads
-                const double *gp = A.gsum + (size_t)(ub % NGP_RING) * NG * NGP_BLK + j;
-#pragma unroll
-                for (int g = 0; g < 8; g++) gv[g] = ld_f64(gp + (size_t)min(g, NG - 1) * NGP_BLK);
-            };
-            auto consume = [&](int ub) {
-                double tot = gv[0];
-#pragma unroll
-                for (int g = 1; g < 8; g++)
-                    if (g < NG) tot = tot + gv[g];
-                r0[(ub & 3) * NGP_BLK + j] = tot;
-                if (dbg && j == 0) dbg[4 * (size_t)ub + 3] = wall_clock64();
-            };
-            int next_fetch = 1;   // first local block whose group sums have not been requested yet
-            bool pend = false;    // loads of block next_fetch - 1 in flight
-            // counter of block next_fetch, read at the end of the previous block: a fetch normally costs ONE round trip
-            // (the loads), and none at all when it can be issued a block early
-            unsigned probe = (nb > 1) ? ld_u32(&A.cnt_gs[(size_t)(1 % NGP_RING) * 32]) : 0u;
+            const double fxi = A.scal->fx_inv;
+            // Two looks may be in flight: at blocks next_fetch (qa) and next_fetch + 1 (qb, only while this wave is less than two
+            // blocks ahead) -- so that a look that came too early costs no blocking round trip later: nothing here waits on memory
+            // except the sum the very next block needs.
+            unsigned long long qa = 0ull, qb = 0ull;
+            int next_fetch = 1;   // first local block whose sum has not been taken yet
+            bool pa = false, pb = false;
+            if (nb > 1) { qa = acc_load(A, 1, j); pa = true; }
+            if (nb > 2) { qb = acc_load(A, 2, j); pb = true; }
             for (int u = 0; u < nb; ++u) {
-                if (pend) { consume(next_fetch - 1); pend = false; }
-                if (next_fetch < nb && next_fetch <= u + 2) {  // r0[(u+2) & 3] is free: block u-2 is done
-                    const bool must = (next_fetch == u + 1);    // the next block needs these sums
+                for (int rep = 0; rep < 2; ++rep) {
+                    if (!(next_fetch < nb && next_fetch <= u + 2)) break;  // r0[(u+2) & 3] is free: block u-2 is done
+                    if (rep == 1 && !pb) break;
+                    const bool must = (next_fetch == u + 1);                // the next block needs this sum
+                    const unsigned terms = acc_terms(A, next_fetch);
+                    unsigned long long q = (rep == 0) ? qa : qb;
+                    if (rep == 0 && !pa) q = acc_load(A, next_fetch, j);   // (only the very first blocks of a short sweep)
+                    bool ready = dbg_mode == 2 || acc_complete(q, terms);
                     int ok = 1;
-                    bool ready = (__builtin_amdgcn_readfirstlane((int)probe) >= (int)target_of(next_fetch)) || dbg_mode == 2;
                     if (!ready && must) {
-                        if (j == 0) ok = wait_ge(&A.cnt_gs[(size_t)(next_fetch % NGP_RING) * 32], target_of(next_fetch), A.abort_w, 3u) ? 1 : 0;
-                        ok = __builtin_amdgcn_readfirstlane(ok);
-                        ready = true;
+                        for (unsigned spins = 0;; ++spins) {
+                            __builtin_amdgcn_s_sleep(2);
+                            q = acc_load(A, next_fetch, j);
+                            if (acc_complete(q, terms)) { ready = true; break; }
+                            if ((spins & 7u) == 7u && ld_u32(A.abort_w) != 0u) { ok = 0; break; }
+                            if (spins > (NGP_SPIN_LIMIT >> 3)) { st_u32(A.abort_w, 3u); ok = 0; break; }
+                        }
                     }
                     if (!ok) {
                         if (j == 0) *sabort = 1;
-                    } else if (ready) {
-                        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
-                        issue(next_fetch);
-                        if (must) consume(next_fetch);
-                        else pend = true;
-                        ++next_fetch;
+                        break;
                     }
+                    if (!ready) break;
+                    r0[(next_fetch & 3) * NGP_BLK + j] = acc_take(A, next_fetch, j, q, fxi);
+                    if (dbg && j == 0) dbg[4 * (size_t)next_fetch + 3] = wall_clock64();
+                    ++next_fetch;
                 }
-                if (next_fetch < nb) probe = ld_u32(&A.cnt_gs[(size_t)(next_fetch % NGP_RING) * 32]);
+                // the looks at the next accumulators travel while the block finishes
+                pa = false; pb = false;
+                if (next_fetch < nb && next_fetch <= u + 3) { qa = acc_load(A, next_fetch, j); pa = true; }
+                if (next_fetch + 1 < nb && next_fetch + 1 <= u + 3) { qb = acc_load(A, next_fetch + 1, j); pb = true; }
                 NGP_END_OF_BLOCK();
             }
         } else {
@@ -2159,12 +2137,12 @@ __device__ __attribute__((always_inline)) inline void role_streamer_multi(const 
     // wave per chain, the fifth chain put that microsecond into phase A of every block (10k x 100k: 2.06 -> 2.85 us per block).
     const bool pubw = wv < 4 && wv < KC;
     const bool pub2 = pubw && (wv + 4 < KC);
-    double *my_part = nullptr, *my_part2 = nullptr;
-    unsigned *my_cnt = nullptr, *my_cnt2 = nullptr;
+    unsigned long long *my_acc = nullptr, *my_acc2 = nullptr;
+    double my_fxs = 0.0, my_fxs2 = 0.0;
 #pragma unroll
     for (int kc = 0; kc < KC; kc++) {
-        if (kc == wv) { my_part = Mp->a[kc].part; my_cnt = Mp->a[kc].cnt_part; }
-        if (kc == wv + 4) { my_part2 = Mp->a[kc].part; my_cnt2 = Mp->a[kc].cnt_part; }
+        if (kc == wv) { my_acc = Mp->a[kc].acc; my_fxs = Mp->a[kc].scal->fx_scale; }
+        if (kc == wv + 4) { my_acc2 = Mp->a[kc].acc; my_fxs2 = Mp->a[kc].scal->fx_scale; }
     }
 #pragma unroll
     for (int kc = 0; kc < KC; kc++) {
@@ -2209,16 +2187,7 @@ __device__ __attribute__((always_inline)) inline void role_streamer_multi(const 
     const size_t gram_bytes = warm_bytes(A, DT), w_thi = warm_t_hi(A), w_shift = warm_shift(A);
     const size_t slice_bytes = ((gram_bytes / nslice + 1023) / 1024) * 1024;
     bool same_xcd = false;
-    constexpr bool LAZY = (DT >= NGP_LAZY_LAG);
-    int sig_pending = -1;  // ring slot of this wave's stored, not yet counted partial
-    auto try_signal = [&](bool force) {
-        if (!LAZY || !pubw || sig_pending < 0) return;
-        if (force) drain_vm();
-        else if ((__builtin_amdgcn_s_getreg((23 << 11) | 7) & 0xC0000Fu) != 0u) return;  // VM_CNT [3:0] and [23:22]
-        if (j == 0) atomicAdd(&my_cnt[((size_t)sig_pending * A.NG + g) * 32], 1u);
-        if (pub2 && j == 1) atomicAdd(&my_cnt2[((size_t)sig_pending * A.NG + g) * 32], 1u);
-        sig_pending = -1;
-    };
+    auto try_signal = [&](bool) {};
     __syncthreads();
     for (int u0 = 0; u0 < nb + DT; u0 += DT) {
 #pragma unroll
@@ -2348,16 +2317,8 @@ __device__ __attribute__((always_inline)) inline void role_streamer_multi(const 
                         const double *red2 = NGP_RED(wv + 4);
                         p2 = ((red2[j] + red2[64 + j]) + (red2[128 + j] + red2[192 + j])) + ((red2[256 + j] + red2[320 + j]) + (red2[384 + j] + red2[448 + j]));
                     }
-                    try_signal(true);  // the previous partials, if their stores were still under way at every boundary
-                    st_f64(&my_part[((size_t)slot * S + s) * NGP_BLK + j], p);
-                    if (pub2) st_f64(&my_part2[((size_t)slot * S + s) * NGP_BLK + j], p2);
-                    if (LAZY) {
-                        sig_pending = slot;
-                    } else {
-                        drain_vm();
-                        if (j == 0) atomicAdd(&my_cnt[((size_t)slot * A.NG + g) * 32], 1u);
-                        if (pub2 && j == 1) atomicAdd(&my_cnt2[((size_t)slot * A.NG + g) * 32], 1u);
-                    }
+                    acc_add(my_acc, A.abort_w, slot, s, j, p, my_fxs);
+                    if (pub2) acc_add(my_acc2, A.abort_w, slot, s, j, p2, my_fxs2);
                 }
             } else if (wv == 7 && DT >= 3) poll_dlt(u + 1);
         }
@@ -2491,16 +2452,7 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows_multi(c
         unsigned long long pg0[KC], pg1[KC];  // poller: granules of the next dlt of every chain
 #pragma unroll
         for (int kc = 0; kc < KC; kc++) { pg0[kc] = 0; pg1[kc] = 0; }
-        int sig_pending = -1;
-        auto try_signal = [&](bool force) __attribute__((always_inline)) {
-            if (wv != NGP_ROWS_PUBW || sig_pending < 0) return;
-            if (force) drain_vm();
-            else if ((__builtin_amdgcn_s_getreg((23 << 11) | 7) & 0xC0000Fu) != 0u) return;
-#pragma unroll
-            for (int kc = 0; kc < KC; kc++)
-                if (lane == kc) atomicAdd(&Mp->a[kc].cnt_part[((size_t)sig_pending * A.NG + g) * 32], 1u);
-            sig_pending = -1;
-        };
+        auto try_signal = [&](bool) __attribute__((always_inline)) {};
         auto publish = [&](const int u) __attribute__((always_inline)) {
             const int slot = u % NGP_RING;
             double p[KC];
@@ -2509,10 +2461,8 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows_multi(c
                 const double *rp = NGP_RED(kc) + (u & 1) * NGP_ROWS_NW * NGP_BLK + lane;
                 p[kc] = ((rp[0] + rp[NGP_BLK]) + (rp[2 * NGP_BLK] + rp[3 * NGP_BLK])) + ((rp[4 * NGP_BLK] + rp[5 * NGP_BLK]) + rp[6 * NGP_BLK]);
             }
-            try_signal(true);
 #pragma unroll
-            for (int kc = 0; kc < KC; kc++) st_f64(&Mp->a[kc].part[((size_t)slot * S + s) * NGP_BLK + lane], p[kc]);
-            sig_pending = slot;
+            for (int kc = 0; kc < KC; kc++) acc_add(Mp->a[kc].acc, A.abort_w, slot, s, lane, p[kc], Mp->a[kc].scal->fx_scale);
         };
         wg_barrier();
         for (int u0 = 0; u0 < nb + DT; u0 += DT) {

@@ -61,13 +61,11 @@ struct SweepArgs {
     const double *mean;  // [Ppad]
     long long N;         // rows of the panel (the last shards carry padding rows, which must stay zero)
     // communication (zeroed before every launch)
-    double *part;        // [RING][S][64]
-    double *gsum;        // [RING][NG][64]
+    unsigned long long *acc;  // [RING][NGP_FX_COPIES][64] fixed-point accumulators of X_t'ycorr (ngp_common.h): shard s adds its term to copy
+                              // s mod 8, the far-lag correctors theirs to copy lag mod 8; the sampler reads, checks the count and zeroes
     double *dlt;         // [RING][64]
     unsigned long long *dltg;  // [RING][64][2] the same values as self-validating 8-byte granules {32 data bits, 32-bit tag}
     unsigned nonce;      // 12-bit launch number inside every tag (the granule ring is not cleared between launches)
-    unsigned *cnt_part;  // [RING][NG] counters, one 128-B line each
-    unsigned *cnt_gs;    // [RING] counters, one 128-B line each
     unsigned *flag_dlt;  // number of blocks the sampler has finished
     unsigned *abort_w;   // [0] != 0: the sweep gave up (code = role whose spin timed out; NGP_ABORT_CENSUS: not every workgroup became
                          // resident, NOTHING was changed); [1] = iter_tag of the launch that gave up.  Every kernel of the iteration
@@ -116,9 +114,9 @@ struct MultiArgs {
     SweepArgs a[NGP_MAXC];  // same tiles / gramx / layout in every entry; a[c].abort_w, census of chain 0 are the launch's
 };
 struct ChainPtrs {  // what a streamer needs of one chain (LDS copy: lanes index it by chain)
-    double *ycorr, *part;
+    double *ycorr;
+    unsigned long long *acc;
     const double *dlt;
-    unsigned *cnt_part;
     const unsigned *flag_dlt;
 };
 // doubles of per-chain LDS state of a multi-chain streamer: shard R | 8 x 64 chain sums | 2 x 64 dlt | 8 x R update partials

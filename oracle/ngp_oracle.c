@@ -1237,6 +1237,17 @@ static double wave_butterfly_up(double *v) { /* 64 lanes, xor 1..32 (compact sto
     return v[0];
 }
 
+/* exponent of the fixed-point scale (csrc/ngp_common.h, fx_exponent): E = floor(ilogb(m) / 2) + 5 for finite m > 0, else 5; clamped */
+static int fx_exponent(double m) {
+    union { double d; uint64_t u; } v; v.d = m;
+    const int ef = (int)((v.u >> 52) & 0x7ff);
+    int e2 = 0;
+    if (m > 0.0 && ef != 0x7ff) e2 = ef - 1023;
+    int e = (e2 >> 1) + 5;
+    if (e < -900) e = -900;
+    if (e > 900) e = 900;
+    return e;
+}
 static void iter_blocked(ora_t *h) {
     const int64_t N = h->N, R = h->R, S = h->S, L = R * S, NBLK = h->NBLK;
     const int64_t it = h->iter + 1;
@@ -1254,6 +1265,13 @@ static void iter_blocked(ora_t *h) {
     }
     double yy = wyy[0], sy = wsy[0];
     for (int wv = 1; wv < 16; wv++) { yy = yy + wyy[wv]; sy = sy + wsy[wv]; }
+    /* fixed-point scale of this iteration's X_t'ycorr accumulators (csrc/ngp_common.h): every shard
+       partial and every far look-ahead term is scaled by 2^(52 - E), rounded to the nearest integer and added as an integer -- an
+       order-free sum.  2^E > 16 sqrt(max_j x_j'x_j * ycorr'ycorr), the norms as they stand at the head of the iteration. */
+    double mpm_max = 0.0;
+    for (int64_t k = 0; k < h->Ppad; k++) if (h->mpm[k] > mpm_max) mpm_max = h->mpm[k];
+    const int fe = fx_exponent(mpm_max * yy);
+    const double fxs = ldexp(1.0, 52 - fe), fxi = ldexp(1.0, fe - 52);
     rng_seed(&r, h->seed, h->chain, it, KIND_VARE_CHI2, 0);
     double chi = rng_chisq(&r, h->e_df + (double)N);
     double t = h->e_df * h->e_scale; t = t + yy;
@@ -1465,7 +1483,6 @@ static void iter_blocked(ora_t *h) {
         }
         double rr[BLK], dlt[BLK]; int inc[BLK];
         const double *G = h->gram + (size_t)tb * BLK * BLK;
-        const int64_t NGq = (S + GRP - 1) / GRP;
         int has_r = 0, has_t = -1;
         int lane_set[BLK];
         for (int j = 0; j < BLK; j++) {
@@ -1480,14 +1497,9 @@ static void iter_blocked(ora_t *h) {
         for (int j = 0; j < BLK; j++)
             if (lane_set[j] >= 0 && h->sets[lane_set[j]].method != METHOD_PR) raw_linear = 0;
         for (int j = 0; j < BLK; j++) {
-            /* group sums: shards of a group added in order */
-            double gs[64];
-            for (int64_t g = 0; g < NGq; g++) {
-                int64_t s0 = g * GRP, s1 = s0 + GRP < S ? s0 + GRP : S;
-                double v = part[s0 * BLK + j];
-                for (int64_t s = s0 + 1; s < s1; s++) v = v + part[s * BLK + j];
-                gs[g] = v;
-            }
+            /* the shard partials as fixed-point terms: integer addition, no order */
+            long long qsum = 0;
+            for (int64_t s = 0; s < S; s++) qsum += llrint(part[s * BLK + j] * fxs);
             /* look-ahead corrections v_d = G[tb, tb-d] dlt_{tb-d} of the blocks whose update the GEMV has not seen.
                Far lags d = h->near+1 .. D-1 are folded into the group sums (the reducer workgroups compute them):
                lag d goes to group (d-h->near-1) mod NG, ascending d.  Lags h->near .. 1 stay with the sampler. */
@@ -1502,9 +1514,8 @@ static void iter_blocked(ora_t *h) {
                 vd[d] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
             }
             for (int64_t d = h->near + 1; d < D; d++)
-                if (hv[d]) { int64_t g = (d - h->near - 1) % NGq; gs[g] = gs[g] - vd[d]; }
-            double tot = gs[0];
-            for (int64_t g = 1; g < NGq; g++) tot = tot + gs[g];
+                if (hv[d]) qsum += llrint((-vd[d]) * fxs);   /* far lags: one more term each (the "reducer" workgroups) */
+            double tot = (double)qsum * fxi;
             {   /* near lags stay with the sampler: cor = (((v_near + ...) + v_2) + v_1) over the terms that exist */
                 double c = 0.0; int have = 0;
                 for (int64_t d = (D - 1 < h->near ? D - 1 : h->near); d >= 1; d--)

@@ -72,3 +72,10 @@ worst = np.argsort(Acc[:,3])[-3:]
 for i in worst: print("   streamer", int(i), "xcc", int(Aall[i,1])-1, np.round(Acc[i],2))
 best = np.argsort(Acc[:,3])[:2]
 for i in best: print("   streamer", int(i), "xcc", int(Aall[i,1])-1, np.round(Acc[i],2))
+
+# raw timeline of a few consecutive blocks (us relative to the block's start stamp): where the period goes
+print("raw: block | next start | chain end | dlt published | sum in r0 (this block's) | end-of-work of waves 0..7")
+for ub in range(nb // 2, nb // 2 + 10):
+    s0 = S[ub, 0]
+    print(f"  {ub:6d} | {(S[ub + 1, 0] - s0) / 100.0:6.2f} | {(S[ub, 1] - s0) / 100.0:6.2f} | {(S[ub, 2] - s0) / 100.0:6.2f} | {(S[ub, 3] - s0) / 100.0:7.2f} | "
+          + " ".join(f"{(W[ub, w] - s0) / 100.0:6.2f}" for w in range(8)))
