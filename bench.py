@@ -198,6 +198,7 @@ def main():
     ap.add_argument("--same-device", action="store_true", help="rehearsal: every rank uses GPU 0 (the persistent kernels then run one after the other)")
     ap.add_argument("--cpu-cols", type=int, default=None, help="columns of the CPU baseline sample (default: about 1.6e8 / N)")
     ap.add_argument("--cpu-seconds", type=float, default=20.0)
+    ap.add_argument("--seed-offset", type=int, default=0, help="chain seed = 1001 + rank + this (tests: a rank's chain run alone)")
     args = ap.parse_args()
 
     import torch
@@ -231,7 +232,7 @@ def main():
         torch.cuda.synchronize()
 
     compact_main = args.storage == "u8"
-    s, setup_s = build_chain(ngp, local_rank, 1001 + rank, N, P, sets, storage="u8" if compact_main else None)
+    s, setup_s = build_chain(ngp, local_rank, 1001 + rank + args.seed_offset, N, P, sets, storage="u8" if compact_main else None)
     K, W = args.steps, args.warmup
     loci = np.unique(np.linspace(0, P - 1, N_TRACE_LOCI).astype(np.int64))
     ntvb = min(s.nvb, 8)
@@ -289,6 +290,7 @@ def main():
     R, S, nblk = s.layout()
     mode, lag = s.config()
     variant, nchain = s.streamer()
+    main_census = s.census() if mode == 1 else {"retries": 0, "exclusive": 0}
 
     if rank == 0:
         its = world * K / dt
@@ -341,6 +343,7 @@ def main():
                         + ("" if ess is not None else "; not estimated: fewer than 200 timed iterations (run with --steps 1000 for an ESS figure)"),
             },
             "device_iter_ms": tm["iter_ms"] / max(tm["iters"], 1),
+            "census_retries": main_census["retries"], "exclusive": bool(main_census["exclusive"]),   # launches run again alone on the device
             "setup_s": setup_s,
             "allreduce_ms": allreduce_ms,
             "posterior_mean_varE": post_mean_varE,
@@ -392,7 +395,9 @@ def main():
             ngp.Sampler.run_many(cs, K)
             torch.cuda.synchronize()
             kdt = time.perf_counter() - tk
+            gcen = [c.census() for c in cs]
             out["chains_per_gpu"] = {"chains": kc, "value": kc * K / kdt, "unit": "it/s (aggregate over the chains of this GPU)",
+                                     "census_retries": int(sum(g["retries"] for g in gcen)), "exclusive": bool(any(g["exclusive"] for g in gcen)),
                                      "ms_per_step_of_a_chain": kdt / K * 1e3, "rows_per_shard": cs[0].layout()[0], "shards_per_chain": cs[0].layout()[1],
                                      "speedup_vs_single_chain": (kc * K / kdt) / its}
             for c in cs:
@@ -430,6 +435,8 @@ def main():
                 "algorithmic_bytes_per_pass": 4.0 * N * P, "panel_stream_GBps": 4.0 * N * P * (K / kdt) / 1e9,
                 "panel_stream_frac_of_peak": 4.0 * N * P * (K / kdt) / 1e9 / HBM_PEAK_GBS,
                 "grid_workgroups": cen["grid"], "rows_per_shard": pR, "shards": pS, "lag": cs[0].config()[1],
+                "census_retries": cen["retries"], "exclusive": bool(cen["exclusive"]),
+                "fused": bool(ptm["sweep_launches"] == K),   # ONE launch per iteration served all the chains (else they ran side by side)
                 "speedup_vs_single_chain": (kp * K / kdt) / its if its else None,
                 "note": "independent chains (own seeds, own draws); every chain bit-identical to the chain it is alone with this layout "
                         "(tests/test_gpu_chains_per_pass.py)",

@@ -63,9 +63,11 @@ int32_t ngp_get_config(ngp_handle *h, int32_t *mode, int32_t *lag);
 int32_t ngp_set_near_lags(ngp_handle *h, int32_t near);
 int32_t ngp_get_near_lags(ngp_handle *h, int32_t *near);
 /* Form of the block chain of BayesPR blocks (every lane BayesPR or unowned; replaces the per-SNP loop of src/functions.jl:124-136).
- * 1 (default): dlt = T e0 with T = inv(I + diag(c) strictLower(G)) of the block formed explicitly before every sweep (k_tinv) -- the
- * forward substitution the 64 serial steps carry out, as one 64 x 64 product; 0: the 64 serial steps.  The same Markov chain in real
- * arithmetic; the floating-point order differs, so the blocked oracle is told (ora_set_tform).  Any time before ngp_run. */
+ * 0 (default): the 64 serial steps.  1: dlt = T e0 with T = inv(I + diag(c) strictLower(G)) of the block formed explicitly before every
+ * sweep (k_tinv) -- the forward substitution the 64 steps carry out, as one 64 x 64 product.  The same Markov chain in real
+ * arithmetic; the floating-point order differs, so the blocked oracle is told (ora_set_tform).  Measured:
+ * pays where the sampler's serial chain is the bound (compact storage), costs 2-4 % where its CU's memory traffic is.  Any time
+ * before ngp_run. */
 int32_t ngp_set_chain_form(ngp_handle *h, int32_t form);
 int32_t ngp_get_chain_form(ngp_handle *h, int32_t *form);
 /* Diagnostic only: enable != 0 makes the persistent kernel write 100 MHz time stamps (sampler: 4 words per

@@ -39,6 +39,36 @@ def read_sample_file(path):
     return out
 
 
+def iter_sample_file(path):
+    """The records of a sample file ONE AT A TIME (a record of a 600k-SNP model is 5 MB; a whole file of 1000 kept samples would be
+    5 GB): yields dicts with the fields of read_sample_file for a single kept iteration.  Memory-mapped, nothing is copied but
+    the record being looked at."""
+    with open(path, "rb") as f:
+        if f.read(8) != b"NGPSMP01":
+            raise NextGPHipError(f"not a sample file: {path}")
+        P, nvb, nsets, nfix, ncls, rec = (int(v) for v in np.frombuffer(f.read(48), dtype=np.int64))
+        sets = [dict(zip(("method", "K", "col0", "ncol", "nvb", "tk"), np.frombuffer(f.read(48), dtype=np.int64).tolist())) for _ in range(nsets)]
+        off = f.tell()
+        size = os.fstat(f.fileno()).st_size
+    n = (size - off) // rec
+    if n <= 0:
+        return
+    nd = 3 + nfix + P + nvb + 2 * nsets + ncls
+    mm = np.memmap(path, dtype=np.uint8, mode="r", offset=off, shape=(n, rec))
+    for i in range(n):
+        d = np.frombuffer(mm[i, :nd * 8].tobytes(), dtype=np.float64)
+        o = 3
+        out = dict(iter=int(np.frombuffer(mm[i, :8].tobytes(), dtype=np.int64)[0]), varE=d[1], b=d[2], sets=sets)
+        out["b_fixed"] = d[o:o + nfix]; o += nfix
+        out["beta"] = d[o:o + P]; o += P
+        out["varBeta"] = d[o:o + nvb]; o += nvb
+        out["piHat"] = d[o:o + 2 * nsets]; o += 2 * nsets
+        out["class_pi"] = d[o:o + ncls]
+        out["delta"] = np.asarray(mm[i, nd * 8:nd * 8 + P])
+        yield out
+    del mm
+
+
 def tuple_columns(col0, nloc, k):
     """Panel columns of a Tuple (correlated BayesPR) set: array [nloc, k], component m of locus l at col0 + 64 (l // Lb) + k (l % Lb) + m
     with Lb = 64 // k loci per 64-column block (include/nextgp_hip.h, ngp_add_marker_set_tuple)."""

@@ -312,35 +312,41 @@ def summaryMCMC(param, outFolder=None):
 
 def samples_to_out_files(sample_path, outFolder, sets, intercept, has_fixed):
     """Binary sample stream (ngp_set_sample_file) -> the rows of the reference's *Out text files (src/samplers.jl:56-104), appended
-    behind the header rows: the same text, number for number, as writing them at every kept iteration."""
-    from ._lib import read_sample_file
-    S = read_sample_file(sample_path)
-    files = {}
+    behind the header rows: the same text, number for number, as writing them at every kept iteration.  Record by record -- one
+    kept iteration in memory at a time, every *Out file open for appending -- so a long chain of a large model converts in
+    constant memory and an interrupted conversion leaves the rows written so far (the caller keeps the binary file until the
+    conversion has succeeded)."""
+    from ._lib import iter_sample_file
+    handles = {}
 
-    def rows(name, lines):
-        files.setdefault(name, []).extend(lines)
+    def row(name, fields):
+        f = handles.get(name)
+        if f is None:
+            f = handles[name] = open(os.path.join(outFolder, f"{name}Out"), "a")
+        f.write("\t".join(fields) + "\n")
 
-    n = len(S["iter"])
-    for i in range(n):
-        rows("b", ["\t".join((_fmt(S["b"][i]) if intercept else []) + (_fmt(S["b_fixed"][i]) if has_fixed else []))])
-        rows("varE", ["\t".join(_fmt(S["varE"][i]))])
-    vb_off, cls_off = 0, 0
-    for k, s in enumerate(sets):
-        K = len(s["prior"].pi) if isinstance(s["prior"], BayesRType) else 0
-        for i in range(n):
-            for m, nm in enumerate(s["members"]):
-                rows(f"beta{nm}", ["\t".join(_fmt(S["beta"][i, s["cols"][:, m]]))])
-                rows(f"delta{nm}", ["\t".join(str(int(v)) for v in S["delta"][i, s["cols"][:, m]])])
-            if isinstance(s["prior"], (BayesBType, BayesCType)):
-                rows(f"pi{s['name']}", ["\t".join(_fmt(S["piHat"][i, 2 * k:2 * k + 2]))])
-            if K:
-                rows(f"pi{s['name']}", ["\t".join(_fmt(S["class_pi"][i, cls_off:cls_off + K]))])
-            rows(f"var{s['name']}", ["\t".join(_fmt(S["varBeta"][i, vb_off:vb_off + s["nvb"]]))])
-        vb_off += s["nvb"]
-        cls_off += K
-    for name, lines in files.items():
-        with open(os.path.join(outFolder, f"{name}Out"), "a") as f:
-            f.write("\n".join(lines) + ("\n" if lines else ""))
+    n = 0
+    try:
+        for S in iter_sample_file(sample_path):
+            n += 1
+            row("b", (_fmt(S["b"]) if intercept else []) + (_fmt(S["b_fixed"]) if has_fixed else []))
+            row("varE", _fmt(S["varE"]))
+            vb_off, cls_off = 0, 0
+            for k, s in enumerate(sets):
+                K = len(s["prior"].pi) if isinstance(s["prior"], BayesRType) else 0
+                for m, nm in enumerate(s["members"]):
+                    row(f"beta{nm}", _fmt(S["beta"][s["cols"][:, m]]))
+                    row(f"delta{nm}", [str(int(v)) for v in S["delta"][s["cols"][:, m]]])
+                if isinstance(s["prior"], (BayesBType, BayesCType)):
+                    row(f"pi{s['name']}", _fmt(S["piHat"][2 * k:2 * k + 2]))
+                if K:
+                    row(f"pi{s['name']}", _fmt(S["class_pi"][cls_off:cls_off + K]))
+                row(f"var{s['name']}", _fmt(S["varBeta"][vb_off:vb_off + s["nvb"]]))
+                vb_off += s["nvb"]
+                cls_off += K
+    finally:
+        for f in handles.values():
+            f.close()
     return n
 
 

@@ -122,7 +122,7 @@ struct ngp_handle {
     unsigned *d_blin = nullptr;   // [NBLK] 1 = linear block (static for a model and an active set: written by sync_linear_blocks)
     int blin_for = -2;            // active set d_blin was written for (-1: the whole model, -2: stale)
     int lin_all = 0, lin_any = 0; // every / any block of d_blin is linear
-    int chain_form = 1;       // ngp_set_chain_form: 1 = linear blocks as dlt = T e0 (default), 0 = every block by the 64-step chain
+    int chain_form = 0;       // ngp_set_chain_form: 0 = every block by the 64-step chain (default), 1 = linear blocks as dlt = T e0
     int8_t *d_setof = nullptr;
     int32_t *d_loc = nullptr, *d_vbidx = nullptr;
     uint8_t *d_delta = nullptr;

@@ -463,7 +463,7 @@ int ora_create(int order, uint64_t seed, uint32_t chain, ora_t **out) {
     h->order = order; h->seed = seed; h->chain = chain;
     h->e_df = 4.0; h->e_scale = 0.0005; h->intercept = 1;
     h->chainLength = 0; h->burnIn = 0; h->thin = 1;
-    h->near = 3; h->nchain = 8; h->tform = 1;
+    h->near = 3; h->nchain = 8; h->tform = 0;
     *out = h; return ORA_OK;
 }
 /* which look-ahead lags the sampler corrects itself (the library reports its choice: ngp_get_near_lags) */
@@ -476,7 +476,7 @@ int ora_set_nchain(ora_t *h, int64_t n) {
     if (n != 7 && n != 8) { snprintf(h->err, 256, "GEMV chains must be 7 or 8"); return ORA_ERR; }
     h->nchain = n; return ORA_OK;
 }
-/* chain form of the linear blocks (the library reports its choice: ngp_get_chain_form): 1 = inverse form (default), 0 = 64 steps */
+/* chain form of the linear blocks (the library reports its choice: ngp_get_chain_form): 0 = 64 steps (default), 1 = inverse form */
 int ora_set_tform(ora_t *h, int on) { h->tform = on ? 1 : 0; return ORA_OK; }
 static void free_sets(ora_t *h) {
     for (int s = 0; s < h->nsets; s++) { free(h->sets[s].reg_start); free(h->sets[s].reg_stop); free(h->sets[s].tmpm); }

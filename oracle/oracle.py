@@ -126,12 +126,14 @@ class Oracle:
         except Exception:
             pass
 
-    def set_panel_f32(self, X, R=0, S=0, D=1, near=3, nchain=8):
-        """Blocked order: the layout the library reports (ngp_get_layout, ngp_get_config, ngp_get_near_lags, ngp_get_streamer)."""
+    def set_panel_f32(self, X, R=0, S=0, D=1, near=3, nchain=8, tform=0):
+        """Blocked order: the layout the library reports (ngp_get_layout, ngp_get_config, ngp_get_near_lags, ngp_get_streamer,
+        ngp_get_chain_form)."""
         X = np.asfortranarray(X, dtype=np.float32)
         self.N, self.P = X.shape
         self._chk(self.L.ora_set_near(self.h, C.c_int64(near)))
         self._chk(self.L.ora_set_nchain(self.h, C.c_int64(nchain)))
+        self.set_tform(tform)
         self._chk(self.L.ora_set_panel_f32(self.h, _p(X, C.c_float), C.c_int64(self.N), C.c_int64(self.P), C.c_int64(R),
                                            C.c_int64(S), C.c_int64(D)))
 
@@ -139,7 +141,7 @@ class Oracle:
         """Blocked order: linear blocks as dlt = T e0 (the library's default, ngp_get_chain_form) or as the 64-step chain."""
         self._chk(self.L.ora_set_tform(self.h, C.c_int(1 if on else 0)))
 
-    def set_panel_u8(self, G, R=0, S=0, D=1, near=3, centre=True):
+    def set_panel_u8(self, G, R=0, S=0, D=1, near=3, centre=True, tform=0):
         """Compact storage (one byte per genotype, analytic centring).  Blocked order: the layout the library reports; reference
         order: the Float64 panel the reference would hold for these genotypes (g - mean, mean = integer column sum / N)."""
         G = np.asfortranarray(G, dtype=np.uint8)
@@ -148,6 +150,7 @@ class Oracle:
             mu = G.sum(axis=0, dtype=np.int64).astype(np.float64) / float(self.N) if centre else np.zeros(self.P)
             return self.set_panel_f64(G.astype(np.float64) - mu[None, :])
         self._chk(self.L.ora_set_near(self.h, C.c_int64(near)))
+        self.set_tform(tform)
         self._chk(self.L.ora_set_panel_u8(self.h, _p(G, C.c_uint8), C.c_int64(self.N), C.c_int64(self.P), C.c_int64(R), C.c_int64(S),
                                           C.c_int64(D), C.c_int(1 if centre else 0)))
 

@@ -51,8 +51,8 @@ for case in range(ncases):
         if shards: s.set_max_shards(shards)
         s.set_panel(G if storage == "u8" else X, centre=(storage == "u8"))
         o = O.Oracle(order=1, seed=sd, chain=ch)
-        if storage == "u8": o.set_panel_u8(G, R=R, S=S, D=D, near=s.near())
-        else: o.set_panel_f32(X, R=R, S=S, D=D, near=s.near(), nchain=nchain)
+        if storage == "u8": o.set_panel_u8(G, R=R, S=S, D=D, near=s.near(), tform=s.chain_form())
+        else: o.set_panel_f32(X, R=R, S=S, D=D, near=s.near(), nchain=nchain, tform=s.chain_form())
         niter = int(rng.integers(3, 9))
         for m in (s, o):
             add_sets(m, spec, v); m.set_y(y); m.set_residual_prior(4.0, 0.5); m.set_schedule(niter, 1, 2); m.run(niter)

@@ -44,7 +44,7 @@ def test_fused_chains_equal_the_chains_alone_and_the_oracle(ngp, O, K, lag):
         alone.set_max_shards(S); alone.set_panel(X)
         assert alone.layout()[:2] == (R, S)
         o = O.Oracle(order=1, seed=1001 + c, chain=c)
-        o.set_panel_f32(X, R=R, S=S, D=alone.config()[1], near=alone.near(), nchain=alone.streamer()[1])
+        o.set_panel_f32(X, R=R, S=S, D=alone.config()[1], near=alone.near(), nchain=alone.streamer()[1], tform=alone.chain_form())
         for m in (alone, o):
             add_sets(m, spec, v); m.set_y(y + 0.01 * c); m.set_residual_prior(4.0, 1.0); m.set_schedule(20, 4, 2); m.run(20)
         a, b, f = alone.get_state(), o.get_state(), fused[c].get_state()
@@ -75,7 +75,7 @@ def test_fused_chains_on_the_row_owning_streamer(ngp, O, K, lag):
     assert fused[0].census()["grid"] == K * (1 + (S + 31) // 32) + S
     for c in range(K):
         o = O.Oracle(order=1, seed=1001 + c, chain=c)
-        o.set_panel_f32(X, R=R, S=S, D=lag, near=fused[0].near(), nchain=7)
+        o.set_panel_f32(X, R=R, S=S, D=lag, near=fused[0].near(), nchain=7, tform=fused[0].chain_form())
         add_sets(o, spec, v); o.set_y(y + 0.01 * c); o.set_residual_prior(4.0, 1.0); o.set_schedule(20, 4, 2); o.run(20)
         f, b = fused[c].get_state(), o.get_state()
         for key in ("ycorr", "beta", "delta", "varBeta", "piHat"):

@@ -28,7 +28,7 @@ def _pair(ngp, O, G, lag, near=None, max_shards=0, seed=1001, chain=0):
     mode, D = s.config()
     assert mode == 1 and R % 16 == 0 and s.streamer() == (3, 7) and s.storage() == 1
     o = O.Oracle(order=1, seed=seed, chain=chain)
-    o.set_panel_u8(G, R=R, S=S, D=D, near=s.near())
+    o.set_panel_u8(G, R=R, S=S, D=D, near=s.near(), tform=s.chain_form())
     return s, o
 
 

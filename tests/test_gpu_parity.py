@@ -48,9 +48,11 @@ ENGINE_IDS = ["blocklaunch", "persist_lag1", "persist_lag2", "persist_lag3", "pe
               "persist_lag8_near2", "rows_lag6_near2", "rows_lag6_near1", "persist_lag8_near1"]
 
 
-def _pair(ngp, O, X, seed=1001, chain=0, engine=(1, 6)):
+def _pair(ngp, O, X, seed=1001, chain=0, engine=(1, 6), chain_form=None):
     """engine = (mode, lag), (mode, lag, near lags) or (mode, lag, near lags, streamer variant)."""
     s = ngp.Sampler(device=0, seed=seed, chain=chain, mode=engine[0], lag=engine[1], streamer=engine[3] if len(engine) > 3 else 1)
+    if chain_form is not None:
+        s.set_chain_form(chain_form)
     if len(engine) > 2:
         s.set_near(engine[2])
     s.set_panel(X)
@@ -61,7 +63,7 @@ def _pair(ngp, O, X, seed=1001, chain=0, engine=(1, 6)):
     variant, nchain = s.streamer()
     assert (variant, nchain) == ((2, 7) if len(engine) > 3 and engine[3] == 2 else ((1, 8) if mode == 1 else (0, 8)))
     o = O.Oracle(order=1, seed=seed, chain=chain)
-    o.set_panel_f32(X, R=R, S=S, D=D, near=s.near(), nchain=nchain)
+    o.set_panel_f32(X, R=R, S=S, D=D, near=s.near(), nchain=nchain, tform=s.chain_form())
     return s, o
 
 
@@ -180,6 +182,27 @@ CASES = [
 ]
 
 
+def test_inverse_form_of_the_bayespr_chain(ngp, O):
+    """ngp_set_chain_form(1): BayesPR blocks as dlt = T e0 (k_tinv) -- bit for bit the blocked oracle told the same (every engine
+    family, models with and without non-linear blocks, the fine seam), and the chain of the 64-step form to rounding."""
+    for name, N, P, spec in [c for c in CASES if c[0] in ("pr_single", "pr_ragged", "pr_regions", "multi", "tiny")]:
+        X, y, bt, v = make_problem(O, N, P, seed=5)
+        for engine in [(0, 1), (1, 1), (1, 4), (1, 8), (1, 6, 2, 2), (1, 3, 3, 2)]:
+            s, o = _pair(ngp, O, X, engine=engine, chain_form=1)
+            assert s.chain_form() == 1
+            for m in (s, o):
+                add_sets(m, spec, v); m.set_y(y); m.set_residual_prior(4.0, 0.25 * y.var()); m.set_schedule(10, 4, 2); m.run(10)
+            a, b = s.get_state(), o.get_state()
+            for k in ("ycorr", "beta", "delta", "varBeta", "piHat"):
+                assert np.array_equal(a[k], b[k]), (name, engine, k)
+            assert a["varE"] == b["varE"] and a["b"] == b["b"]
+        s0, _ = _pair(ngp, O, X, engine=(1, 8), chain_form=0)
+        add_sets(s0, spec, v); s0.set_y(y); s0.set_residual_prior(4.0, 0.25 * y.var()); s0.set_schedule(10, 4, 2); s0.run(10)
+        c = s0.get_state()
+        assert np.array_equal(c["delta"], a["delta"]) or name == "multi"   # (the last engine's chain, same draws)
+        assert np.abs(c["beta"] - a["beta"]).max() <= 1e-8 * max(1e-300, np.abs(c["beta"]).max())
+
+
 @pytest.mark.parametrize("engine", ENGINES, ids=ENGINE_IDS)
 @pytest.mark.parametrize("name,N,P,spec", CASES, ids=[c[0] for c in CASES])
 def test_chain_bit_exact_vs_blocked_oracle(ngp, O, name, N, P, spec, engine):
@@ -249,7 +272,7 @@ def test_several_shards_per_workgroup_bit_exact(ngp, O, name, N, P, spec, shards
     if "padded" in name:
         assert R * (S - 1) >= N                 # the last shard holds no row of the panel
     o = O.Oracle(order=1, seed=1001, chain=0)
-    o.set_panel_f32(X, R=R, S=S, D=D, near=s.near(), nchain=7)
+    o.set_panel_f32(X, R=R, S=S, D=D, near=s.near(), nchain=7, tform=s.chain_form())
     niter = 12
     for m in (s, o):
         add_sets(m, spec, v)
@@ -390,7 +413,7 @@ def test_shard_height_boundaries_bit_exact(ngp, O, N):
     assert (variant, nchain) == ((2, 7) if 64 <= R <= 224 else (1, 8))   # row-owning waves from 64-row shards on (measured ahead there)
     assert (D, s.near()) == ((6, 2) if variant == 2 else ((8, 3) if R <= 128 else (5, 4)))
     o = O.Oracle(order=1, seed=21, chain=0)
-    o.set_panel_f32(X, R=R, S=S, D=D, near=s.near(), nchain=nchain)
+    o.set_panel_f32(X, R=R, S=S, D=D, near=s.near(), nchain=nchain, tform=s.chain_form())
     v = 0.01
     for m in (s, o):
         add_sets(m, [(0, 300, "PR"), (300, P - 300, "B")], v)

@@ -21,7 +21,7 @@ def oracle_like(O, s, X, order=1, seed=21, chain=0):
     o = O.Oracle(order=order, seed=seed, chain=chain)
     if order == 1:
         R, S, _ = s.layout()
-        o.set_panel_f32(X, R=R, S=S, D=s.config()[1], near=s.near(), nchain=s.streamer()[1])
+        o.set_panel_f32(X, R=R, S=S, D=s.config()[1], near=s.near(), nchain=s.streamer()[1], tform=s.chain_form())
     else:
         o.set_panel_f32(X)
     return o
@@ -81,7 +81,6 @@ def test_one_set_tuple_is_the_symbol_method_on_the_device(ngp, O):
     res = []
     for tup in (True, False):
         s = ngp.Sampler(device=0, seed=9, chain=2)
-        s.set_chain_form(0)   # step chains on both sides (BayesPR blocks otherwise take the inverse form, ngp_set_chain_form)
         s.set_panel(X)
         if tup:
             s.add_marker_set_tuple(0, nloc, 1, 4.0, [[sv * 4.0]], regions, [[v]])
@@ -110,7 +109,7 @@ def test_tuple_compact_storage_snapshot_and_fine_seam(ngp, O, tmp_path):
     s.set_panel(Gt, centre=True)
     R, S, _ = s.layout()
     o = O.Oracle(order=1, seed=3, chain=0)
-    o.set_panel_u8(Gt, R=R, S=S, D=s.config()[1], near=s.near())
+    o.set_panel_u8(Gt, R=R, S=S, D=s.config()[1], near=s.near(), tform=s.chain_form())
     for m in (s, o):
         add_tuple(m, nloc, k, vm, regions)
         m.set_y(y); m.set_residual_prior(4.0, 0.5); m.set_schedule(14, 2, 2); m.run(6)

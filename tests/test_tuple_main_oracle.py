@@ -62,7 +62,6 @@ def test_one_set_tuple_is_the_symbol_path(O, ngp, order):
     for tup in (True, False):
         o = O.Oracle(order=order, seed=9, chain=2)
         o.set_panel_f32(X, R=32, S=4, D=4, near=3, nchain=8) if order else o.set_panel_f32(X)
-        o.set_tform(False)                                    # step chains on both sides (BayesPR blocks otherwise take the inverse form)
         s = v * 0.5                                           # the Symbol path's scale = v (df - 2) / df, df = 4
         if tup:
             o.add_marker_set_tuple(0, nloc, 1, 4.0, [[s * 4.0]], regions, [[v]])   # InverseWishart(df + n, scale + b'b): scale = s df

@@ -7,7 +7,9 @@ ngp = load_pkg()
 N, P = int(sys.argv[1]), int(sys.argv[2])
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 30
 for kind in ("PR", "B", "C", "R4", "R8"):
-    s = ngp.Sampler(device=0, seed=1001, chain=0)
+    s = ngp.Sampler(device=0, seed=1001, chain=0, lag=int(os.environ["NGP_TOOL_LAG"]) if "NGP_TOOL_LAG" in os.environ else None)
+    if "NGP_TOOL_NEAR" in os.environ: s.set_near(int(os.environ["NGP_TOOL_NEAR"]))
+    if "NGP_TOOL_CHAIN_FORM" in os.environ: s.set_chain_form(int(os.environ["NGP_TOOL_CHAIN_FORM"]))
     s.generate_panel(N, P)
     rng = np.random.default_rng(1); bt = np.zeros(P); idx = rng.choice(P, max(10, P // 100), replace=False); bt[idx] = rng.normal(size=len(idx))
     g = s.xbeta(bt); y = 10 + g + np.random.default_rng(2).normal(size=N) * np.sqrt(g.var())
@@ -21,4 +23,4 @@ for kind in ("PR", "B", "C", "R4", "R8"):
     s.run(5)
     t = time.perf_counter(); s.run(iters); dt = (time.perf_counter() - t) / iters
     R, S, nb = s.layout()
-    print(f"{kind:3s} N={N} P={P} layout R={R} S={S} lag={s.config()[1]}: {dt * 1e3:.3f} ms/iter, {dt / nb * 1e6:.2f} us/block", flush=True)
+    print(f"{kind:3s} N={N} P={P} layout R={R} S={S} lag={s.config()[1]} near={s.near()}: {dt * 1e3:.3f} ms/iter, {dt / nb * 1e6:.2f} us/block", flush=True)
