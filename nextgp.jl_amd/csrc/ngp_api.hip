@@ -671,7 +671,7 @@ int set_panel_host(ngp_handle *h, const TIn *M, int64_t N, int64_t P, int64_t ld
 bool wants_tinv(const ngp_handle *h) {
     if (h->chain_form != 1) return false;
     for (const HSet &st : h->sets)
-        if (st.method == NGP_METHOD_BAYESPR) return true;
+        if (st.method == NGP_METHOD_BAYESPR || st.method == NGP_METHOD_TUPLE) return true;
     return false;
 }
 
@@ -681,16 +681,19 @@ bool wants_tinv(const ngp_handle *h) {
 int sync_linear_blocks(ngp_handle *h, int active_set) {
     if (!wants_tinv(h) || h->tinv_blocks != h->NBLK) { h->lin_all = 0; h->lin_any = 0; return NGP_OK; }
     if (h->blin_for == active_set) return NGP_OK;
+    // 1 = BayesPR / unowned / inactive lanes only; 1 + k = a block of a k-set Tuple (its chain is linear too: one step per locus);
+    // 0 = a lane of BayesB / BayesC / BayesR: the step chains
     std::vector<unsigned> bl((size_t)h->NBLK, 1u);
     for (size_t si = 0; si < h->sets.size(); si++) {
         const HSet &st = h->sets[si];
         if (st.method == NGP_METHOD_BAYESPR || (active_set >= 0 && (int)si != active_set)) continue;
-        for (int64_t t = st.col0 / NGP_BLK; t <= (st.col0 + st.ncol - 1) / NGP_BLK && t < h->NBLK; t++) bl[(size_t)t] = 0u;
+        const unsigned code = (st.method == NGP_METHOD_TUPLE) ? 1u + (unsigned)st.tk : 0u;
+        for (int64_t t = st.col0 / NGP_BLK; t <= (st.col0 + st.ncol - 1) / NGP_BLK && t < h->NBLK; t++) bl[(size_t)t] = code;
     }
-    int64_t n = 0;
-    for (unsigned v : bl) n += v;
-    h->lin_all = (n == h->NBLK) ? 1 : 0;
-    h->lin_any = (n > 0) ? 1 : 0;
+    int64_t n1 = 0, nany = 0;
+    for (unsigned v : bl) { n1 += (v == 1u); nany += (v != 0u); }
+    h->lin_all = (n1 == h->NBLK) ? 1 : 0;
+    h->lin_any = (nany > 0) ? 1 : 0;
     HCHK(hipMemcpyAsync(h->d_blin, bl.data(), (size_t)h->NBLK * sizeof(unsigned), hipMemcpyHostToDevice, h->stream));
     HCHK(hipStreamSynchronize(h->stream));  // (bl is a local)
     h->blin_for = active_set;
@@ -902,7 +905,7 @@ int sample_enqueue(ngp_handle *h);  // (below)
 void launch_tinv(ngp_handle *h) {  // (sync_linear_blocks has run for this call's active set)
     if (!wants_tinv(h) || h->tinv_blocks != h->NBLK || !h->lin_any) return;
     hipLaunchKernelGGL(k_tinv, dim3((unsigned)h->NBLK), dim3(64), 0, h->stream, (const double *)h->d_gramx, h->D, (const double *)h->d_c,
-                       (const unsigned *)h->d_blin, h->d_tinv, (const unsigned *)h->d_abort);
+                       (const unsigned *)h->d_blin, h->d_tinv, (const unsigned *)h->d_abort, (const double *)h->d_tupc, (long long)h->Ppad);
 }
 
 void iteration_pre(ngp_handle *h, int64_t trace_idx, bool resume_mid) {  // everything in front of the sweep

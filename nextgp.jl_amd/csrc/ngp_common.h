@@ -312,8 +312,9 @@ __device__ inline int tuple_nvalid(const int k, const long long nloc, const long
 // K = k as a compile-time constant: with a run-time k every "component b exists" test is a branch, every load sits in a basic block
 // of its own behind a full wait (64 LDS round trips in a row per sixteen steps: 7 us per block); here the loads of sixteen steps
 // leave together
-template <int K, typename GAt>
-__device__ __attribute__((always_inline)) inline double tuple_chain_k(const int nvalid, const int j, const double tot, const double bo, const TupLane &T, GAt G) {
+// e0 of a Tuple block's lane: its candidate dlt before any column of the block has been drawn
+template <int K>
+__device__ __attribute__((always_inline)) inline double tuple_e0_k(const int nvalid, const int j, const double tot, const double bo, const TupLane &T) {
     const int gbase = tuple_gbase(K, j);
     const bool valid = j < nvalid;
     // x_m'(ycorr + X_l beta_l): the add-back of all k effects of the locus, components in order
@@ -332,6 +333,21 @@ __device__ __attribute__((always_inline)) inline double tuple_chain_k(const int 
 #pragma unroll
     for (int b = 0; b < K; b++) e = __builtin_fma(rb[b], T.crow[b], e);
     if (!valid) e = 0.0;
+    return e;
+}
+__device__ __attribute__((always_inline)) inline double tuple_e0(const int k, const int nvalid, const int j, const double tot, const double bo, const TupLane &T) {
+    switch (k) {
+        case 1: return tuple_e0_k<1>(nvalid, j, tot, bo, T);
+        case 2: return tuple_e0_k<2>(nvalid, j, tot, bo, T);
+        case 3: return tuple_e0_k<3>(nvalid, j, tot, bo, T);
+        default: return tuple_e0_k<4>(nvalid, j, tot, bo, T);
+    }
+}
+template <int K, typename GAt>
+__device__ __attribute__((always_inline)) inline double tuple_chain_k(const int nvalid, const int j, const double tot, const double bo, const TupLane &T, GAt G) {
+    const int gbase = tuple_gbase(K, j);
+    const bool valid = j < nvalid;
+    double e = tuple_e0_k<K>(nvalid, j, tot, bo, T);
     // a finished column s changes e by H(s) dlt_s, H(s) = -(sum_b C[b] G[s][column b of this lane's locus]), for the columns of
     // LATER loci only (the k effects of a locus are drawn together).  The H of sixteen steps are formed first -- independent loads
     // and fma, in flight together -- so that the serial part of a step is what it is on the Symbol path: one readlane, one fma.

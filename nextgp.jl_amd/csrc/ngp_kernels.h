@@ -336,82 +336,100 @@ __global__ __launch_bounds__(256) void k_prep(long long Ppad, const int8_t *__re
 
 // ------------------------------------------------------------------------------------------
 // Inverse form of the LINEAR blocks.  In a block whose lanes are all BayesPR (always included,
-// src/functions.jl:124-136) or unowned, the 64 serial steps  dlt_k = e_k, e_j += H_jk dlt_k (j > k)  are the forward
-// substitution of  L dlt = e0,  L = I + diag(c) strictLower(G') : dlt = T e0 with T = inv(L).  L depends on this iteration's
-// c (k_prep) and on the Gram block only -- not on the residual -- so T is formed here, before the sweep, for every such block
-// at once (one wave per block, the whole device), and the sampler's critical wave replaces its 64 dependent cross-lane steps
+// src/functions.jl:124-136) or unowned -- or that belongs to a Tuple set (src/functions.jl:140-154) -- the serial steps
+//   dlt_k = e_k,  e_j += H_jk dlt_k  (j in a later locus than k)
+// are the forward substitution of  L dlt = e0,  L = I - H' : dlt = T e0 with T = inv(L).  L depends on this iteration's
+// coefficients (k_prep) and on the Gram block only -- not on the residual -- so T is formed here, before the sweep, for every such
+// block at once (one wave per block, the whole device), and the sampler's critical wave replaces its dependent cross-lane steps
 // (v_readlane -> SGPR -> fma: 24.6 clocks each) by one 64 x 64 product from LDS.
-// Lane i forms column i of T by forward substitution, in the order of the steps it replaces:
-//   x_m = 0 (m < i), 1 (m = i), -(c_m acc_m) (m > i);   then acc_j = fma(G[m][j], x_m, acc_j) for j > m
-// (G[m][j], c_m are wave-uniform: scalar loads; nothing crosses a lane).  Output: tinv[t][i][j] = T[j][i], the layout of the
-// one-sided diagonal Gram block it stands in for (lane j of the chain reads row j with stride 64).
+// Lane i forms column i of T by forward substitution, row after row in the order of the steps it replaces:
+//   x_m = 0 (m < i), 1 (m = i), else  -(c_m acc_m)                                   BayesPR / unowned block (K = 0)
+//                                     -(C_m[0] acc_g (+) fma(C_m[b], acc_{g+b}))       block of a k-set Tuple, g = first column of m's locus
+//   then acc_j = fma(G[m][j], x_m, acc_j) for the columns j of later loci (K = 0: j > m)
+// (G[m][j] is wave-uniform: broadcast reads from the block's copy in LDS; nothing but the coefficients of row m crosses a lane).
+// Output: tinv[t][i][j] = T[j][i], the layout of the one-sided diagonal Gram block it stands in for (lane j of the chain reads row j
+// with stride 64).  blin[t]: 0 = not linear, 1 = BayesPR / unowned, 1 + k = block of a k-set Tuple.
 // ------------------------------------------------------------------------------------------
-typedef double ngp_v8d __attribute__((ext_vector_type(8)));
-// sixteen consecutive doubles at a wave-uniform address into SGPRs (two s_load_dwordx16), and the wait that hands them over.
-// Written out because the compiler, given plain uniform loads in the unrolled substitution below, hoists all 2016 of them to the
-// top of the kernel and spills them through v_writelane / v_readlane (25,000 readlanes for 2,000 fma).
-__device__ __attribute__((always_inline)) inline void sload16(const double *p, ngp_v8d &a, ngp_v8d &b) {
-    asm volatile("s_load_dwordx16 %0, %2, 0x0\n\ts_load_dwordx16 %1, %2, 0x40" : "=&s"(a), "=&s"(b) : "s"(p) : "memory");
-}
-__device__ __attribute__((always_inline)) inline void swait16(ngp_v8d &a, ngp_v8d &b) {
-    asm volatile("s_waitcnt lgkmcnt(0)" : "+s"(a), "+s"(b)::"memory");
-}
-// step n = (panel p, row m) of the substitution, 16 + 32 + 48 + 64 steps; templates, because the unroller leaves a 160-trip loop
-// with inline asm in its body rolled (and the accumulators then live in scratch)
-template <int n>
-__device__ __attribute__((always_inline)) inline void tinv_step(double (&acc)[NGP_BLK], ngp_v8d &a0, ngp_v8d &a1, ngp_v8d &b0, ngp_v8d &b1,
-                                                                const double *G1, const double cv, const int i) {
-    constexpr int p = n < 16 ? 0 : (n < 48 ? 1 : (n < 96 ? 2 : 3));
-    constexpr int m = n - (p == 0 ? 0 : (p == 1 ? 16 : (p == 2 ? 48 : 96)));
-    constexpr int n1 = n + 1;
-    constexpr int pn = n1 < 16 ? 0 : (n1 < 48 ? 1 : (n1 < 96 ? 2 : 3));
-    constexpr int mn = n1 - (pn == 0 ? 0 : (pn == 1 ? 16 : (pn == 2 ? 48 : 96)));
-    if constexpr ((n & 1) == 0) {
-        swait16(a0, a1);
-        if constexpr (n1 < 160) sload16(G1 + mn * NGP_BLK + 16 * pn, b0, b1);
-    } else {
-        swait16(b0, b1);
-        if constexpr (n1 < 160) sload16(G1 + mn * NGP_BLK + 16 * pn, a0, a1);
-    }
-    if constexpr (m >= 16 * p) {  // acc_m is complete: x_m
-        const double cm = readlane_d(cv, m);
-        const double tcm = cm * acc[m];
-        acc[m] = (i == m) ? 1.0 : ((i > m) ? 0.0 : -tcm);
-    }
-    const double xm = acc[m];
-#pragma unroll
-    for (int jj = 0; jj < 16; jj++) {
-        const int j = 16 * p + jj;
-        if (j <= m) continue;
-        const double g = (n & 1) == 0 ? (jj < 8 ? a0[jj & 7] : a1[jj & 7]) : (jj < 8 ? b0[jj & 7] : b1[jj & 7]);
-        acc[j] = __builtin_fma(g, xm, acc[j]);
-    }
-    // (the sixteen fma stay in front of the next step's wait: sunk below it, their SGPR operands outlive the next load and spill)
-    asm volatile("" : "+v"(acc[16 * p + 0]), "+v"(acc[16 * p + 1]), "+v"(acc[16 * p + 2]), "+v"(acc[16 * p + 3]), "+v"(acc[16 * p + 4]),
-                      "+v"(acc[16 * p + 5]), "+v"(acc[16 * p + 6]), "+v"(acc[16 * p + 7]), "+v"(acc[16 * p + 8]), "+v"(acc[16 * p + 9]),
-                      "+v"(acc[16 * p + 10]), "+v"(acc[16 * p + 11]), "+v"(acc[16 * p + 12]), "+v"(acc[16 * p + 13]), "+v"(acc[16 * p + 14]),
-                      "+v"(acc[16 * p + 15]));
-    if constexpr (n1 < 160) tinv_step<n1>(acc, a0, a1, b0, b1, G1, cv, i);
-}
-__global__ __launch_bounds__(64) void k_tinv(const double *__restrict__ gramx, int D, const double *__restrict__ c,
-                                             const unsigned *__restrict__ blin, double *__restrict__ tinv, const unsigned *__restrict__ abort_w) {
-    if (abort_w && *abort_w != 0u) return;
-    const int t = blockIdx.x, i = threadIdx.x;
-    if (blin[t] == 0u) return;  // (which blocks are linear is static for a model: the host's table, ngp_api.hip sync_linear_blocks)
-    const double *G1 = gramx + (size_t)t * D * (NGP_BLK * NGP_BLK);  // element (m, j) at m * 64 + j, zero for j <= m
-    const double cv = c[(size_t)t * NGP_BLK + i];                    // lane m holds c_m
+template <int K>
+__host__ __device__ constexpr int tinv_gbase(const int j) { return K <= 1 ? j : (K == 2 ? (j & ~1) : (K == 3 ? (j / 3) * 3 : (j & ~3))); }
+// One wave forms T of one block: the Gram block goes through LDS once (coalesced), its rows come back as broadcast reads (G[m][j] is
+// the same for every lane: the lanes differ in the column of T they carry), the substitution is unrolled completely -- 2016 fma with
+// the accumulators in registers.  (A first version fed G through scalar loads into SGPRs, double-buffered by hand: the compiler
+// spilled SGPR tuples whose loads were still in flight -- it cannot know that -- and T came out wrong in a few rows.)
+template <int K>
+__device__ __attribute__((always_inline)) inline void tinv_block(const double *__restrict__ G1, const double (&cv)[K > 0 ? K : 1], const int i,
+                                                                 double *__restrict__ dst_col, double *__restrict__ Gs) {
+#pragma unroll 8
+    for (int idx = i; idx < NGP_BLK * NGP_BLK; idx += NGP_BLK) Gs[idx] = G1[idx];
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");  // (one wave: LDS serves it in order)
     double acc[NGP_BLK];
 #pragma unroll
     for (int j = 0; j < NGP_BLK; j++) acc[j] = 0.0;
-    // Panels of 16 columns j, rows m ascending inside a panel: every acc_j still receives its terms in the order m = 0, 1, .., j-1
-    // (the order of the row sweep), and the loop is regular -- one 128-byte piece of row m per step, the next one requested
-    // before the sixteen fma of this one (SMEM returns out of order: only lgkmcnt(0) is a safe wait, so one piece is in flight).
-    ngp_v8d a0, a1, b0, b1;
-    sload16(G1, a0, a1);
-    tinv_step<0>(acc, a0, a1, b0, b1, G1, cv, i);
-    double2 *dst = (double2 *)(tinv + (size_t)t * (NGP_BLK * NGP_BLK) + (size_t)i * NGP_BLK);
+#pragma unroll
+    for (int m = 0; m < NGP_BLK; m++) {
+        // every acc of m's locus is complete: x of the whole locus at its first column (the sums acc_g .. acc_{g+K-1} feed all K of them,
+        // so none is replaced by its x before the last one is formed)
+        if constexpr (K <= 1) {
+            const double t = readlane_d(cv[0], m) * acc[m];
+            acc[m] = (i == m) ? 1.0 : ((i > m) ? 0.0 : -t);
+        } else {
+            const int g = tinv_gbase<K>(m);
+            if (m == g) {
+                double tx[K];
+#pragma unroll
+                for (int bp = 0; bp < K; bp++) {
+                    if (g + K > NGP_BLK) {
+                        tx[bp] = 0.0;  // (the unused last column of a 3-set block)
+                    } else {
+                        double t = readlane_d(cv[0], g + bp) * acc[g];
+#pragma unroll
+                        for (int b = 1; b < K; b++) t = __builtin_fma(readlane_d(cv[b], g + bp), acc[g + b], t);
+                        tx[bp] = t;
+                    }
+                }
+#pragma unroll
+                for (int bp = 0; bp < K; bp++)
+                    if (g + bp < NGP_BLK) acc[g + bp] = (i == g + bp) ? 1.0 : ((i > g + bp) ? 0.0 : -tx[bp]);
+            }
+        }
+        const double xm = acc[m];
+#pragma unroll
+        for (int j = m + 1; j < NGP_BLK; j++) {
+            if (tinv_gbase<K>(j) <= m) continue;  // (K = 0: never) same locus as m
+            acc[j] = __builtin_fma(Gs[m * NGP_BLK + j], xm, acc[j]);
+        }
+    }
+    double2 *dst = (double2 *)dst_col;
 #pragma unroll
     for (int jj = 0; jj < NGP_BLK / 2; jj++) dst[jj] = make_double2(acc[2 * jj], acc[2 * jj + 1]);
+}
+__global__ __launch_bounds__(64) void k_tinv(const double *__restrict__ gramx, int D, const double *__restrict__ c,
+                                             const unsigned *__restrict__ blin, double *__restrict__ tinv, const unsigned *__restrict__ abort_w,
+                                             const double *__restrict__ tupc, long long Ppad) {
+    if (abort_w && *abort_w != 0u) return;
+    const int t = blockIdx.x, i = threadIdx.x;
+    const unsigned code = blin[t];  // (which blocks are linear is static for a model: the host's table, ngp_api.hip sync_linear_blocks)
+    if (code == 0u) return;
+    __shared__ double Gs[NGP_BLK * NGP_BLK];
+    const double *G1 = gramx + (size_t)t * D * (NGP_BLK * NGP_BLK);  // element (m, j) at m * 64 + j, zero for j <= m
+    double *dst = tinv + (size_t)t * (NGP_BLK * NGP_BLK) + (size_t)i * NGP_BLK;
+    const size_t col = (size_t)t * NGP_BLK + i;
+    if (code == 1u) {
+        const double cv[1] = {c[col]};  // lane m holds c_m
+        tinv_block<0>(G1, cv, i, dst, Gs);
+    } else if (code == 2u) {
+        const double cv[1] = {tupc[col]};
+        tinv_block<1>(G1, cv, i, dst, Gs);
+    } else if (code == 3u) {
+        const double cv[2] = {tupc[col], tupc[(size_t)Ppad + col]};
+        tinv_block<2>(G1, cv, i, dst, Gs);
+    } else if (code == 4u) {
+        const double cv[3] = {tupc[col], tupc[(size_t)Ppad + col], tupc[(size_t)2 * Ppad + col]};
+        tinv_block<3>(G1, cv, i, dst, Gs);
+    } else {
+        const double cv[4] = {tupc[col], tupc[(size_t)Ppad + col], tupc[(size_t)2 * Ppad + col], tupc[(size_t)3 * Ppad + col]};
+        tinv_block<4>(G1, cv, i, dst, Gs);
+    }
 }
 
 // ------------------------------------------------------------------------------------------
@@ -518,7 +536,13 @@ __global__ __launch_bounds__(256) void k_recur(const double *__restrict__ part, 
     const int meth0 = (si0 >= 0) ? sets[si0].method : -1;
     if (tinv && blin[t] != 0u) {  // linear block: dlt = T e0 (k_tinv)
         const double *Tt = tinv + (size_t)t * (NGP_BLK * NGP_BLK) + j;  // element (i, j) = T[j][i]
-        const double e0 = __builtin_fma(r, cc, ww);
+        double e0 = __builtin_fma(r, cc, ww);
+        if (blin[t] > 1u) {  // a Tuple block: e0 from the k x k conditional of the lane's locus
+            const DTup Tp = tup[__builtin_amdgcn_readfirstlane(__shfl(si0, 0))];  // (column 0 of a Tuple block is always the set's)
+            const TupLane TL = load_tuplane(tupc, tupg, w, Ppad, k);
+            const long long first_locus = ((long long)t - Tp.col0 / NGP_BLK) * (NGP_BLK / Tp.k);
+            e0 = tuple_e0(Tp.k, tuple_nvalid(Tp.k, Tp.nloc, first_locus), j, tot, bo, TL);
+        }
         gs[j] = e0;  // (only wave 0 is left and it has read its group sums: LDS serves a wave in order, no barrier needed)
         __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront");
         double s4[4] = {0.0, 0.0, 0.0, 0.0};

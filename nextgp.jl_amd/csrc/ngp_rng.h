@@ -106,22 +106,33 @@ __device__ inline double det_log(double x) {
     return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
 }
 
-// det_exp for x <= 0: fixed IEEE sequence (fdlibm's argument reduction and degree-5 rational), bit for bit the oracle's; results
-// below 2^-1021 come back as 0.  Only the blocked BayesR class search uses it (on L - max L <= 0).
+// det_exp for x <= 0: fixed IEEE sequence (fdlibm's argument reduction, then the Taylor series to degree 13 by Horner), bit for bit the
+// oracle's; results below 2^-1021 come back as 0.  Only the blocked BayesR class search uses it (on L - max L <= 0).  No division
+// since round 4: the four exponentials of a class evaluation run interleaved, and the v_div_scale / v_div_fmas pairs of the
+// rational form serialised them on VCC (2.2 us per evaluation of a block's lanes).  Within 1 ulp of libm (tests/test_oracle.py).
 __device__ inline double det_exp(double x) {
     const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00;
-    const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
-                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
     if (x != x) return x;
     if (x < -708.0) return 0.0;
     if (x > 0.0) x = 0.0;
     const int k = (int)(invln2 * x - 0.5);
     const double t = (double)k;
     const double hi = x - t * ln2HI, lo = t * ln2LO;
-    const double xr = hi - lo;
+    const double xr = hi - lo;  // |xr| <= ln 2 / 2
+    double q = 1.0 / 6227020800.0;
+    q = __builtin_fma(q, xr, 1.0 / 479001600.0);
+    q = __builtin_fma(q, xr, 1.0 / 39916800.0);
+    q = __builtin_fma(q, xr, 1.0 / 3628800.0);
+    q = __builtin_fma(q, xr, 1.0 / 362880.0);
+    q = __builtin_fma(q, xr, 1.0 / 40320.0);
+    q = __builtin_fma(q, xr, 1.0 / 5040.0);
+    q = __builtin_fma(q, xr, 1.0 / 720.0);
+    q = __builtin_fma(q, xr, 1.0 / 120.0);
+    q = __builtin_fma(q, xr, 1.0 / 24.0);
+    q = __builtin_fma(q, xr, 1.0 / 6.0);
+    q = __builtin_fma(q, xr, 0.5);
     const double tt = xr * xr;
-    const double c = xr - tt * (P1 + tt * (P2 + tt * (P3 + tt * (P4 + tt * P5))));
-    const double y = 1.0 - ((lo - (xr * c) / (2.0 - c)) - hi);
+    const double y = 1.0 + __builtin_fma(tt, q, xr);
     const double sc = __longlong_as_double((long long)((uint64_t)(k + 1023) << 52));
     return y * sc;
 }

@@ -1686,7 +1686,19 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
             if (tform && dbg_mode != 5) {
                 // dlt = T e0: e0 goes through the r0 slot of this block (free once the total has been
                 // read) and comes back as broadcast reads, 16 values at a time; four accumulators over i mod 4, ((s0+s1)+(s2+s3))
-                r0[rs * NGP_BLK + j] = e;
+                double e0 = e;
+                if constexpr (TUP) {
+                    if (tk != 0) {  // a Tuple block: e0 from the k x k conditional of the lane's locus (lane coefficients: LDS, wave 1)
+                        const int nvalid = __builtin_amdgcn_readfirstlane(tmeta[buf * 4 + 1]);
+                        const double *tsrc = tl + (size_t)buf * (9 * NGP_BLK) + j;
+                        TupLane TL;
+#pragma unroll
+                        for (int b = 0; b < NGP_KMAX; b++) { TL.crow[b] = tsrc[b * NGP_BLK]; TL.grow[b] = tsrc[(NGP_KMAX + b) * NGP_BLK]; }
+                        TL.ww = tsrc[2 * NGP_KMAX * NGP_BLK];
+                        e0 = tuple_e0(tk, nvalid, j, tot, bo, TL);
+                    }
+                }
+                r0[rs * NGP_BLK + j] = e0;
                 typedef const __attribute__((address_space(3))) double *lds_cdp;
                 const lds_cdp ek = (lds_cdp)(r0 + rs * NGP_BLK);
                 double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;

@@ -34,8 +34,9 @@ struct SweepArgs {
     const double *tinv;   // [block][64][64], written by k_tinv before the sweep: for a LINEAR block (blin[t] != 0) the transposed inverse T
                           // of its chain's unit lower-triangular system, in the layout of the diagonal Gram block (element (i, j) =
                           // T[j][i]); the sampler stages it in place of that block and takes the chain as dlt = T e0.  Null: 64 steps.
-    const unsigned *blin; // [block] 1 = linear: every lane BayesPR, unowned or (fine seam) of another set than the sampled one.  Static
-                          // for a model: written by the host (ngp_api.hip, sync_linear_blocks), read-only on the device
+    const unsigned *blin; // [block] 1 = linear: every lane BayesPR, unowned or (fine seam) of another set than the sampled one; 1 + k: a
+                          // block of a k-set Tuple (linear too).  Static for a model: written by the host (ngp_api.hip,
+                          // sync_linear_blocks), read-only on the device
     int lin_all;          // every block is linear (no per-block look needed)
     int knob;     // tuning knob of the streamers (ngp_debug_set_knob), see role_streamer_rows
     int variant;  // streamer variant: 1 = phase streamer (role_streamer), 2 = row-owning waves + loader wave (role_streamer_rows)

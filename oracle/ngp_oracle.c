@@ -147,22 +147,34 @@ static inline double det_log(double x) {
     return dk * ln2_hi - ((hfsq - (s * (hfsq + R) + dk * ln2_lo)) - f);
 }
 
-/* det_exp for x <= 0: fixed IEEE sequence (fdlibm's argument reduction and degree-5 rational), so that CPU and GPU agree
-   bitwise.  Results below 2^-1021 are returned as 0; the blocked BayesR path only ever calls it on L - max(L) <= 0. */
+/* det_exp for x <= 0: fixed IEEE sequence (fdlibm's argument reduction, then the Taylor series to degree 13 by Horner -- round 4:
+   no division, whose v_div_scale / v_div_fmas pairs serialised the four exponentials of a BayesR class evaluation on the device),
+   so that CPU and GPU agree bitwise.  Results below 2^-1021 are returned as 0; the blocked BayesR path only ever calls it on
+   L - max(L) <= 0. */
 static inline double det_exp(double x) {
     const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00;
-    const double P1 = 1.66666666666666019037e-01, P2 = -2.77777777770155933842e-03, P3 = 6.61375632143793436117e-05,
-                 P4 = -1.65339022054652515390e-06, P5 = 4.13813679705723846039e-08;
     if (x != x) return x;
     if (x < -708.0) return 0.0;
     if (x > 0.0) x = 0.0;
     const int k = (int)(invln2 * x - 0.5);
     const double t = (double)k;
     const double hi = x - t * ln2HI, lo = t * ln2LO;
-    const double xr = hi - lo;
+    const double xr = hi - lo;   /* |xr| <= ln 2 / 2 */
+    /* exp(xr) = 1 + xr + xr^2 q(xr), q = the Taylor series to degree 13 by Horner (fma): no division, no data-dependent branch */
+    double q = 1.0 / 6227020800.0;
+    q = __builtin_fma(q, xr, 1.0 / 479001600.0);
+    q = __builtin_fma(q, xr, 1.0 / 39916800.0);
+    q = __builtin_fma(q, xr, 1.0 / 3628800.0);
+    q = __builtin_fma(q, xr, 1.0 / 362880.0);
+    q = __builtin_fma(q, xr, 1.0 / 40320.0);
+    q = __builtin_fma(q, xr, 1.0 / 5040.0);
+    q = __builtin_fma(q, xr, 1.0 / 720.0);
+    q = __builtin_fma(q, xr, 1.0 / 120.0);
+    q = __builtin_fma(q, xr, 1.0 / 24.0);
+    q = __builtin_fma(q, xr, 1.0 / 6.0);
+    q = __builtin_fma(q, xr, 0.5);
     const double tt = xr * xr;
-    const double c = xr - tt * (P1 + tt * (P2 + tt * (P3 + tt * (P4 + tt * P5))));
-    const double y = 1.0 - ((lo - (xr * c) / (2.0 - c)) - hi);
+    const double y = 1.0 + __builtin_fma(tt, q, xr);
     uint64_t sb = (uint64_t)(k + 1023) << 52; /* 2^k, k >= -1021 */
     double sc; memcpy(&sc, &sb, 8);
     return y * sc;
@@ -1549,6 +1561,41 @@ static void iter_blocked(ora_t *h) {
                 for (int b = 0; b < kk; b++) e = __builtin_fma(rr[gb + b], h->tupc[(size_t)b * PP + c], e);
                 cand[j] = e;
             }
+            if (h->tform) {
+                /* inverse form (k_tinv with K = kk): L dlt = e0, L = I - H'; column i of T = inv(L) by forward substitution, row after
+                   row: x_m = -(C_m[0] acc_g (+) fma(C_m[b], acc_{g+b})), g = first column of m's locus (0 for the unused last column
+                   of a 3-set block); acc_j += G[m][j] x_m for the columns j of later loci.  Then dlt = T e0, four accumulators. */
+                double Tm[BLK][BLK];
+                for (int i = 0; i < BLK; i++) {
+                    double acc[BLK], x[BLK];
+                    for (int j = 0; j < BLK; j++) acc[j] = 0.0;
+                    for (int m = 0; m < BLK; m++) {
+                        double xm;
+                        if (m < i) xm = 0.0;
+                        else if (m == i) xm = 1.0;
+                        else {
+                            const int g = (m / kk) * kk;
+                            double t = 0.0;
+                            if (g + kk <= BLK) {
+                                t = h->tupc[k0 + m] * acc[g];
+                                for (int b = 1; b < kk; b++) t = __builtin_fma(h->tupc[(size_t)b * PP + k0 + m], acc[g + b], t);
+                            }
+                            xm = -t;
+                        }
+                        x[m] = xm;
+                        for (int j = m + 1; j < BLK; j++)
+                            if ((j / kk) * kk > m) acc[j] = __builtin_fma(G[j * BLK + m], xm, acc[j]);
+                    }
+                    for (int m = 0; m < BLK; m++) Tm[m][i] = x[m];
+                }
+                double dl[BLK];
+                for (int j = 0; j < BLK; j++) {
+                    double s4[4] = {0, 0, 0, 0};
+                    for (int i = 0; i < BLK; i++) s4[i & 3] = __builtin_fma(Tm[j][i], cand[i], s4[i & 3]);
+                    dl[j] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+                }
+                for (int j = 0; j < BLK; j++) cand[j] = dl[j];
+            } else
             for (int sl = 0; sl < nvalid; sl++) {
                 const double dk = cand[sl];
                 for (int j = (sl / kk + 1) * kk; j < nvalid; j++) {

@@ -27,14 +27,16 @@ def oracle_like(O, s, X, order=1, seed=21, chain=0):
     return o
 
 
+@pytest.mark.parametrize("form", [0, 1], ids=["steps", "inverse_form"])
 @pytest.mark.parametrize("engine", list(ENGINES))
 @pytest.mark.parametrize("k,nloc", [(1, 90), (2, 75), (3, 50), (4, 40)])
-def test_tuple_chain_bit_exact_vs_blocked_oracle(ngp, O, k, nloc, engine):
+def test_tuple_chain_bit_exact_vs_blocked_oracle(ngp, O, k, nloc, engine, form):
     N = 300
     Xp, y, vm, v, span, off = tuple_problem(O, ngp, N, nloc, k, extra=40)
     regions = [(0, nloc // 3), (nloc // 3, nloc)]
     kw, shards = ENGINES[engine]
     s = ngp.Sampler(device=0, seed=21, chain=0, **kw)
+    s.set_chain_form(form)   # 1: the Tuple blocks (and the BayesPR ones) as dlt = T e0, T by k_tinv
     if shards:
         s.set_max_shards(shards)
     s.set_panel(Xp)
@@ -71,7 +73,8 @@ def test_tuple_chain_vs_reference_order_oracle(ngp, O, k, nloc):
     assert np.allclose(a["varBeta"], b["varBeta"], rtol=1e-8) and abs(a["varE"] / b["varE"] - 1) < 1e-10
 
 
-def test_one_set_tuple_is_the_symbol_method_on_the_device(ngp, O):
+@pytest.mark.parametrize("form", [0, 1], ids=["steps", "inverse_form"])
+def test_one_set_tuple_is_the_symbol_method_on_the_device(ngp, O, form):
     """k = 1 (a 1 x 1 variance 'matrix', InverseWishart = scaled inverse chi-square) draws, bit for bit, the chain of a plain BayesPR
     set with the same regions -- the Tuple method's arithmetic contains the Symbol method's."""
     N, nloc = 250, 100
@@ -81,6 +84,7 @@ def test_one_set_tuple_is_the_symbol_method_on_the_device(ngp, O):
     res = []
     for tup in (True, False):
         s = ngp.Sampler(device=0, seed=9, chain=2)
+        s.set_chain_form(form)
         s.set_panel(X)
         if tup:
             s.add_marker_set_tuple(0, nloc, 1, 4.0, [[sv * 4.0]], regions, [[v]])
