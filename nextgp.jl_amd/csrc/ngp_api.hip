@@ -791,14 +791,11 @@ void launch_sweep(ngp_handle *h, int64_t tb0, int64_t tb1, hipEvent_t *evs) {
         else if (h->nclass_total > 0 && h->lds_sweep_r && !(h->knob & 65536))  // a BayesR set: the flavour that fetches its coefficients ahead
             sweep_r_launch((unsigned)h->last_grid, h->lds_sweep_r, h->stream, A);
         // Models with a Tuple or a BayesR set run the kernel that carries those chains (k_sweep<false>, the kernel of BayesPR / BayesB /
-        // BayesC, does not: ngp_sweep.h, role_sampler).  The two are otherwise the same program, and which one is faster for a model
-        // both can run is a matter of code layout -- measured, interleaved with the library of mid-round (tools/ab3.sh, four to five
-        // repetitions, three boxes): 50k x 600k (204-row shards of the row-owning streamer) 24.0-24.2 ms per iteration in the full
-        // kernel and in the mid-round library against 24.4-24.7 in the lean one; 10k x 100k 2.78 (lean) against 2.94; 20k x 100k
-        // (84-row shards) 3.15 against 3.23.  So tall fp32 shards of the row-owning streamer take the full kernel as well; knob bit 14
-        // forces it, bit 15 forbids it.
-        else if (h->ntuple > 0 || h->nclass_total > 0 || (h->knob & 16384) ||
-                 (!(h->knob & 32768) && h->streamer == 2 && h->storage == 0 && h->R >= 160))
+        // BayesC, does not: ngp_sweep.h, role_sampler).  Every other model takes the lean kernel at every shape (in round 3 tall fp32
+        // shards ran 1.7-2 % faster in the full kernel -- register allocation, not design; since the round-4 hand-off the lean
+        // kernel is level or ahead there too: 23.4-23.6 against 23.3-23.9 ms per iteration at 50k x 600k).  Knob bit 14 forces the
+        // full kernel.
+        else if (h->ntuple > 0 || h->nclass_total > 0 || (h->knob & 16384))
             sweep_tup_launch((unsigned)h->last_grid, h->lds_sweep, h->stream, A);
         else
             sweep_launch_0((unsigned)h->last_grid, h->lds_sweep_lean, h->stream, A);

@@ -1629,8 +1629,8 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
         }
         for (int u = 0; u < nb; ++u) {
             const int t = A.t0 + u, buf = u & 1, slot = u % NGP_RING, rs = u & 3;
-            if (u + 1 < nb) nxt = load_coef(A, (long long)(t + 1) * NGP_BLK + j);
             if (dbg && j == 0) dbg[4 * (size_t)u] = wall_clock64();
+            if (u + 1 < nb) nxt = load_coef(A, (long long)(t + 1) * NGP_BLK + j);
             // Linear block (k_tinv): its chain is dlt = T e0, T staged in place of the diagonal Gram block.  (Row j of T is read chunk by
             // chunk inside the product, behind the total: loaded into registers ahead of the wait -- right after the block's barrier --
             // its 64 LDS reads compete with the lag-1 product of wave 5, which is what the chain waits for: measured slower.)
@@ -1854,28 +1854,41 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
         // only when D >= 4.)
         if (D >= 4) {
             const double fxi = A.scal->fx_inv;
-            // Two looks may be in flight: at blocks next_fetch (qa) and next_fetch + 1 (qb, only while this wave is less than two
-            // blocks ahead) -- so that a look that came too early costs no blocking round trip later: nothing here waits on memory
-            // except the sum the very next block needs.
-            unsigned long long qa = 0ull, qb = 0ull;
-            int next_fetch = 1;   // first local block whose sum has not been taken yet
-            bool pa = false, pb = false;
-            if (nb > 1) { qa = acc_load(A, 1, j); pa = true; }
-            if (nb > 2) { qb = acc_load(A, 2, j); pb = true; }
+            // One look per block, issued a WHOLE block period before it is examined: at the start of block u this wave first requests
+            // the accumulator of the block after the one whose look is in flight (speculating that that one will turn out
+            // complete -- it nearly always is: the sums stand two microseconds before they are needed), and only then examines the
+            // look requested at the start of block u-1.  Requested and examined in one go -- the round 1-3 counter probe, and the first
+            // version of this loop -- the wave sat one loaded memory round trip (1.9 us at 50k x 600k) in every block and was the last
+            // at the barrier in four blocks of five.
+            unsigned long long qa = 0ull;   // the look in flight ...
+            int la = -1;                    // ... and the block it looked at (-1: none)
+            int next_take = 1;              // first local block whose sum has not been taken yet
+            if (nb > 1) {  // once, at the start of the sweep: block 1 by a blocking fetch, so that the loop below runs two blocks ahead
+                double tot1;
+                if (fetch_group_sums<DBG, NGBIG>(A, 1, j, &tot1)) { r0[NGP_BLK + j] = tot1; next_take = 2; }
+                else if (j == 0) *sabort = 1;
+            }
+            if (nb > 2) { qa = acc_load(A, 2, j); la = 2; }
             for (int u = 0; u < nb; ++u) {
-                for (int rep = 0; rep < 2; ++rep) {
-                    if (!(next_fetch < nb && next_fetch <= u + 2)) break;  // r0[(u+2) & 3] is free: block u-2 is done
-                    if (rep == 1 && !pb) break;
-                    const bool must = (next_fetch == u + 1);                // the next block needs this sum
-                    const unsigned terms = acc_terms(A, next_fetch);
-                    unsigned long long q = (rep == 0) ? qa : qb;
-                    if (rep == 0 && !pa) q = acc_load(A, next_fetch, j);   // (only the very first blocks of a short sweep)
-                    bool ready = dbg_mode == 2 || acc_complete(q, terms);
+                // speculative request for the following block (examined a block from now: block ln must then be allowed in r0)
+                unsigned long long qn = 0ull;
+                int ln = -1;
+                {
+                    const int want = (la >= 0 ? la : next_take - 1) + 1;
+                    if (want < nb && want <= u + 3) { qn = acc_load(A, want, j); ln = want; }
+                }
+                if (next_take < nb && next_take <= u + 2) {  // r0[(u+2) & 3] is free: block u-2 is done
+                    const bool must = (next_take == u + 1);   // the next block needs this sum
+                    const unsigned terms = acc_terms(A, next_take);
+                    unsigned long long q = qa;
+                    bool ready = false;
                     int ok = 1;
+                    if (la == next_take) ready = dbg_mode == 2 || acc_complete(q, terms);
+                    else if (must || la < 0) { q = acc_load(A, next_take, j); ready = dbg_mode == 2 || acc_complete(q, terms); }  // (start of the sweep, or after a look that came too early)
                     if (!ready && must) {
                         for (unsigned spins = 0;; ++spins) {
                             __builtin_amdgcn_s_sleep(2);
-                            q = acc_load(A, next_fetch, j);
+                            q = acc_load(A, next_take, j);
                             if (acc_complete(q, terms)) { ready = true; break; }
                             if ((spins & 7u) == 7u && ld_u32(A.abort_w) != 0u) { ok = 0; break; }
                             if (spins > (NGP_SPIN_LIMIT >> 3)) { st_u32(A.abort_w, 3u); ok = 0; break; }
@@ -1883,17 +1896,18 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
                     }
                     if (!ok) {
                         if (j == 0) *sabort = 1;
-                        break;
+                    } else if (ready) {
+                        r0[(next_take & 3) * NGP_BLK + j] = acc_take(A, next_take, j, q, fxi);
+                        if (dbg && j == 0) dbg[4 * (size_t)next_take + 3] = wall_clock64();
+                        ++next_take;
                     }
-                    if (!ready) break;
-                    r0[(next_fetch & 3) * NGP_BLK + j] = acc_take(A, next_fetch, j, q, fxi);
-                    if (dbg && j == 0) dbg[4 * (size_t)next_fetch + 3] = wall_clock64();
-                    ++next_fetch;
                 }
-                // the looks at the next accumulators travel while the block finishes
-                pa = false; pb = false;
-                if (next_fetch < nb && next_fetch <= u + 3) { qa = acc_load(A, next_fetch, j); pa = true; }
-                if (next_fetch + 1 < nb && next_fetch + 1 <= u + 3) { qb = acc_load(A, next_fetch + 1, j); pb = true; }
+                // the speculative look becomes the look in flight if it is the right one for what comes next, else it is dropped
+                if (ln == next_take) { qa = qn; la = ln; }
+                else if (ln > next_take && ln >= 0) {  // its predecessor was not complete: look at that one again next time
+                    la = -1;
+                    if (next_take < nb && next_take <= u + 3) { qa = acc_load(A, next_take, j); la = next_take; }
+                } else la = -1;
                 NGP_END_OF_BLOCK();
             }
         } else {
