@@ -269,7 +269,7 @@ def main():
     # HBM traffic of the dominant kernel: PMC counters cannot be read from inside this process, so the committed rocprofv3
     # summary of the SAME workload (tools/profile_round.sh) is quoted when the configuration matches, else null
     traffic, traffic_src = None, None
-    pmc = next((q for q in (os.path.join(ROOT, "profiles", f"{tag}_pmc_k_sweep_{args.config}{'u8' if compact_main else ''}.json") for tag in ("r03", "r02"))
+    pmc = next((q for q in (os.path.join(ROOT, "profiles", f"{tag}_pmc_k_sweep_{args.config}{'u8' if compact_main else ''}.json") for tag in ("r04", "r03", "r02"))
                 if os.path.exists(q)), "")
     if pmc and not overridden and prof["launches"] == 1:
         pj = json.load(open(pmc))
@@ -291,6 +291,7 @@ def main():
     mode, lag = s.config()
     variant, nchain = s.streamer()
     main_census = s.census() if mode == 1 else {"retries": 0, "exclusive": 0}
+    setup_parts = s.setup_timing()
 
     if rank == 0:
         its = world * K / dt
@@ -320,7 +321,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "ngp::k_sweep / k_sweep_tup (the persistent sweep kernel: one launch streams the whole N x P panel once; models with a Tuple set and tall fp32 shards run the k_sweep_tup instantiation)" if prof["launches"] == 1 else "ngp::k_step (one 64-SNP column block per launch)",
+                "kernel": "ngp::k_sweep<false> (the persistent sweep kernel: one launch streams the whole N x P panel once; models with a Tuple / BayesR set run the k_sweep_tup / k_sweep_r instantiations)" if prof["launches"] == 1 else "ngp::k_step (one 64-SNP column block per launch)",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
@@ -344,7 +345,7 @@ def main():
             },
             "device_iter_ms": tm["iter_ms"] / max(tm["iters"], 1),
             "census_retries": main_census["retries"], "exclusive": bool(main_census["exclusive"]),   # launches run again alone on the device
-            "setup_s": setup_s,
+            "setup_s": setup_s, "setup_parts_ms": setup_parts,   # allocation (+ zeroing) | tile generation | Gram window
             "allreduce_ms": allreduce_ms,
             "posterior_mean_varE": post_mean_varE,
             "pooled_kept_samples": nkept,

@@ -112,6 +112,9 @@ int32_t ngp_generate_panel(ngp_handle *h, int64_t N, int64_t P, double maf_lo, d
 /* Device tiling chosen for the panel: rows per shard R, shards S, 64-SNP blocks NBLK (the blocked
  * oracle needs R and S to reproduce the reduction tree). */
 int32_t ngp_get_layout(ngp_handle *h, int64_t *R, int64_t *S, int64_t *nblk);
+/* Wall time of the last ngp_generate_panel, in its three parts (milliseconds): device allocation with its zeroing, tile generation,
+ * Gram window -- the set-up of a 120 GB panel is dominated by the first, which varies from box to box. */
+int32_t ngp_get_setup_timing(ngp_handle *h, double *alloc_ms, double *tiles_ms, double *gram_ms);
 /* x'x per SNP (M[set][:mpm], src/mme.jl:305-307); out has P entries. */
 int32_t ngp_get_mpm(ngp_handle *h, double *out, int64_t P);
 /* One 64x64 Gram block X_t'X_t (row-major); parity probe. */

@@ -106,7 +106,7 @@ SYMBOLS = [
     "ngp_get_timing", "ngp_profile_iteration", "ngp_draws_indexed", "ngp_eval_math", "ngp_configure", "ngp_get_config", "ngp_debug_stamps", "ngp_set_near_lags", "ngp_get_near_lags",
     "ngp_set_streamer", "ngp_get_streamer", "ngp_set_storage", "ngp_get_storage", "ngp_set_max_shards", "ngp_shards_for_chains", "ngp_run_many", "ngp_write_panel_file", "ngp_read_panel_header", "ngp_load_panel_file", "ngp_debug_set_mode", "ngp_debug_set_knob", "ngp_set_posterior_sums", "ngp_save_snapshot", "ngp_load_snapshot",
     "ngp_set_trace_loci", "ngp_get_trace_ext", "ngp_allreduce_posterior", "ngp_add_marker_set_r", "ngp_get_class_state", "ngp_set_class_state", "ngp_add_fixed_set", "ngp_get_fixed", "ngp_set_fixed", "ngp_debug_throw", "ngp_get_census", "ngp_debug_set_virtual_device", "ngp_debug_fail_census", "ngp_add_marker_set_tuple", "ngp_share_panel", "ngp_shards_for_pass", "ngp_set_sample_file",
-    "ngp_set_chain_form", "ngp_get_chain_form",
+    "ngp_set_chain_form", "ngp_get_chain_form", "ngp_get_setup_timing",
 ]
 
 _lib = None
@@ -182,6 +182,12 @@ class Sampler:
         n = C.c_int32()
         self._chk(self.L.ngp_get_near_lags(self.h, C.byref(n)))
         return n.value
+
+    def setup_timing(self):
+        """Parts of the last generate_panel in ms: dict(alloc_ms, tiles_ms, gram_ms)."""
+        a, t, g = C.c_double(), C.c_double(), C.c_double()
+        self._chk(self.L.ngp_get_setup_timing(self.h, C.byref(a), C.byref(t), C.byref(g)))
+        return dict(alloc_ms=a.value, tiles_ms=t.value, gram_ms=g.value)
 
     def set_chain_form(self, form):
         """1 (default): BayesPR blocks as dlt = T e0 (k_tinv); 0: the 64 serial steps per block."""

@@ -7,6 +7,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <atomic>
 #include <cmath>
 #include <cstdio>
@@ -108,6 +109,7 @@ struct ngp_handle {
     double *d_cdlt = nullptr;
     unsigned long long *d_cacc = nullptr;   // fixed-point accumulators of X_t'ycorr (inside d_ccnt: zeroed with the counters by k_prep)
     double mpm_max = 0.0;                   // max_j x_j'x_j of the panel (scale of the accumulators, k_head)
+    double setup_ms[3] = {0.0, 0.0, 0.0};   // wall time of the last panel set-up: device allocation (+ zeroing) | tiles (generation / upload) | Gram window
     unsigned long long *d_cdltg = nullptr;  // dlt as tagged granules
     unsigned launch_seq = 0;                // launch nonce of the granule tags
     unsigned *d_ccnt = nullptr, *d_abort = nullptr;
@@ -1374,7 +1376,10 @@ int32_t ngp_generate_panel(ngp_handle *h, int64_t N, int64_t P, double maf_lo, d
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(maf_lo > 0.0 && maf_hi < 1.0 && maf_lo <= maf_hi, NGP_ERR_ARG, "maf range must satisfy 0 < lo <= hi < 1");
+    const auto ts0 = std::chrono::steady_clock::now();
     if ((rc = alloc_panel(h, N, P))) return rc;
+    (void)hipStreamSynchronize(h->stream);  // (the allocations' zeroing: timed with them)
+    const auto ts1 = std::chrono::steady_clock::now();
     double *d_mu = nullptr;
     uint32_t *d_thr = nullptr;
     if ((rc = dalloc(h, &d_mu, (size_t)P))) return rc;
@@ -1391,7 +1396,24 @@ int32_t ngp_generate_panel(ngp_handle *h, int64_t N, int64_t P, double maf_lo, d
     hipError_t e = hipStreamSynchronize(h->stream);
     dfree(d_mu); dfree(d_thr);
     if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("generate_panel: ") + hipGetErrorString(e));
-    return build_gram(h);
+    const auto ts2 = std::chrono::steady_clock::now();
+    rc = build_gram(h);
+    const auto ts3 = std::chrono::steady_clock::now();
+    h->setup_ms[0] = std::chrono::duration<double, std::milli>(ts1 - ts0).count();
+    h->setup_ms[1] = std::chrono::duration<double, std::milli>(ts2 - ts1).count();
+    h->setup_ms[2] = std::chrono::duration<double, std::milli>(ts3 - ts2).count();
+    return rc;
+    NGP_CATCH(h)
+}
+
+int32_t ngp_get_setup_timing(ngp_handle *h, double *alloc_ms, double *tiles_ms, double *gram_ms) {
+    NGP_TRY
+    int rc;
+    if ((rc = enter(h))) return rc;
+    if (alloc_ms) *alloc_ms = h->setup_ms[0];
+    if (tiles_ms) *tiles_ms = h->setup_ms[1];
+    if (gram_ms) *gram_ms = h->setup_ms[2];
+    return NGP_OK;
     NGP_CATCH(h)
 }
 

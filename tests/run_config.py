@@ -58,12 +58,15 @@ if cfg == "C1":  # the reference's own CPU-runnable case: the reference-order or
     o.run(warm)
     t0 = time.perf_counter(); o.run(iters); cdt = (time.perf_counter() - t0) / iters
     so = o.get_state()
+    otr = o.get_trace(iters)   # (the last ora_run's trace: the timed iterations)
+    oess = ess_geyer(otr["varE"])
     cpu = dict(ms_per_iter=cdt * 1e3, it_per_s=1 / cdt, cores=1, kind="reference-order C port",
-               max_abs_dbeta_vs_gpu=float(np.abs(so["beta"] - st["beta"]).max()), varE=so["varE"])
+               max_abs_dbeta_vs_gpu=float(np.abs(so["beta"] - st["beta"]).max()), varE=so["varE"],
+               ess_varE=oess, ess_varE_per_iteration=oess / iters, ess_varE_per_s=oess / (cdt * iters))
 tr = s.get_trace(iters)
 ess_varE = ess_geyer(tr["varE"])
 print(json.dumps(dict(config=cfg, N=N, P=P, sets=[k for k, _ in sets], mode=mode, lag=lag, R=R, S=S, nblk=nb, ms_per_iter=dt * 1e3, it_per_s=1 / dt,
                       GBs=4.0 * N * P / dt / 1e9, frac_of_8TBs=4.0 * N * P / dt / 8e12, setup_s=setup, xbeta_s=txb,
                       invariant_max=float(np.abs(st["ycorr"] - resid).max()), varE=st["varE"], piHat=list(map(float, st["piHat"])),
                       included=int(st["delta"].sum()), corr_postmean_true=corr,
-                      ess_varE=ess_varE, ess_varE_per_s=ess_varE / (dt * iters), cpu_oracle=cpu)))
+                      ess_varE=ess_varE, ess_varE_per_iteration=ess_varE / iters, ess_varE_per_s=ess_varE / (dt * iters), cpu_oracle=cpu)))

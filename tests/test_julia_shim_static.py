@@ -88,5 +88,5 @@ def test_every_ccall_matches_the_header():
         "ngp_get_gram", "ngp_xbeta", "ngp_get_timing", "ngp_profile_iteration", "ngp_draws_indexed", "ngp_eval_math", "ngp_set_streamer",
         "ngp_get_streamer", "ngp_get_storage", "ngp_read_panel_header", "ngp_generate_panel", "ngp_get_trace", "ngp_set_trace_loci",
         "ngp_get_trace_ext", "ngp_posterior_len", "ngp_export_posterior_device", "ngp_get_census", "ngp_set_state", "ngp_set_fixed",
-        "ngp_set_class_state", "ngp_set_posterior_sums", "ngp_get_posterior_sums", "ngp_set_panel_f32", "ngp_get_chain_form")}
+        "ngp_set_class_state", "ngp_set_posterior_sums", "ngp_get_posterior_sums", "ngp_set_panel_f32", "ngp_get_chain_form", "ngp_get_setup_timing")}
     assert not (need - used), sorted(need - used)

@@ -6,7 +6,7 @@ from ngp_pkg import load_pkg
 ngp = load_pkg()
 N, P = int(sys.argv[1]), int(sys.argv[2])
 iters = int(sys.argv[3]) if len(sys.argv) > 3 else 30
-for kind in ("PR", "B", "C", "R4", "R8"):
+for kind in os.environ.get("NGP_TOOL_METHODS", "PR,B,C,R4,R8").split(","):
     s = ngp.Sampler(device=0, seed=1001, chain=0, lag=int(os.environ["NGP_TOOL_LAG"]) if "NGP_TOOL_LAG" in os.environ else None)
     if "NGP_TOOL_NEAR" in os.environ: s.set_near(int(os.environ["NGP_TOOL_NEAR"]))
     if "NGP_TOOL_CHAIN_FORM" in os.environ: s.set_chain_form(int(os.environ["NGP_TOOL_CHAIN_FORM"]))

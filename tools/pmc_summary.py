@@ -13,7 +13,7 @@ out = os.path.join(root, "gpurun_out")
 # the persistent sweep kernel in its instantiations (k_sweep_tup: Tuple sets and tall fp32 shards of the row-owning streamer;
 # k_sweep_tall: fp32 panels with several shards per streamer workgroup)
 KERNELS = ("ngp::k_sweep(ngp::SweepArgs)", "void ngp::k_sweep<false>(ngp::SweepArgs)", "void ngp::k_sweep<true>(ngp::SweepArgs)",
-           "ngp::k_sweep_tup(ngp::SweepArgs)", "ngp::k_sweep_tall(ngp::SweepArgs)")
+           "ngp::k_sweep_tup(ngp::SweepArgs)", "ngp::k_sweep_tall(ngp::SweepArgs)", "ngp::k_sweep_r(ngp::SweepArgs)")
 
 
 def counter(kind, name):

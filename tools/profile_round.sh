@@ -4,7 +4,7 @@
 # (third argument u8: the same workload in compact storage, summaries named CONFIGu8)
 # The three rocprofv3 passes are separate on purpose (counters are never combined with traces).
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
 CFG=${2:-C4}
 STO=${3:-f32}
 SFX=""
