@@ -175,10 +175,12 @@ __device__ inline RLane load_rlane(const double *__restrict__ rcls, long long Pp
     for (int v = 0; v < NGP_RREG; v++) {
         const bool on = v < K;
         const size_t o = (size_t)(on ? v : 0) * (size_t)Ppad + (size_t)k;
+        // (a register class the set does not have: log-weight -inf, so its exponential is 0 and no maximum; comparison uniform +inf,
+        // so the search never stops at it -- eval_rform then needs no "does this class exist" select anywhere)
         L.q[v] = on ? rcls[o] : 0.0;
-        L.a[v] = on ? rcls[(size_t)NGP_RMAX * Ppad + o] : 0.0;
+        L.a[v] = on ? rcls[(size_t)NGP_RMAX * Ppad + o] : -__builtin_inf();
         L.t[v] = on ? rcls[(size_t)2 * NGP_RMAX * Ppad + o] : 0.0;
-        L.u[v] = on ? rcls[(size_t)3 * NGP_RMAX * Ppad + o] : 0.0;
+        L.u[v] = on ? rcls[(size_t)3 * NGP_RMAX * Ppad + o] : __builtin_inf();
     }
     return L;
 }
@@ -186,7 +188,7 @@ __device__ inline RLane empty_rlane() {
     RLane L;
     L.K = 2; L.rhs0 = 0.0; L.ext = nullptr; L.Ppad = 0; L.astride = 0;
 #pragma unroll
-    for (int v = 0; v < NGP_RREG; v++) { L.q[v] = 0.0; L.a[v] = 0.0; L.t[v] = 0.0; L.u[v] = 0.0; }
+    for (int v = 0; v < NGP_RREG; v++) { L.q[v] = 0.0; L.a[v] = (v < 2) ? 0.0 : -__builtin_inf(); L.t[v] = 0.0; L.u[v] = (v < 2) ? 0.0 : __builtin_inf(); }
     return L;
 }
 // log-weight of class v given hs = rhs^2 / 2 (src/functions.jl:255 in the stable form): classes >= NGP_RREG come from memory
@@ -209,7 +211,7 @@ __device__ inline void eval_rform(const int meth, const double r, const double b
         const bool more = L.K > NGP_RREG;
         double m = Lv[0];
 #pragma unroll
-        for (int v = 1; v < NGP_RREG; v++) m = (v < L.K && Lv[v] > m) ? Lv[v] : m;
+        for (int v = 1; v < NGP_RREG; v++) m = (Lv[v] > m) ? Lv[v] : m;  // (classes the set does not have: -inf, load_rlane)
         // (more than four classes: the same steps, class after class; their log-weights come from memory ONCE per evaluation)
         double Lx[NGP_RMAX - NGP_RREG], ex[NGP_RMAX - NGP_RREG];
 #pragma unroll
@@ -222,18 +224,27 @@ __device__ inline void eval_rform(const int meth, const double r, const double b
                 if (v < L.K && Lx[v - NGP_RREG] > m) m = Lx[v - NGP_RREG];
         }
         double S = 0.0;
+        {
+            static_assert(NGP_RREG == 4, "det_exp4 serves the four register classes");
+            double xm[4], ev[4];
 #pragma unroll
-        for (int v = 0; v < NGP_RREG; v++) {
-            const double ev = det_exp(Lv[v] - m);
-            e[v] = (v < L.K) ? ev : 0.0;
+            for (int v = 0; v < NGP_RREG; v++) xm[v] = Lv[v] - m;
+            det_exp4(xm, ev);
+#pragma unroll
+            for (int v = 0; v < NGP_RREG; v++) e[v] = ev[v];  // (0 for a class the set does not have: S + 0 = S, cum + 0 = cum)
         }
 #pragma unroll
-        for (int v = 0; v < NGP_RREG; v++) S = (v < L.K) ? S + e[v] : S;
+        for (int v = 0; v < NGP_RREG; v++) S = S + e[v];
         if (more) {
+            static_assert(NGP_RMAX - NGP_RREG == 4, "det_exp4 serves the four memory classes");
+            double xm[4], ev[4];
+#pragma unroll
+            for (int v = 0; v < 4; v++) xm[v] = (NGP_RREG + v < L.K) ? Lx[v] - m : 0.0;
+            det_exp4(xm, ev);
 #pragma unroll
             for (int v = NGP_RREG; v < NGP_RMAX; v++)
                 if (v < L.K) {
-                    ex[v - NGP_RREG] = det_exp(Lx[v - NGP_RREG] - m);
+                    ex[v - NGP_RREG] = ev[v - NGP_RREG];
                     S = S + ex[v - NGP_RREG];
                 }
         }
@@ -242,7 +253,7 @@ __device__ inline void eval_rform(const int meth, const double r, const double b
         bool found = false;
 #pragma unroll
         for (int v = 0; v < NGP_RREG; v++) {
-            const bool take = (v < L.K) && !found;
+            const bool take = !found;  // (a class the set does not have: thr = inf, never a hit)
             const double cn = cum + e[v];
             const double thr = L.u[v] * S;
             const bool hit = take && (cn >= thr);
@@ -261,9 +272,14 @@ __device__ inline void eval_rform(const int meth, const double r, const double b
         }
         double qc = L.q[0], tc = L.t[0];
 #pragma unroll
-        for (int v = 1; v < NGP_RREG; v++)
-            if (c == v) { qc = L.q[v]; tc = L.t[v]; }
-        if (c >= NGP_RREG) { qc = L.ext[(size_t)c * L.Ppad]; tc = L.ext[(size_t)c * L.Ppad + (size_t)2 * L.astride]; }
+        for (int v = 1; v < NGP_RREG; v++) {
+            qc = (c == v) ? L.q[v] : qc;
+            tc = (c == v) ? L.t[v] : tc;
+        }
+        // (the register classes are chosen by selects, and stay so: joined with the memory classes below the compiler made ONE load
+        // through a chosen pointer of it, with L.t spilled to scratch to have an address -- a flat load per evaluation)
+        asm volatile("" : "+v"(qc), "+v"(tc));
+        if (more && c >= NGP_RREG) { qc = L.ext[(size_t)c * L.Ppad]; tc = L.ext[(size_t)c * L.Ppad + (size_t)2 * L.astride]; }
         if (qc != 0.0) {
             const double d = __builtin_fma(rhs, qc, tc);
             cand = d - bo;

@@ -112,9 +112,12 @@ __device__ inline double det_log(double x) {
 // rational form serialised them on VCC (2.2 us per evaluation of a block's lanes).  Within 1 ulp of libm (tests/test_oracle.py).
 __device__ inline double det_exp(double x) {
     const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00;
-    if (x != x) return x;
-    if (x < -708.0) return 0.0;
-    if (x > 0.0) x = 0.0;
+    // (no branch: NaN and underflow replace the result at the end, so that the exponentials of a class evaluation stay in one basic
+    // block and their dependent chains interleave -- behind two early returns each ran alone, 4 x 40 dependent instructions)
+    const bool isnan_x = x != x, under = x < -708.0;
+    const double x_in = x;
+    x = (x > 0.0) ? 0.0 : x;
+    x = (isnan_x || under) ? 0.0 : x;
     const int k = (int)(invln2 * x - 0.5);
     const double t = (double)k;
     const double hi = x - t * ln2HI, lo = t * ln2LO;
@@ -134,7 +137,49 @@ __device__ inline double det_exp(double x) {
     const double tt = xr * xr;
     const double y = 1.0 + __builtin_fma(tt, q, xr);
     const double sc = __longlong_as_double((long long)((uint64_t)(k + 1023) << 52));
-    return y * sc;
+    const double res = under ? 0.0 : y * sc;
+    return isnan_x ? x_in : res;
+}
+
+// Four det_exp side by side for arguments x <= 0 (the class search's L - max L; the same operations per element, so the same bits):
+// every step of the four dependent chains is issued before the next step of any -- the empty asm statements pin that order, which the
+// scheduler does not choose by itself (it kept the four chains one behind the other, 4 x 40 dependent fp64 instructions per class
+// evaluation of the BayesR chain).  x < -708 (and -inf: a class that does not exist) gives 0; a NaN goes through the arithmetic and
+// comes back a NaN.
+__device__ inline void det_exp4(const double (&xin)[4], double (&out)[4]) {
+    const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00;
+    const double coef[11] = {1.0 / 479001600.0, 1.0 / 39916800.0, 1.0 / 3628800.0, 1.0 / 362880.0, 1.0 / 40320.0, 1.0 / 5040.0,
+                             1.0 / 720.0, 1.0 / 120.0, 1.0 / 24.0, 1.0 / 6.0, 0.5};
+    double xr[4], q[4], t[4];
+    int k[4];
+#pragma unroll
+    for (int v = 0; v < 4; v++) xr[v] = (xin[v] < -708.0) ? 0.0 : xin[v];
+#pragma unroll
+    for (int v = 0; v < 4; v++) t[v] = invln2 * xr[v] - 0.5;
+#pragma unroll
+    for (int v = 0; v < 4; v++) { k[v] = (int)t[v]; t[v] = (double)k[v]; }
+    asm volatile("" : "+v"(t[0]), "+v"(t[1]), "+v"(t[2]), "+v"(t[3]));
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        const double hi = xr[v] - t[v] * ln2HI, lo = t[v] * ln2LO;
+        xr[v] = hi - lo;
+    }
+    asm volatile("" : "+v"(xr[0]), "+v"(xr[1]), "+v"(xr[2]), "+v"(xr[3]));
+#pragma unroll
+    for (int v = 0; v < 4; v++) q[v] = 1.0 / 6227020800.0;
+#pragma unroll
+    for (int i = 0; i < 11; i++) {
+#pragma unroll
+        for (int v = 0; v < 4; v++) q[v] = __builtin_fma(q[v], xr[v], coef[i]);
+        asm volatile("" : "+v"(q[0]), "+v"(q[1]), "+v"(q[2]), "+v"(q[3]));
+    }
+#pragma unroll
+    for (int v = 0; v < 4; v++) {
+        const double tt = xr[v] * xr[v];
+        const double y = 1.0 + __builtin_fma(tt, q[v], xr[v]);
+        const double sc = __longlong_as_double((long long)((uint64_t)(k[v] + 1023) << 52));
+        out[v] = (xin[v] < -708.0) ? 0.0 : y * sc;
+    }
 }
 
 // IEEE correctly rounded square root (sqrt() lowers to the ocml routine, which is)

@@ -21,6 +21,9 @@ for kind in os.environ.get("NGP_TOOL_METHODS", "PR,B,C,R4,R8").split(","):
     else: s.add_marker_set_r(0, P, 4.0, v * 0.5, v, [0.0, 1e-4, 1e-3, 0.01, 0.05, 0.2, 0.5, 1.0], [0.9, 0.03, 0.02, 0.02, 0.01, 0.01, 0.005, 0.005], estPi=True)
     s.set_y(y); s.set_residual_prior(4.0, 0.25 * y.var())
     s.run(5)
+    b0 = s.get_state()["beta"][:P] != 0
     t = time.perf_counter(); s.run(iters); dt = (time.perf_counter() - t) / iters
     R, S, nb = s.layout()
-    print(f"{kind:3s} N={N} P={P} layout R={R} S={S} lag={s.config()[1]} near={s.near()}: {dt * 1e3:.3f} ms/iter, {dt / nb * 1e6:.2f} us/block", flush=True)
+    b1 = s.get_state()["beta"][:P] != 0   # steps of a sparse block's chain: loci with an old or a new effect
+    print(f"{kind:3s} N={N} P={P} layout R={R} S={S} lag={s.config()[1]} near={s.near()}: {dt * 1e3:.3f} ms/iter, {dt / nb * 1e6:.2f} us/block"
+          f"   (non-zero effects {b0.mean() * 100:.2f} % before, {b1.mean() * 100:.2f} % after: {64 * b1.mean():.1f} per block)", flush=True)

@@ -1,0 +1,4 @@
+#!/bin/bash
+O=gpurun_out/r04u; mkdir -p $O
+timeout -k 10 1100 python -m pytest tests -m gpu -x -q 2>&1 | tail -4 | tee $O/tests_full.txt
+for rep in 1 2; do for M in C R4 R8; do NGP_TOOL_METHODS=$M timeout -k 10 200 python tools/method_time.py 10000 100000 10; done; done 2>&1 | tee $O/steps2.txt
