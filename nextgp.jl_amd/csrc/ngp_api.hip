@@ -1689,7 +1689,6 @@ bool fusable(ngp_handle **hs, int n) {
     for (int i = 0; i < n; i++) {
         ngp_handle *h = hs[i];
         if (h->pm != h0->pm || h->device != h0->device || h->dbg_mode != 0 || h->d_dbg || h->dbg_census_fail_iter > 0) return false;
-        if (h->ntuple > 0) return false;  // the fused kernel's samplers are compiled without the Tuple chain (role_sampler<.., TUP = false>)
     }
     return (int64_t)n + ngp_multi_reducers(n, h0->NG, fused_pair(h0, n)) + h0->S <= h0->cu_count;
 }
@@ -1706,7 +1705,9 @@ int run_fused(ngp_handle **hs, int n, int64_t niter) {
     const size_t lds_sampler = (size_t)(3 * 4096 + 2 * NGP_RING * NGP_BLK + 6 * NGP_BLK) * sizeof(double) + 2 * NGP_BLK * sizeof(int) + 320 + NGP_SAMPLER_TUPLE_LDS;
     const size_t lds = std::max(h->streamer == 2 ? ngp_rows_multi_lds_bytes((int)h->R, n) : ngp_multi_lds_bytes((int)h->R, n), lds_sampler);
     REQUIRE(lds <= 160 * 1024, NGP_ERR_STATE, "fused sweep: LDS of a streamer with this many chains exceeds 160 KiB");
-    HCHK(sweep_multi_set_max_lds((int)lds));
+    bool tup = false;  // a chain with a Tuple set: the fused kernel whose samplers hold the Tuple chain (k_sweep_multi_tup)
+    for (int i = 0; i < n; i++) tup = tup || hs[i]->ntuple > 0;
+    HCHK(tup ? sweep_multi_tup_set_max_lds((int)lds) : sweep_multi_set_max_lds((int)lds));
     // One abort word: the leader's.  The sweep runs on the leader's stream; every chain's small kernels (head, coefficients, variance
     // draws, posterior sums: six launches of a few microseconds each) stay on the chain's OWN stream, tied to the sweep by events --
     // the K chains' small kernels then run side by side instead of one chain after the other (eight chains: 0.34 ms of a 4.35-ms pass).
@@ -1751,7 +1752,8 @@ int run_fused(ngp_handle **hs, int n, int64_t niter) {
             }
         }
         for (int i = 1; i < n; i++) { M.a[i].census = nullptr; M.a[i].xcc_w = M.a[0].xcc_w; }
-        sweep_multi_launch((unsigned)grid, lds, h->stream, M);
+        if (tup) sweep_multi_tup_launch((unsigned)grid, lds, h->stream, M);
+        else sweep_multi_launch((unsigned)grid, lds, h->stream, M);
         h->sweep_launches += 1; h->last_grid = grid;
         if (!serial) {
             (void)hipEventRecord(evs, h->stream);

@@ -2621,7 +2621,7 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows_multi(c
 #undef NGP_DL
 }
 
-#if !defined(NGP_INST_DBG) || !NGP_INST_DBG  // one definition: the production translation unit (ngp_sweep_inst.hip, -DNGP_INST_DBG=0)
+#if !defined(NGP_INST_DBG) || !NGP_INST_DBG || NGP_INST_DBG == 2  // the production translation unit (ngp_sweep_inst.hip, -DNGP_INST_DBG=0) and the Tuple one
 // A chain's launch arguments by RUN-TIME chain index: indexing the by-value argument M.a[c] makes the compiler copy all of M to
 // scratch (3 KB per lane) and read every field from there.  The arguments already sit in the kernarg segment -- constant address
 // space, read with scalar loads -- so the entry is addressed there directly (M is the kernel's first argument: offset 0).
@@ -2630,59 +2630,17 @@ __device__ __attribute__((always_inline)) inline const SweepArgs &multi_chain_ar
     kptr ka = (kptr)__builtin_amdgcn_kernarg_segment_ptr();
     return *(const SweepArgs *)(ka + offsetof(MultiArgs, a) + (size_t)c * sizeof(SweepArgs));
 }
+#endif
+#if !defined(NGP_INST_DBG) || !NGP_INST_DBG  // one definition: the production translation unit
 __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sweep_multi(MultiArgs M) {
-    extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int b = blockIdx.x, K = M.K, NG = M.a[0].NG;
-    if (ld_u32(M.a[0].abort_w) != 0u) return;
-    if (!sweep_census(M.a[0], b, smem)) return;
-#ifndef NGP_MULTI_STRIDE
-#define NGP_MULTI_STRIDE 8  // samplers at blocks 0, 8, 16, ...: one XCD under round-robin placement
+    constexpr bool TUPM = false;
+#include "ngp_sweep_multi_body.inc"
+}
 #endif
-    if ((b % NGP_MULTI_STRIDE) == 0 && (b / NGP_MULTI_STRIDE) < K) {
-        // (without the Tuple chain, like k_sweep<false>: chains with a Tuple set are not fused -- fusable(), ngp_api.hip)
-        role_sampler<false, false, false, 1>(multi_chain_args(__builtin_amdgcn_readfirstlane(b / NGP_MULTI_STRIDE)), smem);
-        return;
-    }
-    const int idx = b - min(K, (b + NGP_MULTI_STRIDE - 1) / NGP_MULTI_STRIDE);  // rank among the blocks that are not samplers
-    const int NR = ngp_multi_reducers(K, NG, M.pair);
-    if (idx < NR) {
-        if (M.pair) {  // workgroup (p, g): chain 2 p in waves 0-3, chain 2 p + 1 in waves 4-7 (an unpaired last chain keeps all eight)
-            const int pr = idx / NG, wq = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 8));
-            if (2 * pr + 1 >= K) role_reducer<false>(multi_chain_args(__builtin_amdgcn_readfirstlane(2 * pr)), idx % NG, smem);
-            else role_reducer<false>(multi_chain_args(__builtin_amdgcn_readfirstlane(2 * pr + wq)), idx % NG, smem, 4 * wq, 4);
-        } else {
-            role_reducer<false>(multi_chain_args(__builtin_amdgcn_readfirstlane(idx / NG)), idx % NG, smem);
-        }
-        return;
-    }
-    const int s = idx - NR;
-    // host: lag 6 or 8 (shards of at most 64 rows, fp32 tiles), 2..8 chains
-#ifdef NGP_MULTI_ONLY  /* resource-usage experiments: one instantiation (hipcc -DNGP_MULTI_ONLY=8 -Rpass-analysis=kernel-resource-usage) */
-    role_streamer_multi<8, NGP_MULTI_ONLY>(M, s, smem);
-    return;
-#endif
-#define NGP_MULTI_K(DTV)                                              \
-    switch (K) {                                                      \
-        case 2: role_streamer_multi<DTV, 2>(M, s, smem); break;       \
-        case 3: role_streamer_multi<DTV, 3>(M, s, smem); break;       \
-        case 4: role_streamer_multi<DTV, 4>(M, s, smem); break;       \
-        case 5: role_streamer_multi<DTV, 5>(M, s, smem); break;       \
-        case 6: role_streamer_multi<DTV, 6>(M, s, smem); break;       \
-        case 7: role_streamer_multi<DTV, 7>(M, s, smem); break;       \
-        default: role_streamer_multi<DTV, 8>(M, s, smem); break;      \
-    }
-    if (M.a[0].variant == 2) {  // row-owning streamer, lag 4 or 6 (host: fp32 tiles, shards of 64..NGP_ROWS_MAX_R rows), 2 chains
-#ifdef NGP_ROWS_MULTI_ONLY  /* resource-usage experiments: one instantiation */
-        role_streamer_rows_multi<NGP_ROWS_MULTI_ONLY, 2>(M, s, smem);
-#else
-        if (M.a[0].D == 4) role_streamer_rows_multi<4, 2>(M, s, smem);
-        else if (M.a[0].D == 5) role_streamer_rows_multi<5, 2>(M, s, smem);
-        else role_streamer_rows_multi<6, 2>(M, s, smem);
-#endif
-        return;
-    }
-    if (M.a[0].D == 6) { NGP_MULTI_K(6) } else { NGP_MULTI_K(8) }
-#undef NGP_MULTI_K
+#if defined(NGP_INST_DBG) && NGP_INST_DBG == 2  // K chains with a Tuple set per pass: the Tuple translation unit
+__global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sweep_multi_tup(MultiArgs M) {
+    constexpr bool TUPM = true;
+#include "ngp_sweep_multi_body.inc"
 }
 #endif
 

@@ -27,6 +27,13 @@ hipError_t sweep_tup_set_max_lds(int bytes) {
 void sweep_tup_launch(unsigned grid, size_t lds_bytes, hipStream_t stream, const SweepArgs &A) {
     hipLaunchKernelGGL(k_sweep_tup, dim3(grid), dim3(NGP_WG), lds_bytes, stream, A);
 }
+// ... and K such chains per pass
+hipError_t sweep_multi_tup_set_max_lds(int bytes) {
+    return hipFuncSetAttribute((const void *)k_sweep_multi_tup, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+void sweep_multi_tup_launch(unsigned grid, size_t lds_bytes, hipStream_t stream, const MultiArgs &M) {
+    hipLaunchKernelGGL(k_sweep_multi_tup, dim3(grid), dim3(NGP_WG), lds_bytes, stream, M);
+}
 #else
 #if NGP_INST_DBG
 #define NGP_SFX(name) name##_1

@@ -154,9 +154,10 @@ def test_tuple_argument_checks(ngp, O):
     s.add_marker_set(128, 50, 0, 4.0, v * 0.5, [(0, 50)], [v])
 
 
-def test_tuple_sets_through_run_many_and_on_tall_panels(ngp):
-    """Chains with a Tuple set are not fused into one launch (the fused kernel's samplers are compiled without that chain): run_many
-    runs them side by side, each bit for bit the chain it is alone.  And a Tuple set on an fp32 panel too tall for one shard per
+@pytest.mark.parametrize("form", [0, 1], ids=["steps", "inverse_form"])
+def test_tuple_sets_through_run_many_and_on_tall_panels(ngp, form):
+    """Chains with a Tuple set share ONE fused launch per iteration (k_sweep_multi_tup: the fused kernel with the Tuple chain in its
+    samplers), each bit for bit the chain it is alone.  And a Tuple set on an fp32 panel too tall for one shard per
     streamer workgroup (k_sweep_tall) draws the chain of the per-block engine (1e-9: another layout, another summation order)."""
     rng = np.random.default_rng(1)
     N, P, k = 3000, 6400, 2
@@ -164,6 +165,7 @@ def test_tuple_sets_through_run_many_and_on_tall_panels(ngp):
 
     def mk(seed, chain, owner=None):
         s = ngp.Sampler(device=0, seed=seed, chain=chain, mode=1, lag=8)
+        s.set_chain_form(form)
         if owner is None:
             s.set_max_shards(100); s.generate_panel(N, P)
         else:
@@ -179,7 +181,7 @@ def test_tuple_sets_through_run_many_and_on_tall_panels(ngp):
     second = mk(1002, 1, owner=first)
     model(first, y); model(second, y + 0.01)
     ngp.Sampler.run_many([first, second], 15)
-    assert first.census()["grid"] == 1 + (first.layout()[1] + 31) // 32 + first.layout()[1]     # a grid of its own: not fused
+    assert first.census()["grid"] == 2 * (1 + (first.layout()[1] + 31) // 32) + first.layout()[1]     # one grid for both chains
     for f, (seed, chain, yy) in ((first, (1001, 0, y)), (second, (1002, 1, y + 0.01))):
         a = mk(seed, chain); model(a, yy); a.run(15)
         sf, sa = f.get_state(), a.get_state()
