@@ -210,6 +210,12 @@ int32_t ngp_export_posterior_device(ngp_handle *h, void *device_ptr, int64_t len
  * In/out arrays are the caller's: ycorr N, beta ncol, delta ncol (out), varBeta nreg, piHat 2 (BayesB). */
 int32_t ngp_sweep_set(ngp_handle *h, int32_t set_id, double varE, double *ycorr, double *beta, int64_t *delta, double *varBeta,
                       double *piHat);
+/* The same call with the caller's state in DEVICE memory of the handle's device (ycorr N, beta ncol, varBeta nreg doubles; delta
+ * ncol int64, may be null; piHat 2 doubles, BayesB / BayesC): device-to-device copies on the handle's stream, no PCIe round trip per
+ * set and iteration for a host that keeps its state on the GPU (ROCArrays).  Values are not validated on the host: a variance that
+ * is not finite poisons the chain visibly, as in ngp_run.  Returns after the stream has drained. */
+int32_t ngp_sweep_set_dev(ngp_handle *h, int32_t set_id, double varE, void *d_ycorr, void *d_beta, void *d_delta, void *d_varBeta,
+                          void *d_piHat);
 
 /* Device time of the iterations of ngp_run (HIP events on the handle's stream) and the number of sweep-kernel launches,
  * both accumulated since the last call. */

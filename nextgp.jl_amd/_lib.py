@@ -102,7 +102,7 @@ SYMBOLS = [
     "ngp_begin_panel", "ngp_panel_columns_f64", "ngp_panel_columns_f32", "ngp_panel_columns_u8", "ngp_end_panel",
     "ngp_generate_panel", "ngp_get_layout", "ngp_get_mpm", "ngp_get_gram", "ngp_xbeta", "ngp_add_marker_set", "ngp_set_y",
     "ngp_set_residual_prior", "ngp_set_intercept", "ngp_set_schedule", "ngp_run", "ngp_get_state", "ngp_set_state",
-    "ngp_get_trace", "ngp_get_posterior_sums", "ngp_posterior_len", "ngp_export_posterior_device", "ngp_sweep_set",
+    "ngp_get_trace", "ngp_get_posterior_sums", "ngp_posterior_len", "ngp_export_posterior_device", "ngp_sweep_set", "ngp_sweep_set_dev",
     "ngp_get_timing", "ngp_profile_iteration", "ngp_draws_indexed", "ngp_eval_math", "ngp_configure", "ngp_get_config", "ngp_debug_stamps", "ngp_set_near_lags", "ngp_get_near_lags",
     "ngp_set_streamer", "ngp_get_streamer", "ngp_set_storage", "ngp_get_storage", "ngp_set_max_shards", "ngp_shards_for_chains", "ngp_run_many", "ngp_write_panel_file", "ngp_read_panel_header", "ngp_load_panel_file", "ngp_debug_set_mode", "ngp_debug_set_knob", "ngp_set_posterior_sums", "ngp_save_snapshot", "ngp_load_snapshot",
     "ngp_set_trace_loci", "ngp_get_trace_ext", "ngp_allreduce_posterior", "ngp_add_marker_set_r", "ngp_get_class_state", "ngp_set_class_state", "ngp_add_fixed_set", "ngp_get_fixed", "ngp_set_fixed", "ngp_debug_throw", "ngp_get_census", "ngp_debug_set_virtual_device", "ngp_debug_fail_census", "ngp_add_marker_set_tuple", "ngp_share_panel", "ngp_shards_for_pass", "ngp_set_sample_file",
@@ -492,6 +492,12 @@ class Sampler:
         self._chk(self.L.ngp_sweep_set(self.h, C.c_int32(set_id), C.c_double(varE), _p(ycorr, C.c_double), _p(beta, C.c_double),
                                        _p(delta, C.c_int64), _p(varBeta, C.c_double), _p(piHat, C.c_double)))
         return delta
+
+    def sweep_set_dev(self, set_id, varE, d_ycorr, d_beta, d_varBeta, d_delta=0, d_piHat=0):
+        """The fine seam over DEVICE arrays (addresses, e.g. torch.Tensor.data_ptr(): ycorr N, beta ncol, varBeta nreg float64; delta
+        ncol int64 or 0; piHat 2 float64 or 0), updated in place on the device."""
+        self._chk(self.L.ngp_sweep_set_dev(self.h, C.c_int32(set_id), C.c_double(varE), C.c_void_p(d_ycorr), C.c_void_p(d_beta),
+                                           C.c_void_p(d_delta or None), C.c_void_p(d_varBeta), C.c_void_p(d_piHat or None)))
 
     def get_timing(self):
         it = C.c_double()

@@ -1944,11 +1944,10 @@ int32_t ngp_export_posterior_device(ngp_handle *h, void *device_ptr, int64_t len
     NGP_CATCH(h)
 }
 
-int32_t ngp_sweep_set(ngp_handle *h, int32_t set_id, double varE, double *ycorr, double *beta, int64_t *delta, double *varBeta,
-                      double *piHat) {
-    NGP_TRY
+namespace {
+// one fine-seam call; dev: the caller's arrays (and piHat) are DEVICE memory of this handle's device, delta is int64 there too
+int sweep_set_impl(ngp_handle *h, int32_t set_id, double varE, double *ycorr, double *beta, int64_t *delta, double *varBeta, double *piHat, bool dev) {
     int rc;
-    if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
     REQUIRE(set_id >= 0 && set_id < (int)h->sets.size(), NGP_ERR_ARG, "unknown set id");
     REQUIRE(ycorr && beta && varBeta, NGP_ERR_ARG, "null state pointer");
@@ -1957,18 +1956,23 @@ int32_t ngp_sweep_set(ngp_handle *h, int32_t set_id, double varE, double *ycorr,
     if ((rc = sync_linear_blocks(h, (int)set_id))) return rc;
     HSet &hs = h->sets[set_id];
     const int64_t nvbs = (int64_t)hs.vb0.size();  // variance entries of the set: regions (loci for BayesB), k x k per region for a tuple set
-    for (int64_t r = 0; r < nvbs; r++) REQUIRE(std::isfinite(varBeta[r]) && (varBeta[r] >= 0.0 || hs.tk > 1), NGP_ERR_ARG, "varBeta must be finite, >= 0");
-    if (hs.method != NGP_METHOD_BAYESPR && hs.method != NGP_METHOD_TUPLE) REQUIRE(piHat != nullptr, NGP_ERR_ARG, "BayesB / BayesC need piHat");
+    // (device arrays are not read back to be looked at: a variance that is not finite poisons the chain visibly -- k_prep -- as in ngp_run)
+    if (!dev) for (int64_t r = 0; r < nvbs; r++) REQUIRE(std::isfinite(varBeta[r]) && (varBeta[r] >= 0.0 || hs.tk > 1), NGP_ERR_ARG, "varBeta must be finite, >= 0");
+    const bool has_pi = hs.method != NGP_METHOD_BAYESPR && hs.method != NGP_METHOD_TUPLE;
+    if (has_pi) REQUIRE(piHat != nullptr, NGP_ERR_ARG, "BayesB / BayesC need piHat");
+    const hipMemcpyKind in = dev ? hipMemcpyDeviceToDevice : hipMemcpyHostToDevice, out = dev ? hipMemcpyDeviceToDevice : hipMemcpyDeviceToHost;
     const uint64_t it = ++hs.fine_calls;
     const int64_t tb0 = hs.col0 / NGP_BLK, tb1 = (hs.col0 + hs.ncol - 1) / NGP_BLK + 1;
     CuLease lease(h);
     for (int attempt = 0;; ++attempt) {
         HCHK(hipMemsetAsync(h->d_ycorr, 0, (size_t)h->L * sizeof(double), h->stream));
-        HCHK(hipMemcpyAsync(h->d_ycorr, ycorr, (size_t)h->N * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        HCHK(hipMemcpyAsync(h->d_beta + hs.col0, beta, (size_t)hs.ncol * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        HCHK(hipMemcpyAsync(h->d_varBeta + hs.vb_off, varBeta, (size_t)nvbs * sizeof(double), hipMemcpyHostToDevice, h->stream));
-        if (hs.method != NGP_METHOD_BAYESPR && hs.method != NGP_METHOD_TUPLE)
-            hipLaunchKernelGGL(k_set_pi, dim3(1), dim3(1), 0, h->stream, h->d_sets, (int)set_id, piHat[0], piHat[1]);
+        HCHK(hipMemcpyAsync(h->d_ycorr, ycorr, (size_t)h->N * sizeof(double), in, h->stream));
+        HCHK(hipMemcpyAsync(h->d_beta + hs.col0, beta, (size_t)hs.ncol * sizeof(double), in, h->stream));
+        HCHK(hipMemcpyAsync(h->d_varBeta + hs.vb_off, varBeta, (size_t)nvbs * sizeof(double), in, h->stream));
+        if (has_pi) {
+            if (dev) hipLaunchKernelGGL(k_set_pi_dev, dim3(1), dim3(1), 0, h->stream, h->d_sets, (int)set_id, (const double *)piHat);
+            else hipLaunchKernelGGL(k_set_pi, dim3(1), dim3(1), 0, h->stream, h->d_sets, (int)set_id, piHat[0], piHat[1]);
+        }
         hipLaunchKernelGGL(k_set_varE, dim3(1), dim3(1), 0, h->stream, h->d_scal, varE);
         // (no draws, no intercept: ycorr'ycorr of the caller's residual sets the scale of the fixed-point accumulators)
         hipLaunchKernelGGL(k_head, dim3(1), dim3(1024), 0, h->stream, h->d_ycorr, (long long)h->L, (long long)h->N, h->d_scal, h->e_df,
@@ -1992,10 +1996,17 @@ int32_t ngp_sweep_set(ngp_handle *h, int32_t set_id, double varE, double *ycorr,
         if (rc) return rc;
         break;
     }
-    HCHK(hipMemcpy(ycorr, h->d_ycorr, (size_t)h->N * sizeof(double), hipMemcpyDeviceToHost));
-    HCHK(hipMemcpy(beta, h->d_beta + hs.col0, (size_t)hs.ncol * sizeof(double), hipMemcpyDeviceToHost));
-    HCHK(hipMemcpy(varBeta, h->d_varBeta + hs.vb_off, (size_t)nvbs * sizeof(double), hipMemcpyDeviceToHost));
+    HCHK(hipMemcpyAsync(ycorr, h->d_ycorr, (size_t)h->N * sizeof(double), out, h->stream));
+    HCHK(hipMemcpyAsync(beta, h->d_beta + hs.col0, (size_t)hs.ncol * sizeof(double), out, h->stream));
+    HCHK(hipMemcpyAsync(varBeta, h->d_varBeta + hs.vb_off, (size_t)nvbs * sizeof(double), out, h->stream));
+    if (dev) {
+        if (delta) hipLaunchKernelGGL(k_delta_widen, dim3((unsigned)((hs.ncol + 255) / 256)), dim3(256), 0, h->stream, (const uint8_t *)(h->d_delta + hs.col0), (long long *)delta, (long long)hs.ncol);
+        if (piHat) hipLaunchKernelGGL(k_get_pi_dev, dim3(1), dim3(1), 0, h->stream, (const DSet *)h->d_sets, (int)set_id, piHat);
+    }
+    HCHK(hipStreamSynchronize(h->stream));
+    HCHK(hipGetLastError());
     if (h->dbg_mode != 0) return fail(h, NGP_ERR_DEBUG, "diagnostic timing mode is active: the sweep is invalid");
+    if (dev) return NGP_OK;
     if (delta) {
         std::vector<uint8_t> d((size_t)hs.ncol);
         HCHK(hipMemcpy(d.data(), h->d_delta + hs.col0, (size_t)hs.ncol, hipMemcpyDeviceToHost));
@@ -2007,6 +2018,25 @@ int32_t ngp_sweep_set(ngp_handle *h, int32_t set_id, double varE, double *ycorr,
         piHat[0] = ds.piHat0; piHat[1] = ds.piHat1;
     }
     return NGP_OK;
+}
+}  // namespace
+
+int32_t ngp_sweep_set(ngp_handle *h, int32_t set_id, double varE, double *ycorr, double *beta, int64_t *delta, double *varBeta,
+                      double *piHat) {
+    NGP_TRY
+    int rc;
+    if ((rc = enter(h))) return rc;
+    return sweep_set_impl(h, set_id, varE, ycorr, beta, delta, varBeta, piHat, false);
+    NGP_CATCH(h)
+}
+
+/* The fine seam with the caller's state in DEVICE memory (a host that keeps ycorr, beta, varBeta on the GPU between the calls of
+ * src/samplers.jl:52 -- ROCArrays -- pays no PCIe round trip per set and iteration): device-to-device copies on the handle's stream. */
+int32_t ngp_sweep_set_dev(ngp_handle *h, int32_t set_id, double varE, void *d_ycorr, void *d_beta, void *d_delta, void *d_varBeta, void *d_piHat) {
+    NGP_TRY
+    int rc;
+    if ((rc = enter(h))) return rc;
+    return sweep_set_impl(h, set_id, varE, (double *)d_ycorr, (double *)d_beta, (int64_t *)d_delta, (double *)d_varBeta, (double *)d_piHat, true);
     NGP_CATCH(h)
 }
 

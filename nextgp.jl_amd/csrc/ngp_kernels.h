@@ -916,6 +916,23 @@ __global__ __launch_bounds__(256) void k_add_inplace(double *__restrict__ out, c
     const long long k = (long long)blockIdx.x * 256 + threadIdx.x;
     if (k < n) out[k] = out[k] + in[k];
 }
+// the fine seam with device-resident state (ngp_sweep_set_dev): pi in and out, delta as the caller's 64-bit integers
+__global__ void k_set_pi_dev(DSet *__restrict__ sets, int si, const double *__restrict__ pi) {  // (k_set_pi, the values read here)
+    const double p0 = pi[0], p1 = pi[1];
+    sets[si].piHat0 = p0;
+    sets[si].piHat1 = p1;
+    sets[si].logPi0 = det_log(p0);
+    sets[si].logPi1 = det_log(p1);
+    sets[si].nloci = 0;
+}
+__global__ void k_get_pi_dev(const DSet *__restrict__ sets, int si, double *__restrict__ pi) {
+    pi[0] = sets[si].piHat0;
+    pi[1] = sets[si].piHat1;
+}
+__global__ void k_delta_widen(const uint8_t *__restrict__ d8, long long *__restrict__ d64, long long n) {
+    const long long k = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (k < n) d64[k] = d8[k];
+}
 __global__ void k_set_varE(DScal *__restrict__ sc, double varE) {
     sc->varE = varE;
     sc->iVarE = 1.0 / varE;

@@ -240,6 +240,21 @@ function sweep!(h::Handle, set_id::Integer, mSet, M, beta, delta, ycorr::Vector{
 end
 
 """
+    sweep_dev!(h, set_id, varE, d_ycorr, d_beta, d_delta, d_varBeta, d_piHat = C_NULL)
+
+The fine seam for a host that keeps its state on the GPU (`ROCArray`s of AMDGPU.jl: pass `pointer(a)` converted to `Ptr{Cvoid}`):
+`ycorr` (N), the set's `beta` (ncol) and `varBeta` (regions) as Float64, `delta` (ncol) as Int64 or `C_NULL`, `piHat` (2, BayesB /
+BayesC) -- all in device memory of the handle's device, updated in place by device-to-device copies (`ngp_sweep_set_dev`).
+"""
+function sweep_dev!(h::Handle, set_id::Integer, varE::Float64, d_ycorr::Ptr{Cvoid}, d_beta::Ptr{Cvoid}, d_delta::Ptr{Cvoid},
+                    d_varBeta::Ptr{Cvoid}, d_piHat::Ptr{Cvoid} = C_NULL)
+    check(h, ccall((:ngp_sweep_set_dev, LIB), Int32,
+                   (Ptr{Cvoid}, Int32, Float64, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}),
+                   h.ptr, set_id, varE, d_ycorr, d_beta, d_delta, d_varBeta, d_piHat))
+    return nothing
+end
+
+"""
     runSampler!(ycorr, nData, E, X, b, Z, u, varU, M, beta, varBeta, delta, chainLength, burnIn, outputFreq, outPut; seed=1)
 
 Coarse seam: drop-in for `samplers.runSampler!` (src/samplers.jl:23) for models made of fixed effects (intercept, covariates,

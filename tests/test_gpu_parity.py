@@ -332,6 +332,34 @@ def test_fine_seam_matches_coarse(ngp, O, engine):
         assert np.abs(ycorr - resid).max() < 1e-10
 
 
+@pytest.mark.parametrize("method", ["PR", "B"])
+def test_fine_seam_over_device_arrays(ngp, O, method):
+    """ngp_sweep_set_dev: the caller's state stays in device memory (torch tensors here, ROCArrays in a Julia host) -- the same
+    keyed draws, so bit for bit what ngp_sweep_set leaves in host arrays."""
+    import torch
+    N, P = 300, 192
+    X, y, bt, v = make_problem(O, N, P, seed=2)
+    host, devs = (ngp.Sampler(device=0, seed=5, chain=0, mode=1, lag=4) for _ in range(2))
+    nvb = P if method == "B" else 1
+    for s in (host, devs):
+        s.set_panel(X); add_sets(s, [(0, P, method)], v)
+    ycorr = y - y.mean(); beta = np.zeros(P); vb = np.full(nvb, v); pi = np.array([0.7, 0.3]) if method == "B" else None
+    t = {k: torch.tensor(a, dtype=torch.float64, device="cuda:0") for k, a in (("ycorr", ycorr), ("beta", beta), ("vb", vb))}
+    t["delta"] = torch.zeros(P, dtype=torch.int64, device="cuda:0")
+    t["pi"] = torch.tensor(pi if pi is not None else [0.0, 0.0], dtype=torch.float64, device="cuda:0")
+    torch.cuda.synchronize()
+    for it in range(3):
+        d = host.sweep_set(0, 1.3, ycorr, beta, vb, pi)
+        devs.sweep_set_dev(0, 1.3, t["ycorr"].data_ptr(), t["beta"].data_ptr(), t["vb"].data_ptr(), t["delta"].data_ptr(),
+                           t["pi"].data_ptr() if pi is not None else 0)
+        assert np.array_equal(t["ycorr"].cpu().numpy(), ycorr) and np.array_equal(t["beta"].cpu().numpy(), beta)
+        assert np.array_equal(t["vb"].cpu().numpy(), vb) and np.array_equal(t["delta"].cpu().numpy(), d)
+        if pi is not None:
+            assert np.array_equal(t["pi"].cpu().numpy(), pi)
+    with pytest.raises(ngp.NextGPHipError, match="null state pointer"):
+        devs.sweep_set_dev(0, 1.3, 0, t["beta"].data_ptr(), t["vb"].data_ptr())
+
+
 def test_resume_state_roundtrip(ngp, O):
     N, P = 200, 128
     X, y, bt, v = make_problem(O, N, P, seed=4)
