@@ -1681,16 +1681,23 @@ int fused_pair(const ngp_handle *h0, int n) {
 bool fusable(ngp_handle **hs, int n) {
     if (n < 2 || n > NGP_MAXC) return false;
     ngp_handle *h0 = hs[0];
-    if (!h0->pm || h0->mode != 1 || h0->storage != 0 || h0->V != 1) return false;
-    const bool phase = h0->streamer == 1 && h0->R <= 64 && (h0->D == 6 || h0->D == 8);                 // role_streamer_multi
-    const bool rows = h0->streamer == 2 && (h0->D >= 4 && h0->D <= 6) && n == 2 &&                       // role_streamer_rows_multi
+    if (!h0->pm || h0->mode != 1 || h0->V != 1) return false;
+    const bool phase = h0->storage == 0 && h0->streamer == 1 && h0->R <= 64 && (h0->D == 6 || h0->D == 8);   // role_streamer_multi
+    const bool rows = h0->storage == 0 && h0->streamer == 2 && (h0->D >= 4 && h0->D <= 6) && n == 2 &&        // role_streamer_rows_multi
                       ngp_rows_multi_lds_bytes((int)h0->R, n) <= (size_t)160 * 1024;
-    if (!phase && !rows) return false;
+    bool bytes = false;                                                                                     // ... over byte tiles
+    if (h0->storage == 1 && h0->streamer == 3 && n == 2 && ngp_rows_multi_lds_bytes((int)h0->R, n, true) <= (size_t)160 * 1024) {
+        const int nt = ngp_u8_tasks((int)h0->R);
+        bytes = (nt == 1 && (h0->D == 4 || h0->D == 6 || h0->D == 8)) || (nt == 2 && (h0->D == 4 || h0->D == 8)) || (nt == 4 && h0->D == 4);
+    }
+    if (!phase && !rows && !bytes) return false;
     for (int i = 0; i < n; i++) {
         ngp_handle *h = hs[i];
         if (h->pm != h0->pm || h->device != h0->device || h->dbg_mode != 0 || h->d_dbg || h->dbg_census_fail_iter > 0) return false;
     }
-    return (int64_t)n + ngp_multi_reducers(n, h0->NG, fused_pair(h0, n)) + h0->S <= h0->cu_count;
+    // (the samplers sit at blocks 0, 8, .., 8 (n - 1) of the grid -- one XCD under round-robin placement: the grid must reach the last)
+    const int64_t grid = (int64_t)n + ngp_multi_reducers(n, h0->NG, fused_pair(h0, n)) + h0->S;
+    return grid <= h0->cu_count && grid > (int64_t)8 * (n - 1);
 }
 
 // niter iterations of n chains, every iteration ONE fused sweep launch on the first handle's stream; each chain's small kernels
@@ -1703,7 +1710,8 @@ int run_fused(ngp_handle **hs, int n, int64_t niter) {
     const int pair = fused_pair(h, n);
     const int64_t grid = (int64_t)n + ngp_multi_reducers(n, h->NG, pair) + h->S;
     const size_t lds_sampler = (size_t)(3 * 4096 + 2 * NGP_RING * NGP_BLK + 6 * NGP_BLK) * sizeof(double) + 2 * NGP_BLK * sizeof(int) + 320 + NGP_SAMPLER_TUPLE_LDS;
-    const size_t lds = std::max(h->streamer == 2 ? ngp_rows_multi_lds_bytes((int)h->R, n) : ngp_multi_lds_bytes((int)h->R, n), lds_sampler);
+    const size_t lds = std::max(h->streamer == 3 ? ngp_rows_multi_lds_bytes((int)h->R, n, true)
+                                                 : (h->streamer == 2 ? ngp_rows_multi_lds_bytes((int)h->R, n) : ngp_multi_lds_bytes((int)h->R, n)), lds_sampler);
     REQUIRE(lds <= 160 * 1024, NGP_ERR_STATE, "fused sweep: LDS of a streamer with this many chains exceeds 160 KiB");
     bool tup = false;  // a chain with a Tuple set: the fused kernel whose samplers hold the Tuple chain (k_sweep_multi_tup)
     for (int i = 0; i < n; i++) tup = tup || hs[i]->ntuple > 0;

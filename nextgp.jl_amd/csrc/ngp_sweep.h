@@ -2371,13 +2371,18 @@ __device__ __attribute__((always_inline)) inline void role_streamer_multi(const 
 // fetches their dlt granules.  Per chain: the arithmetic of role_streamer_rows<DT, 0>, operation for operation.
 // LDS: ring | per chain: shard (R) | 2 x 7 x 64 chain sums | 2 x 72 dlt | then flags, counters and the 1 KiB sink.
 // ------------------------------------------------------------------------------------------
-template <int DT, int KC>
+template <int DT, int KC, int ST = 0>
 __device__ __attribute__((always_inline)) inline void role_streamer_rows_multi(const MultiArgs &Mr, const int s, char *smem) {
+    // ST = 0: fp32 tiles; ST = 1, 2, 4: compact storage (byte tiles, ST update tasks per lane), as role_streamer_rows<.., DT, ST>:
+    // a byte is converted ONCE and multiplied into every chain's sums -- the conversions are what bounds the one-chain byte streamer
+    constexpr bool U8 = (ST != 0);
+    constexpr int NT = U8 ? ST : 1;
+    constexpr bool early = !U8;  // (the publisher ahead of the block's barrier: a gain on fp32 tiles, a loss on byte tiles -- role_streamer_rows)
     const MultiArgs *Mp = &Mr;
     const SweepArgs &A = Mp->a[0];
     const int R = A.R, S = A.S, tid = threadIdx.x;
     const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
-    const int NQ = R >> 2;
+    const int NQ = U8 ? (R >> 4) : (R >> 2);
     const int H = min(NGP_ROWS_HMAX, (NQ + 1) >> 1);
     const int RQ = 2 * NQ + H;
     char *ring = smem;
@@ -2386,11 +2391,11 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows_multi(c
 #define NGP_YS(kc) (cbase + (size_t)(kc) * CH)
 #define NGP_RED(kc) (NGP_YS(kc) + ((R + 7) & ~7))
 #define NGP_DL(kc) (NGP_RED(kc) + 2 * NGP_ROWS_NW * NGP_BLK)
+#define NGP_RSY(kc) (NGP_DL(kc) + 2 * NGP_DLS)
     int *sflag = (int *)(cbase + (size_t)KC * CH);
     int *gcnt0 = sflag + 4, *gcnt1 = sflag + 8;
     char *scratch = (char *)sflag + 64 + 64;
     const size_t tile_bytes = (size_t)NQ * 1024;
-    const int g = s / NGP_GRP;
     const int nb = A.t1 - A.t0;
 #pragma unroll
     for (int kc = 0; kc < KC; kc++) {
@@ -2467,17 +2472,43 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows_multi(c
         // ------------------------------ row-owning waves ------------------------------
         const int c = lane & 7, ql = lane >> 3;
         const int nqw = (NQ - wv + NGP_ROWS_NW - 1) / NGP_ROWS_NW;
-        const int qt = wv + NGP_ROWS_NW * ql;
-        const bool thas = qt < NQ;
-        const int tslot = thas ? qt : wv, trow = 4 * qt;
-        float4 keep[DT][8];
+        int tslot[NT], trow[NT];  // update tasks of this lane (role_streamer_rows)
+        bool thas[NT];
+#pragma unroll
+        for (int i = 0; i < NT; i++) {
+            if constexpr (U8) {
+                const int tau = ql + 8 * i;
+                thas[i] = (tau >> 2) < nqw;
+                tslot[i] = thas[i] ? wv + NGP_ROWS_NW * (tau >> 2) : wv;
+                trow[i] = 16 * tslot[i] + 4 * (tau & 3);
+            } else {
+                const int qt = wv + NGP_ROWS_NW * ql;
+                thas[i] = qt < NQ;
+                tslot[i] = thas[i] ? qt : wv;
+                trow[i] = 4 * qt;
+            }
+        }
+        const int nvalid = U8 ? (int)max(0ll, min((long long)R, A.N - (long long)s * R)) : R;
+        float4 keep[U8 ? 1 : DT][8];
+        unsigned keep8[U8 ? DT : 1][NT][8];
 #pragma unroll
         for (int d = 0; d < DT; d++)
 #pragma unroll
-            for (int jj = 0; jj < 8; jj++) keep[d][jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int jj = 0; jj < 8; jj++) {
+                if constexpr (U8) {
+#pragma unroll
+                    for (int i = 0; i < NT; i++) keep8[d][i][jj] = 0u;
+                } else {
+                    keep[d][jj] = make_float4(0.f, 0.f, 0.f, 0.f);
+                }
+            }
         unsigned long long pg0[KC], pg1[KC];  // poller: granules of the next dlt of every chain
 #pragma unroll
         for (int kc = 0; kc < KC; kc++) { pg0[kc] = 0; pg1[kc] = 0; }
+        double pm = 0.0;   // poller, compact storage: column mean of (block pm_blk, column lane) -- the panel's, one for all chains
+        int pm_blk = -1;
+        double mpub = 0.0;  // publisher, compact storage: column mean of the block published next
+        if (U8 && wv == NGP_ROWS_PUBW && nb > 0) mpub = A.mean[(size_t)A.t0 * NGP_BLK + lane];
         auto try_signal = [&](bool) __attribute__((always_inline)) {};
         auto publish = [&](const int u) __attribute__((always_inline)) {
             const int slot = u % NGP_RING;
@@ -2486,7 +2517,14 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows_multi(c
             for (int kc = 0; kc < KC; kc++) {
                 const double *rp = NGP_RED(kc) + (u & 1) * NGP_ROWS_NW * NGP_BLK + lane;
                 p[kc] = ((rp[0] + rp[NGP_BLK]) + (rp[2 * NGP_BLK] + rp[3 * NGP_BLK])) + ((rp[4 * NGP_BLK] + rp[5 * NGP_BLK]) + rp[6 * NGP_BLK]);
+                if constexpr (U8) {  // partial = sum_i g_ij y_i - m_j sum_i y_i
+                    const double *sp = NGP_RSY(kc) + (u & 1) * 8;
+                    const double sy = ((sp[0] + sp[1]) + (sp[2] + sp[3])) + ((sp[4] + sp[5]) + sp[6]);
+                    const double ms = mpub * sy;
+                    p[kc] = p[kc] - ms;
+                }
             }
+            if (U8 && u + 1 < nb) mpub = A.mean[(size_t)(A.t0 + u + 1) * NGP_BLK + lane];  // (requested before the adds leave)
 #pragma unroll
             for (int kc = 0; kc < KC; kc++) acc_add(Mp->a[kc].acc, A.abort_w, slot, s, lane, p[kc], Mp->a[kc].scal->fx_scale);
         };
@@ -2513,8 +2551,10 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows_multi(c
                             pg1[kc] = ld_u64(gp + 1);
                         }
                     }
+                    if (U8 && pm_blk != pa) { pm = A.mean[(size_t)(A.t0 + pa) * NGP_BLK + lane]; pm_blk = pa; }
                 }
                 // ---- ycorr -= X_a dlt_a for the rows of this wave, chain after chain (the tile elements wait in keep[d]) ----
+                if constexpr (!U8) {
                 if (a >= 0) {
 #pragma unroll
                     for (int kc = 0; kc < KC; kc++) {
@@ -2533,10 +2573,77 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows_multi(c
                         p0 = p0 + dpp_f64(p0, 0); p1 = p1 + dpp_f64(p1, 0); p2 = p2 + dpp_f64(p2, 0); p3 = p3 + dpp_f64(p3, 0);
                         p0 = p0 + dpp_f64(p0, 1); p1 = p1 + dpp_f64(p1, 1); p2 = p2 + dpp_f64(p2, 1); p3 = p3 + dpp_f64(p3, 1);
                         p0 = p0 + dpp_f64(p0, 2); p1 = p1 + dpp_f64(p1, 2); p2 = p2 + dpp_f64(p2, 2); p3 = p3 + dpp_f64(p3, 2);
-                        if (c == 0 && thas) {
-                            double *yq = NGP_YS(kc) + trow;
+                        if (c == 0 && thas[0]) {
+                            double *yq = NGP_YS(kc) + trow[0];
                             const double y0 = yq[0], y1 = yq[1], y2 = yq[2], y3 = yq[3];
                             yq[0] = y0 - p0; yq[1] = y1 - p1; yq[2] = y2 - p2; yq[3] = y3 - p3;
+                        }
+                    }
+                }
+                } else {
+                    // compact storage (role_streamer_rows): y_i -= (sum_j g_ij dlt_j - sum_j m_j dlt_j) for the rows inside the panel,
+                    // and the sum of this wave's rows of y; every byte of the delay line converted once for all chains
+                    double dqv[KC][8], cm[KC], vsum[KC];
+#pragma unroll
+                    for (int kc = 0; kc < KC; kc++) {
+                        const double *dq = NGP_DL(kc) + (u & 1) * NGP_DLS + 8 * c;
+#pragma unroll
+                        for (int jj = 0; jj < 8; jj++) dqv[kc][jj] = (a >= 0) ? dq[jj] : 0.0;
+                        cm[kc] = (a >= 0) ? NGP_DL(kc)[(u & 1) * NGP_DLS + NGP_BLK] : 0.0;
+                        vsum[kc] = 0.0;
+                    }
+#pragma unroll
+                    for (int i = 0; i < NT; i++) {
+                        double p0[KC], p1[KC], p2[KC], p3[KC];
+#pragma unroll
+                        for (int kc = 0; kc < KC; kc++) { p0[kc] = 0.0; p1[kc] = 0.0; p2[kc] = 0.0; p3[kc] = 0.0; }
+                        if (a >= 0) {
+#pragma unroll
+                            for (int jj = 0; jj < 8; jj++) {
+                                const unsigned w = keep8[d][i][jj];
+                                const double g0 = (double)(float)(w & 0xffu), g1 = (double)(float)((w >> 8) & 0xffu);
+                                const double g2 = (double)(float)((w >> 16) & 0xffu), g3 = (double)(float)(w >> 24);
+#pragma unroll
+                                for (int kc = 0; kc < KC; kc++) {
+                                    p0[kc] = __builtin_fma(g0, dqv[kc][jj], p0[kc]);
+                                    p1[kc] = __builtin_fma(g1, dqv[kc][jj], p1[kc]);
+                                    p2[kc] = __builtin_fma(g2, dqv[kc][jj], p2[kc]);
+                                    p3[kc] = __builtin_fma(g3, dqv[kc][jj], p3[kc]);
+                                }
+                            }
+#pragma unroll
+                            for (int kc = 0; kc < KC; kc++) {
+                                p0[kc] = p0[kc] + dpp_f64(p0[kc], 0); p1[kc] = p1[kc] + dpp_f64(p1[kc], 0); p2[kc] = p2[kc] + dpp_f64(p2[kc], 0); p3[kc] = p3[kc] + dpp_f64(p3[kc], 0);
+                                p0[kc] = p0[kc] + dpp_f64(p0[kc], 1); p1[kc] = p1[kc] + dpp_f64(p1[kc], 1); p2[kc] = p2[kc] + dpp_f64(p2[kc], 1); p3[kc] = p3[kc] + dpp_f64(p3[kc], 1);
+                                p0[kc] = p0[kc] + dpp_f64(p0[kc], 2); p1[kc] = p1[kc] + dpp_f64(p1[kc], 2); p2[kc] = p2[kc] + dpp_f64(p2[kc], 2); p3[kc] = p3[kc] + dpp_f64(p3[kc], 2);
+                            }
+                        }
+                        if (c == 0 && thas[i]) {
+#pragma unroll
+                            for (int kc = 0; kc < KC; kc++) {
+                                double *yq = NGP_YS(kc) + trow[i];
+                                double y0 = yq[0], y1 = yq[1], y2 = yq[2], y3 = yq[3];
+                                if (a >= 0) {
+                                    const int r0 = trow[i];
+                                    const double t0 = p0[kc] - cm[kc], t1 = p1[kc] - cm[kc], t2 = p2[kc] - cm[kc], t3 = p3[kc] - cm[kc];
+                                    if (r0 + 0 < nvalid) y0 = y0 - t0;
+                                    if (r0 + 1 < nvalid) y1 = y1 - t1;
+                                    if (r0 + 2 < nvalid) y2 = y2 - t2;
+                                    if (r0 + 3 < nvalid) y3 = y3 - t3;
+                                    yq[0] = y0; yq[1] = y1; yq[2] = y2; yq[3] = y3;
+                                }
+                                const double q4 = (y0 + y1) + (y2 + y3);
+                                vsum[kc] = (i == 0) ? q4 : vsum[kc] + q4;
+                            }
+                        }
+                    }
+                    if (u < nb) {
+#pragma unroll
+                        for (int kc = 0; kc < KC; kc++) {
+                            double vs = vsum[kc];
+                            vs = vs + dpp_f64(vs, 4);
+                            const double r0 = readlane_d(vs, 0), r1 = readlane_d(vs, 16), r2 = readlane_d(vs, 32), r3 = readlane_d(vs, 48);
+                            if (lane == 0) NGP_RSY(kc)[(u & 1) * 8 + wv] = (r0 + r1) + (r2 + r3);
                         }
                     }
                 }
@@ -2548,29 +2655,60 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows_multi(c
                     for (int kc = 0; kc < KC; kc++) acc[kc] = 0.0;
                     for (int k = 0; k < nqw; k++) {
                         const int q = wv + NGP_ROWS_NW * k;
-                        const float4 x = *(const float4 *)(ring + (size_t)wrap(base + q) * NGP_QS + (size_t)lane * 16);
+                        if constexpr (U8) {
+                            const uint4 x = *(const uint4 *)(ring + (size_t)wrap(base + q) * NGP_QS + (size_t)lane * 16);
+                            const unsigned xw[4] = {x.x, x.y, x.z, x.w};
 #pragma unroll
-                        for (int kc = 0; kc < KC; kc++) {
-                            const double *yq = NGP_YS(kc) + 4 * q;
-                            const double y0 = yq[0], y1 = yq[1], y2 = yq[2], y3 = yq[3];
-                            acc[kc] = __builtin_fma((double)x.x, y0, acc[kc]);
-                            acc[kc] = __builtin_fma((double)x.y, y1, acc[kc]);
-                            acc[kc] = __builtin_fma((double)x.z, y2, acc[kc]);
-                            acc[kc] = __builtin_fma((double)x.w, y3, acc[kc]);
+                            for (int e4 = 0; e4 < 4; e4++) {
+                                const unsigned w = xw[e4];
+                                const double g0 = (double)(float)(w & 0xffu), g1 = (double)(float)((w >> 8) & 0xffu);
+                                const double g2 = (double)(float)((w >> 16) & 0xffu), g3 = (double)(float)(w >> 24);
+#pragma unroll
+                                for (int kc = 0; kc < KC; kc++) {
+                                    const double *yq = NGP_YS(kc) + 16 * q + 4 * e4;
+                                    const double y0 = yq[0], y1 = yq[1], y2 = yq[2], y3 = yq[3];
+                                    acc[kc] = __builtin_fma(g0, y0, acc[kc]);
+                                    acc[kc] = __builtin_fma(g1, y1, acc[kc]);
+                                    acc[kc] = __builtin_fma(g2, y2, acc[kc]);
+                                    acc[kc] = __builtin_fma(g3, y3, acc[kc]);
+                                }
+                            }
+                        } else {
+                            const float4 x = *(const float4 *)(ring + (size_t)wrap(base + q) * NGP_QS + (size_t)lane * 16);
+#pragma unroll
+                            for (int kc = 0; kc < KC; kc++) {
+                                const double *yq = NGP_YS(kc) + 4 * q;
+                                const double y0 = yq[0], y1 = yq[1], y2 = yq[2], y3 = yq[3];
+                                acc[kc] = __builtin_fma((double)x.x, y0, acc[kc]);
+                                acc[kc] = __builtin_fma((double)x.y, y1, acc[kc]);
+                                acc[kc] = __builtin_fma((double)x.z, y2, acc[kc]);
+                                acc[kc] = __builtin_fma((double)x.w, y3, acc[kc]);
+                            }
                         }
                     }
 #pragma unroll
                     for (int kc = 0; kc < KC; kc++) NGP_RED(kc)[((u & 1) * NGP_ROWS_NW + wv) * NGP_BLK + lane] = acc[kc];
-                    asm volatile("" ::: "memory");  // LDS serves a wave in order: the count follows the sums
-                    if (lane == 0) __hip_atomic_fetch_add((lds_int_t *)((u & 1) ? gcnt1 : gcnt0), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    if (early) {
+                        asm volatile("" ::: "memory");  // LDS serves a wave in order: the count follows the sums
+                        if (lane == 0) __hip_atomic_fetch_add((lds_int_t *)((u & 1) ? gcnt1 : gcnt0), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                     try_signal(false);
                     // ---- tile u into the delay line ----
-                    const char *tq = ring + (size_t)wrap(base + tslot) * NGP_QS + c * 128;
+                    if constexpr (U8) {
 #pragma unroll
-                    for (int jj = 0; jj < 8; jj++) keep[d][jj] = *(const float4 *)(tq + jj * 16);
+                        for (int i = 0; i < NT; i++) {
+                            const char *tq = ring + (size_t)wrap(base + tslot[i]) * NGP_QS + c * 128 + (trow[i] & 15);
+#pragma unroll
+                            for (int jj = 0; jj < 8; jj++) keep8[d][i][jj] = *(const unsigned *)(tq + jj * 16);
+                        }
+                    } else {
+                        const char *tq = ring + (size_t)wrap(base + tslot[0]) * NGP_QS + c * 128;
+#pragma unroll
+                        for (int jj = 0; jj < 8; jj++) keep[d][jj] = *(const float4 *)(tq + jj * 16);
+                    }
                 }
                 // the publisher waits for the seven chain waves through the LDS counter and publishes at once (before the barrier)
-                if (wv == NGP_ROWS_PUBW && u < nb) {
+                if (early && wv == NGP_ROWS_PUBW && u < nb) {
                     const int *gc = (u & 1) ? gcnt1 : gcnt0;
                     for (unsigned sp = 0; lds_flag_ld(gc) < NGP_ROWS_NW; ++sp) {
                         if ((sp & 255u) == 255u && (lds_flag_ld(sflag) == 0 || sp > (NGP_SPIN_LIMIT << 4))) {
@@ -2591,7 +2729,19 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows_multi(c
                             ok = wait_dlt_granules_all(Mp->a[kc].dltg, Mp->a[kc].nonce, pa, lane, A.abort_w, 1u, pg0[kc], pg1[kc]) ? 1 : 0;
                             if (!ok && lane == 0) *sflag = 0;
                         }
-                        if (ok) NGP_DL(kc)[((u + 1) & 1) * NGP_DLS + lane] = dlt_granules_value(pg0[kc], pg1[kc]);
+                        if (ok) {
+                            const double dv = dlt_granules_value(pg0[kc], pg1[kc]);
+                            NGP_DL(kc)[((u + 1) & 1) * NGP_DLS + lane] = dv;
+                            if constexpr (U8) {  // sum_j m_j dlt_j (role_streamer_rows: the same butterfly)
+                                double v = pm * dv;
+                                v = v + dpp_f64(v, 0);
+                                v = v + dpp_f64(v, 1);
+                                v = v + dpp_f64(v, 2);
+                                v = v + dpp_f64(v, 3);
+                                const double r0 = readlane_d(v, 0), r1 = readlane_d(v, 16), r2 = readlane_d(v, 32), r3 = readlane_d(v, 48);
+                                if (lane == 0) NGP_DL(kc)[((u + 1) & 1) * NGP_DLS + NGP_BLK] = (r0 + r1) + (r2 + r3);
+                            }
+                        }
                     }
                 }
                 if (wv == NGP_ROWS_POLLW && pa + 1 >= 0 && u + 2 < nb + DT) {
@@ -2601,10 +2751,12 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows_multi(c
                         pg0[kc] = ld_u64(gp);
                         pg1[kc] = ld_u64(gp + 1);
                     }
+                    if (U8 && pa + 1 < nb) { pm = A.mean[(size_t)(A.t0 + pa + 1) * NGP_BLK + lane]; pm_blk = pa + 1; }
                 }
                 try_signal(DT < 4);
                 wg_barrier();
                 if (!*sflag) return;
+                if (!early && wv == NGP_ROWS_PUBW && u < nb) publish(u);
                 base = wrap(base + NQ);
             }
         }
@@ -2619,6 +2771,7 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows_multi(c
 #undef NGP_YS
 #undef NGP_RED
 #undef NGP_DL
+#undef NGP_RSY
 }
 
 #if !defined(NGP_INST_DBG) || !NGP_INST_DBG || NGP_INST_DBG == 2  // the production translation unit (ngp_sweep_inst.hip, -DNGP_INST_DBG=0) and the Tuple one

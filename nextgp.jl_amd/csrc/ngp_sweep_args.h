@@ -127,9 +127,10 @@ __host__ __device__ inline size_t ngp_multi_lds_bytes(int R, int K) {
 }
 
 // the same for the row-owning streamer (fp32 tiles, shards of 64..NGP_ROWS_MAX_R rows, lag 6; 2 or 3 chains)
-__host__ __device__ inline size_t ngp_rows_multi_chain_doubles(int R) { return (size_t)((R + 7) & ~7) + 2 * NGP_ROWS_NW * NGP_BLK + 2 * NGP_DLS; }
-__host__ __device__ inline size_t ngp_rows_multi_lds_bytes(int R, int K) {
-    const size_t nq = (size_t)R / 4, hq = nq + 1 < 2 * (size_t)NGP_ROWS_HMAX ? (nq + 1) / 2 : (size_t)NGP_ROWS_HMAX;
+// (per chain: shard | 2 x 7 x 64 chain sums | 2 x 72 dlt | 2 x 8 row sums of the compact update; u8: ring slots of 16 rows x 64 bytes)
+__host__ __device__ inline size_t ngp_rows_multi_chain_doubles(int R) { return (size_t)((R + 7) & ~7) + 2 * NGP_ROWS_NW * NGP_BLK + 2 * NGP_DLS + 16; }
+__host__ __device__ inline size_t ngp_rows_multi_lds_bytes(int R, int K, bool u8 = false) {
+    const size_t nq = (size_t)R / (u8 ? 16 : 4), hq = nq + 1 < 2 * (size_t)NGP_ROWS_HMAX ? (nq + 1) / 2 : (size_t)NGP_ROWS_HMAX;
     return (2 * nq + hq) * NGP_QS + (size_t)K * ngp_rows_multi_chain_doubles(R) * 8 + 64 + 64 + 1024;
 }
 hipError_t sweep_multi_set_max_lds(int bytes);

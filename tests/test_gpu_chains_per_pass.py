@@ -83,6 +83,45 @@ def test_fused_chains_on_the_row_owning_streamer(ngp, O, K, lag):
         assert f["varE"] == b["varE"]
 
 
+@pytest.mark.parametrize("lag,N,shards,tasks", [(8, 500, 0, 1), (6, 500, 0, 1), (4, 500, 0, 1), (8, 1500, 6, 2), (4, 1500, 6, 2), (6, 2900, 6, 4)],
+                         ids=["lag8", "lag6", "lag4", "two_tasks_lag8", "two_tasks_lag4", "four_tasks"])
+def test_fused_chains_over_compact_storage(ngp, O, lag, N, shards, tasks):
+    """Two chains per pass over byte tiles (role_streamer_rows_multi<.., ST>): every byte converted once for both chains; each chain
+    bit for bit the blocked oracle's compact chain (oracle/ngp_oracle.c ora_set_panel_u8) and the chain it is alone."""
+    from test_gpu_compact import make_codes
+    P = 450
+    G, y, v = make_codes(O, N, P)
+    spec = [(0, 150, "PR"), (150, 170, "B"), (320, 130, "R")]
+    fused = []
+    for c in range(2):
+        s = ngp.Sampler(device=0, seed=1001 + c, chain=c, mode=1, lag=lag, storage="u8")
+        if c == 0:
+            s.set_max_shards(shards if shards else s.shards_for_pass(2))
+            s.set_panel(G, centre=True)
+        else:
+            s.share_panel(fused[0])
+        add_sets(s, spec, v); s.set_y(y + 0.01 * c); s.set_residual_prior(4.0, 1.0); s.set_schedule(20, 4, 2)
+        fused.append(s)
+    R, S, _ = fused[0].layout()
+    D = fused[0].config()[1]
+    assert fused[0].streamer() == (3, 7) and fused[1].storage() == 1
+    nuw = -(-(R // 16) // 7)                                 # units of 16 rows per row-owning wave -> update tasks per lane
+    assert {1: 1, 2: 2, 3: 4, 4: 4}[(4 * nuw + 7) // 8] == tasks
+    ngp.Sampler.run_many(fused, 20)
+    assert fused[0].census()["grid"] == 2 * (1 + (S + 31) // 32) + S          # one launch for both chains
+    for c in range(2):
+        o = O.Oracle(order=1, seed=1001 + c, chain=c)
+        o.set_panel_u8(G, R=R, S=S, D=D, near=fused[0].near(), tform=fused[0].chain_form())
+        add_sets(o, spec, v); o.set_y(y + 0.01 * c); o.set_residual_prior(4.0, 1.0); o.set_schedule(20, 4, 2); o.run(20)
+        f, b = fused[c].get_state(), o.get_state()
+        for k in ("ycorr", "beta", "delta", "varBeta", "piHat"):
+            assert np.array_equal(f[k], b[k]), (c, k)
+        assert f["varE"] == b["varE"] and f["b"] == b["b"]
+        pf, pb = fused[c].get_posterior_sums(), o.get_posterior_sums()
+        for k in ("sum_beta", "sum_beta2", "sum_delta", "sum_varBeta"):
+            assert np.array_equal(pf[k], pb[k]), (c, k)
+
+
 def test_shared_panel_lifetime_and_fallback(ngp, O):
     """The panel arrays live as long as any handle refers to them; handles whose engine the fused kernel does not serve still run
     through ngp_run_many (side by side, one thread each), with the same results."""

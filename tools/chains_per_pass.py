@@ -11,7 +11,7 @@ lag = int(sys.argv[5]) if len(sys.argv) > 5 else 0
 method = os.environ.get("NGP_TOOL_METHOD", "PR")
 chains = []
 for k in range(K):
-    s = ngp.Sampler(device=0, seed=1001 + k, chain=k, **({"mode": 1, "lag": lag} if lag else {}))
+    s = ngp.Sampler(device=0, seed=1001 + k, chain=k, storage=os.environ.get("NGP_TOOL_STORAGE"), **({"mode": 1, "lag": lag} if lag else {}))
     if "NGP_TOOL_KNOB" in os.environ: s.debug_set_knob(int(os.environ["NGP_TOOL_KNOB"]))  # 2048 / 4096: reducers serve two chains each / one
     if k == 0:
         if K > 1:
@@ -34,9 +34,10 @@ chains[0].get_timing()
 t0 = time.perf_counter(); run(iters); dt = time.perf_counter() - t0
 tm = chains[0].get_timing()
 R, S, nblk = chains[0].layout()
+bpe = 1.0 if os.environ.get("NGP_TOOL_STORAGE") == "u8" else 4.0
 print(f"N={N} P={P} method={method} chains per pass={K} layout R={R} S={S} lag={chains[0].config()[1]} grid={chains[0].census()['grid']}: "
       f"{K * iters / dt:.1f} it/s aggregate, {dt / iters * 1e3:.3f} ms per pass ({dt / iters / nblk * 1e6:.3f} us per 64-SNP block), "
-      f"device {tm['iter_ms'] / max(tm['iters'], 1):.3f} ms, sweep launches {tm['sweep_launches']}, panel stream {4.0 * N * P * iters / dt / 1e12:.2f} TB/s", flush=True)
+      f"device {tm['iter_ms'] / max(tm['iters'], 1):.3f} ms, sweep launches {tm['sweep_launches']}, panel stream {bpe * N * P * iters / dt / 1e12:.2f} TB/s", flush=True)
 for s in chains:
     st = s.get_state()
     assert np.isfinite(st["beta"]).all() and st["varE"] > 0
