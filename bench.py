@@ -64,7 +64,7 @@ def simulate_y(xbeta, N, P):
 def build_chain(ngp, device, seed, N, P, sets, panel_seed=20250509, storage=None, share=0, per_pass=0, owner=None, y=None):
     # chains per pass on tall shards (row-owning streamer): two chains at lag 4 -- its register delay line leaves room for the second
     # chain's arithmetic there (measured at 50k x 600k: 58.6 it/s aggregate at lag 4, 55.2 at lag 5, 47.5 at lag 6; one chain: 41.9 at lag 6)
-    eng = dict(mode=1, lag=4) if (per_pass > 1 or owner is not None) and N >= 64 * 247 else {}
+    eng = dict(mode=1, lag=4) if (per_pass > 1 or owner is not None) and N >= 64 * 247 and storage is None else {}
     s = ngp.Sampler(device=device, seed=seed, chain=seed - 1001, storage=storage, **eng)
     if share > 1:  # this chain is one of `share` that run side by side on the device
         s.set_max_shards(s.shards_for_chains(share))
@@ -378,6 +378,27 @@ def main():
                 "speedup_vs_fp32_storage": (K / cdt) / (K / dt), "setup_s": csetup,
             }
             c.close()
+            # ... and two chains per pass over the byte tiles (every byte converted once for both chains)
+            first, _ = build_chain(ngp, local_rank, 1001, N, P, sets, storage="u8", per_pass=2)
+            ysh = simulate_y(first.xbeta, N, P)
+            cs = [first, build_chain(ngp, local_rank, 1002, N, P, sets, storage="u8", owner=first, y=ysh)[0]]
+            for c in cs:
+                c.set_schedule(W + K, W, 1)
+            ngp.Sampler.run_many(cs, W)
+            cs[0].get_timing()
+            torch.cuda.synchronize()
+            tk = time.perf_counter()
+            ngp.Sampler.run_many(cs, K)
+            torch.cuda.synchronize()
+            kdt = time.perf_counter() - tk
+            ptm, cen = cs[0].get_timing(), cs[0].census()
+            out["compact_storage"]["chains_per_pass"] = {
+                "chains": 2, "value": 2 * K / kdt, "unit": "it/s (aggregate over the chains of ONE fused launch per iteration)",
+                "ms_per_pass": kdt / K * 1e3, "rows_per_shard": cs[0].layout()[0], "shards": cs[0].layout()[1], "lag": cs[0].config()[1],
+                "census_retries": cen["retries"], "exclusive": bool(cen["exclusive"]), "fused": bool(ptm["sweep_launches"] == K),
+                "speedup_vs_single_chain": (2 * K / kdt) / (K / cdt)}
+            for c in cs:
+                c.close()
         if world == 1 and args.chains_per_gpu > 1 and not compact_main:
             # independent chains side by side on ONE GPU (disjoint CU shares, one thread each inside the library): the aggregate
             # rate of the same metric where a single chain is bound by its sampler workgroup -- beside the single-chain value
