@@ -363,7 +363,8 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
     (4) storage="u8" keeps the panel one byte per genotype on the device, centred analytically (ngp_set_storage: a quarter of
     the memory, no fp32 rounding of the panel) -- every SNP set must then hold integer codes 0..255 (uint8 arrays, binary panel
     files, or text files whose values are such integers); (5) chains=K runs K independent chains (chain ids chain .. chain+K-1, the
-    same seed) over ONE copy of the panel on the device -- one fused sweep launch per iteration where the engine serves it
+    same seed) over ONE copy of the panel on the device -- one fused sweep launch per iteration where the engine serves it (the result's
+    "fused" says whether it did; a warning otherwise)
     (ngp_share_panel + ngp_run_many), side by side otherwise; every chain is bit for bit the chain it is alone with that layout,
     writes its own *Out files to outFolder/chain<c>/, and the returned means are pooled over the chains (res["chains"] holds each).
     Returns a dict of posterior means taken from the on-device sums."""
@@ -447,7 +448,8 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
     if max_shards:  # an explicit shard count (ngp_set_max_shards): e.g. the layout of a fused run, to repeat one of its chains alone
         smp.set_max_shards(int(max_shards))
     elif K > 1:  # the layout with which K chains share one fused sweep launch (fp32 tiles), or the device side by side
-        smp.set_max_shards(smp.shards_for_pass(K) if storage is None else smp.shards_for_chains(K))
+        # (compact storage: the fused kernel serves two chains; more run side by side on disjoint CU shares)
+        smp.set_max_shards(smp.shards_for_pass(K) if (storage is None or K == 2) else smp.shards_for_chains(K))
     kinds = {np.asarray(pc).dtype == np.uint8 for pc in pieces if pc.shape[1]}
     if (storage is None and kinds == {False}) or kinds == {True}:
         # the sets go to the device one after another (ngp_begin_panel / ngp_panel_columns_* / ngp_end_panel): no concatenated host copy
@@ -578,7 +580,14 @@ def _run_model(samplers, folders, sets, fixed_names, intercept, nChain, nBurn, n
                 _write_headers(f, sets, fixed_names)
             if samples in ("text", "binary"):
                 sc.set_sample_file(pth)
+        samplers[0].get_timing()
         Sampler.run_many(samplers, nChain)  # ONE fused sweep launch per iteration for all chains where the engine serves it
+        fused = samplers[0].get_timing()["sweep_launches"] == nChain
+        if not fused:  # (the layout was chosen for a fused launch: side by side each chain's grid takes most of the device, so they take turns)
+            import warnings
+            warnings.warn(f"runLMEM(chains={K}): this layout / engine is not served by the fused sweep kernel (fp32 tiles: shards of at most "
+                          "64 rows with lag 6 or 8, or two chains on 64-224-row shards with lag 4-6; compact storage: two chains); the chains "
+                          "ran one launch each per iteration. Results are the same; pass max_shards=Sampler.shards_for_chains(K) for side-by-side runs.")
         results = []
         for sc, f, pth in zip(samplers, folders, paths):
             if samples in ("text", "binary"):
@@ -587,7 +596,9 @@ def _run_model(samplers, folders, sets, fixed_names, intercept, nChain, nBurn, n
                 samples_to_out_files(pth, f, sets, intercept, len(fixed_names) > int(intercept))
                 os.remove(pth)
             results.append(_posterior_means(sc, sets, fixed_names, intercept))
-        return _pool_results(results)
+        pooled = _pool_results(results)
+        pooled["fused"] = bool(fused)
+        return pooled
     smp, outFolder = samplers[0], folders[0]
     # header rows (src/mme.jl:543-595)
     if samples in ("text", "text-sync"):

@@ -1079,10 +1079,16 @@ int sample_enqueue(ngp_handle *h) {
     hipLaunchKernelGGL(k_sample_pack, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, h->stream, S->d_slot[slot], (long long)h->P, (long long)h->nvb,
                        (int)h->sets.size(), (long long)h->nfixcol, (long long)h->nclass_total, (long long)h->iter, h->d_beta, h->d_delta, h->d_varBeta,
                        h->d_sets, h->d_scal, h->d_bfix, h->d_abort);
-    HCHK(hipEventRecord(S->ev_packed[slot], h->stream));
-    HCHK(hipStreamWaitEvent(S->copy_stream, S->ev_packed[slot], 0));
-    HCHK(hipMemcpyAsync(S->h_slot[slot], S->d_slot[slot], S->rec_bytes, hipMemcpyDeviceToHost, S->copy_stream));
-    HCHK(hipEventRecord(S->ev_copied[slot], S->copy_stream));
+    // (a HIP call that fails here gives the slot back: the next enqueue would otherwise wait for it forever instead of reporting)
+    hipError_t e = hipEventRecord(S->ev_packed[slot], h->stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(S->copy_stream, S->ev_packed[slot], 0);
+    if (e == hipSuccess) e = hipMemcpyAsync(S->h_slot[slot], S->d_slot[slot], S->rec_bytes, hipMemcpyDeviceToHost, S->copy_stream);
+    if (e == hipSuccess) e = hipEventRecord(S->ev_copied[slot], S->copy_stream);
+    if (e != hipSuccess) {
+        { std::lock_guard<std::mutex> lk(S->mu); S->busy[slot] = false; }
+        S->cv.notify_all();
+        return fail(h, NGP_ERR_HIP, std::string("sample stream: ") + hipGetErrorString(e));
+    }
     { std::lock_guard<std::mutex> lk(S->mu); S->queue.push_back(slot); }
     S->cv.notify_all();
     S->nenq++;
@@ -1434,6 +1440,7 @@ int32_t ngp_get_mpm(ngp_handle *h, double *out, int64_t P) {
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
+    REQUIRE(!h->panel_open, NGP_ERR_STATE, "the panel is still open: x'x and the Gram window exist after ngp_end_panel");
     REQUIRE(out && P == h->P, NGP_ERR_ARG, "mpm buffer must hold P entries");
     HCHK(hipMemcpy(out, h->d_mpm, (size_t)P * sizeof(double), hipMemcpyDeviceToHost));
     return NGP_OK;
@@ -1445,6 +1452,7 @@ int32_t ngp_get_gram(ngp_handle *h, int64_t t, double *out) {
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
+    REQUIRE(!h->panel_open, NGP_ERR_STATE, "the panel is still open: x'x and the Gram window exist after ngp_end_panel");
     REQUIRE(out && t >= 0 && t < h->NBLK, NGP_ERR_ARG, "block index out of range");
     HCHK(hipMemcpy(out, h->d_gramx + (size_t)t * h->D * NGP_BLK * NGP_BLK, NGP_BLK * NGP_BLK * sizeof(double), hipMemcpyDeviceToHost));
     // the device keeps entry [k][j] for j > k only (plus x'x in mpm); hand back the symmetric block
@@ -1463,6 +1471,7 @@ int32_t ngp_xbeta(ngp_handle *h, const double *beta, int64_t P, double *out, int
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
+    REQUIRE(!h->panel_open, NGP_ERR_STATE, "the panel is still open: x'x and the Gram window exist after ngp_end_panel");
     REQUIRE(beta && out && P == h->P && N == h->N, NGP_ERR_ARG, "xbeta: size mismatch");
     double *d_b = nullptr, *d_o = nullptr;
     if ((rc = dalloc(h, &d_b, (size_t)h->Ppad))) return rc;
@@ -1490,6 +1499,7 @@ int32_t ngp_add_marker_set(ngp_handle *h, int64_t col0, int64_t ncol, int32_t me
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
+    REQUIRE(!h->panel_open, NGP_ERR_STATE, "the panel is still open: x'x and the Gram window exist after ngp_end_panel");
     REQUIRE(h->sets.size() < 16, NGP_ERR_ARG, "at most 16 marker sets");
     REQUIRE(col0 >= 0 && ncol > 0 && col0 + ncol <= h->P, NGP_ERR_ARG, "marker set outside the panel");
     REQUIRE(method == NGP_METHOD_BAYESPR || method == NGP_METHOD_BAYESB || method == NGP_METHOD_BAYESC || method == NGP_METHOD_BAYESR, NGP_ERR_ARG,
@@ -1734,11 +1744,19 @@ int run_fused(ngp_handle **hs, int n, int64_t niter) {
         for (int i = 0; i < n; i++) { hs[i]->stream = st[i]; hs[i]->d_abort = ab[i]; if (evp[i]) (void)hipEventDestroy(evp[i]); }
         if (evs) (void)hipEventDestroy(evs);
     };
+    // (a scope guard: an exception on the way -- a std::string or std::vector that cannot allocate -- unwinds to the ABI's barrier
+    // with every handle's own abort word and stream back in place; ngp_destroy would otherwise free the leader's buffer once per handle)
+    struct Guard {
+        decltype(restore) &f;
+        bool armed = true;
+        ~Guard() { if (armed) f(); }
+        void now() { if (armed) { armed = false; f(); } }
+    } guard{restore};
     hipError_t e = hipSuccess;
     if (!serial) {
         for (int i = 1; i < n && e == hipSuccess; i++) e = hipEventCreateWithFlags(&evp[i], hipEventDisableTiming);
         if (e == hipSuccess) e = hipEventCreateWithFlags(&evs, hipEventDisableTiming);
-        if (e != hipSuccess) { restore(); return fail(h, NGP_ERR_HIP, std::string("fused run: ") + hipGetErrorString(e)); }
+        if (e != hipSuccess) { guard.now(); return fail(h, NGP_ERR_HIP, std::string("fused run: ") + hipGetErrorString(e)); }
     }
     auto sync_all = [&]() {
         hipError_t r = hipStreamSynchronize(h->stream);
@@ -1781,7 +1799,7 @@ int run_fused(ngp_handle **hs, int n, int64_t niter) {
     else (void)sync_all();
     if (e == hipSuccess) e = hipEventRecord(h->ev1, h->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(h->stream);
-    restore();
+    guard.now();
     if (e != hipSuccess) return fail(h, NGP_ERR_HIP, std::string("fused run: ") + hipGetErrorString(e));
     if (rc) return rc;
     float ms = 0.f;
@@ -2729,6 +2747,7 @@ int32_t ngp_add_marker_set_r(ngp_handle *h, int64_t col0, int64_t ncol, double d
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
+    REQUIRE(!h->panel_open, NGP_ERR_STATE, "the panel is still open: x'x and the Gram window exist after ngp_end_panel");
     REQUIRE(vClass && pi && K >= 2 && K <= NGP_RMAX, NGP_ERR_ARG, "BayesR needs 2..8 variance classes with their probabilities");
     double ps = 0.0;
     for (int v = 0; v < K; v++) {
@@ -2772,6 +2791,7 @@ int32_t ngp_add_marker_set_tuple(ngp_handle *h, int64_t col0, int64_t nloc, int3
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
+    REQUIRE(!h->panel_open, NGP_ERR_STATE, "the panel is still open: x'x and the Gram window exist after ngp_end_panel");
     REQUIRE(h->sets.size() < 16, NGP_ERR_ARG, "at most 16 marker sets");
     REQUIRE(k >= 1 && k <= NGP_KMAX, NGP_ERR_ARG, "a tuple holds 1..4 correlated sets");
     REQUIRE(nloc >= 1 && col0 >= 0 && col0 % NGP_BLK == 0, NGP_ERR_ARG, "tuple set: first column on a 64-column block boundary");
@@ -2779,6 +2799,7 @@ int32_t ngp_add_marker_set_tuple(ngp_handle *h, int64_t col0, int64_t nloc, int3
     REQUIRE(std::isfinite(df) && df > 0, NGP_ERR_ARG, "df must be finite and positive");
     const int64_t Lb = NGP_BLK / k, nblk = (nloc + Lb - 1) / Lb, span = NGP_BLK * (nblk - 1) + (int64_t)k * (nloc - Lb * (nblk - 1));
     REQUIRE(col0 + span <= h->P, NGP_ERR_ARG, "tuple set outside the panel");
+    REQUIRE((int64_t)nloc * k < ((int64_t)1 << 31), NGP_ERR_ARG, "tuple set too large");  // (every check in front of the first change to the host tables)
     // the set owns its 64-column blocks to the end of the last one (its block chain draws whole loci; no other set's column may sit there)
     for (int64_t c = col0; c < std::min<int64_t>(col0 + NGP_BLK * nblk, h->Ppad); c++) REQUIRE(h->h_setof[c] == -1, NGP_ERR_ARG, "marker sets overlap");
     for (int a = 0; a < k * k; a++) REQUIRE(std::isfinite(scale[a]) && std::isfinite(varBeta0[a]), NGP_ERR_ARG, "scale / varBeta0 must be finite");
@@ -2836,7 +2857,6 @@ int32_t ngp_add_marker_set_tuple(ngp_handle *h, int64_t col0, int64_t nloc, int3
         tr.nseg = ns;
         h->h_tregs.push_back(tr);
     }
-    REQUIRE((int64_t)nloc * k < ((int64_t)1 << 31), NGP_ERR_ARG, "tuple set too large");
     DTup tp;
     memset(&tp, 0, sizeof(tp));
     tp.k = k; tp.col0 = col0; tp.nloc = nloc; tp.vb_off = h->nvb; tp.df = df;
@@ -2900,6 +2920,7 @@ int32_t ngp_add_fixed_set(ngp_handle *h, const double *X, int64_t N, int64_t nco
     int rc;
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
+    REQUIRE(!h->panel_open, NGP_ERR_STATE, "the panel is still open: x'x and the Gram window exist after ngp_end_panel");
     REQUIRE(X && N == h->N && ncol >= 1 && ncol <= 64 && ld >= N, NGP_ERR_ARG, "fixed-effect set: N rows, 1..64 columns");
     REQUIRE(h->fix.size() < 16, NGP_ERR_ARG, "at most 16 fixed-effect sets");
     std::vector<double> xc((size_t)N * ncol), x0((size_t)ncol * ncol), xr;

@@ -105,6 +105,9 @@ def test_panel_in_column_ranges_equals_whole_panel(ngp, O):
         parts.add_marker_set(0, P, 0, 4.0, 1.0, [(0, P)], [1.0]); parts.set_y(np.zeros(N)); parts.run(1)
     parts = ngp.Sampler(device=0, seed=1, chain=0)
     parts.begin_panel(N, P)
+    for call in (parts.mpm, lambda: parts.xbeta(np.zeros(P)), lambda: parts.gram(0)):   # x'x and the Gram window do not exist yet
+        with pytest.raises(ngp.NextGPHipError, match="still open"):
+            call()
     for a, b in ((130, 300), (0, 57), (57, 130)):       # any order, boundaries inside 64-column blocks
         parts.panel_columns(a, G[:, a:b], centre=True)
     with pytest.raises(ngp.NextGPHipError, match="outside the panel"):
