@@ -196,6 +196,14 @@ __device__ inline double rlane_L(const RLane &L, const int v, const double hs) {
     const double q = L.ext[(size_t)v * L.Ppad], a = L.ext[(size_t)v * L.Ppad + (size_t)L.astride];
     return (q == 0.0) ? a : __builtin_fma(hs, q, a);
 }
+// candidate of a lane of another method inside an r-form block (the rule of step 5 in r-form)
+__device__ inline void eval_rform_other(const double r, const double bo, const double cc, const double ww, const double st, double &cand, int &cls) {
+    const double f = r * cc;
+    const int in = __builtin_fabs(f) > st;
+    const double e1 = __builtin_fma(r, cc, ww);
+    cand = in ? e1 : -bo;
+    cls = in;
+}
 __device__ inline void eval_rform(const int meth, const double r, const double bo, const double cc, const double ww, const double st,
                                   const RLane &L, const double iVarE, double &cand, int &cls) {
     if (meth == 3) {
@@ -286,11 +294,7 @@ __device__ inline void eval_rform(const int meth, const double r, const double b
         } else cand = -bo;
         cls = c + 1;
     } else {
-        const double f = r * cc;
-        const int in = __builtin_fabs(f) > st;
-        const double e1 = __builtin_fma(r, cc, ww);
-        cand = in ? e1 : -bo;
-        cls = in;
+        eval_rform_other(r, bo, cc, ww, st, cand, cls);
     }
 }
 

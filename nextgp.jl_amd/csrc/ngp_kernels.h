@@ -249,14 +249,18 @@ __global__ __launch_bounds__(256) void k_prep(long long Ppad, const int8_t *__re
         const double t2r = t1r + lhs0[k];
         Rng rz = rng_seed(seed, chain, it, NGP_KIND_BETA_NORMAL, key);
         const double zr = rng_normal(rz);
+        double qv[NGP_RMAX], av[NGP_RMAX], u0 = 1.0;  // (kept for the lazy threshold below)
         for (int v = 0; v < S.K; v++) {
             const double varc = varB * S.vcls[v];
             Rng ruu = rng_seed(seed, chain, it, NGP_KIND_R_UNIFORM, ((uint64_t)si << 40) | (l << 3) | (uint64_t)v);
-            ru[(size_t)v * Ppad + k] = rng_uniform(ruu);
+            const double uv = rng_uniform(ruu);
+            ru[(size_t)v * Ppad + k] = uv;
+            if (v == 0) u0 = uv;
             if (varc == 0.0) {
                 rq[(size_t)v * Ppad + k] = 0.0;
                 ra[(size_t)v * Ppad + k] = S.logpic[v];
                 rt[(size_t)v * Ppad + k] = 0.0;
+                qv[v] = 0.0; av[v] = S.logpic[v];
             } else {
                 const double iv = 1.0 / varc;
                 const double lhsv = t2r + iv;
@@ -268,7 +272,50 @@ __global__ __launch_bounds__(256) void k_prep(long long Ppad, const int8_t *__re
                 rq[(size_t)v * Ppad + k] = ilhs;
                 ra[(size_t)v * Ppad + k] = S.logpic[v] - hl;
                 rt[(size_t)v * Ppad + k] = sd * zr;
+                qv[v] = ilhs; av[v] = S.logpic[v] - hl;
             }
+        }
+        // Lazy threshold of the class search (speed only): with a zero first class the search ends at class 0
+        // iff e_0 >= u_0 S, i.e. F(hs) = sum_{v>=1} exp(q_v hs + a_v - a_0) <= 1 / u_0 - 1, and F grows with hs = rhs^2 / 2.  h* below
+        // satisfies F(h*) <= (1 - 1e-6)(1 / u_0 - 1) AS EVALUATED HERE (bisection, its lower end): for hs <= h* the comparison of the
+        // full evaluation holds with a relative margin of 1e-6 (1 - u_0) >= 1e-9, six orders above its rounding -- such a locus without an
+        // old effect is passed over without being evaluated, with the result the evaluation would give (class 1, dlt = -beta).
+        // -1: never lazy.  The value travels in the slot of class 0's sd * z, which a zero class does not use.
+        if (S.K >= 2 && qv[0] == 0.0) {
+            double hst = -1.0;
+            if (u0 > 0.0 && u0 <= 0.999) {
+                const double tau = (1.0 / u0 - 1.0) * (1.0 - 1e-6);
+                const double lt = det_log(tau);
+                double dv[NGP_RMAX];
+                double hi = __builtin_inf();
+                bool ok = true;
+                for (int v = 1; v < S.K; v++) {
+                    dv[v] = (av[v] - av[0]) - lt;
+                    if (qv[v] > 0.0) { const double hb = -dv[v] / qv[v]; hi = (hb < hi) ? hb : hi; }
+                    else if (!(dv[v] <= 0.0)) ok = false;
+                }
+                if (ok && hi >= 0.0) {  // every exponent below is <= 0 on [0, hi]
+                    double g0 = 0.0;
+                    for (int v = 1; v < S.K; v++) g0 += det_exp(dv[v]);
+                    if (g0 <= 1.0) {
+                        if (hi == __builtin_inf()) hst = 1.7976931348623157e308;
+                        else {
+                            double lo = 0.0;
+                            for (int itb = 0; itb < 30; itb++) {
+                                const double mid = 0.5 * (lo + hi);
+                                double g = 0.0;
+                                for (int v = 1; v < S.K; v++) g += det_exp(__builtin_fma(mid, qv[v], dv[v]));
+                                if (g <= 1.0) lo = mid; else hi = mid;
+                            }
+                            hst = lo;
+                        }
+                    }
+                }
+            }
+#ifdef NGP_NO_LAZY  /* timing experiment: every locus evaluated */
+            hst = -1.0;
+#endif
+            rt[k] = hst;  // (class 0)
         }
         c[k] = 0.0;
         w[k] = 0.0;

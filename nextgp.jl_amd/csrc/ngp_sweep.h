@@ -1734,26 +1734,137 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
             } else if (RCLS != 0 && A.rcls && (RCLS == 2 ? rblk != 0 : __ballot(meth0 == 3) != 0ull)) {
                 // r-form chain (eval_rform, ngp_kernels.h): candidates of all lanes from the current r, the first non-zero one at
                 // or behind the cursor takes its step.  With most loci in the zero class that is a few steps per block.
+                double dfin = 0.0;
+                int cfin = 1;
+                if constexpr (RCLS == 2) {
+                    // LAZY class search: a pass over the lanes costs a compare, not an evaluation -- a BayesR
+                    // locus without an old effect whose hs = rhs^2 / 2 is at or below its threshold h* (k_prep) is certain to stay in
+                    // the zero class and is passed over; the first lane at or behind the cursor that is NOT certain is evaluated
+                    // ALONE, its classes spread over lanes 0 .. K-1 (one exponential deep instead of four wide), with the operations
+                    // of eval_rform in their order: the same class, the same dlt, bit for bit.
+                    const double *cq = rl + (size_t)buf * (17 * NGP_BLK);   // array arr of class v < 4 of lane l: cq[(4 arr + v) 64 + l]
+                    const double *cx = rlx + (size_t)buf * (16 * NGP_BLK);  // classes 4..7: cx[(4 arr + v - 4) 64 + l]
+                    const bool isr = (meth0 == 3);
+                    const double q0j = cq[j], hstar = (isr && q0j == 0.0) ? cq[8 * NGP_BLK + j] : -1.0;
+                    const double rhs0j = cq[16 * NGP_BLK + j];
+                    const int Kj = rlm[buf * 128 + 64 + j];
+                    const double iVarE = iVarE_sweep;
+                    double rcur = r;
+                    int kstart = 0;
+                    for (int guard = 0; guard < NGP_BLK + 1; ++guard) {
+                        double lazy_d, rhs = 0.0, hs = 0.0;
+                        int lazy_c;
+                        bool need;
+                        if (isr) {
+                            const double tt = rcur * iVarE;
+                            rhs = tt + rhs0j;
+                            const double s2 = rhs * rhs;
+                            hs = 0.5 * s2;
+                            need = (bo != 0.0) || !(hs <= hstar);
+                            lazy_d = -bo;
+                            lazy_c = 1;
+                        } else {
+                            eval_rform_other(rcur, bo, cc, ww, st, lazy_d, lazy_c);
+                            need = (lazy_d != 0.0);
+                        }
+                        if (j >= kstart) { dfin = lazy_d; cfin = lazy_c; }
+                        const unsigned long long todo = __ballot(need) & (~0ull << kstart);
+                        if (!todo) break;
+                        const int kk = __builtin_ctzll(todo);
+                        double dk;
+                        if (__builtin_amdgcn_readlane(meth0, kk) == 3) {
+                            const double rhs_k = readlane_d(rhs, kk), hs_k = readlane_d(hs, kk), bo_k = readlane_d(bo, kk);
+                            const int Kk = __builtin_amdgcn_readlane(Kj, kk);
+                            // lane v < K: class v of locus kk
+                            const bool on = j < Kk;
+                            const int vv = on ? j : 0;
+                            const double *cp = (vv < NGP_RREG) ? cq + vv * NGP_BLK + kk : cx + (vv - NGP_RREG) * NGP_BLK + kk;
+                            const double qv = cp[0], av = cp[4 * NGP_BLK], tv = cp[8 * NGP_BLK], uv = cp[12 * NGP_BLK];
+                            const double Lraw = (qv == 0.0) ? av : __builtin_fma(hs_k, qv, av);
+                            int c;
+                            if (Kk <= NGP_RREG) {
+                                // up to four classes (the usual BayesR): no branch -- a lane beyond the set's classes carries log-weight -inf
+                                // and comparison uniform +inf, as the padded register classes of eval_rform do
+                                const double Lv = on ? Lraw : -__builtin_inf();
+                                const double up = on ? uv : __builtin_inf();
+                                const double L0 = readlane_d(Lv, 0), L1 = readlane_d(Lv, 1), L2 = readlane_d(Lv, 2), L3 = readlane_d(Lv, 3);
+                                double m = L0;
+                                m = (L1 > m) ? L1 : m;
+                                m = (L2 > m) ? L2 : m;
+                                m = (L3 > m) ? L3 : m;
+                                const double ev = det_exp(Lv - m);
+                                const double e0 = readlane_d(ev, 0), e1 = readlane_d(ev, 1), e2 = readlane_d(ev, 2), e3 = readlane_d(ev, 3);
+                                const double u0 = readlane_d(up, 0), u1 = readlane_d(up, 1), u2 = readlane_d(up, 2), u3 = readlane_d(up, 3);
+                                double S = 0.0;
+                                S = S + e0; S = S + e1; S = S + e2; S = S + e3;
+                                const double ee[4] = {e0, e1, e2, e3}, uu[4] = {u0, u1, u2, u3};
+                                c = Kk - 1;
+                                double cum = 0.0;
+                                bool found = false;
+#pragma unroll
+                                for (int v = 0; v < NGP_RREG; v++) {
+                                    const bool take = !found;
+                                    const double cn = cum + ee[v];
+                                    const double thr = uu[v] * S;
+                                    const bool hit = take && (cn >= thr);
+                                    cum = take ? cn : cum;
+                                    c = hit ? v : c;
+                                    found = found || hit;
+                                }
+                            } else {
+                                const double Lv = Lraw;
+                                // m = L_0, then (L_v > m) ? L_v : m in class order (eval_rform), on the gathered values
+                                double m = readlane_d(Lv, 0);
+#pragma unroll
+                                for (int v = 1; v < NGP_RMAX; v++) {
+                                    if (v < Kk) {
+                                        const double Lu = readlane_d(Lv, v);
+                                        m = (Lu > m) ? Lu : m;
+                                    }
+                                }
+                                const double ev = on ? det_exp(Lv - m) : 0.0;
+                                // S = ((e_0 + e_1) + e_2) + ..., then the comparisons cum_v >= u_v S in class order
+                                double S = 0.0;
+#pragma unroll
+                                for (int v = 0; v < NGP_RMAX; v++)
+                                    if (v < Kk) S = S + readlane_d(ev, v);
+                                c = Kk - 1;
+                                double cum = 0.0;
+                                bool found = false;
+#pragma unroll
+                                for (int v = 0; v < NGP_RMAX; v++) {
+                                    if (v < Kk && !found) {
+                                        cum = cum + readlane_d(ev, v);
+                                        const double thr = readlane_d(uv, v) * S;
+                                        if (cum >= thr) { c = v; found = true; }
+                                    }
+                                }
+                            }
+                            const double qc = readlane_d(qv, c), tc = readlane_d(tv, c);
+                            if (qc != 0.0) {
+                                const double d = __builtin_fma(rhs_k, qc, tc);
+                                dk = d - bo_k;
+                            } else dk = -bo_k;
+                            if (j == kk) { dfin = dk; cfin = c + 1; }
+                        } else {
+                            dk = readlane_d(lazy_d, kk);
+                        }
+                        if (dk != 0.0) {
+                            const double Hk = -(gdb[kk * NGP_BLK]);  // row kk of the one-sided block: 0 for lanes <= kk
+                            rcur = __builtin_fma(Hk, dk, rcur);
+                        }
+                        kstart = kk + 1;
+                        if (kstart >= NGP_BLK) break;
+                    }
+                } else {
                 RLane RL = empty_rlane();
                 double iVarE;
-                if constexpr (RCLS == 2) {  // the coefficients wait in LDS (wave 1, one block ahead), the classes 5..8 too
-                    const double *src = rl + (size_t)buf * (17 * NGP_BLK) + j;
-#pragma unroll
-                    for (int v = 0; v < NGP_RREG; v++) {
-                        RL.q[v] = src[v * NGP_BLK]; RL.a[v] = src[(4 + v) * NGP_BLK]; RL.t[v] = src[(8 + v) * NGP_BLK]; RL.u[v] = src[(12 + v) * NGP_BLK];
-                    }
-                    RL.rhs0 = src[16 * NGP_BLK];
-                    RL.K = rlm[buf * 128 + 64 + j];
-                    RL.ext = rlx + (size_t)buf * (16 * NGP_BLK) + j - NGP_RREG * NGP_BLK;  // class stride 64, array stride 4 x 64
-                    RL.Ppad = NGP_BLK;
-                    RL.astride = 4 * NGP_BLK;
-                    iVarE = iVarE_sweep;
-                } else {
+                {
                     if (meth0 == 3) RL = load_rlane(A.rcls, A.Ppad, (long long)t * NGP_BLK + j, sK[si0], A.rhs0);
                     iVarE = A.scal->iVarE;
                 }
-                double rcur = r, dfin = 0.0;
-                int cfin = 1, kstart = 0;
+                double rcur = r;
+                int kstart = 0;
                 for (int guard = 0; guard < NGP_BLK + 1; ++guard) {
                     double cand;
                     int cls;
@@ -1767,6 +1878,7 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
                     rcur = __builtin_fma(Hk, dk, rcur);
                     kstart = kk + 1;
                     if (kstart >= NGP_BLK) break;
+                }
                 }
                 dsave = dfin;
                 isave = cfin;
