@@ -645,6 +645,16 @@ __device__ inline double dpp_f64(double v, const int ctrl_sel) {
     return __hiloint2double(hi, lo);
 }
 
+// quad_perm DPP of a double: lane l of every quad reads lane SEL[l mod 4] of its quad (CTRL = SEL0 | SEL1 << 2 | SEL2 << 4 | SEL3 << 6;
+// 0x00 / 0x55 / 0xAA / 0xFF broadcast lane 0 / 1 / 2 / 3 of the quad)
+template <int CTRL>
+__device__ __attribute__((always_inline)) inline double dpp_quad_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(lo, lo, CTRL, 0xF, 0xF, false);
+    hi = __builtin_amdgcn_update_dpp(hi, hi, CTRL, 0xF, 0xF, false);
+    return __hiloint2double(hi, lo);
+}
+
 // s_waitcnt vmcnt(n) for a wave-uniform run-time n in 0..63 (the instruction takes an immediate; the counter has 6 bits)
 __device__ inline void wait_vmcnt_le(int n) {
 #define NGP_VMC(i) case i: asm volatile("s_waitcnt vmcnt(" #i ")" ::: "memory"); break;
@@ -1749,6 +1759,8 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
                     const double rhs0j = cq[16 * NGP_BLK + j];
                     const int Kj = rlm[buf * 128 + 64 + j];
                     const double iVarE = iVarE_sweep;
+                    const int vj = (j < NGP_RMAX) ? j : 0;  // the class this lane holds when a locus is evaluated alone
+                    const double *cls_base = (vj < NGP_RREG) ? cq + vj * NGP_BLK : cx + (vj - NGP_RREG) * NGP_BLK;
                     double rcur = r;
                     int kstart = 0;
                     for (int guard = 0; guard < NGP_BLK + 1; ++guard) {
@@ -1771,14 +1783,14 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
                         const unsigned long long todo = __ballot(need) & (~0ull << kstart);
                         if (!todo) break;
                         const int kk = __builtin_ctzll(todo);
+                        const double Hk = -(gdb[kk * NGP_BLK]);  // row kk of the one-sided block (0 for lanes <= kk): asked for now, used after the evaluation
                         double dk;
                         if (__builtin_amdgcn_readlane(meth0, kk) == 3) {
                             const double rhs_k = readlane_d(rhs, kk), hs_k = readlane_d(hs, kk), bo_k = readlane_d(bo, kk);
                             const int Kk = __builtin_amdgcn_readlane(Kj, kk);
                             // lane v < K: class v of locus kk
                             const bool on = j < Kk;
-                            const int vv = on ? j : 0;
-                            const double *cp = (vv < NGP_RREG) ? cq + vv * NGP_BLK + kk : cx + (vv - NGP_RREG) * NGP_BLK + kk;
+                            const double *cp = cls_base + kk;  // (lanes beyond the locus' classes read what is there and do not use it)
                             const double qv = cp[0], av = cp[4 * NGP_BLK], tv = cp[8 * NGP_BLK], uv = cp[12 * NGP_BLK];
                             const double Lraw = (qv == 0.0) ? av : __builtin_fma(hs_k, qv, av);
                             int c;
@@ -1787,30 +1799,20 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
                                 // and comparison uniform +inf, as the padded register classes of eval_rform do
                                 const double Lv = on ? Lraw : -__builtin_inf();
                                 const double up = on ? uv : __builtin_inf();
-                                const double L0 = readlane_d(Lv, 0), L1 = readlane_d(Lv, 1), L2 = readlane_d(Lv, 2), L3 = readlane_d(Lv, 3);
-                                double m = L0;
-                                m = (L1 > m) ? L1 : m;
-                                m = (L2 > m) ? L2 : m;
-                                m = (L3 > m) ? L3 : m;
+                                // (lanes 0..3 are one DPP quad: the maximum by two exchanges -- exact, so the order does not matter --, the
+                                // ordered sums from four quad broadcasts; the other quads of the wave compute along on nothing)
+                                double m = __builtin_fmax(Lv, dpp_quad_f64<0xB1>(Lv));
+                                m = __builtin_fmax(m, dpp_quad_f64<0x4E>(m));
                                 const double ev = det_exp(Lv - m);
-                                const double e0 = readlane_d(ev, 0), e1 = readlane_d(ev, 1), e2 = readlane_d(ev, 2), e3 = readlane_d(ev, 3);
-                                const double u0 = readlane_d(up, 0), u1 = readlane_d(up, 1), u2 = readlane_d(up, 2), u3 = readlane_d(up, 3);
-                                double S = 0.0;
-                                S = S + e0; S = S + e1; S = S + e2; S = S + e3;
-                                const double ee[4] = {e0, e1, e2, e3}, uu[4] = {u0, u1, u2, u3};
-                                c = Kk - 1;
-                                double cum = 0.0;
-                                bool found = false;
-#pragma unroll
-                                for (int v = 0; v < NGP_RREG; v++) {
-                                    const bool take = !found;
-                                    const double cn = cum + ee[v];
-                                    const double thr = uu[v] * S;
-                                    const bool hit = take && (cn >= thr);
-                                    cum = take ? cn : cum;
-                                    c = hit ? v : c;
-                                    found = found || hit;
-                                }
+                                const double c0 = dpp_quad_f64<0x00>(ev);  // 0.0 + e_0
+                                const double c1 = c0 + dpp_quad_f64<0x55>(ev);
+                                const double c2 = c1 + dpp_quad_f64<0xAA>(ev);
+                                const double c3 = c2 + dpp_quad_f64<0xFF>(ev);  // = S
+                                const int vq = j & 3;
+                                const double mycum = (vq == 0) ? c0 : ((vq == 1) ? c1 : ((vq == 2) ? c2 : c3));
+                                const double thr = up * c3;
+                                const unsigned hitm = (unsigned)__ballot(mycum >= thr) & 0xFu;  // class v stops the search: cum_v >= u_v S
+                                c = hitm ? __builtin_ctz(hitm) : Kk - 1;
                             } else {
                                 const double Lv = Lraw;
                                 // m = L_0, then (L_v > m) ? L_v : m in class order (eval_rform), on the gathered values
@@ -1849,10 +1851,7 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
                         } else {
                             dk = readlane_d(lazy_d, kk);
                         }
-                        if (dk != 0.0) {
-                            const double Hk = -(gdb[kk * NGP_BLK]);  // row kk of the one-sided block: 0 for lanes <= kk
-                            rcur = __builtin_fma(Hk, dk, rcur);
-                        }
+                        if (dk != 0.0) rcur = __builtin_fma(Hk, dk, rcur);
                         kstart = kk + 1;
                         if (kstart >= NGP_BLK) break;
                     }
