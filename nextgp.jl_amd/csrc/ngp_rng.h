@@ -141,6 +141,34 @@ __device__ inline double det_exp(double x) {
     return isnan_x ? x_in : res;
 }
 
+// det_exp for an argument that is <= 0 or a NaN (the class search's L - max L): the same operations, so the same bits, without the
+// guards such an argument does not need -- x < -708 (and -inf: a class that does not exist) gives 0, a NaN comes back a NaN.
+__device__ inline double det_exp_le0(const double xin) {
+    const double ln2HI = 6.93147180369123816490e-01, ln2LO = 1.90821492927058770002e-10, invln2 = 1.44269504088896338700e+00;
+    const bool under = xin < -708.0;
+    const double x = under ? 0.0 : xin;
+    const int k = (int)(invln2 * x - 0.5);
+    const double t = (double)k;
+    const double hi = x - t * ln2HI, lo = t * ln2LO;
+    const double xr = hi - lo;
+    double q = 1.0 / 6227020800.0;
+    q = __builtin_fma(q, xr, 1.0 / 479001600.0);
+    q = __builtin_fma(q, xr, 1.0 / 39916800.0);
+    q = __builtin_fma(q, xr, 1.0 / 3628800.0);
+    q = __builtin_fma(q, xr, 1.0 / 362880.0);
+    q = __builtin_fma(q, xr, 1.0 / 40320.0);
+    q = __builtin_fma(q, xr, 1.0 / 5040.0);
+    q = __builtin_fma(q, xr, 1.0 / 720.0);
+    q = __builtin_fma(q, xr, 1.0 / 120.0);
+    q = __builtin_fma(q, xr, 1.0 / 24.0);
+    q = __builtin_fma(q, xr, 1.0 / 6.0);
+    q = __builtin_fma(q, xr, 0.5);
+    const double tt = xr * xr;
+    const double y = 1.0 + __builtin_fma(tt, q, xr);
+    const double sc = __longlong_as_double((long long)((uint64_t)(k + 1023) << 52));
+    return under ? 0.0 : y * sc;
+}
+
 // Four det_exp side by side for arguments x <= 0 (the class search's L - max L; the same operations per element, so the same bits):
 // every step of the four dependent chains is issued before the next step of any -- the empty asm statements pin that order, which the
 // scheduler does not choose by itself (it kept the four chains one behind the other, 4 x 40 dependent fp64 instructions per class

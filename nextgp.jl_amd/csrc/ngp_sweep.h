@@ -1793,6 +1793,9 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
                             const double *cp = cls_base + kk;  // (lanes beyond the locus' classes read what is there and do not use it)
                             const double qv = cp[0], av = cp[4 * NGP_BLK], tv = cp[8 * NGP_BLK], uv = cp[12 * NGP_BLK];
                             const double Lraw = (qv == 0.0) ? av : __builtin_fma(hs_k, qv, av);
+                            // every lane's candidate should ITS class be the one (in the shadow of the exponential): dlt = rhs / lhs_c + sd_c z - beta
+                            const double dcls = __builtin_fma(rhs_k, qv, tv);
+                            const double dmine = (qv != 0.0) ? dcls - bo_k : -bo_k;
                             int c;
                             if (Kk <= NGP_RREG) {
                                 // up to four classes (the usual BayesR): no branch -- a lane beyond the set's classes carries log-weight -inf
@@ -1803,7 +1806,7 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
                                 // ordered sums from four quad broadcasts; the other quads of the wave compute along on nothing)
                                 double m = __builtin_fmax(Lv, dpp_quad_f64<0xB1>(Lv));
                                 m = __builtin_fmax(m, dpp_quad_f64<0x4E>(m));
-                                const double ev = det_exp(Lv - m);
+                                const double ev = det_exp_le0(Lv - m);
                                 const double c0 = dpp_quad_f64<0x00>(ev);  // 0.0 + e_0
                                 const double c1 = c0 + dpp_quad_f64<0x55>(ev);
                                 const double c2 = c1 + dpp_quad_f64<0xAA>(ev);
@@ -1842,11 +1845,7 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
                                     }
                                 }
                             }
-                            const double qc = readlane_d(qv, c), tc = readlane_d(tv, c);
-                            if (qc != 0.0) {
-                                const double d = __builtin_fma(rhs_k, qc, tc);
-                                dk = d - bo_k;
-                            } else dk = -bo_k;
+                            dk = readlane_d(dmine, c);
                             if (j == kk) { dfin = dk; cfin = c + 1; }
                         } else {
                             dk = readlane_d(lazy_d, kk);
