@@ -134,7 +134,7 @@ int32_t ngp_add_marker_set(ngp_handle *h, int64_t col0, int64_t ncol, int32_t me
                            const int64_t *reg_start, const int64_t *reg_stop, int64_t nreg, const double *varBeta0,
                            double pi0, int32_t estPi, const double *lhs0, const double *rhs0, int32_t *set_id);
 
-/* BayesR marker set (set-up src/mme.jl:374-383): ONE variance for the set (varBeta0, nVarCov = 1), K = 2..8 variance classes with
+/* BayesR marker set (set-up src/mme.jl:374-383): ONE variance for the set (varBeta0, nVarCov = 1), K = 2..16 variance classes with
  * multipliers vClass[v] of that variance (multiplier 0: the effect is exactly 0) and class probabilities pi[v] (sum 1);
  * estPi: pi ~ Dirichlet(nLoci + 1) after every sweep (src/functions.jl:284-288).  delta then holds the CLASS of a locus,
  * counted from 1 as the reference writes it (src/functions.jl:262).  The reference's class search compares cumulative

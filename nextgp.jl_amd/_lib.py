@@ -417,7 +417,7 @@ class Sampler:
         return sid.value
 
     def get_class_state(self, set_id):
-        pi = np.empty(8); sp = np.empty(8); K = C.c_int64()
+        pi = np.empty(16); sp = np.empty(16); K = C.c_int64()
         self._chk(self.L.ngp_get_class_state(self.h, C.c_int32(set_id), _p(pi, C.c_double), _p(sp, C.c_double), C.byref(K)))
         return dict(piHat=pi[:K.value].copy(), sum_pi=sp[:K.value].copy())
 

@@ -2748,7 +2748,7 @@ int32_t ngp_add_marker_set_r(ngp_handle *h, int64_t col0, int64_t ncol, double d
     if ((rc = enter(h))) return rc;
     REQUIRE(h->d_tiles != nullptr, NGP_ERR_STATE, "panel not set");
     REQUIRE(!h->panel_open, NGP_ERR_STATE, "the panel is still open: x'x and the Gram window exist after ngp_end_panel");
-    REQUIRE(vClass && pi && K >= 2 && K <= NGP_RMAX, NGP_ERR_ARG, "BayesR needs 2..8 variance classes with their probabilities");
+    REQUIRE(vClass && pi && K >= 2 && K <= NGP_RMAX, NGP_ERR_ARG, "BayesR needs 2..16 variance classes with their probabilities");
     double ps = 0.0;
     for (int v = 0; v < K; v++) {
         REQUIRE(std::isfinite(vClass[v]) && vClass[v] >= 0.0 && std::isfinite(pi[v]) && pi[v] > 0.0, NGP_ERR_ARG,

@@ -11,7 +11,8 @@
 #define NGP_BLK 64
 #define NGP_SEG 256
 #define NGP_GRP 32
-#define NGP_RMAX 8  // variance classes of a BayesR set (src/functions.jl:241-262 sizes everything by length(vClass))
+#define NGP_RMAX 16  // variance classes of a BayesR set (src/functions.jl:241-262 sizes everything by length(vClass))
+#define NGP_RLDS 8   // ... of which the sampler stages the coefficients of the first eight in LDS / register arrays; classes 9..16 come from memory each time
 #define NGP_RREG 4  // ... of which the block chain keeps the coefficients of the first four in registers; further classes are read
                     // from the coefficient arrays of k_prep each time a candidate is formed
 #define NGP_KMAX 4  // marker sets of one tuple (correlated BayesPR, src/functions.jl:140-154)
@@ -221,15 +222,20 @@ __device__ inline void eval_rform(const int meth, const double r, const double b
 #pragma unroll
         for (int v = 1; v < NGP_RREG; v++) m = (Lv[v] > m) ? Lv[v] : m;  // (classes the set does not have: -inf, load_rlane)
         // (more than four classes: the same steps, class after class; their log-weights come from memory ONCE per evaluation)
-        double Lx[NGP_RMAX - NGP_RREG], ex[NGP_RMAX - NGP_RREG];
+        double Lx[NGP_RLDS - NGP_RREG], ex[NGP_RLDS - NGP_RREG];
 #pragma unroll
-        for (int v = NGP_RREG; v < NGP_RMAX; v++) { Lx[v - NGP_RREG] = 0.0; ex[v - NGP_RREG] = 0.0; }
+        for (int v = NGP_RREG; v < NGP_RLDS; v++) { Lx[v - NGP_RREG] = 0.0; ex[v - NGP_RREG] = 0.0; }
         if (more) {
 #pragma unroll
-            for (int v = NGP_RREG; v < NGP_RMAX; v++) Lx[v - NGP_RREG] = (v < L.K) ? rlane_L(L, v, hs) : 0.0;
+            for (int v = NGP_RREG; v < NGP_RLDS; v++) Lx[v - NGP_RREG] = (v < L.K) ? rlane_L(L, v, hs) : 0.0;
 #pragma unroll
-            for (int v = NGP_RREG; v < NGP_RMAX; v++)
+            for (int v = NGP_RREG; v < NGP_RLDS; v++)
                 if (v < L.K && Lx[v - NGP_RREG] > m) m = Lx[v - NGP_RREG];
+            // classes 9..16 (rare): nothing kept, their log-weights are formed again wherever they are needed -- the same operations, the same bits
+            for (int v = NGP_RLDS; v < L.K; v++) {
+                const double Lw = rlane_L(L, v, hs);
+                if (Lw > m) m = Lw;
+            }
         }
         double S = 0.0;
         {
@@ -244,17 +250,18 @@ __device__ inline void eval_rform(const int meth, const double r, const double b
 #pragma unroll
         for (int v = 0; v < NGP_RREG; v++) S = S + e[v];
         if (more) {
-            static_assert(NGP_RMAX - NGP_RREG == 4, "det_exp4 serves the four memory classes");
+            static_assert(NGP_RLDS - NGP_RREG == 4, "det_exp4 serves the four memory classes");
             double xm[4], ev[4];
 #pragma unroll
             for (int v = 0; v < 4; v++) xm[v] = (NGP_RREG + v < L.K) ? Lx[v] - m : 0.0;
             det_exp4(xm, ev);
 #pragma unroll
-            for (int v = NGP_RREG; v < NGP_RMAX; v++)
+            for (int v = NGP_RREG; v < NGP_RLDS; v++)
                 if (v < L.K) {
                     ex[v - NGP_RREG] = ev[v - NGP_RREG];
                     S = S + ex[v - NGP_RREG];
                 }
+            for (int v = NGP_RLDS; v < L.K; v++) S = S + det_exp(rlane_L(L, v, hs) - m);
         }
         int c = L.K - 1;
         double cum = 0.0;
@@ -271,12 +278,17 @@ __device__ inline void eval_rform(const int meth, const double r, const double b
         }
         if (more) {
 #pragma unroll
-            for (int v = NGP_RREG; v < NGP_RMAX; v++)
+            for (int v = NGP_RREG; v < NGP_RLDS; v++)
                 if (v < L.K && !found) {
                     cum = cum + ex[v - NGP_RREG];
                     const double thr = L.ext[(size_t)v * L.Ppad + (size_t)3 * L.astride] * S;
                     if (cum >= thr) { c = v; found = true; }
                 }
+            for (int v = NGP_RLDS; v < L.K && !found; v++) {
+                cum = cum + det_exp(rlane_L(L, v, hs) - m);
+                const double thr = L.ext[(size_t)v * L.Ppad + (size_t)3 * L.astride] * S;
+                if (cum >= thr) { c = v; found = true; }
+            }
         }
         double qc = L.q[0], tc = L.t[0];
 #pragma unroll

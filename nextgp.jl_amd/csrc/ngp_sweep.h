@@ -1514,6 +1514,45 @@ __device__ __attribute__((always_inline)) inline void publish_block(const SweepA
 // RCLS: 0 = no BayesR chain, 1 = BayesR with the lane coefficients fetched inside the block, 2 = fetched one block ahead through LDS by
 // wave 1 like the Tuple ones (10.4 -> 8.9 us per block; a flavour of its own, k_sweep_r: inside the full kernel this code cost the
 // 50k x 600k sweep of the other methods 2 %)
+// Class search of ONE BayesR locus with nine to sixteen classes, its classes spread over lanes 0 .. K-1 (role_sampler's lazy search,
+// RCLS == 2): lanes 8 .. K-1 read their class from the coefficient arrays in memory -- the sampler's LDS holds eight -- and the
+// steps of eval_rform run as loops over the classes.  Returns the class; dmine = this lane's dlt should its class be the one.
+struct RWide { double dmine; int c; };
+__device__ __attribute__((noinline)) RWide rform_search_wide(const double *rcls, const size_t Ppad, const size_t col, const int j, const int Kk,
+                                                             const double qv, const double av, const double tv, const double uv,
+                                                             const double hs_k, const double rhs_k, const double bo_k) {
+    const bool on = j < Kk;
+    double q2 = qv, a2 = av, t2 = tv, u2 = uv;
+    if (j >= NGP_RLDS && on) {
+        const double *gp = rcls + (size_t)j * Ppad + col;
+        const size_t gstr = (size_t)NGP_RMAX * Ppad;
+        q2 = gp[0]; a2 = gp[gstr]; t2 = gp[2 * gstr]; u2 = gp[3 * gstr];
+    }
+    const double Lv = (q2 == 0.0) ? a2 : __builtin_fma(hs_k, q2, a2);
+    RWide out;
+    out.dmine = (q2 != 0.0) ? __builtin_fma(rhs_k, q2, t2) - bo_k : -bo_k;
+    double m = readlane_d(Lv, 0);
+#pragma unroll 1
+    for (int v = 1; v < Kk; v++) {
+        const double Lu = readlane_d(Lv, v);
+        m = (Lu > m) ? Lu : m;
+    }
+    const double ev = on ? det_exp(Lv - m) : 0.0;
+    double S = 0.0;
+#pragma unroll 1
+    for (int v = 0; v < Kk; v++) S = S + readlane_d(ev, v);
+    int c = Kk - 1;
+    double cum = 0.0;
+#pragma unroll 1
+    for (int v = 0; v < Kk; v++) {
+        cum = cum + readlane_d(ev, v);
+        const double thr = readlane_d(u2, v) * S;
+        if (cum >= thr) { c = v; break; }
+    }
+    out.c = c;
+    return out;
+}
+
 template <bool DBG, bool NGBIG = false, bool TUP = true, int RCLS = 1>
 __device__ __attribute__((always_inline)) inline void role_sampler(const SweepArgs &A, char *smem) {
     NGP_DBG_LOCALS
@@ -1588,7 +1627,7 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
 #pragma unroll
             for (int arr = 0; arr < 4; arr++)
 #pragma unroll
-                for (int v = NGP_RREG; v < NGP_RMAX; v++) {
+                for (int v = NGP_RREG; v < NGP_RLDS; v++) {
                     const bool on = (meth == 3) && v < Kc;
                     dx[(arr * 4 + v - NGP_RREG) * NGP_BLK] = on ? A.rcls[((size_t)arr * NGP_RMAX + v) * (size_t)A.Ppad + (size_t)kcol] : 0.0;
                 }
@@ -1759,7 +1798,7 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
                     const double rhs0j = cq[16 * NGP_BLK + j];
                     const int Kj = rlm[buf * 128 + 64 + j];
                     const double iVarE = iVarE_sweep;
-                    const int vj = (j < NGP_RMAX) ? j : 0;  // the class this lane holds when a locus is evaluated alone
+                    const int vj = (j < NGP_RLDS) ? j : 0;  // the class this lane holds when a locus is evaluated alone (classes 9..16: from memory, below)
                     const double *cls_base = (vj < NGP_RREG) ? cq + vj * NGP_BLK : cx + (vj - NGP_RREG) * NGP_BLK;
                     double rcur = r;
                     int kstart = 0;
@@ -1795,7 +1834,7 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
                             const double Lraw = (qv == 0.0) ? av : __builtin_fma(hs_k, qv, av);
                             // every lane's candidate should ITS class be the one (in the shadow of the exponential): dlt = rhs / lhs_c + sd_c z - beta
                             const double dcls = __builtin_fma(rhs_k, qv, tv);
-                            const double dmine = (qv != 0.0) ? dcls - bo_k : -bo_k;
+                            double dmine = (qv != 0.0) ? dcls - bo_k : -bo_k;
                             int c;
                             if (Kk <= NGP_RREG) {
                                 // up to four classes (the usual BayesR): no branch -- a lane beyond the set's classes carries log-weight -inf
@@ -1816,12 +1855,12 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
                                 const double thr = up * c3;
                                 const unsigned hitm = (unsigned)__ballot(mycum >= thr) & 0xFu;  // class v stops the search: cum_v >= u_v S
                                 c = hitm ? __builtin_ctz(hitm) : Kk - 1;
-                            } else {
+                            } else if (Kk <= NGP_RLDS) {
                                 const double Lv = Lraw;
                                 // m = L_0, then (L_v > m) ? L_v : m in class order (eval_rform), on the gathered values
                                 double m = readlane_d(Lv, 0);
 #pragma unroll
-                                for (int v = 1; v < NGP_RMAX; v++) {
+                                for (int v = 1; v < NGP_RLDS; v++) {
                                     if (v < Kk) {
                                         const double Lu = readlane_d(Lv, v);
                                         m = (Lu > m) ? Lu : m;
@@ -1831,19 +1870,24 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
                                 // S = ((e_0 + e_1) + e_2) + ..., then the comparisons cum_v >= u_v S in class order
                                 double S = 0.0;
 #pragma unroll
-                                for (int v = 0; v < NGP_RMAX; v++)
+                                for (int v = 0; v < NGP_RLDS; v++)
                                     if (v < Kk) S = S + readlane_d(ev, v);
                                 c = Kk - 1;
                                 double cum = 0.0;
                                 bool found = false;
 #pragma unroll
-                                for (int v = 0; v < NGP_RMAX; v++) {
+                                for (int v = 0; v < NGP_RLDS; v++) {
                                     if (v < Kk && !found) {
                                         cum = cum + readlane_d(ev, v);
                                         const double thr = readlane_d(uv, v) * S;
                                         if (cum >= thr) { c = v; found = true; }
                                     }
                                 }
+                            } else {
+                                // nine to sixteen classes (rare): a function of its own, out of the way of the two paths above
+                                const RWide rw = rform_search_wide(A.rcls, (size_t)A.Ppad, (size_t)((long long)t * NGP_BLK + kk), j, Kk, qv, av, tv, uv, hs_k, rhs_k, bo_k);
+                                c = rw.c;
+                                dmine = rw.dmine;
                             }
                             dk = readlane_d(dmine, c);
                             if (j == kk) { dfin = dk; cfin = c + 1; }

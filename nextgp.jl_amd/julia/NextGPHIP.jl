@@ -183,7 +183,7 @@ function read_sample_file(path::AbstractString)
 end
 
 function class_state(h::Handle, set_id::Integer)
-    pi = zeros(8); sp = zeros(8); K = Ref{Int64}(0)
+    pi = zeros(16); sp = zeros(16); K = Ref{Int64}(0)
     check(h, ccall((:ngp_get_class_state, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Float64}, Ptr{Float64}, Ref{Int64}), h.ptr, set_id, pi, sp, K))
     return pi[1:K[]], sp[1:K[]]
 end

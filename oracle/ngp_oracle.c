@@ -63,7 +63,7 @@
 #define METHOD_B 1
 #define METHOD_C 2 /* BayesC: src/functions.jl:197-235 */
 #define METHOD_R 3 /* BayesR: src/functions.jl:238-289 */
-#define RMAX 8     /* variance classes of a BayesR set (functions.jl:241-262 sizes everything by length(vClass)) */
+#define RMAX 16    /* variance classes of a BayesR set (functions.jl:241-262 sizes everything by length(vClass)) */
 #define METHOD_T 4 /* correlated (Tuple) BayesPR: src/functions.jl:140-154, 513-516; set-up src/mme.jl:448-489 */
 #define KMAX 4     /* marker sets of one tuple */
 #define KIND_T_WISHART 11 /* Bartlett factor of a region's inverse-Wishart draw: index (set << 40) | (region << 8) | (i << 4) | j */

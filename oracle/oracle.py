@@ -223,7 +223,7 @@ class Oracle:
         return sid.value
 
     def get_class_state(self, set_id):
-        pi = np.empty(8); sp = np.empty(8); K = C.c_int64()
+        pi = np.empty(16); sp = np.empty(16); K = C.c_int64()
         self._chk(self.L.ora_get_class_state(self.h, C.c_int(set_id), _p(pi, C.c_double), _p(sp, C.c_double), C.byref(K)))
         return dict(piHat=pi[:K.value].copy(), sum_pi=sp[:K.value].copy())
 

@@ -77,6 +77,11 @@ def add_sets(m, spec, v):
             m.add_marker_set_r(col0, ncol, df, v * (df - 2) / df, v, [0.0, 0.0001, 0.001, 0.01, 0.1, 1.0], [0.5, 0.2, 0.12, 0.1, 0.05, 0.03], estPi=True)
         elif kind == "R8":     # eight classes, no zero class, pi fixed
             m.add_marker_set_r(col0, ncol, df, v * (df - 2) / df, v, [1e-5, 1e-4, 1e-3, 0.01, 0.05, 0.2, 0.5, 1.0], [0.3, 0.2, 0.15, 0.1, 0.1, 0.06, 0.05, 0.04], estPi=False)
+        elif kind == "R12":    # twelve classes (a zero class first): classes 9..12 come from memory, not from the sampler's LDS copy
+            m.add_marker_set_r(col0, ncol, df, v * (df - 2) / df, v, [0.0, 1e-5, 3e-5, 1e-4, 3e-4, 1e-3, 3e-3, 0.01, 0.03, 0.1, 0.3, 1.0],
+                               [0.4, 0.1, 0.08, 0.08, 0.07, 0.06, 0.05, 0.05, 0.04, 0.03, 0.02, 0.02], estPi=True)
+        elif kind == "R16":    # sixteen classes, no zero class, pi fixed
+            m.add_marker_set_r(col0, ncol, df, v * (df - 2) / df, v, [2.0 ** (i - 15) for i in range(16)], [1.0 / 16] * 16, estPi=False)
         elif kind == "R2":     # two classes: the zero class first is not required by the reference
             m.add_marker_set_r(col0, ncol, df, v * (df - 2) / df, v, [1.0, 0.0], [0.3, 0.7], estPi=True)
         else:

@@ -10,7 +10,7 @@ from conftest import add_sets
 ngp = load_pkg()
 ncases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 rng = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
-KINDS = ["PR", "B", "Bfix", "C", "Cfix", "PR1", "R", "Rfix", "R2", "R6", "R8", ("PRw", 37)]
+KINDS = ["PR", "B", "Bfix", "C", "Cfix", "PR1", "R", "Rfix", "R2", "R6", "R8", "R12", "R16", ("PRw", 37)]
 bad = 0
 for case in range(ncases):
     N = int(rng.choice([7, 33, 100, 257, 500, 900, 1500, 2600, 4000]))

@@ -182,6 +182,7 @@ CASES = [
     ("r_single", 400, 520, [(0, 520, "R")]),                                     # BayesR (src/functions.jl:238-289)
     ("r_multi", 300, 330, [(0, 100, "Rfix"), (100, 90, "B"), (190, 100, "R2"), (290, 40, "PR")]),   # BayesR lanes beside others in one block
     ("r_six_eight", 300, 400, [(0, 150, "R6"), (150, 100, "PR"), (250, 150, "R8")]),             # more classes than the chain keeps in registers
+    ("r_twelve_sixteen", 300, 400, [(0, 150, "R12"), (150, 100, "B"), (250, 150, "R16")]),       # more classes than the sampler stages in LDS
 ]
 
 

@@ -393,6 +393,36 @@ def test_bayesr_with_more_than_four_classes(O):
     assert a["delta"][:70].max() <= 6 and a["delta"][70:].max() <= 8 and len(np.unique(a["delta"])) > 4
     assert len(o1.get_class_state(0)["piHat"]) == 6 and abs(o1.get_class_state(0)["piHat"].sum() - 1) < 1e-12
 
+def test_bayesr_with_twelve_and_sixteen_classes(O):
+    """... and twelve / sixteen classes (the device reads classes 9..16 from memory): both oracle orders and the numpy restatement."""
+    from ref_numpy import RefChain
+    N, P = 90, 120
+    X, y, bt, v = make_problem(O, N, P, seed=17)
+    vc12 = [0.0, 1e-5, 3e-5, 1e-4, 3e-4, 1e-3, 3e-3, 0.01, 0.03, 0.1, 0.3, 1.0]
+    pi12 = [0.4, 0.1, 0.08, 0.08, 0.07, 0.06, 0.05, 0.05, 0.04, 0.03, 0.02, 0.02]
+    vc16, pi16 = [2.0 ** (i - 15) for i in range(16)], [1.0 / 16] * 16
+    o0 = O.Oracle(0, seed=23, chain=0); o0.set_panel_f32(X)
+    o1 = O.Oracle(1, seed=23, chain=0); o1.set_panel_f32(X, R=8, S=12, D=4, near=3)
+    ref = RefChain(O, X.astype(np.float64), y, seed=23, chain=0)
+    for m in (o0, o1):
+        m.add_marker_set_r(0, 70, 4.0, v * 0.5, v, vc12, pi12, estPi=True)
+        m.add_marker_set_r(70, 50, 4.0, v * 0.5, v, vc16, pi16, estPi=False)
+        m.set_y(y); m.set_residual_prior(4.0, 0.3 * y.var())
+    ref.add_set_r(0, 70, 4.0, v * 0.5, v, vc12, pi12, estPi=True); ref.add_set_r(70, 50, 4.0, v * 0.5, v, vc16, pi16, estPi=False)
+    ref.E_df, ref.E_scale = 4.0, 0.3 * y.var()
+    for it in range(6):
+        o0.run(1); o1.run(1); ref.run(1)
+        a, b, c = o0.get_state(), o1.get_state(), ref.state()
+        assert np.array_equal(a["delta"], c["delta"]) and np.array_equal(a["delta"], b["delta"]), it
+        for k in ("beta", "ycorr", "varBeta"):
+            assert np.abs(a[k] - c[k]).max() <= 1e-10 * max(1e-6, np.abs(c[k]).max()), (it, k)
+            assert np.abs(a[k] - b[k]).max() <= 1e-10 * max(1e-6, np.abs(a[k]).max()), (it, k)
+    assert a["delta"][:70].max() <= 12 and a["delta"][70:].max() <= 16 and a["delta"].max() > 8
+    assert len(o1.get_class_state(1)["piHat"]) == 16
+    with pytest.raises(Exception):
+        o0.add_marker_set_r(0, 10, 4.0, v * 0.5, v, [0.1] * 17, [1.0 / 17] * 17)
+
+
 
 def test_det_exp_within_one_ulp(O):
     xs = -np.concatenate([10.0 ** np.random.default_rng(0).uniform(-12, 2.8, 20000), [0.0, 1e-30, 0.3465, 0.3466, 0.35, 707.9]])
