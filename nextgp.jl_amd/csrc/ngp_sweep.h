@@ -2812,20 +2812,19 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows_multi(c
                         if constexpr (U8) {
                             const uint4 x = *(const uint4 *)(ring + (size_t)wrap(base + q) * NGP_QS + (size_t)lane * 16);
                             const unsigned xw[4] = {x.x, x.y, x.z, x.w};
+                            // (every chain's y of a quad: ONE 8-byte read per lane and the DPP broadcast -- a quarter of the LDS read cycles of four
+                            // broadcast reads: 50k x 600k 63.7 -> 66.9 it/s, 10k x 100k 475 -> 491.  The same change measured WORSE on fp32 tiles with two
+                            // chains (67.8 -> 66.6) and on byte tiles with one (17.7 -> 17.9 ms): left as they are)
+                            double y4[4][KC];
+#pragma unroll
+                            for (int e4 = 0; e4 < 4; e4++)
+#pragma unroll
+                                for (int kc = 0; kc < KC; kc++) y4[e4][kc] = NGP_YS(kc)[16 * q + 4 * e4 + (lane & 3)];
 #pragma unroll
                             for (int e4 = 0; e4 < 4; e4++) {
                                 const unsigned w = xw[e4];
-                                const double g0 = (double)(float)(w & 0xffu), g1 = (double)(float)((w >> 8) & 0xffu);
-                                const double g2 = (double)(float)((w >> 16) & 0xffu), g3 = (double)(float)(w >> 24);
-#pragma unroll
-                                for (int kc = 0; kc < KC; kc++) {
-                                    const double *yq = NGP_YS(kc) + 16 * q + 4 * e4;
-                                    const double y0 = yq[0], y1 = yq[1], y2 = yq[2], y3 = yq[3];
-                                    acc[kc] = __builtin_fma(g0, y0, acc[kc]);
-                                    acc[kc] = __builtin_fma(g1, y1, acc[kc]);
-                                    acc[kc] = __builtin_fma(g2, y2, acc[kc]);
-                                    acc[kc] = __builtin_fma(g3, y3, acc[kc]);
-                                }
+                                const double xd[4] = {(double)(float)(w & 0xffu), (double)(float)((w >> 8) & 0xffu), (double)(float)((w >> 16) & 0xffu), (double)(float)(w >> 24)};
+                                fmac4_bcast<KC>(acc, y4[e4], xd);
                             }
                         } else {
                             const float4 x = *(const float4 *)(ring + (size_t)wrap(base + q) * NGP_QS + (size_t)lane * 16);
