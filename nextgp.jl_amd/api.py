@@ -448,8 +448,8 @@ def runLMEM(formula, userData, nChain, nBurn, nThin, myHints=None, blockThese=No
     if max_shards:  # an explicit shard count (ngp_set_max_shards): e.g. the layout of a fused run, to repeat one of its chains alone
         smp.set_max_shards(int(max_shards))
     elif K > 1:  # the layout with which K chains share one fused sweep launch (fp32 tiles), or the device side by side
-        # (compact storage: the fused kernel serves two chains; more run side by side on disjoint CU shares)
-        smp.set_max_shards(smp.shards_for_pass(K) if (storage is None or K == 2) else smp.shards_for_chains(K))
+        # (compact storage: the fused kernel serves two or three chains; more run side by side on disjoint CU shares)
+        smp.set_max_shards(smp.shards_for_pass(K) if (storage is None or K <= 3) else smp.shards_for_chains(K))
     kinds = {np.asarray(pc).dtype == np.uint8 for pc in pieces if pc.shape[1]}
     if (storage is None and kinds == {False}) or kinds == {True}:
         # the sets go to the device one after another (ngp_begin_panel / ngp_panel_columns_* / ngp_end_panel): no concatenated host copy
@@ -586,7 +586,7 @@ def _run_model(samplers, folders, sets, fixed_names, intercept, nChain, nBurn, n
         if not fused:  # (the layout was chosen for a fused launch: side by side each chain's grid takes most of the device, so they take turns)
             import warnings
             warnings.warn(f"runLMEM(chains={K}): this layout / engine is not served by the fused sweep kernel (fp32 tiles: shards of at most "
-                          "64 rows with lag 6 or 8, or two chains on 64-224-row shards with lag 4-6; compact storage: two chains); the chains "
+                          "64 rows with lag 6 or 8, or two chains on 64-224-row shards with lag 4-6; compact storage: two or three chains); the chains "
                           "ran one launch each per iteration. Results are the same; pass max_shards=Sampler.shards_for_chains(K) for side-by-side runs.")
         results = []
         for sc, f, pth in zip(samplers, folders, paths):

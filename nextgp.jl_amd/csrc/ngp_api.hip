@@ -1696,9 +1696,9 @@ bool fusable(ngp_handle **hs, int n) {
     const bool rows = h0->storage == 0 && h0->streamer == 2 && (h0->D >= 4 && h0->D <= 6) && n == 2 &&        // role_streamer_rows_multi
                       ngp_rows_multi_lds_bytes((int)h0->R, n) <= (size_t)160 * 1024;
     bool bytes = false;                                                                                     // ... over byte tiles
-    if (h0->storage == 1 && h0->streamer == 3 && n == 2 && ngp_rows_multi_lds_bytes((int)h0->R, n, true) <= (size_t)160 * 1024) {
-        const int nt = ngp_u8_tasks((int)h0->R);
-        bytes = (nt == 1 && (h0->D == 4 || h0->D == 6 || h0->D == 8)) || (nt == 2 && (h0->D == 4 || h0->D == 8)) || (nt == 4 && h0->D == 4);
+    if (h0->storage == 1 && h0->streamer == 3 && n <= 3 && ngp_rows_multi_lds_bytes((int)h0->R, n, true) <= (size_t)160 * 1024) {
+        const int nt = ngp_u8_tasks((int)h0->R);  // update tasks per lane: what the delay line leaves for more chains' arithmetic
+        bytes = (nt == 1 && (h0->D == 4 || h0->D == 6 || h0->D == 8)) || (nt == 2 && (h0->D == 4 || h0->D == 8)) || (nt == 4 && n == 2 && h0->D == 4);
     }
     if (!phase && !rows && !bytes) return false;
     for (int i = 0; i < n; i++) {

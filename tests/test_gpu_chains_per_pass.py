@@ -83,20 +83,22 @@ def test_fused_chains_on_the_row_owning_streamer(ngp, O, K, lag):
         assert f["varE"] == b["varE"]
 
 
-@pytest.mark.parametrize("lag,N,shards,tasks", [(8, 500, 0, 1), (6, 500, 0, 1), (4, 500, 0, 1), (8, 1500, 6, 2), (4, 1500, 6, 2), (6, 2900, 6, 4)],
-                         ids=["lag8", "lag6", "lag4", "two_tasks_lag8", "two_tasks_lag4", "four_tasks"])
-def test_fused_chains_over_compact_storage(ngp, O, lag, N, shards, tasks):
-    """Two chains per pass over byte tiles (role_streamer_rows_multi<.., ST>): every byte converted once for both chains; each chain
-    bit for bit the blocked oracle's compact chain (oracle/ngp_oracle.c ora_set_panel_u8) and the chain it is alone."""
+@pytest.mark.parametrize("K,lag,N,shards,tasks", [(2, 8, 500, 0, 1), (2, 6, 500, 0, 1), (2, 4, 500, 0, 1), (2, 8, 1500, 6, 2), (2, 4, 1500, 6, 2), (2, 6, 2900, 6, 4),
+                                                   (3, 8, 500, 0, 1), (3, 6, 500, 0, 1), (3, 4, 500, 0, 1), (3, 8, 4000, 12, 2), (3, 4, 4000, 12, 2)],
+                         ids=["lag8", "lag6", "lag4", "two_tasks_lag8", "two_tasks_lag4", "four_tasks",
+                              "three_chains", "three_chains_lag6", "three_chains_lag4", "three_chains_two_tasks", "three_chains_two_tasks_lag4"])
+def test_fused_chains_over_compact_storage(ngp, O, K, lag, N, shards, tasks):
+    """Two or three chains per pass over byte tiles (role_streamer_rows_multi<.., K, ST>): every byte converted once for all chains; each
+    chain bit for bit the blocked oracle's compact chain (oracle/ngp_oracle.c ora_set_panel_u8) and the chain it is alone."""
     from test_gpu_compact import make_codes
     P = 450
     G, y, v = make_codes(O, N, P)
     spec = [(0, 150, "PR"), (150, 170, "B"), (320, 130, "R")]
     fused = []
-    for c in range(2):
+    for c in range(K):
         s = ngp.Sampler(device=0, seed=1001 + c, chain=c, mode=1, lag=lag, storage="u8")
         if c == 0:
-            s.set_max_shards(shards if shards else s.shards_for_pass(2))
+            s.set_max_shards(shards if shards else s.shards_for_pass(K))
             s.set_panel(G, centre=True)
         else:
             s.share_panel(fused[0])
@@ -108,8 +110,8 @@ def test_fused_chains_over_compact_storage(ngp, O, lag, N, shards, tasks):
     nuw = -(-(R // 16) // 7)                                 # units of 16 rows per row-owning wave -> update tasks per lane
     assert {1: 1, 2: 2, 3: 4, 4: 4}[(4 * nuw + 7) // 8] == tasks
     ngp.Sampler.run_many(fused, 20)
-    assert fused[0].census()["grid"] == 2 * (1 + (S + 31) // 32) + S          # one launch for both chains
-    for c in range(2):
+    assert fused[0].census()["grid"] == K * (1 + (S + 31) // 32) + S          # one launch for both chains
+    for c in range(K):
         o = O.Oracle(order=1, seed=1001 + c, chain=c)
         o.set_panel_u8(G, R=R, S=S, D=D, near=fused[0].near(), tform=fused[0].chain_form())
         add_sets(o, spec, v); o.set_y(y + 0.01 * c); o.set_residual_prior(4.0, 1.0); o.set_schedule(20, 4, 2); o.run(20)
