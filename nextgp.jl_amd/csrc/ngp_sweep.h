@@ -1705,6 +1705,7 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
                 asm volatile("" ::: "memory");  // r0 is read after the flag (LDS serves a wave in order)
                 tot = r0[rs * NGP_BLK + j];
             }
+            if (DBG && dbg && j == 0) dbg[NGP_DBG_W5 + 4 * (size_t)u + 2] = wall_clock64();  // the chain wave has its total
             const double bo = cur.bo, cc = cur.cc, ww = cur.ww, st = cur.st;
             const double r = __builtin_fma(cur.gd, bo, tot);
             // scaled recursion: e = c r + w is the candidate draw, f = c r feeds the
@@ -1928,6 +1929,10 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
                 dsave = e;  // timing experiment: BayesPR blocks without the 64-step recursion
             } else if (__ballot(st >= 0.0) == 0ull) {
                 NGP_LOAD_G()
+                if (DBG && dbg) {  // diagnostic kernel: the diagonal block is in the registers
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    if (j == 0) dbg[NGP_DBG_W5 + 4 * (size_t)u + 3] = wall_clock64();
+                }
 #pragma unroll
                 for (int kk = 0; kk < NGP_BLK; kk += 4) {
                     double dk;
@@ -2116,6 +2121,10 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
                 const bool have_far = (D >= 3) && (u >= 2) && (A.near >= 2);
                 const bool have_one = (u >= 1);
                 double cor = have_far ? vacc[slot * NGP_BLK + j] : 0.0;
+                if (DBG && dbg) {  // diagnostic kernel: when are this block's lag-1 rows in the registers?
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+                    if (j == 0) dbg[NGP_DBG_W5 + 4 * (size_t)u] = wall_clock64();
+                }
                 if (have_one) {
                     // dlt of the previous block by broadcast reads from LDS (every lane reads the same 16 bytes): 32 LDS
                     // instructions instead of 128 v_readlane in front of the 64 fma -- this wave is what the chain waits for
@@ -2142,6 +2151,7 @@ __device__ __attribute__((always_inline)) inline void role_sampler(const SweepAr
                     cor = have_far ? cor + v1 : v1;
                 }
                 if (have_far || have_one) tot = tot - cor;
+                if (DBG && dbg && j == 0) dbg[NGP_DBG_W5 + 4 * (size_t)u + 1] = wall_clock64();
                 r0[rs * NGP_BLK + j] = tot;
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 if (j == 0) lds_flag_st(totflag, u + 1);

@@ -8,6 +8,7 @@
 #define NGP_WG 512          // threads per workgroup of the persistent kernel
 #define NGP_DBG_WAVES (1u << 19)   // sampler: 8 words per block, end-of-work stamp of every wave
 #define NGP_DBG_RED (3u << 18)     // reducer 0: 2 words per block (counter complete, group sum published)
+#define NGP_DBG_W5 (5u << 17)      // sampler: 4 words per block (lag-1 wave: its Gram rows have arrived, its product is done; chain wave: has its total, has the diagonal block)
 #define NGP_DBG_ALL (7u << 17)     // every streamer: publish time of local block 800 and its XCC id
 #define NGP_SPARSE_MAX 16  // BayesB / BayesC blocks with at most this many active lanes take the sparse chain
 // LDS distance of two quads of a tile: 1 KiB of data + 16 B, so that the update tasks (lanes = consecutive quads, same

@@ -49,6 +49,12 @@ for w in range(8):
     print(f"wave {w} end-of-work after block start us:", np.median(W[u,w]-S[u,0])/100.0,
           " even blocks", np.median(W[ue,w]-S[ue,0])/100.0, " odd blocks", np.median(W[uo,w]-S[uo,0])/100.0)
 print("slowest wave per block (histogram):", np.bincount(np.argmax(W[u], axis=1), minlength=8))
+W5 = d[(5<<17):(5<<17)+4*nb].reshape(nb,4)
+print("lag-1 wave: its Gram rows arrived after block start us:", np.median(W5[u,0]-S[u,0])/100.0, " 10/90 %:", np.percentile(W5[u,0]-S[u,0],10)/100.0, np.percentile(W5[u,0]-S[u,0],90)/100.0)
+print("lag-1 wave: product done after block start us:", np.median(W5[u,1]-S[u,0])/100.0, " (rows -> product:", np.median(W5[u,1]-W5[u,0])/100.0, ")")
+print("lag-1 wave: rows asked for (end of work of the previous block) -> arrived us:", np.median(W5[u,0]-W[u-1,5])/100.0)
+print("chain wave: has its total after block start us:", np.median(W5[u,2]-S[u,0])/100.0, " (lag-1 product done -> total read:", np.median(W5[u,2]-W5[u,1])/100.0, ")")
+print("chain wave: diagonal block in registers after its total us:", np.median(W5[u,3]-W5[u,2])/100.0, "; the 64 steps + publication (block in registers -> chain end) us:", np.median(S[u,1]-W5[u,3])/100.0)
 
 Rd = d[(3<<18):(3<<18)+2*nb].reshape(nb,2)
 print("reducer0: counter complete for block u, relative to sampler start(u) us:", np.median(Rd[u,0]-S[u,0])/100.0)
