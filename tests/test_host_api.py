@@ -325,5 +325,13 @@ def test_runLMEM_with_several_chains_over_one_panel(ngp, O, tmp_path):
         for pth in alone.iterdir():
             assert pth.read_bytes() == (cdir / pth.name).read_bytes(), (c, pth.name)
         assert np.array_equal(r1["sets"]["M2"]["delta"], res["chains"][c]["sets"]["M2"]["delta"])
+    assert res["fused"] is True
+    # the same model over genotype codes (compact storage), three chains: fused as well, each chain the chain alone
+    outc = tmp_path / "outChainsU8"
+    rc = ngp.runLMEM(f, {"y": y}, 12, 3, 3, outFolder=str(outc), VCV=VCV, seed=9, chains=3, storage="u8", samples="none")
+    assert rc["fused"] is True and rc["samplers"][0].storage() == 1 and rc["samplers"][0].census()["retries"] == 0
+    Sc = rc["samplers"][0].layout()[1]
+    r2 = ngp.runLMEM(f, {"y": y}, 12, 3, 3, outFolder=str(tmp_path / "aloneU8"), VCV=VCV, seed=9, chain=2, max_shards=Sc, storage="u8", samples="none")
+    assert np.array_equal(r2["sets"]["M1"]["beta"], rc["chains"][2]["sets"]["M1"]["beta"]) and r2["varE"] == rc["chains"][2]["varE"]
     with pytest.raises(ValueError):
         ngp.runLMEM(f, {"y": y}, 4, 0, 1, outFolder=str(tmp_path / "bad"), VCV=VCV, chains=2, samples="text-sync")
