@@ -1723,9 +1723,13 @@ int run_fused(ngp_handle **hs, int n, int64_t niter) {
     const size_t lds = std::max(h->streamer == 3 ? ngp_rows_multi_lds_bytes((int)h->R, n, true)
                                                  : (h->streamer == 2 ? ngp_rows_multi_lds_bytes((int)h->R, n) : ngp_multi_lds_bytes((int)h->R, n)), lds_sampler);
     REQUIRE(lds <= 160 * 1024, NGP_ERR_STATE, "fused sweep: LDS of a streamer with this many chains exceeds 160 KiB");
-    bool tup = false;  // a chain with a Tuple set: the fused kernel whose samplers hold the Tuple chain (k_sweep_multi_tup)
-    for (int i = 0; i < n; i++) tup = tup || hs[i]->ntuple > 0;
-    HCHK(tup ? sweep_multi_tup_set_max_lds((int)lds) : sweep_multi_set_max_lds((int)lds));
+    bool tup = false, rset = false;  // a chain with a Tuple / BayesR set: the fused kernel whose samplers hold that chain
+    for (int i = 0; i < n; i++) { tup = tup || hs[i]->ntuple > 0; rset = rset || hs[i]->nclass_total > 0; }
+    // (BayesR: the samplers of k_sweep_r, their class coefficients staged in LDS -- where that fits beside the sampler's own; else the chain of k_sweep_multi(_tup))
+    const size_t lds_r = std::max(lds, lds_sampler + (size_t)NGP_SAMPLER_R_LDS);
+    const bool use_r = rset && lds_r <= (size_t)160 * 1024 && !(h->knob & 65536);
+    const size_t lds_launch = use_r ? lds_r : lds;
+    HCHK(use_r ? sweep_multi_r_set_max_lds((int)lds_launch) : (tup ? sweep_multi_tup_set_max_lds((int)lds_launch) : sweep_multi_set_max_lds((int)lds_launch)));
     // One abort word: the leader's.  The sweep runs on the leader's stream; every chain's small kernels (head, coefficients, variance
     // draws, posterior sums: six launches of a few microseconds each) stay on the chain's OWN stream, tied to the sweep by events --
     // the K chains' small kernels then run side by side instead of one chain after the other (eight chains: 0.34 ms of a 4.35-ms pass).
@@ -1778,8 +1782,9 @@ int run_fused(ngp_handle **hs, int n, int64_t niter) {
             }
         }
         for (int i = 1; i < n; i++) { M.a[i].census = nullptr; M.a[i].xcc_w = M.a[0].xcc_w; }
-        if (tup) sweep_multi_tup_launch((unsigned)grid, lds, h->stream, M);
-        else sweep_multi_launch((unsigned)grid, lds, h->stream, M);
+        if (use_r) sweep_multi_r_launch((unsigned)grid, lds_launch, h->stream, M);
+        else if (tup) sweep_multi_tup_launch((unsigned)grid, lds_launch, h->stream, M);
+        else sweep_multi_launch((unsigned)grid, lds_launch, h->stream, M);
         h->sweep_launches += 1; h->last_grid = grid;
         if (!serial) {
             (void)hipEventRecord(evs, h->stream);

@@ -2937,7 +2937,7 @@ __device__ __attribute__((always_inline)) inline void role_streamer_rows_multi(c
 #undef NGP_RSY
 }
 
-#if !defined(NGP_INST_DBG) || !NGP_INST_DBG || NGP_INST_DBG == 2  // the production translation unit (ngp_sweep_inst.hip, -DNGP_INST_DBG=0) and the Tuple one
+#if !defined(NGP_INST_DBG) || !NGP_INST_DBG || NGP_INST_DBG == 2 || NGP_INST_DBG == 3  // the production translation unit (ngp_sweep_inst.hip, -DNGP_INST_DBG=0), the Tuple and the BayesR one
 // A chain's launch arguments by RUN-TIME chain index: indexing the by-value argument M.a[c] makes the compiler copy all of M to
 // scratch (3 KB per lane) and read every field from there.  The arguments already sit in the kernarg segment -- constant address
 // space, read with scalar loads -- so the entry is addressed there directly (M is the kernel's first argument: offset 0).
@@ -2950,12 +2950,22 @@ __device__ __attribute__((always_inline)) inline const SweepArgs &multi_chain_ar
 #if !defined(NGP_INST_DBG) || !NGP_INST_DBG  // one definition: the production translation unit
 __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sweep_multi(MultiArgs M) {
     constexpr bool TUPM = false;
+    constexpr int RCLSM = 1;
 #include "ngp_sweep_multi_body.inc"
 }
 #endif
 #if defined(NGP_INST_DBG) && NGP_INST_DBG == 2  // K chains with a Tuple set per pass: the Tuple translation unit
 __global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sweep_multi_tup(MultiArgs M) {
     constexpr bool TUPM = true;
+    constexpr int RCLSM = 1;
+#include "ngp_sweep_multi_body.inc"
+}
+#endif
+#if defined(NGP_INST_DBG) && NGP_INST_DBG == 3  // K chains with a BayesR set per pass: the samplers of k_sweep_r (class coefficients one block ahead
+                                                // through LDS, the lazy class search) -- the BayesR translation unit
+__global__ __launch_bounds__(NGP_WG) __attribute__((amdgpu_waves_per_eu(2, 2))) void k_sweep_multi_r(MultiArgs M) {
+    constexpr bool TUPM = true;
+    constexpr int RCLSM = 2;
 #include "ngp_sweep_multi_body.inc"
 }
 #endif

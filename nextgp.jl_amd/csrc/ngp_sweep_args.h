@@ -138,6 +138,8 @@ hipError_t sweep_multi_set_max_lds(int bytes);
 void sweep_multi_launch(unsigned grid, size_t lds_bytes, hipStream_t stream, const MultiArgs &M);
 hipError_t sweep_multi_tup_set_max_lds(int bytes);  // (chains with a Tuple set: k_sweep_multi_tup, the Tuple translation unit)
 void sweep_multi_tup_launch(unsigned grid, size_t lds_bytes, hipStream_t stream, const MultiArgs &M);
+hipError_t sweep_multi_r_set_max_lds(int bytes);  // (chains with a BayesR set: k_sweep_multi_r, the BayesR translation unit)
+void sweep_multi_r_launch(unsigned grid, size_t lds_bytes, hipStream_t stream, const MultiArgs &M);
 
 // Host entry points of the two instantiations of the persistent kernel (ngp_sweep_inst.hip is compiled twice, once per value of
 // NGP_INST_DBG, so that the production kernel and the diagnostic one build in parallel and apart from the API's own kernels):

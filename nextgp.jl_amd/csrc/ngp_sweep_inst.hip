@@ -19,6 +19,13 @@ hipError_t sweep_r_set_max_lds(int bytes) {
 void sweep_r_launch(unsigned grid, size_t lds_bytes, hipStream_t stream, const SweepArgs &A) {
     hipLaunchKernelGGL(k_sweep_r, dim3(grid), dim3(NGP_WG), lds_bytes, stream, A);
 }
+// ... and K such chains per pass
+hipError_t sweep_multi_r_set_max_lds(int bytes) {
+    return hipFuncSetAttribute((const void *)k_sweep_multi_r, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+}
+void sweep_multi_r_launch(unsigned grid, size_t lds_bytes, hipStream_t stream, const MultiArgs &M) {
+    hipLaunchKernelGGL(k_sweep_multi_r, dim3(grid), dim3(NGP_WG), lds_bytes, stream, M);
+}
 #elif NGP_INST_DBG == 2
 // the production kernel of models with a Tuple (correlated BayesPR) set: a translation unit of its own (the units compile in parallel)
 hipError_t sweep_tup_set_max_lds(int bytes) {

@@ -22,7 +22,9 @@ for k in range(K):
         v = 0.5 * y.var() / (s.mpm().sum() / N)
     else:
         s.share_panel(chains[0])
-    if method == "B":
+    if method == "R":
+        s.add_marker_set_r(0, P, 4.0, v * 0.5, v, [0.0, 0.01, 0.1, 1.0], [0.95, 0.03, 0.015, 0.005], estPi=True)
+    elif method == "B":
         s.add_marker_set(0, P, 1, 4.0, v * 0.5, [(j, j + 1) for j in range(P)], np.full(P, v), pi0=0.01, estPi=True)
     else:
         s.add_marker_set(0, P, 0, 4.0, v * 0.5, [(0, P)], [v])
