@@ -9,15 +9,15 @@ export TMPDIR=/tmp
 OUT=$PWD/gpurun_out
 mkdir -p $OUT/profiles
 # TK: eight chains with a Tuple set in one fused launch per iteration (k_sweep_multi_tup); UK: two chains over compact storage
-# (k_sweep_multi, byte tiles) -- kernel statistics only
-for W in TK UK; do
-  unset NGP_TOOL_CHAIN_FORM NGP_TOOL_STORAGE
-  if [ "$W" = "TK" ]; then CMD="tools/tuple_chains_time.py 10000 100000 2 8 10"; else export NGP_TOOL_STORAGE=u8; CMD="tools/chains_per_pass.py 10000 100000 2 30"; fi
+# (k_sweep_multi, byte tiles); RK: eight chains with a BayesR set (k_sweep_multi_r) -- kernel statistics only
+for W in TK UK RK; do
+  unset NGP_TOOL_CHAIN_FORM NGP_TOOL_STORAGE NGP_TOOL_METHOD
+  if [ "$W" = "TK" ]; then CMD="tools/tuple_chains_time.py 10000 100000 2 8 10"; elif [ "$W" = "RK" ]; then export NGP_TOOL_METHOD=R; CMD="tools/chains_per_pass.py 10000 100000 8 20"; else export NGP_TOOL_STORAGE=u8; CMD="tools/chains_per_pass.py 10000 100000 2 30"; fi
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_${W}_stats -o run -- python3 $CMD > $OUT/${TAG}_${W}_stats.log 2>&1
   cp "$(find $OUT/${TAG}_${W}_stats -name '*kernel_stats.csv' | head -1)" $OUT/profiles/${TAG}_kernel_stats_${W}.csv
   tail -3 $OUT/${TAG}_${W}_stats.log
 done
-unset NGP_TOOL_STORAGE
+unset NGP_TOOL_STORAGE NGP_TOOL_METHOD
 for W in T R; do
   if [ "$W" = "T" ]; then export NGP_TOOL_CHAIN_FORM=1; CMD="tools/tuple_time.py 10000 100000 2 10"; else unset NGP_TOOL_CHAIN_FORM; export NGP_TOOL_METHODS=R4; CMD="tools/method_time.py 10000 100000 10"; fi
   rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/${TAG}_${W}_stats -o run -- python3 $CMD > $OUT/${TAG}_${W}_stats.log 2>&1
