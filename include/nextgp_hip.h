@@ -274,8 +274,9 @@ int32_t ngp_shards_for_chains(ngp_handle *h, int32_t chains, int32_t *max_shards
  * every chain keeps its own sampler workgroup, reducers, hand-off rings and draws, and stays bit for bit the chain it is alone with
  * the same layout.  Set-up: the first handle sets the panel (after ngp_set_max_shards(ngp_shards_for_pass(K))), the others call
  * ngp_share_panel(h, first) in place of a panel upload -- no copy of the panel is made; then each handle gets its own marker sets,
- * y and seeds, and ngp_run_many(handles, K, niter) runs them fused (engine served: persistent sweep over fp32 tiles, shards of at
- * most 64 rows, lag 6 or 8 -- e.g. 10k x 100k; other engines run the handles side by side as before).  Independent chains are
+ * y and seeds, and ngp_run_many(handles, K, niter) runs them fused (engines served: persistent sweep over fp32 tiles with shards of at
+ * most 64 rows, lag 6 or 8, 2..8 chains -- e.g. 10k x 100k; shards of 64..224 rows, lag 4..6, two chains -- e.g. 50k x 600k; compact storage,
+ * two or three chains; every method, Tuple and BayesR sets included; other layouts run the handles side by side as before).  Independent chains are
  * the path's own parallelism (src/samplers.jl:23: one chain per Julia task). */
 int32_t ngp_share_panel(ngp_handle *h, ngp_handle *owner);
 int32_t ngp_shards_for_pass(ngp_handle *h, int32_t chains, int32_t *max_shards);
