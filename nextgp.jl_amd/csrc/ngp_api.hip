@@ -409,6 +409,10 @@ int alloc_panel(ngp_handle *h, int64_t N, int64_t P, ngp_handle *owner = nullptr
         if (h->D > 6) h->D = 6;  // register delay line: 32 VGPRs per lag
         if (h->V > 1) h->D = (h->V == 2) ? 3 : 2;  // ... and per shard of the workgroup
     } else if (h->mode == 1 && h->R > 128 && h->D > 5) h->D = 5;  // tall shards: the register delay line holds 5 tiles at most
+    // short shards (phase streamer), lag left to the library: 6.  Lag 8 was the better one while the shard partials crossed two hops (rounds 1-3);
+    // with the one-hop fixed-point sums: 10k x 100k 2.66-2.71 ms at lag 6 against 2.77-2.81 at lag 8 (7: 2.82-2.91, 5: 3.16-3.21, 4: 3.02-3.16),
+    // 8k x 100k 2.64 / 2.70, 14k x 100k 2.83 / 2.87, eight chains per pass 1839 / 1775 it/s (tools/r4_run41.sh)
+    else if (h->mode == 1 && h->lag_auto && h->D > 6) h->D = 6;
     // a fourth near lag overloads the sampler CU at short shards (+17 % time at 10k x 100k); the phase streamer of tall shards,
     // where with lag 5 nothing is left for the reducers then, saves 8 % with it; with the row-owning streamer (lag 6) the sampler
     // CU is again the busier end (its Gram traffic: 32 KB per near lag and block) and three near lags measure better

@@ -184,15 +184,17 @@ def test_north_star_shape_50k_x_600k(ngp, O):
     assert a["varE"] == b["varE"] and not np.array_equal(a["beta"], c["beta"]) and abs(a["varE"] - d["varE"]) <= 1e-9 * a["varE"]
 
 
-@pytest.mark.parametrize("lag", [8], ids=["lag8_default"])
+@pytest.mark.parametrize("lag", [6, 8], ids=["lag6_default", "lag8"])
 def test_default_engine_at_full_size(ngp, lag):
-    """The default production engine of short shards (lag 8, lazily counted partials) at 10k x 100k: residual invariant and
-    equality with the per-block engine (round 1 ran these checks at lag 6 only)."""
+    """The production engine of short shards (lag 6 by default since round 4, lag 8 before) at 10k x 100k: residual invariant and
+    equality with the per-block engine."""
     P_ = 20032
     a, y = _chain(ngp, "multi", 8, engine=(0, 1), P_=P_)
     b, _ = _chain(ngp, "multi", 8, engine=(1, lag), P_=P_)
     sa, sb = a.get_state(), b.get_state()
-    assert b.config() == (1, 8)
+    assert b.config() == (1, lag)
+    if lag == 6:   # what the library picks when the caller leaves the lag to it
+        d = ngp.Sampler(device=0, seed=1, chain=0); d.generate_panel(N, 6400); assert d.config() == (1, 6) and d.streamer() == (1, 8)
     assert np.array_equal(sa["delta"], sb["delta"])
     assert np.abs(sa["beta"] - sb["beta"]).max() <= 1e-9 * max(1e-3, np.abs(sa["beta"]).max())
     c, y2 = _chain(ngp, "PR", 12, engine=(1, lag))

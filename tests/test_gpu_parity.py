@@ -443,7 +443,7 @@ def test_shard_height_boundaries_bit_exact(ngp, O, N):
     assert mode == 1 and R == {14700: 60, 16000: 68, 30400: 124, 31700: 132, 54000: 220, 55000: 228, 62000: 252, 63232: 256}[N]
     variant, nchain = s.streamer()
     assert (variant, nchain) == ((2, 7) if 64 <= R <= 224 else (1, 8))   # row-owning waves from 64-row shards on (measured ahead there)
-    assert (D, s.near()) == ((6, 2) if variant == 2 else ((8, 3) if R <= 128 else (5, 4)))
+    assert (D, s.near()) == ((6, 2) if variant == 2 else ((6, 3) if R <= 128 else (5, 4)))   # (short shards: lag 6 since round 4, 8 before)
     o = O.Oracle(order=1, seed=21, chain=0)
     o.set_panel_f32(X, R=R, S=S, D=D, near=s.near(), nchain=nchain, tform=s.chain_form())
     v = 0.01
