@@ -108,7 +108,9 @@ struct DScal {  // chain scalars
 // a term beyond 2^53 stops the sweep (abort 7).
 // ------------------------------------------------------------------------------------------
 #define NGP_FX_CNT_BITS 10  // up to 1023 terms per block (699 shards of the tall layouts + far lags)
+#ifndef NGP_FX_COPIES
 #define NGP_FX_COPIES 8     // accumulator copies per block (shard s adds to copy s mod 8: eight memory lines share the atomics)
+#endif
 // exact conversions (|x| <= 2^53: x is rounded to an integer first, then split into halves the 32-bit converts carry exactly)
 __host__ __device__ inline long long fx_from_f64(const double x) {
     const double r = __builtin_rint(x);  // round to nearest, ties to even
